@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the IMPORTED reference.
+
+Runs only in the build container (needs /root/reference, which does not exist on the GPU
+box). Nothing of the reference's source travels: the outputs are plain arrays (inputs and
+expected outputs) saved as ``*.npz``. Re-run with
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/capture.py
+
+``fastprogress`` (a progress-bar dependency of the reference, not installed here) is replaced
+by a no-op stub created in a temp dir; nothing is written under /root/reference.
+
+Only the sequential path (``cores=1``) is captured: the reference's multi-process path returns
+the start point for every draw.
+"""
+import os
+import sys
+import tempfile
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+_stub = tempfile.mkdtemp(prefix="fp_stub_")
+os.makedirs(os.path.join(_stub, "fastprogress"))
+open(os.path.join(_stub, "fastprogress", "__init__.py"), "w").close()
+with open(os.path.join(_stub, "fastprogress", "fastprogress.py"), "w") as fh:
+    fh.write(
+        "class progress_bar:\n"
+        "    def __init__(self, gen, total=None, display=True, **kw):\n"
+        "        self.gen, self.total, self.comment = gen, total, ''\n"
+        "    def __iter__(self):\n"
+        "        return iter(self.gen)\n"
+        "    def update(self, val):\n"
+        "        pass\n"
+    )
+sys.path.insert(0, _stub)
+sys.path.insert(0, "/root/reference")
+
+import logging  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+import littlemcmc as ref  # noqa: E402
+from littlemcmc.quadpotential import QuadPotentialDiagAdapt, _WeightedVariance  # noqa: E402
+from littlemcmc.step_sizes import DualAverageAdaptation  # noqa: E402
+
+from oracle import targets  # noqa: E402
+
+logging.getLogger("littlemcmc").setLevel(logging.ERROR)
+SEED = 20260928
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %8.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024.0))
+
+
+def state_rows(states):
+    return dict(
+        q=np.array([np.asarray(s.q, dtype="d") for s in states]),
+        p=np.array([np.asarray(s.p, dtype="d") for s in states]),
+        v=np.array([np.asarray(s.v, dtype="d") for s in states]),
+        g=np.array([np.asarray(s.q_grad, dtype="d") for s in states]),
+        energy=np.array([float(np.ravel(s.energy)[0]) for s in states]),
+        logp=np.array([float(np.ravel(s.model_logp)[0]) for s in states]),
+    )
+
+
+# ---------------------------------------------------------------------------------------
+# 1. integrator unit fixtures: compute_state + n steps forward then n steps back
+# ---------------------------------------------------------------------------------------
+def capture_leapfrog():
+    out = {}
+    cases = []
+    for fam, d in [("std_normal", 1), ("std_normal", 10), ("std_normal", 128), ("ar1", 10),
+                   ("funnel", 8), ("diag_gaussian", 50), ("ar1", 200)]:
+        for pot_kind in ("adapt", "scaling"):
+            cases.append((fam, d, pot_kind))
+    for ci, (fam, d, pot_kind) in enumerate(cases):
+        f = targets.make(fam, d)
+        np.random.seed(1000 + ci)
+        scaling = (0.5 + np.random.rand(d))
+        if pot_kind == "adapt":
+            pot = QuadPotentialDiagAdapt(d, np.zeros(d), scaling, 10)
+            step = ref.HamiltonianMC(f, d, potential=pot)
+        else:
+            step = ref.HamiltonianMC(f, d, scaling=scaling, is_cov=True)
+        q0 = 0.3 * np.random.randn(d)
+        p0 = step.potential.random()
+        eps = 0.07
+        n = 20 if d <= 16 else 5
+        s = step.integrator.compute_state(q0, p0)
+        states = [s]
+        for _ in range(n):
+            s = step.integrator.step(eps, s)
+            states.append(s)
+        for _ in range(n):
+            s = step.integrator.step(-eps, s)
+            states.append(s)
+        rows = state_rows(states)
+        key = "c%d_" % ci
+        out[key + "family"] = np.array(fam)
+        out[key + "pot"] = np.array(pot_kind)
+        out[key + "d"] = np.array(d)
+        out[key + "eps"] = np.array(eps)
+        out[key + "n"] = np.array(n)
+        out[key + "var"] = np.asarray(step.potential._var if pot_kind == "adapt" else step.potential.v)
+        out[key + "p0_dtype"] = np.array(str(p0.dtype))
+        out[key + "params"] = f.params()
+        for k, v in rows.items():
+            out[key + k] = v
+    out["n_cases"] = np.array(len(cases))
+    save("leapfrog", **out)
+
+
+# ---------------------------------------------------------------------------------------
+# 2. iteration sequences at a FIXED step size (tune off): momentum draw + transition
+# ---------------------------------------------------------------------------------------
+def capture_transitions():
+    out = {}
+    cases = [
+        # family, d, kind, eps, iters, extra kwargs
+        ("std_normal", 2, "nuts", 0.9, 400, {}),
+        ("std_normal", 16, "nuts", 0.55, 300, {}),
+        ("std_normal", 128, "nuts", 0.6, 60, {}),
+        ("funnel", 8, "nuts", 0.45, 300, {"max_treedepth": 12}),
+        ("ar1", 16, "nuts", 0.2, 150, {}),
+        ("std_normal", 2, "nuts", 0.05, 40, {"max_treedepth": 5}),  # hits max depth
+        ("std_normal", 10, "hmc", 0.4, 300, {"path_length": 2.0}),
+        ("funnel", 8, "hmc", 0.5, 200, {"path_length": 3.0}),
+        ("std_normal", 3, "nuts_scaling", 0.7, 200, {}),
+    ]
+    for ci, (fam, d, kind, eps, iters, kw) in enumerate(cases):
+        f = targets.make(fam, d)
+        if kind == "nuts":
+            step = ref.NUTS(f, d, adapt_step_size=False, **kw)
+        elif kind == "nuts_scaling":
+            step = ref.NUTS(f, d, scaling=np.linspace(0.5, 2.0, d), is_cov=True, adapt_step_size=False, **kw)
+        else:
+            step = ref.HamiltonianMC(f, d, adapt_step_size=False, **kw)
+        step.tune = False
+        step.step_adapt._log_bar = np.log(eps)
+        step.step_adapt._log_step = np.log(eps)
+        seed = 4242 + ci
+        np.random.seed(seed)
+        q = np.full(d, 0.1)
+        qs, stats = [], []
+        for _ in range(iters):
+            q, st = step._astep(q)
+            qs.append(np.array(q, dtype="d"))
+            stats.append(st[0])
+        key = "c%d_" % ci
+        out[key + "family"] = np.array(fam)
+        out[key + "kind"] = np.array(kind)
+        out[key + "d"] = np.array(d)
+        out[key + "eps"] = np.array(eps)
+        out[key + "seed"] = np.array(seed)
+        out[key + "iters"] = np.array(iters)
+        out[key + "q0"] = np.full(d, 0.1)
+        out[key + "kw_names"] = np.array(list(kw.keys()), dtype="U32")
+        out[key + "kw_vals"] = np.array(list(kw.values()), dtype="d")
+        out[key + "q"] = np.array(qs)
+        for name, dt in step.stats_dtypes[0].items():
+            out[key + "stat_" + name] = np.array([np.ravel(s[name])[0] for s in stats]).astype(dt)
+        out[key + "final_rng_pos"] = np.array(np.random.get_state()[2])
+        out[key + "final_rng_key0"] = np.array(np.random.get_state()[1][:4])
+    out["n_cases"] = np.array(len(cases))
+    save("transitions", **out)
+
+
+# ---------------------------------------------------------------------------------------
+# 3. adaptation unit fixtures
+# ---------------------------------------------------------------------------------------
+def capture_adapt():
+    rs = np.random.RandomState(7)
+    accepts = rs.beta(4, 1.5, size=300)
+    da = DualAverageAdaptation(0.25 / 128 ** 0.25, 0.8, 0.05, 0.75, 10)
+    rows = []
+    for a in accepts:
+        da.update(a, True)
+        rows.append((da._log_step, da._log_bar, da._hbar, da._count))
+    d = 12
+    samples = rs.randn(250, d) * np.linspace(0.1, 30.0, d) + np.linspace(-3, 3, d)
+    mean0 = rs.randn(d)
+    pot = QuadPotentialDiagAdapt(d, mean0, np.ones(d), 10)
+    var_rows, istd_rows = [], []
+    for x in samples:
+        pot.update(x, None, True)
+        var_rows.append(pot._var.copy())
+        istd_rows.append(pot._inv_stds.copy())
+    save(
+        "adapt",
+        accepts=accepts, initial_step=np.array(0.25 / 128 ** 0.25), da=np.array(rows, dtype="d"),
+        samples=samples, mean0=mean0, var=np.array(var_rows), inv_stds=np.array(istd_rows),
+        n_samples=np.array(pot._n_samples), fore_mean=pot._foreground_var.mean,
+        fore_raw_var=pot._foreground_var.raw_var, fore_w=np.array(pot._foreground_var.w_sum),
+        back_mean=pot._background_var.mean, back_raw_var=pot._background_var.raw_var,
+        back_w=np.array(pot._background_var.w_sum),
+    )
+
+
+# ---------------------------------------------------------------------------------------
+# 4/5. end-to-end sample() runs (sequential path)
+# ---------------------------------------------------------------------------------------
+def capture_e2e():
+    runs = [
+        # name, family, d, kind, chains, tune, draws, kwargs
+        ("e2e_hmc_c1", "std_normal", 10, "hmc", 4, 300, 200, {"path_length": 2.0}),
+        ("e2e_nuts_std64", "std_normal", 64, "nuts", 2, 250, 150, {}),
+        ("e2e_nuts_std128", "std_normal", 128, "nuts", 2, 110, 20, {}),
+        ("e2e_nuts_ar1_16", "ar1", 16, "nuts", 4, 250, 150, {}),
+        ("e2e_nuts_funnel8", "funnel", 8, "nuts", 4, 250, 150, {"max_treedepth": 12}),
+        ("e2e_nuts_diag50", "diag_gaussian", 50, "nuts", 2, 250, 100, {}),
+        ("e2e_nuts_normal1d", "normal1d", 1, "nuts", 2, 120, 80, {}),
+    ]
+    for name, fam, d, kind, chains, tune, draws, kw in runs:
+        f = targets.make(fam, d)
+        if kind == "hmc":
+            step = ref.HamiltonianMC(f, d, **kw)
+            trace, stats = ref.sample(f, d, draws=draws, tune=tune, step=step, chains=chains, cores=1,
+                                      progressbar=False, random_seed=SEED, discard_tuned_samples=False)
+        else:
+            # the plain API call; init_nuts is wrapped only to get hold of the step object it builds
+            import littlemcmc.sampling as ref_sampling
+            made = {}
+            orig = ref_sampling.init_nuts
+
+            def spy(*a, **k):
+                st, sp = orig(*a, **k)
+                made["step"] = sp
+                return st, sp
+
+            ref_sampling.init_nuts = spy
+            try:
+                trace, stats = ref.sample(f, d, draws=draws, tune=tune, chains=chains, cores=1,
+                                          progressbar=False, random_seed=SEED,
+                                          discard_tuned_samples=False, **kw)
+            finally:
+                ref_sampling.init_nuts = orig
+            step = made["step"]
+        np.random.seed(SEED)
+        seeds = np.array([np.random.randint(2 ** 30) for _ in range(chains)])
+        np.random.seed(int(seeds[0]))
+        jitter = 2 * np.random.rand(d) - 1
+        arrays = dict(
+            family=np.array(fam), kind=np.array(kind), d=np.array(d), chains=np.array(chains),
+            tune=np.array(tune), draws=np.array(draws), random_seed=np.array(SEED), seeds=seeds,
+            start=jitter, params=f.params(), trace=trace,
+            kw_names=np.array(list(kw.keys()), dtype="U32"), kw_vals=np.array(list(kw.values()), dtype="d"),
+            final_var=np.asarray(step.potential._var),
+            final_da=np.array([float(np.ravel(x)[0]) for x in (
+                step.step_adapt._log_step, step.step_adapt._log_bar, step.step_adapt._hbar,
+                step.step_adapt._count)]),
+            final_n_samples=np.array(step.potential._n_samples),
+        )
+        for k, v in stats.items():
+            arrays["stat_" + k] = v
+        save(name, **arrays)
+
+
+# ---------------------------------------------------------------------------------------
+# 6. seed derivation
+# ---------------------------------------------------------------------------------------
+def capture_seeds():
+    out = {}
+    for chains in (2, 4, 64):
+        np.random.seed(SEED)
+        seeds = np.array([np.random.randint(2 ** 30) for _ in range(chains)])
+        np.random.seed(int(seeds[0]))
+        out["seeds_%d" % chains] = seeds
+        out["jitter_%d" % chains] = 2 * np.random.rand(7) - 1
+    # raw stream checks for the device RNG: seed -> u32 words, doubles, normals
+    rs = np.random.RandomState(12345)
+    out["stream_seed"] = np.array(12345)
+    out["stream_doubles"] = rs.random_sample(700)
+    out["stream_normals"] = rs.normal(size=1001)
+    out["stream_after_uniform"] = np.array(rs.uniform())
+    out["stream_normals2"] = rs.normal(size=10)
+    out["stream_state_pos"] = np.array(rs.get_state()[2])
+    save("seeds", **out)
+
+
+if __name__ == "__main__":
+    capture_leapfrog()
+    capture_transitions()
+    capture_adapt()
+    capture_e2e()
+    capture_seeds()
