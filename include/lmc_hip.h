@@ -1,0 +1,201 @@
+/*
+ * lmc_hip.h -- C ABI of the MI355X-native many-chain HMC/NUTS engine (liblmc_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of eigenfoo/littlemcmc 0.2.2. The reference has
+ * no FFI: its boundary is a set of duck-typed Python contracts. Each entry
+ * point below names the reference interface it replaces (paths relative to
+ * /root/reference/littlemcmc/); the Python mirror in littlemcmc_amd/ binds them with ctypes
+ * (see INTEGRATION.md for the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - plain C: opaque handle, pointers + sizes, int status returns (0 = LMC_OK); no C++ exceptions
+ *     and no torch types cross this boundary;
+ *   - array arguments may be HOST or DEVICE pointers (copies use hipMemcpyDefault); shapes are
+ *     row-major and UNPADDED: positions [chains][dim], per-chain scalars [chains];
+ *   - one engine == one GPU == one HIP stream; a handle is not thread-safe;
+ *   - all work is enqueued on the engine's stream; calls that return data synchronise it;
+ *   - per-chain numerical failures are reported through status bits, never by aborting the launch.
+ */
+#ifndef LMC_HIP_H_
+#define LMC_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMC_ABI_VERSION 1
+
+/* status codes */
+#define LMC_OK 0
+#define LMC_ERR_INVALID 1      /* bad argument / unsupported configuration */
+#define LMC_ERR_HIP 2          /* a HIP runtime call failed; see lmc_last_error() */
+#define LMC_ERR_STATE 3        /* call sequence error (e.g. run before reserve) */
+
+/* step method: nuts.py:32 (NUTS) / hmc.py:30 (HamiltonianMC) */
+#define LMC_KIND_NUTS 0
+#define LMC_KIND_HMC 1
+
+/* mass matrix: quadpotential.py:148 (QuadPotentialDiagAdapt, float32 momentum draw, adapted during
+ * tuning) / quadpotential.py:346 (QuadPotentialDiag, fixed diagonal, float64 momentum draw) */
+#define LMC_POT_DIAG_ADAPT 0
+#define LMC_POT_DIAG 1
+
+/* built-in device log-densities (littlemcmc_amd/csrc/lmc_targets.hpp); LMC_TARGET_USER exists only in
+ * libraries built with a user target header (littlemcmc_amd/targets.py: UserTarget) */
+#define LMC_TARGET_STD_NORMAL 0
+#define LMC_TARGET_DIAG_GAUSSIAN 1   /* params: prec[dim] */
+#define LMC_TARGET_AR1 2             /* params: {c_end, c_mid, off} */
+#define LMC_TARGET_FUNNEL 3
+#define LMC_TARGET_NORMAL1D 4        /* params: {loc, scale}; dim must be 1 */
+#define LMC_TARGET_USER 5
+
+/* per-chain status bits (lmc_engine_get_status) */
+#define LMC_STATUS_BAD_INITIAL_ENERGY 1   /* base_hmc.py:145-148 (ValueError in the reference) */
+#define LMC_STATUS_NAN_LOGBERN 2          /* math.py:23-24 (FloatingPointError in the reference) */
+
+/* per-draw statistics. f64 slots */
+#define LMC_STAT_STEP_SIZE 0        /* "step_size": exp(log_step) after the update (step_sizes.py:94-99) */
+#define LMC_STAT_STEP_SIZE_BAR 1    /* "step_size_bar" */
+#define LMC_STAT_ACCEPT 2           /* NUTS "mean_tree_accept" (nuts.py:421-425) / HMC "accept" (hmc.py:164) */
+#define LMC_STAT_ENERGY_ERROR 3     /* "energy_error" */
+#define LMC_STAT_ENERGY 4           /* "energy" */
+#define LMC_STAT_MAX_ENERGY_ERROR 5 /* NUTS "max_energy_error" / HMC "path_length" */
+#define LMC_STAT_MODEL_LOGP 6       /* "model_logp" */
+#define LMC_NUM_STAT_F64 7
+/* i32 slots */
+#define LMC_STAT_DEPTH 0            /* NUTS "depth" / HMC "n_steps" */
+#define LMC_STAT_TREE_SIZE 1        /* NUTS "tree_size" (= leapfrog steps, nuts.py:432) / HMC n_steps */
+#define LMC_NUM_STAT_I32 2
+/* u8 slots */
+#define LMC_STAT_DIVERGING 0        /* "diverging" */
+#define LMC_STAT_TUNE 1             /* "tune" */
+#define LMC_STAT_ACCEPTED 2         /* HMC "accepted" */
+#define LMC_NUM_STAT_U8 3
+
+/* per-chain counters (lmc_engine_get_counters), int64 [chains][LMC_NUM_COUNTERS] */
+#define LMC_CT_REACHED_MAX_TREEDEPTH 0   /* nuts.py:218-220 */
+#define LMC_CT_DIVS_AFTER_TUNE 1         /* base_hmc.py:171 */
+#define LMC_CT_SAMPLES_AFTER_TUNE 2      /* base_hmc.py:183 */
+#define LMC_CT_LEAPFROGS 3               /* sum of tree_size / n_steps: the bench metric's numerator */
+#define LMC_NUM_COUNTERS 4
+
+typedef struct lmc_engine lmc_engine;
+
+/* Constructor arguments of the step method: BaseHMC.__init__ (base_hmc.py:32-126) +
+ * NUTS.__init__ (nuts.py:103-202) + HamiltonianMC.__init__ (hmc.py:52-138). */
+typedef struct lmc_config {
+    int32_t abi_version;          /* LMC_ABI_VERSION */
+    int32_t device;               /* HIP device ordinal */
+    int32_t chains;               /* chains owned by this engine (one wavefront each) */
+    int32_t dim;                  /* model_ndim */
+    int32_t kind;                 /* LMC_KIND_* */
+    int32_t target_family;        /* LMC_TARGET_* */
+    int32_t potential;            /* LMC_POT_* */
+    int32_t adapt_step_size;      /* bool */
+    double target_accept;         /* 0.8 */
+    double emax;                  /* 1000 */
+    double step_scale;            /* 0.25; initial step = step_scale / dim**0.25 (base_hmc.py:102) */
+    double gamma;                 /* 0.05 */
+    double k;                     /* 0.75 */
+    double t0;                    /* 10 */
+    int32_t max_treedepth;        /* 10 */
+    int32_t early_max_treedepth;  /* 8 */
+    double path_length;           /* 2.0 (HMC) */
+    int32_t max_steps;            /* 1024 (HMC) */
+    int32_t adaptation_window;    /* 101 (quadpotential.py:156) */
+    int32_t lds_levels;           /* subtree-stack levels kept in LDS; 0 = choose automatically */
+} lmc_config;
+
+/* Fill *cfg with the reference's defaults for the given shape. */
+void lmc_config_defaults(lmc_config* cfg, int32_t chains, int32_t dim);
+
+/* Library-wide: message of the last failure on this thread (engine may be NULL). */
+const char* lmc_last_error(const lmc_engine* e);
+int32_t lmc_abi_version(void);
+/* 1 if this library was built with the given LMC_TARGET_* family. */
+int32_t lmc_has_target(int32_t family);
+
+/* ---- lifecycle: NUTS(...) / HamiltonianMC(...) construction ------------------------------------ */
+int lmc_engine_create(const lmc_config* cfg, lmc_engine** out);
+void lmc_engine_destroy(lmc_engine* e);
+/* Launch on an externally owned hipStream_t (e.g. torch's current stream). NULL = engine's own. */
+int lmc_engine_set_stream(lmc_engine* e, void* hip_stream);
+int lmc_engine_synchronize(lmc_engine* e);
+
+/* ---- plug-in parameters: the closure of the user's logp_dlogp_func (integration.py:40) ----------- */
+int lmc_engine_set_target_params(lmc_engine* e, const double* params, int64_t n);
+
+/* ---- potential: QuadPotentialDiagAdapt(n, initial_mean, initial_diag, initial_weight)
+ *      (quadpotential.py:151-204) or QuadPotentialDiag(v) (quadpotential.py:349-365).
+ *      initial_mean / initial_diag: [dim] (per_chain = 0, shared) or [chains][dim].
+ *      Also performs reset(). initial_mean may be NULL for LMC_POT_DIAG. */
+int lmc_engine_set_potential(lmc_engine* e, const double* initial_mean, const double* initial_diag,
+                             double initial_weight, int32_t per_chain);
+
+/* ---- RNG: np.random.seed(seeds[c]) for every chain (sampling.py:496-497) ------------------------- */
+int lmc_engine_seed(lmc_engine* e, const uint32_t* seeds);
+/* np.random.get_state()/set_state() of one chain: key[624], pos, has_gauss, cached_gaussian */
+int lmc_engine_set_rng_state(lmc_engine* e, int32_t chain, const uint32_t* key, int32_t pos,
+                             int32_t has_gauss, double gauss);
+int lmc_engine_get_rng_state(lmc_engine* e, int32_t chain, uint32_t* key, int32_t* pos,
+                             int32_t* has_gauss, double* gauss);
+
+/* ---- positions: the `q` threaded through step._astep(q) (sampling.py:498,512) ------------------- */
+int lmc_engine_set_position(lmc_engine* e, const double* q, int32_t per_chain);
+int lmc_engine_get_position(lmc_engine* e, double* q);
+
+/* ---- tuning lifecycle: step.reset_tuning() + iter_count = 0 (base_hmc.py:192-200, sampling.py:503-509) */
+int lmc_engine_reset_tuning(lmc_engine* e);
+/* Overwrite the dual-averaging state of every chain (step_sizes.py:49-56 fields). */
+int lmc_engine_set_dual_average(lmc_engine* e, double log_step, double log_bar, double hbar,
+                                int32_t count);
+
+/* ---- sampling: the body of _iter_sample (sampling.py:507-521) for ALL chains ---------------------
+ * reserve(): allocate output storage for `capacity` iterations per chain (trace optional).
+ * run(): iterations [iter_begin, iter_begin + n_iters) of every chain; iterations with global index
+ *        < n_tune are tuning iterations (stop_tuning happens at index n_tune, sampling.py:510-511).
+ *        Asynchronous on the engine's stream. */
+int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int32_t keep_trace);
+int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters);
+
+/* ---- results (synchronise the stream). dst shapes: trace [chains][n_iters][dim]; stats [chains][n_iters] */
+int lmc_engine_get_trace(lmc_engine* e, double* dst, int64_t iter_begin, int64_t n_iters);
+int lmc_engine_get_stat_f64(lmc_engine* e, int32_t stat, double* dst, int64_t iter_begin, int64_t n_iters);
+int lmc_engine_get_stat_i32(lmc_engine* e, int32_t stat, int32_t* dst, int64_t iter_begin, int64_t n_iters);
+int lmc_engine_get_stat_u8(lmc_engine* e, int32_t stat, uint8_t* dst, int64_t iter_begin, int64_t n_iters);
+/* Device pointers of the engine-owned outputs for zero-copy consumers (layout [chains][capacity][dim]
+ * and [n_stats][chains][capacity]); valid until the next reserve()/destroy(). */
+void* lmc_engine_trace_device_ptr(lmc_engine* e);
+void* lmc_engine_stat_f64_device_ptr(lmc_engine* e);
+int64_t lmc_engine_capacity(lmc_engine* e);
+
+/* adaptation state: potential._var [chains][dim] (float32), step_adapt fields [chains][4] =
+ * {log_step, log_bar, hbar, mu}, step_adapt._count [chains], potential._n_samples [chains].
+ * Any pointer may be NULL. */
+int lmc_engine_get_adapt_state(lmc_engine* e, float* var, double* dual_avg, int32_t* da_count,
+                               int32_t* n_samples);
+int lmc_engine_get_status(lmc_engine* e, int32_t* status);
+int lmc_engine_get_counters(lmc_engine* e, int64_t* counters);
+
+/* ---- unit entry points --------------------------------------------------------------------------
+ * trajectory(): integrator.compute_state(q0, p0) followed by n_fwd steps of +eps and n_back steps of
+ * -eps (integration.py:52-121), every chain from its own (q0, p0) [chains][dim]. Outputs hold
+ * n_fwd + n_back + 1 states: q/p/v/g [chains][n_states][dim], energy/logp [chains][n_states].
+ * p0_is_f32 selects the float32 start-state dtype flow of QuadPotentialDiagAdapt. */
+int lmc_engine_trajectory(lmc_engine* e, const double* q0, const double* p0, int32_t p0_is_f32,
+                          double eps, int32_t n_fwd, int32_t n_back, double* out_q, double* out_p,
+                          double* out_v, double* out_g, double* out_energy, double* out_logp);
+/* logp_dlogp_func(q) for every chain: q [chains][dim] -> logp [chains], grad [chains][dim]. */
+int lmc_engine_logp_dlogp(lmc_engine* e, const double* q, double* logp, double* grad);
+/* Draw from every chain's stream: ops[i] > 0 -> normal(size=ops[i]); ops[i] < 0 -> -ops[i] uniforms.
+ * out [chains][sum |ops|]. */
+int lmc_engine_rng_draw(lmc_engine* e, const int32_t* ops, int32_t n_ops, double* out);
+/* potential.random() for every chain (quadpotential.py:221-224 / :374-376): out [chains][dim]. */
+int lmc_engine_draw_momentum(lmc_engine* e, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMC_HIP_H_ */

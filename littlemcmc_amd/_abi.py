@@ -1,0 +1,125 @@
+"""ctypes binding of the C ABI in include/lmc_hip.h (liblmc_hip.so).
+
+There is no CPU fallback: if the HIP library is missing this module raises, and every product
+entry point fails loudly with it.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblmc_hip.so")
+
+ABI_VERSION = 1
+OK = 0
+
+KIND_NUTS, KIND_HMC = 0, 1
+POT_DIAG_ADAPT, POT_DIAG = 0, 1
+TARGET_STD_NORMAL, TARGET_DIAG_GAUSSIAN, TARGET_AR1, TARGET_FUNNEL, TARGET_NORMAL1D, TARGET_USER = range(6)
+STATUS_BAD_INITIAL_ENERGY, STATUS_NAN_LOGBERN = 1, 2
+(STAT_STEP_SIZE, STAT_STEP_SIZE_BAR, STAT_ACCEPT, STAT_ENERGY_ERROR, STAT_ENERGY, STAT_MAX_ENERGY_ERROR,
+ STAT_MODEL_LOGP) = range(7)
+STAT_DEPTH, STAT_TREE_SIZE = 0, 1
+STAT_DIVERGING, STAT_TUNE, STAT_ACCEPTED = 0, 1, 2
+CT_REACHED_MAX_TREEDEPTH, CT_DIVS_AFTER_TUNE, CT_SAMPLES_AFTER_TUNE, CT_LEAPFROGS = range(4)
+NUM_COUNTERS = 4
+
+
+class Config(C.Structure):
+    """struct lmc_config (include/lmc_hip.h)."""
+
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32), ("chains", C.c_int32), ("dim", C.c_int32),
+        ("kind", C.c_int32), ("target_family", C.c_int32), ("potential", C.c_int32),
+        ("adapt_step_size", C.c_int32),
+        ("target_accept", C.c_double), ("emax", C.c_double), ("step_scale", C.c_double),
+        ("gamma", C.c_double), ("k", C.c_double), ("t0", C.c_double),
+        ("max_treedepth", C.c_int32), ("early_max_treedepth", C.c_int32),
+        ("path_length", C.c_double), ("max_steps", C.c_int32), ("adaptation_window", C.c_int32),
+        ("lds_levels", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    # name: (restype, [argtypes])
+    "lmc_config_defaults": (None, [C.POINTER(Config), C.c_int32, C.c_int32]),
+    "lmc_last_error": (C.c_char_p, [_P]),
+    "lmc_abi_version": (C.c_int32, []),
+    "lmc_has_target": (C.c_int32, [C.c_int32]),
+    "lmc_engine_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "lmc_engine_destroy": (None, [_P]),
+    "lmc_engine_set_stream": (C.c_int, [_P, _P]),
+    "lmc_engine_synchronize": (C.c_int, [_P]),
+    "lmc_engine_set_target_params": (C.c_int, [_P, _P, C.c_int64]),
+    "lmc_engine_set_potential": (C.c_int, [_P, _P, _P, C.c_double, C.c_int32]),
+    "lmc_engine_seed": (C.c_int, [_P, _P]),
+    "lmc_engine_set_rng_state": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_double]),
+    "lmc_engine_get_rng_state": (C.c_int, [_P, C.c_int32, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_double)]),
+    "lmc_engine_set_position": (C.c_int, [_P, _P, C.c_int32]),
+    "lmc_engine_get_position": (C.c_int, [_P, _P]),
+    "lmc_engine_reset_tuning": (C.c_int, [_P]),
+    "lmc_engine_set_dual_average": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_int32]),
+    "lmc_engine_reserve": (C.c_int, [_P, C.c_int64, C.c_int32]),
+    "lmc_engine_run": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32]),
+    "lmc_engine_get_trace": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    "lmc_engine_get_stat_f64": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int64]),
+    "lmc_engine_get_stat_i32": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int64]),
+    "lmc_engine_get_stat_u8": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int64]),
+    "lmc_engine_trace_device_ptr": (_P, [_P]),
+    "lmc_engine_stat_f64_device_ptr": (_P, [_P]),
+    "lmc_engine_capacity": (C.c_int64, [_P]),
+    "lmc_engine_get_adapt_state": (C.c_int, [_P, _P, _P, _P, _P]),
+    "lmc_engine_get_status": (C.c_int, [_P, _P]),
+    "lmc_engine_get_counters": (C.c_int, [_P, _P]),
+    "lmc_engine_trajectory": (C.c_int, [_P, _P, _P, C.c_int32, C.c_double, C.c_int32, C.c_int32,
+                                        _P, _P, _P, _P, _P, _P]),
+    "lmc_engine_logp_dlogp": (C.c_int, [_P, _P, _P, _P]),
+    "lmc_engine_rng_draw": (C.c_int, [_P, _P, C.c_int32, _P]),
+    "lmc_engine_draw_momentum": (C.c_int, [_P, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+_libs = {}
+
+
+class HipLibraryError(RuntimeError):
+    """The HIP library is missing, stale or failed; there is no CPU path to fall back to."""
+
+
+def load(path=None):
+    """dlopen liblmc_hip.so (or a user-target build of it) and type its entry points."""
+    path = os.path.abspath(path or LIB_PATH)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise HipLibraryError(
+            "%s not found: the HIP extension is not built. Run `python -c \"import __graft_entry__ as g; "
+            "g.build()\"` (needs hipcc). littlemcmc_amd has no CPU fallback." % path)
+    try:
+        lib = C.CDLL(path)
+    except OSError as err:
+        raise HipLibraryError("cannot load %s: %s" % (path, err))
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise HipLibraryError("%s does not export %s (stale build?)" % (path, name))
+        fn.restype = res
+        fn.argtypes = args
+    if lib.lmc_abi_version() != ABI_VERSION:
+        raise HipLibraryError("ABI version mismatch: python %d, library %d" % (ABI_VERSION, lib.lmc_abi_version()))
+    _libs[path] = lib
+    return lib
+
+
+def ptr(a):
+    """Raw pointer of a C-contiguous numpy array (or pass through an int device pointer / None)."""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return C.c_void_p(int(a))
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return C.c_void_p(a.ctypes.data)

@@ -1,0 +1,886 @@
+// liblmc_hip.so: host side of the C ABI declared in include/lmc_hip.h.
+// Owns the per-chain state in HBM, dispatches the (target family x vector width) kernel
+// instantiation, and moves results in and out. No torch, no exceptions across the boundary.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/lmc_hip.h"
+#include "lmc_sampler.hpp"
+#ifdef LMC_USER_TARGET_HEADER
+#include LMC_USER_TARGET_HEADER
+#endif
+
+using namespace lmc;
+
+// ---------------------------------------------------------------------------------------------
+// unit kernels (share the device functions with run_kernel)
+// ---------------------------------------------------------------------------------------------
+namespace lmc {
+
+__global__ __launch_bounds__(64) void seed_kernel(ChainArrays A, const uint32_t* seeds) {
+    const int c = blockIdx.x;
+    RngState r;
+    r.mt = A.mt + static_cast<long long>(c) * kMtN;
+    mt_seed(r, seeds[c]);
+    if (lane_id() == 0) {
+        A.rng_pos[c] = r.pos;
+        A.rng_has_gauss[c] = 0;
+        A.rng_gauss[c] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(64) void rng_draw_kernel(ChainArrays A, const int* ops, int n_ops, double* out,
+                                                      long long out_stride) {
+    const int c = blockIdx.x;
+    const int lane = lane_id();
+    RngState r;
+    r.mt = A.mt + static_cast<long long>(c) * kMtN;
+    r.pos = first_i32(A.rng_pos[c]);
+    r.has_gauss = first_i32(A.rng_has_gauss[c]);
+    r.gauss = first_f64(A.rng_gauss[c]);
+    double* o = out + static_cast<long long>(c) * out_stride;
+    for (int k = 0; k < n_ops; ++k) {
+        const int op = ops[k];
+        if (op > 0) {
+            rng_normals(r, op, o);
+            o += op;
+        } else {
+            for (int i = 0; i < -op; ++i) {
+                const double u = rng_uniform(r);
+                if (lane == 0) o[i] = u;
+            }
+            o += -op;
+        }
+    }
+    if (lane == 0) {
+        A.rng_pos[c] = r.pos;
+        A.rng_has_gauss[c] = r.has_gauss;
+        A.rng_gauss[c] = r.gauss;
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(64) void momentum_kernel(ChainArrays A, int momentum_f32, double* out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int c = blockIdx.x;
+    const int lane = lane_id();
+    const int d = A.d;
+    RngState r;
+    r.mt = A.mt + static_cast<long long>(c) * kMtN;
+    r.pos = first_i32(A.rng_pos[c]);
+    r.has_gauss = first_i32(A.rng_has_gauss[c]);
+    r.gauss = first_f64(A.rng_gauss[c]);
+    rng_normals(r, d, lds);
+    const long long row = static_cast<long long>(c) * A.dpad;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = lane * NS + s;
+        if (e < d) {
+            const float is = A.inv_std[row + e];
+            const double z = lds[e];
+            out[static_cast<long long>(c) * d + e] =
+                momentum_f32 ? static_cast<double>(is * static_cast<float>(z)) : z * static_cast<double>(is);
+        }
+    }
+    if (lane == 0) {
+        A.rng_pos[c] = r.pos;
+        A.rng_has_gauss[c] = r.has_gauss;
+        A.rng_gauss[c] = r.gauss;
+    }
+}
+
+template <int NS, template <int> class TargetT>
+__global__ __launch_bounds__(64) void logp_kernel(ChainArrays A, const double* tparams, const double* qin,
+                                                  double* logp_out, double* grad_out) {
+    const int c = blockIdx.x;
+    const int lane = lane_id();
+    const int d = A.d;
+    TargetT<NS> tgt;
+    tgt.init(tparams, d);
+    double q[NS], g[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = lane * NS + s;
+        q[s] = (e < d) ? qin[static_cast<long long>(c) * d + e] : 0.0;
+    }
+    const double logp = tgt.logp_grad(q, g);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = lane * NS + s;
+        if (e < d) grad_out[static_cast<long long>(c) * d + e] = g[s];
+    }
+    if (lane == 0) logp_out[c] = logp;
+}
+
+// compute_state + n_fwd steps (+eps) + n_back steps (-eps); all states written out.
+template <int NS, template <int> class TargetT>
+__global__ __launch_bounds__(64) void trajectory_kernel(ChainArrays A, const double* tparams, const double* q0,
+                                                        const double* p0, int p0_is_f32, double eps, int n_fwd,
+                                                        int n_back, double* oq, double* op, double* ov,
+                                                        double* og, double* oe, double* ol) {
+    const int c = blockIdx.x;
+    const int lane = lane_id();
+    const int d = A.d;
+    const long long row = static_cast<long long>(c) * A.dpad;
+    TargetT<NS> tgt;
+    tgt.init(tparams, d);
+    double q[NS], p[NS], g[NS];
+    float var[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = lane * NS + s;
+        q[s] = (e < d) ? q0[static_cast<long long>(c) * d + e] : 0.0;
+        p[s] = (e < d) ? p0[static_cast<long long>(c) * d + e] : 0.0;
+        var[s] = A.var[row + e];
+    }
+    const int n_states = n_fwd + n_back + 1;
+    double logp = tgt.logp_grad(q, g);
+    double energy;
+    double v[NS];
+    if (p0_is_f32) {
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float pf = static_cast<float>(p[s]);
+            const float vf = var[s] * pf;
+            v[s] = static_cast<double>(vf);
+            part = __builtin_fma(static_cast<double>(pf), static_cast<double>(vf), part);
+        }
+        energy = static_cast<double>(0.5f * static_cast<float>(wave_sum(part))) - logp;
+    } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) v[s] = static_cast<double>(var[s]) * p[s];
+        energy = 0.5 * wave_sum(pdot_v<NS>(p, var, p)) - logp;
+    }
+    for (int k = 0; k < n_states; ++k) {
+        if (k > 0) {
+            leapfrog<NS>(tgt, var, (k <= n_fwd) ? eps : -eps, q, p, g, energy, logp);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) v[s] = static_cast<double>(var[s]) * p[s];
+        }
+        const long long base = (static_cast<long long>(c) * n_states + k) * d;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int e = lane * NS + s;
+            if (e < d) {
+                oq[base + e] = q[s];
+                op[base + e] = p[s];
+                ov[base + e] = v[s];
+                og[base + e] = g[s];
+            }
+        }
+        if (lane == 0) {
+            oe[static_cast<long long>(c) * n_states + k] = energy;
+            ol[static_cast<long long>(c) * n_states + k] = logp;
+        }
+    }
+}
+
+// QuadPotentialDiagAdapt.reset() (quadpotential.py:195-204) / QuadPotentialDiag.__init__ (:349-365)
+// + DualAverageAdaptation.reset() (step_sizes.py:49-56) + iter_count = 0.
+__global__ void reset_kernel(ChainArrays A, const double* init_mean, const float* init_diag, double init_weight,
+                             int adapt, double log_step0, double mu, int reset_step, int reset_mass) {
+    const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const long long n = static_cast<long long>(A.chains) * A.dpad;
+    if (idx >= n) return;
+    const int c = static_cast<int>(idx / A.dpad);
+    const int e = static_cast<int>(idx % A.dpad);
+    if (reset_mass) {
+        const float diag = (e < A.d) ? init_diag[idx] : 1.0f;
+        const float sd = sqrtf(diag);
+        A.var[idx] = diag;
+        A.inv_std[idx] = 1.0f / sd;
+        if (adapt) {
+            // foreground: mean = initial_mean, raw_var = initial_diag * weight; background: zeros
+            A.wmean[idx] = (e < A.d) ? init_mean[idx] : 0.0;
+            A.wraw[idx] = (e < A.d) ? static_cast<double>(diag) * init_weight : 0.0;
+            A.wmean[n + idx] = 0.0;
+            A.wraw[n + idx] = 0.0;
+        }
+        if (e == 0) {
+            A.wsum[c * 2 + 0] = init_weight;
+            A.wsum[c * 2 + 1] = 0.0;
+            A.wsel[c] = 0;
+            A.n_samples[c] = 0;
+        }
+    }
+    if (reset_step && e == 0) {
+        A.da[c * 4 + 0] = log_step0;
+        A.da[c * 4 + 1] = log_step0;
+        A.da[c * 4 + 2] = 0.0;
+        A.da[c * 4 + 3] = mu;
+        A.da_count[c] = 1;
+        A.iter_count[c] = 0;
+    }
+}
+
+__global__ void set_da_kernel(ChainArrays A, double log_step, double log_bar, double hbar, int count) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= A.chains) return;
+    A.da[c * 4 + 0] = log_step;
+    A.da[c * 4 + 1] = log_bar;
+    A.da[c * 4 + 2] = hbar;
+    A.da_count[c] = count;
+}
+
+}  // namespace lmc
+
+// ---------------------------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+struct lmc_engine {
+    lmc_config cfg;
+    int ns = 0, dpad = 0, nlds = 1, lds_bytes = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    ChainArrays A;
+    double* tparams = nullptr;
+    int64_t n_tparams = 0;
+    double* init_mean = nullptr;   // [C][dpad]
+    float* init_diag = nullptr;    // [C][dpad]
+    double init_weight = 10.0;
+    bool potential_set = false;
+    double initial_step = 0.0;
+    std::vector<void*> allocs;
+    std::string err;
+};
+
+static int fail(lmc_engine* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (e) e->err = buf;
+    return code;
+}
+
+#define HIP_TRY(e, call)                                                                        \
+    do {                                                                                        \
+        hipError_t err__ = (call);                                                              \
+        if (err__ != hipSuccess)                                                                \
+            return fail((e), LMC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+template <class T>
+static int dev_alloc(lmc_engine* e, T** p, size_t count, bool zero = true) {
+    void* ptr = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    HIP_TRY(e, hipMalloc(&ptr, bytes));
+    e->allocs.push_back(ptr);
+    if (zero) HIP_TRY(e, hipMemsetAsync(ptr, 0, bytes, e->stream));
+    *p = static_cast<T*>(ptr);
+    return LMC_OK;
+}
+
+static void dev_free(lmc_engine* e, void* p) {
+    if (!p) return;
+    for (auto& a : e->allocs)
+        if (a == p) { a = nullptr; break; }
+    (void)hipFree(p);
+}
+
+// ---- (family, NS) dispatch --------------------------------------------------------------------------
+#define LMC_NS_SWITCH(e, ns, BODY)                                      \
+    switch (ns) {                                                       \
+        case 1: { constexpr int NS = 1; BODY; } break;                  \
+        case 2: { constexpr int NS = 2; BODY; } break;                  \
+        case 4: { constexpr int NS = 4; BODY; } break;                  \
+        case 8: { constexpr int NS = 8; BODY; } break;                  \
+        case 16: { constexpr int NS = 16; BODY; } break;                \
+        default: return fail(e, LMC_ERR_INVALID, "unsupported vector width ns=%d", ns); \
+    }
+
+#ifdef LMC_USER_TARGET_HEADER
+#define LMC_USER_CASE(KERNEL_CALL) \
+    case LMC_TARGET_USER: { KERNEL_CALL(UserTarget); } break;
+#else
+#define LMC_USER_CASE(KERNEL_CALL)
+#endif
+
+#define LMC_FAMILY_SWITCH(e, family, KERNEL_CALL)                                       \
+    switch (family) {                                                                   \
+        case LMC_TARGET_STD_NORMAL: { KERNEL_CALL(StdNormalTarget); } break;            \
+        case LMC_TARGET_DIAG_GAUSSIAN: { KERNEL_CALL(DiagGaussianTarget); } break;      \
+        case LMC_TARGET_AR1: { KERNEL_CALL(AR1Target); } break;                         \
+        case LMC_TARGET_FUNNEL: { KERNEL_CALL(FunnelTarget); } break;                   \
+        case LMC_TARGET_NORMAL1D: { KERNEL_CALL(Normal1DTarget); } break;               \
+        LMC_USER_CASE(KERNEL_CALL)                                                      \
+        default: return fail(e, LMC_ERR_INVALID, "unknown target family %d", family);   \
+    }
+
+template <class T>
+struct DevBuf {   // RAII staging buffer: device copy of a host-or-device array
+    T* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(reinterpret_cast<void**>(&p), (n ? n : 1) * sizeof(T)); }
+};
+
+static int ns_for_dim(int d) {
+    const int need = (d + 63) / 64;
+    int ns = 1;
+    while (ns < need) ns *= 2;
+    return ns;
+}
+
+extern "C" {
+
+int32_t lmc_abi_version(void) { return LMC_ABI_VERSION; }
+
+int32_t lmc_has_target(int32_t family) {
+    if (family >= LMC_TARGET_STD_NORMAL && family <= LMC_TARGET_NORMAL1D) return 1;
+#ifdef LMC_USER_TARGET_HEADER
+    if (family == LMC_TARGET_USER) return 1;
+#endif
+    return 0;
+}
+
+const char* lmc_last_error(const lmc_engine* e) {
+    if (e && !e->err.empty()) return e->err.c_str();
+    return g_last_error.c_str();
+}
+
+void lmc_config_defaults(lmc_config* cfg, int32_t chains, int32_t dim) {
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->abi_version = LMC_ABI_VERSION;
+    cfg->device = 0;
+    cfg->chains = chains;
+    cfg->dim = dim;
+    cfg->kind = LMC_KIND_NUTS;
+    cfg->target_family = LMC_TARGET_STD_NORMAL;
+    cfg->potential = LMC_POT_DIAG_ADAPT;
+    cfg->adapt_step_size = 1;
+    cfg->target_accept = 0.8;
+    cfg->emax = 1000.0;
+    cfg->step_scale = 0.25;
+    cfg->gamma = 0.05;
+    cfg->k = 0.75;
+    cfg->t0 = 10.0;
+    cfg->max_treedepth = 10;
+    cfg->early_max_treedepth = 8;
+    cfg->path_length = 2.0;
+    cfg->max_steps = 1024;
+    cfg->adaptation_window = 101;
+    cfg->lds_levels = 0;
+}
+
+static int launch_reset(lmc_engine* e, int reset_step, int reset_mass) {
+    const long long n = static_cast<long long>(e->cfg.chains) * e->dpad;
+    const int threads = 256;
+    const int blocks = static_cast<int>((n + threads - 1) / threads);
+    const double log_step0 = std::log(e->initial_step);         // step_sizes.py:51
+    const double mu = std::log(10 * e->initial_step);           // step_sizes.py:55
+    hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(threads), 0, e->stream, e->A, e->init_mean, e->init_diag,
+                       e->init_weight, e->cfg.potential == LMC_POT_DIAG_ADAPT ? 1 : 0, log_step0, mu, reset_step,
+                       reset_mass);
+    HIP_TRY(e, hipGetLastError());
+    return LMC_OK;
+}
+
+int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
+    if (!cfg || !out) return fail(nullptr, LMC_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != LMC_ABI_VERSION)
+        return fail(nullptr, LMC_ERR_INVALID, "ABI version mismatch: header %d, library %d", cfg->abi_version,
+                    LMC_ABI_VERSION);
+    if (cfg->chains < 1 || cfg->dim < 1) return fail(nullptr, LMC_ERR_INVALID, "chains and dim must be >= 1");
+    if (cfg->dim > 1024) return fail(nullptr, LMC_ERR_INVALID, "dim > 1024 is not supported (one wavefront per chain)");
+    if (!lmc_has_target(cfg->target_family))
+        return fail(nullptr, LMC_ERR_INVALID, "target family %d is not built into this library", cfg->target_family);
+    if (cfg->target_family == LMC_TARGET_NORMAL1D && cfg->dim != 1)
+        return fail(nullptr, LMC_ERR_INVALID, "LMC_TARGET_NORMAL1D requires dim == 1");
+    if (cfg->kind != LMC_KIND_NUTS && cfg->kind != LMC_KIND_HMC)
+        return fail(nullptr, LMC_ERR_INVALID, "unknown step kind %d", cfg->kind);
+    if (cfg->max_treedepth < 1 || cfg->max_treedepth > 20 || cfg->early_max_treedepth < 1 ||
+        cfg->early_max_treedepth > 20)
+        return fail(nullptr, LMC_ERR_INVALID, "max_treedepth must be in [1, 20]");
+    int ndev = 0;
+    hipError_t herr = hipGetDeviceCount(&ndev);
+    if (herr != hipSuccess || ndev < 1)
+        return fail(nullptr, LMC_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(herr));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, LMC_ERR_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
+
+    lmc_engine* e = new (std::nothrow) lmc_engine();
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "out of host memory");
+    e->cfg = *cfg;
+    e->ns = ns_for_dim(cfg->dim);
+    e->dpad = 64 * e->ns;
+    e->initial_step = cfg->step_scale / std::pow(static_cast<double>(cfg->dim), 0.25);   // base_hmc.py:102
+
+    auto bail = [&](int rc) {
+        lmc_engine_destroy(e);
+        return rc;
+    };
+    hipError_t se = hipSetDevice(cfg->device);
+    if (se != hipSuccess) return bail(fail(nullptr, LMC_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(se)));
+    se = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    if (se != hipSuccess) return bail(fail(nullptr, LMC_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)));
+    e->stream = e->own_stream;
+
+    // subtree-stack levels in LDS: as many as fit in ~10 KiB per wave (16 waves/CU), at least one
+    const int max_levels = (cfg->max_treedepth > cfg->early_max_treedepth ? cfg->max_treedepth
+                                                                          : cfg->early_max_treedepth);
+    int nlds = cfg->lds_levels;
+    if (nlds <= 0) {
+        nlds = 1;
+        while (nlds < max_levels && (2 + 4 * nlds) * e->dpad * 8 <= 10240) ++nlds;
+    }
+    if (nlds > max_levels) nlds = max_levels;
+    if (nlds < 1) nlds = 1;
+    e->nlds = nlds;
+    e->lds_bytes = (2 + 4 * (nlds - 1)) * e->dpad * 8;
+    if (e->lds_bytes > 64 * 1024) return bail(fail(nullptr, LMC_ERR_INVALID, "lds_levels too large"));
+
+    const size_t C = cfg->chains, dp = e->dpad;
+    ChainArrays& A = e->A;
+    std::memset(&A, 0, sizeof(A));
+    A.chains = cfg->chains;
+    A.d = cfg->dim;
+    A.dpad = e->dpad;
+    int rc = LMC_OK;
+#define TRY_ALLOC(x) if ((rc = (x)) != LMC_OK) return bail(rc)
+    TRY_ALLOC(dev_alloc(e, &A.q, C * dp));
+    TRY_ALLOC(dev_alloc(e, &A.var, C * dp));
+    TRY_ALLOC(dev_alloc(e, &A.inv_std, C * dp));
+    TRY_ALLOC(dev_alloc(e, &A.wmean, 2 * C * dp));
+    TRY_ALLOC(dev_alloc(e, &A.wraw, 2 * C * dp));
+    TRY_ALLOC(dev_alloc(e, &A.wsum, C * 2));
+    TRY_ALLOC(dev_alloc(e, &A.wsel, C));
+    TRY_ALLOC(dev_alloc(e, &A.n_samples, C));
+    TRY_ALLOC(dev_alloc(e, &A.da, C * 4));
+    TRY_ALLOC(dev_alloc(e, &A.da_count, C));
+    TRY_ALLOC(dev_alloc(e, &A.iter_count, C));
+    TRY_ALLOC(dev_alloc(e, &A.mt, C * kMtN));
+    TRY_ALLOC(dev_alloc(e, &A.rng_pos, C));
+    TRY_ALLOC(dev_alloc(e, &A.rng_has_gauss, C));
+    TRY_ALLOC(dev_alloc(e, &A.rng_gauss, C));
+    TRY_ALLOC(dev_alloc(e, &A.status, C));
+    TRY_ALLOC(dev_alloc(e, &A.counters, C * kNumCounters));
+    A.scratch_stride = static_cast<long long>(max_levels - nlds + 1) * 4 * dp;
+    TRY_ALLOC(dev_alloc(e, &A.scratch, C * static_cast<size_t>(A.scratch_stride), false));
+    TRY_ALLOC(dev_alloc(e, &e->init_mean, C * dp));
+    TRY_ALLOC(dev_alloc(e, &e->init_diag, C * dp));
+    TRY_ALLOC(dev_alloc(e, &e->tparams, 8));
+#undef TRY_ALLOC
+    // default potential of BaseHMC (base_hmc.py:109-113): QuadPotentialDiagAdapt(d, zeros, ones, 10)
+    {
+        std::vector<double> ones(cfg->dim, 1.0), zeros(cfg->dim, 0.0);
+        rc = lmc_engine_set_potential(e, zeros.data(), ones.data(), 10.0, 0);
+        if (rc != LMC_OK) return bail(rc);
+        // seed 0 so that an engine used without lmc_engine_seed() is still deterministic
+        std::vector<uint32_t> seeds(C, 0u);
+        rc = lmc_engine_seed(e, seeds.data());
+        if (rc != LMC_OK) return bail(rc);
+    }
+    se = hipStreamSynchronize(e->stream);
+    if (se != hipSuccess) return bail(fail(nullptr, LMC_ERR_HIP, "engine init: %s", hipGetErrorString(se)));
+    *out = e;
+    return LMC_OK;
+}
+
+void lmc_engine_destroy(lmc_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void* p : e->allocs)
+        if (p) (void)hipFree(p);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+int lmc_engine_set_stream(lmc_engine* e, void* hip_stream) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->own_stream;
+    return LMC_OK;
+}
+
+int lmc_engine_synchronize(lmc_engine* e) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return LMC_OK;
+}
+
+int lmc_engine_set_target_params(lmc_engine* e, const double* params, int64_t n) {
+    if (!e || n < 0 || (n > 0 && !params)) return fail(e, LMC_ERR_INVALID, "bad target params");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (e->cfg.target_family == LMC_TARGET_DIAG_GAUSSIAN && n != e->cfg.dim)
+        return fail(e, LMC_ERR_INVALID, "diag_gaussian needs %d precisions, got %lld", e->cfg.dim, (long long)n);
+    if (e->cfg.target_family == LMC_TARGET_AR1 && n != 3)
+        return fail(e, LMC_ERR_INVALID, "ar1 needs params {c_end, c_mid, off}");
+    if (e->cfg.target_family == LMC_TARGET_NORMAL1D && n != 2)
+        return fail(e, LMC_ERR_INVALID, "normal1d needs params {loc, scale}");
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    dev_free(e, e->tparams);
+    e->tparams = nullptr;
+    int rc = dev_alloc(e, &e->tparams, static_cast<size_t>(n > 8 ? n : 8));
+    if (rc != LMC_OK) return rc;
+    if (n > 0) HIP_TRY(e, hipMemcpyAsync(e->tparams, params, n * sizeof(double), hipMemcpyDefault, e->stream));
+    e->n_tparams = n;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return LMC_OK;
+}
+
+int lmc_engine_set_potential(lmc_engine* e, const double* initial_mean, const double* initial_diag,
+                             double initial_weight, int32_t per_chain) {
+    if (!e || !initial_diag) return fail(e, LMC_ERR_INVALID, "initial_diag is required");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const int C = e->cfg.chains, d = e->cfg.dim, dp = e->dpad;
+    // stage on the host: float32 cast of the diagonal (quadpotential.py:181-183 / :359) and padding
+    std::vector<double> hdiag(static_cast<size_t>(per_chain ? C : 1) * d), hmean(hdiag.size(), 0.0);
+    HIP_TRY(e, hipMemcpy(hdiag.data(), initial_diag, hdiag.size() * sizeof(double), hipMemcpyDefault));
+    if (initial_mean)
+        HIP_TRY(e, hipMemcpy(hmean.data(), initial_mean, hmean.size() * sizeof(double), hipMemcpyDefault));
+    for (size_t i = 0; i < hdiag.size(); ++i)
+        if (!(hdiag[i] > 0.0))   // partial_check_positive_definite (quadpotential.py:68-77)
+            return fail(e, LMC_ERR_INVALID, "Scaling is not positive definite: diagonal entry %zu is %g", i, hdiag[i]);
+    std::vector<float> fdiag(static_cast<size_t>(C) * dp, 1.0f);
+    std::vector<double> fmean(static_cast<size_t>(C) * dp, 0.0);
+    for (int c = 0; c < C; ++c)
+        for (int i = 0; i < d; ++i) {
+            const size_t src = static_cast<size_t>(per_chain ? c : 0) * d + i;
+            fdiag[static_cast<size_t>(c) * dp + i] = static_cast<float>(hdiag[src]);
+            fmean[static_cast<size_t>(c) * dp + i] = hmean[src];
+        }
+    HIP_TRY(e, hipMemcpyAsync(e->init_diag, fdiag.data(), fdiag.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->init_mean, fmean.data(), fmean.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    e->init_weight = initial_weight;
+    e->potential_set = true;
+    int rc = launch_reset(e, 1, 1);
+    if (rc != LMC_OK) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));   // host staging buffers go out of scope
+    return LMC_OK;
+}
+
+int lmc_engine_seed(lmc_engine* e, const uint32_t* seeds) {
+    if (!e || !seeds) return fail(e, LMC_ERR_INVALID, "null argument");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    uint32_t* dseeds = nullptr;
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&dseeds), e->cfg.chains * sizeof(uint32_t)));
+    hipError_t err = hipMemcpyAsync(dseeds, seeds, e->cfg.chains * sizeof(uint32_t), hipMemcpyDefault, e->stream);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(seed_kernel, dim3(e->cfg.chains), dim3(64), 0, e->stream, e->A, dseeds);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    (void)hipFree(dseeds);
+    if (err != hipSuccess) return fail(e, LMC_ERR_HIP, "seed: %s", hipGetErrorString(err));
+    return LMC_OK;
+}
+
+int lmc_engine_set_rng_state(lmc_engine* e, int32_t chain, const uint32_t* key, int32_t pos, int32_t has_gauss,
+                             double gauss) {
+    if (!e || !key || chain < 0 || chain >= e->cfg.chains || pos < 0 || pos > kMtN)
+        return fail(e, LMC_ERR_INVALID, "bad rng state");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(e->A.mt + static_cast<size_t>(chain) * kMtN, key, kMtN * sizeof(uint32_t), hipMemcpyDefault));
+    HIP_TRY(e, hipMemcpy(e->A.rng_pos + chain, &pos, sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->A.rng_has_gauss + chain, &has_gauss, sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->A.rng_gauss + chain, &gauss, sizeof(double), hipMemcpyHostToDevice));
+    return LMC_OK;
+}
+
+int lmc_engine_get_rng_state(lmc_engine* e, int32_t chain, uint32_t* key, int32_t* pos, int32_t* has_gauss,
+                             double* gauss) {
+    if (!e || chain < 0 || chain >= e->cfg.chains) return fail(e, LMC_ERR_INVALID, "bad chain index");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (key) HIP_TRY(e, hipMemcpy(key, e->A.mt + static_cast<size_t>(chain) * kMtN, kMtN * sizeof(uint32_t), hipMemcpyDefault));
+    if (pos) HIP_TRY(e, hipMemcpy(pos, e->A.rng_pos + chain, sizeof(int), hipMemcpyDeviceToHost));
+    if (has_gauss) HIP_TRY(e, hipMemcpy(has_gauss, e->A.rng_has_gauss + chain, sizeof(int), hipMemcpyDeviceToHost));
+    if (gauss) HIP_TRY(e, hipMemcpy(gauss, e->A.rng_gauss + chain, sizeof(double), hipMemcpyDeviceToHost));
+    return LMC_OK;
+}
+
+int lmc_engine_set_position(lmc_engine* e, const double* q, int32_t per_chain) {
+    if (!e || !q) return fail(e, LMC_ERR_INVALID, "null argument");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const size_t C = e->cfg.chains, d = e->cfg.dim, dp = e->dpad;
+    HIP_TRY(e, hipMemsetAsync(e->A.q, 0, C * dp * sizeof(double), e->stream));
+    if (per_chain) {
+        HIP_TRY(e, hipMemcpy2DAsync(e->A.q, dp * sizeof(double), q, d * sizeof(double), d * sizeof(double), C,
+                                    hipMemcpyDefault, e->stream));
+    } else {   // same start for every chain (sampling.py:163-164): pitch 0 is not portable, loop rows
+        std::vector<double> host(d);
+        HIP_TRY(e, hipMemcpy(host.data(), q, d * sizeof(double), hipMemcpyDefault));
+        std::vector<double> all(C * d);
+        for (size_t c = 0; c < C; ++c) std::memcpy(all.data() + c * d, host.data(), d * sizeof(double));
+        HIP_TRY(e, hipMemcpy2DAsync(e->A.q, dp * sizeof(double), all.data(), d * sizeof(double), d * sizeof(double), C,
+                                    hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return LMC_OK;
+}
+
+int lmc_engine_get_position(lmc_engine* e, double* q) {
+    if (!e || !q) return fail(e, LMC_ERR_INVALID, "null argument");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const size_t C = e->cfg.chains, d = e->cfg.dim, dp = e->dpad;
+    HIP_TRY(e, hipMemcpy2DAsync(q, d * sizeof(double), e->A.q, dp * sizeof(double), d * sizeof(double), C,
+                                hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return LMC_OK;
+}
+
+int lmc_engine_reset_tuning(lmc_engine* e) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    // QuadPotentialDiag.reset() is a no-op (quadpotential.py:138-140): only the adaptive potential resets
+    return launch_reset(e, 1, e->cfg.potential == LMC_POT_DIAG_ADAPT ? 1 : 0);
+}
+
+int lmc_engine_set_dual_average(lmc_engine* e, double log_step, double log_bar, double hbar, int32_t count) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const int threads = 256, blocks = (e->cfg.chains + threads - 1) / threads;
+    hipLaunchKernelGGL(set_da_kernel, dim3(blocks), dim3(threads), 0, e->stream, e->A, log_step, log_bar, hbar, count);
+    HIP_TRY(e, hipGetLastError());
+    return LMC_OK;
+}
+
+int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int32_t keep_trace) {
+    if (!e || capacity < 1) return fail(e, LMC_ERR_INVALID, "capacity must be >= 1");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    ChainArrays& A = e->A;
+    dev_free(e, A.trace); A.trace = nullptr;
+    dev_free(e, A.stat_f64); A.stat_f64 = nullptr;
+    dev_free(e, A.stat_i32); A.stat_i32 = nullptr;
+    dev_free(e, A.stat_u8); A.stat_u8 = nullptr;
+    const size_t C = e->cfg.chains, cap = static_cast<size_t>(capacity);
+    int rc;
+    if (keep_trace && (rc = dev_alloc(e, &A.trace, C * cap * e->cfg.dim, false)) != LMC_OK) return rc;
+    if ((rc = dev_alloc(e, &A.stat_f64, kNumStatF64 * C * cap)) != LMC_OK) return rc;
+    if ((rc = dev_alloc(e, &A.stat_i32, kNumStatI32 * C * cap)) != LMC_OK) return rc;
+    if ((rc = dev_alloc(e, &A.stat_u8, kNumStatU8 * C * cap)) != LMC_OK) return rc;
+    A.cap = capacity;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return LMC_OK;
+}
+
+int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    if (e->A.cap <= 0 || !e->A.stat_f64) return fail(e, LMC_ERR_STATE, "lmc_engine_reserve() must be called before run()");
+    if (iter_begin < 0 || n_iters < 0 || iter_begin + n_iters > e->A.cap)
+        return fail(e, LMC_ERR_INVALID, "iterations [%lld, %lld) exceed reserved capacity %lld", (long long)iter_begin,
+                    (long long)(iter_begin + n_iters), (long long)e->A.cap);
+    if (n_iters == 0) return LMC_OK;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    SamplerParams P;
+    std::memset(&P, 0, sizeof(P));
+    P.kind = e->cfg.kind;
+    P.momentum_f32 = e->cfg.potential == LMC_POT_DIAG_ADAPT;
+    P.adapt_mass = e->cfg.potential == LMC_POT_DIAG_ADAPT;
+    P.adapt_step_size = e->cfg.adapt_step_size;
+    P.target_accept = e->cfg.target_accept;
+    P.emax = e->cfg.emax;
+    P.gamma = e->cfg.gamma;
+    P.k = e->cfg.k;
+    P.t0 = e->cfg.t0;
+    P.max_treedepth = e->cfg.max_treedepth;
+    P.early_max_treedepth = e->cfg.early_max_treedepth;
+    P.path_length = e->cfg.path_length;
+    P.max_steps = e->cfg.max_steps;
+    P.window = e->cfg.adaptation_window;
+    P.n_tune = n_tune;
+    P.iter_begin = iter_begin;
+    P.n_iters = n_iters;
+    P.nlds = e->nlds;
+    P.lds_doubles = e->lds_bytes / 8;
+    const dim3 grid(e->cfg.chains), block(64);
+#define RUN_CALL(T) \
+    LMC_NS_SWITCH(e, e->ns, hipLaunchKernelGGL((run_kernel<NS, T>), grid, block, e->lds_bytes, e->stream, e->A, P, e->tparams))
+    LMC_FAMILY_SWITCH(e, e->cfg.target_family, RUN_CALL)
+#undef RUN_CALL
+    HIP_TRY(e, hipGetLastError());
+    return LMC_OK;
+}
+
+static int copy_rows(lmc_engine* e, void* dst, const void* src, size_t elem, int64_t iter_begin, int64_t n_iters,
+                     size_t per_iter) {
+    // src layout [C][cap][per_iter], dst layout [C][n_iters][per_iter]
+    const size_t C = e->cfg.chains;
+    const char* s = static_cast<const char*>(src) + static_cast<size_t>(iter_begin) * per_iter * elem;
+    HIP_TRY(e, hipMemcpy2DAsync(dst, n_iters * per_iter * elem, s, e->A.cap * per_iter * elem, n_iters * per_iter * elem,
+                                C, hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return LMC_OK;
+}
+
+static int check_window(lmc_engine* e, const void* dst, int64_t iter_begin, int64_t n_iters) {
+    if (!e || !dst) return fail(e, LMC_ERR_INVALID, "null argument");
+    if (iter_begin < 0 || n_iters < 1 || iter_begin + n_iters > e->A.cap)
+        return fail(e, LMC_ERR_INVALID, "window [%lld, %lld) outside reserved capacity %lld", (long long)iter_begin,
+                    (long long)(iter_begin + n_iters), (long long)e->A.cap);
+    hipError_t err = hipSetDevice(e->cfg.device);
+    if (err != hipSuccess) return fail(e, LMC_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(err));
+    return LMC_OK;
+}
+
+int lmc_engine_get_trace(lmc_engine* e, double* dst, int64_t iter_begin, int64_t n_iters) {
+    int rc = check_window(e, dst, iter_begin, n_iters);
+    if (rc != LMC_OK) return rc;
+    if (!e->A.trace) return fail(e, LMC_ERR_STATE, "trace was not reserved (keep_trace = 0)");
+    return copy_rows(e, dst, e->A.trace, sizeof(double), iter_begin, n_iters, e->cfg.dim);
+}
+
+int lmc_engine_get_stat_f64(lmc_engine* e, int32_t stat, double* dst, int64_t iter_begin, int64_t n_iters) {
+    int rc = check_window(e, dst, iter_begin, n_iters);
+    if (rc != LMC_OK) return rc;
+    if (stat < 0 || stat >= kNumStatF64) return fail(e, LMC_ERR_INVALID, "bad f64 stat %d", stat);
+    return copy_rows(e, dst, e->A.stat_f64 + static_cast<size_t>(stat) * e->cfg.chains * e->A.cap, sizeof(double),
+                     iter_begin, n_iters, 1);
+}
+
+int lmc_engine_get_stat_i32(lmc_engine* e, int32_t stat, int32_t* dst, int64_t iter_begin, int64_t n_iters) {
+    int rc = check_window(e, dst, iter_begin, n_iters);
+    if (rc != LMC_OK) return rc;
+    if (stat < 0 || stat >= kNumStatI32) return fail(e, LMC_ERR_INVALID, "bad i32 stat %d", stat);
+    return copy_rows(e, dst, e->A.stat_i32 + static_cast<size_t>(stat) * e->cfg.chains * e->A.cap, sizeof(int32_t),
+                     iter_begin, n_iters, 1);
+}
+
+int lmc_engine_get_stat_u8(lmc_engine* e, int32_t stat, uint8_t* dst, int64_t iter_begin, int64_t n_iters) {
+    int rc = check_window(e, dst, iter_begin, n_iters);
+    if (rc != LMC_OK) return rc;
+    if (stat < 0 || stat >= kNumStatU8) return fail(e, LMC_ERR_INVALID, "bad u8 stat %d", stat);
+    return copy_rows(e, dst, e->A.stat_u8 + static_cast<size_t>(stat) * e->cfg.chains * e->A.cap, sizeof(uint8_t),
+                     iter_begin, n_iters, 1);
+}
+
+void* lmc_engine_trace_device_ptr(lmc_engine* e) { return e ? e->A.trace : nullptr; }
+void* lmc_engine_stat_f64_device_ptr(lmc_engine* e) { return e ? e->A.stat_f64 : nullptr; }
+int64_t lmc_engine_capacity(lmc_engine* e) { return e ? e->A.cap : 0; }
+
+int lmc_engine_get_adapt_state(lmc_engine* e, float* var, double* dual_avg, int32_t* da_count, int32_t* n_samples) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const size_t C = e->cfg.chains, d = e->cfg.dim, dp = e->dpad;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (var)
+        HIP_TRY(e, hipMemcpy2D(var, d * sizeof(float), e->A.var, dp * sizeof(float), d * sizeof(float), C, hipMemcpyDefault));
+    if (dual_avg) HIP_TRY(e, hipMemcpy(dual_avg, e->A.da, C * 4 * sizeof(double), hipMemcpyDefault));
+    if (da_count) HIP_TRY(e, hipMemcpy(da_count, e->A.da_count, C * sizeof(int), hipMemcpyDefault));
+    if (n_samples) HIP_TRY(e, hipMemcpy(n_samples, e->A.n_samples, C * sizeof(int), hipMemcpyDefault));
+    return LMC_OK;
+}
+
+int lmc_engine_get_status(lmc_engine* e, int32_t* status) {
+    if (!e || !status) return fail(e, LMC_ERR_INVALID, "null argument");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(status, e->A.status, e->cfg.chains * sizeof(int), hipMemcpyDefault));
+    return LMC_OK;
+}
+
+int lmc_engine_get_counters(lmc_engine* e, int64_t* counters) {
+    if (!e || !counters) return fail(e, LMC_ERR_INVALID, "null argument");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(counters, e->A.counters, static_cast<size_t>(e->cfg.chains) * kNumCounters * sizeof(long long),
+                         hipMemcpyDefault));
+    return LMC_OK;
+}
+
+// ---- unit entry points -----------------------------------------------------------------------------------
+int lmc_engine_trajectory(lmc_engine* e, const double* q0, const double* p0, int32_t p0_is_f32, double eps,
+                          int32_t n_fwd, int32_t n_back, double* out_q, double* out_p, double* out_v, double* out_g,
+                          double* out_energy, double* out_logp) {
+    if (!e || !q0 || !p0 || !out_q || !out_p || !out_v || !out_g || !out_energy || !out_logp || n_fwd < 0 || n_back < 0)
+        return fail(e, LMC_ERR_INVALID, "bad trajectory arguments");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const size_t C = e->cfg.chains, d = e->cfg.dim, ns = static_cast<size_t>(n_fwd + n_back + 1);
+    DevBuf<double> dq0, dp0, oq, op, ov, og, oe, ol;
+    HIP_TRY(e, dq0.alloc(C * d)); HIP_TRY(e, dp0.alloc(C * d));
+    HIP_TRY(e, oq.alloc(C * ns * d)); HIP_TRY(e, op.alloc(C * ns * d));
+    HIP_TRY(e, ov.alloc(C * ns * d)); HIP_TRY(e, og.alloc(C * ns * d));
+    HIP_TRY(e, oe.alloc(C * ns)); HIP_TRY(e, ol.alloc(C * ns));
+    HIP_TRY(e, hipMemcpyAsync(dq0.p, q0, C * d * sizeof(double), hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(dp0.p, p0, C * d * sizeof(double), hipMemcpyDefault, e->stream));
+    const dim3 grid(e->cfg.chains), block(64);
+#define TRAJ_CALL(T)                                                                                          \
+    LMC_NS_SWITCH(e, e->ns, hipLaunchKernelGGL((trajectory_kernel<NS, T>), grid, block, 0, e->stream, e->A,   \
+                                               e->tparams, dq0.p, dp0.p, p0_is_f32, eps, n_fwd, n_back, oq.p, \
+                                               op.p, ov.p, og.p, oe.p, ol.p))
+    LMC_FAMILY_SWITCH(e, e->cfg.target_family, TRAJ_CALL)
+#undef TRAJ_CALL
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipMemcpyAsync(out_q, oq.p, C * ns * d * sizeof(double), hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(out_p, op.p, C * ns * d * sizeof(double), hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(out_v, ov.p, C * ns * d * sizeof(double), hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(out_g, og.p, C * ns * d * sizeof(double), hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(out_energy, oe.p, C * ns * sizeof(double), hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(out_logp, ol.p, C * ns * sizeof(double), hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return LMC_OK;
+}
+
+int lmc_engine_logp_dlogp(lmc_engine* e, const double* q, double* logp, double* grad) {
+    if (!e || !q || !logp || !grad) return fail(e, LMC_ERR_INVALID, "null argument");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const size_t C = e->cfg.chains, d = e->cfg.dim;
+    DevBuf<double> dq, dl, dg;
+    HIP_TRY(e, dq.alloc(C * d)); HIP_TRY(e, dl.alloc(C)); HIP_TRY(e, dg.alloc(C * d));
+    HIP_TRY(e, hipMemcpyAsync(dq.p, q, C * d * sizeof(double), hipMemcpyDefault, e->stream));
+    const dim3 grid(e->cfg.chains), block(64);
+#define LOGP_CALL(T) \
+    LMC_NS_SWITCH(e, e->ns, hipLaunchKernelGGL((logp_kernel<NS, T>), grid, block, 0, e->stream, e->A, e->tparams, dq.p, dl.p, dg.p))
+    LMC_FAMILY_SWITCH(e, e->cfg.target_family, LOGP_CALL)
+#undef LOGP_CALL
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipMemcpyAsync(logp, dl.p, C * sizeof(double), hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(grad, dg.p, C * d * sizeof(double), hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return LMC_OK;
+}
+
+int lmc_engine_rng_draw(lmc_engine* e, const int32_t* ops, int32_t n_ops, double* out) {
+    if (!e || !ops || !out || n_ops < 1) return fail(e, LMC_ERR_INVALID, "bad rng_draw arguments");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    std::vector<int32_t> hops(n_ops);
+    HIP_TRY(e, hipMemcpy(hops.data(), ops, n_ops * sizeof(int32_t), hipMemcpyDefault));
+    long long total = 0;
+    for (int32_t op : hops) total += op > 0 ? op : -op;
+    const size_t C = e->cfg.chains;
+    DevBuf<int> dops;
+    DevBuf<double> dout;
+    HIP_TRY(e, dops.alloc(n_ops)); HIP_TRY(e, dout.alloc(C * total));
+    HIP_TRY(e, hipMemcpyAsync(dops.p, hops.data(), n_ops * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(rng_draw_kernel, dim3(e->cfg.chains), dim3(64), 0, e->stream, e->A, dops.p, n_ops, dout.p, total);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipMemcpyAsync(out, dout.p, C * total * sizeof(double), hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return LMC_OK;
+}
+
+int lmc_engine_draw_momentum(lmc_engine* e, double* out) {
+    if (!e || !out) return fail(e, LMC_ERR_INVALID, "null argument");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const size_t C = e->cfg.chains, d = e->cfg.dim;
+    DevBuf<double> dout;
+    HIP_TRY(e, dout.alloc(C * d));
+    const int f32 = e->cfg.potential == LMC_POT_DIAG_ADAPT;
+    const dim3 grid(e->cfg.chains), block(64);
+    const int lds = e->dpad * 8;
+    LMC_NS_SWITCH(e, e->ns, hipLaunchKernelGGL((momentum_kernel<NS>), grid, block, lds, e->stream, e->A, f32, dout.p))
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipMemcpyAsync(out, dout.p, C * d * sizeof(double), hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return LMC_OK;
+}
+
+}  // extern "C"

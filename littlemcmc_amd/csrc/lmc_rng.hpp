@@ -1,0 +1,205 @@
+// Per-chain numpy-legacy random stream on the device: MT19937 + 53-bit doubles + polar gaussian.
+//
+// The reference draws everything from the global legacy np.random generator, re-seeded per chain
+// (/root/reference/littlemcmc/sampling.py:496-497); same-seed parity therefore needs the same
+// stream. This is the wave-parallel form of that stream (scalar statement: oracle/mt19937.py):
+//   * state = 624 words per chain in HBM (row of the [chains x 624] array) + pos/has_gauss/gauss;
+//   * the twist runs as three dependent batches (i < 227, 227 <= i < 454, 454 <= i < 623, then 623);
+//   * normal(size=d) evaluates up to 64 polar attempts at once (one per lane), compacts the accepted
+//     pairs with ballot/popcount into the consumer's order, and advances pos by exactly the number
+//     of words the sequential algorithm would have consumed;
+//   * uniform() is a wave-uniform read of two words.
+// The translation unit is compiled with -ffp-contract=off, so every variate is the same IEEE
+// operation sequence as numpy's C code (no fused multiply-add).
+#pragma once
+#include "lmc_wave.hpp"
+
+namespace lmc {
+
+constexpr int kMtN = 624;
+constexpr int kMtM = 397;
+
+struct RngState {   // wave-uniform registers mirroring numpy's rk_state / legacy gauss cache
+    uint32_t* mt;   // this chain's 624 words (global memory)
+    int pos;
+    int has_gauss;
+    double gauss;
+};
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9D2C5680u;
+    y ^= (y << 15) & 0xEFC60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7FFFFFFFu);
+    return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+}
+
+// np.random.seed(s): Knuth LCG fill. Serial by nature; every lane runs it redundantly in
+// registers and lanes store disjoint words (executed once per chain).
+__device__ inline void mt_seed(RngState& r, uint32_t s) {
+    const int lane = lane_id();
+    uint32_t x = s;
+    if (lane == 0) r.mt[0] = x;
+    for (int i = 1; i < kMtN; ++i) {
+        x = 1812433253u * (x ^ (x >> 30)) + static_cast<uint32_t>(i);
+        if ((i & 63) == lane) r.mt[i] = x;
+    }
+    r.pos = kMtN;
+    r.has_gauss = 0;
+    r.gauss = 0.0;
+    wave_sync();
+}
+
+// genrand twist, in place, 64 words per pass. Batch A/B/C only read words that are either still
+// old or were written in an earlier batch; wave_sync() between batches makes those writes visible.
+__device__ inline void mt_regen(RngState& r) {
+    const int lane = lane_id();
+    uint32_t* mt = r.mt;
+    // batch A: i in [0, 227): reads old mt[i], mt[i+1], mt[i+397]
+    {
+        uint32_t nv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = lane + 64 * k;
+            nv[k] = (i < 227) ? mt_twist(mt[i], mt[i + 1], mt[i + kMtM]) : 0u;
+        }
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = lane + 64 * k;
+            if (i < 227) mt[i] = nv[k];
+        }
+        wave_sync();
+    }
+    // batch B: i in [227, 454): reads old mt[i], mt[i+1], new mt[i-227]
+    {
+        uint32_t nv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = 227 + lane + 64 * k;
+            nv[k] = (i < 454) ? mt_twist(mt[i], mt[i + 1], mt[i - 227]) : 0u;
+        }
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = 227 + lane + 64 * k;
+            if (i < 454) mt[i] = nv[k];
+        }
+        wave_sync();
+    }
+    // batch C: i in [454, 623): reads old mt[i], mt[i+1], new mt[i-227]
+    {
+        uint32_t nv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = 454 + lane + 64 * k;
+            nv[k] = (i < 623) ? mt_twist(mt[i], mt[i + 1], mt[i - 227]) : 0u;
+        }
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = 454 + lane + 64 * k;
+            if (i < 623) mt[i] = nv[k];
+        }
+        wave_sync();
+    }
+    // i = 623: old mt[623], NEW mt[0], new mt[396]
+    if (lane == 0) mt[623] = mt_twist(mt[623], mt[0], mt[396]);
+    wave_sync();
+    r.pos = 0;
+}
+
+// rk_double: (a >> 5, b >> 6) -> 53-bit fraction. Wave-uniform.
+__device__ __forceinline__ double mt_words_to_double(uint32_t w0, uint32_t w1) {
+    const uint32_t a = mt_temper(w0) >> 5;
+    const uint32_t b = mt_temper(w1) >> 6;
+    return (static_cast<double>(a) * 67108864.0 + static_cast<double>(b)) / 9007199254740992.0;
+}
+
+__device__ inline double rng_uniform(RngState& r) {
+    if (r.pos >= kMtN) mt_regen(r);   // pos is always even inside a chain stream, so pos+1 < 624
+    const uint32_t w0 = first_u32(r.mt[r.pos]);
+    const uint32_t w1 = first_u32(r.mt[r.pos + 1]);
+    r.pos += 2;
+    return first_f64(mt_words_to_double(w0, w1));
+}
+
+// normal(size=d) -> out[0..d) (LDS or global scratch, any lane may write any slot).
+// Consumer order: attempt k accepted => normals (f*x2, f*x1) in that order; an odd tail leaves
+// f*x1 in the cache for the next call (numpy legacy_gauss).
+__device__ inline void rng_normals(RngState& r, int d, double* out) {
+    const int lane = lane_id();
+    int produced = 0;
+    if (r.has_gauss && d > 0) {
+        if (lane == 0) out[0] = r.gauss;
+        r.has_gauss = 0;
+        r.gauss = 0.0;
+        produced = 1;
+    }
+    while (produced < d) {
+        const int avail = (kMtN - r.pos) >> 2;   // whole attempts left in this generation
+        if (avail == 0) {                         // 0 or 2 words left: one attempt across the twist
+            const double x1 = 2.0 * rng_uniform(r) - 1.0;
+            const double x2 = 2.0 * rng_uniform(r) - 1.0;
+            const double r2 = x1 * x1 + x2 * x2;
+            if (r2 > 0.0 && r2 < 1.0) {
+                const double f = sqrt(-2.0 * log(r2) / r2);
+                if (lane == 0) out[produced] = f * x2;
+                if (produced + 1 < d) {
+                    if (lane == 0) out[produced + 1] = f * x1;
+                } else {
+                    r.gauss = first_f64(f * x1);
+                    r.has_gauss = 1;
+                }
+                produced += 2;
+            }
+            continue;
+        }
+        const int n_att = avail < 64 ? avail : 64;
+        const int need_pairs = (d - produced + 1) >> 1;
+        bool acc = false;
+        double x1 = 0.0, x2 = 0.0, r2 = 1.0;
+        if (lane < n_att) {
+            const uint32_t* w = r.mt + r.pos + 4 * lane;
+            x1 = 2.0 * mt_words_to_double(w[0], w[1]) - 1.0;
+            x2 = 2.0 * mt_words_to_double(w[2], w[3]) - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+            acc = (r2 > 0.0) && (r2 < 1.0);
+        }
+        unsigned long long mask = __ballot(acc);
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        int rank = __popcll(mask & below);
+        int consumed = n_att;
+        if (__popcll(mask) >= need_pairs) {
+            const unsigned long long lastm = __ballot(acc && rank == need_pairs - 1);
+            const int last = __ffsll(static_cast<long long>(lastm)) - 1;
+            consumed = last + 1;
+            mask &= (last == 63) ? ~0ull : ((1ull << (last + 1)) - 1ull);
+        }
+        const bool mine = acc && ((mask >> lane) & 1ull);
+        double g1 = 0.0;
+        if (mine) {
+            const double f = sqrt(-2.0 * log(r2) / r2);
+            const int idx = produced + 2 * rank;
+            out[idx] = f * x2;
+            g1 = f * x1;
+            if (idx + 1 < d) out[idx + 1] = g1;
+        }
+        const int got = 2 * __popcll(mask);
+        if (produced + got > d) {   // odd tail: the last accepted attempt's second variate is cached
+            const int last = 63 - __clzll(static_cast<long long>(mask));
+            r.gauss = readlane_f64(g1, last);
+            r.has_gauss = 1;
+        }
+        produced += got;
+        r.pos += 4 * consumed;
+    }
+    wave_sync();
+}
+
+}  // namespace lmc

@@ -1,0 +1,617 @@
+// The hot path as device code: one chain per wavefront, whole iterations on the GPU.
+//
+//   leapfrog        <- /root/reference/littlemcmc/integration.py:52-66,100-121  (+ quadpotential.py:206-219)
+//   momentum draw   <- quadpotential.py:221-224 (float32) / :374-376 (float64)
+//   NUTS transition <- nuts.py:204-224 (_hamiltonian_step), :251-435 (_Tree), iterative post-order
+//   HMC transition  <- hmc.py:140-182
+//   dual averaging  <- step_sizes.py:49-99
+//   mass adaptation <- quadpotential.py:226-245, :294-340
+//   iteration body  <- base_hmc.py:140-190 (_astep)
+//
+// Storage plan per chain (wave):
+//   registers : current state (q,p,g), trajectory ends L/R (q,p,g), p_sum, proposal q, the
+//               in-flight subtree node (lp, rp, psum, prop q), float32 mass (var, inv_std),
+//               per-level subtree scalars (lane j holds level j)
+//   LDS       : subtree stack levels [0, nlds)   (level 0 = {p, q}; level j>0 = {lp, rp, psum, prop q})
+//   HBM       : subtree stack levels >= nlds (per-chain scratch rows, L2 resident while hot),
+//               MT19937 state, Welford accumulators, persistent chain state, trace/stat outputs
+// Velocities are never stored: v = var (.) p is recomputed (bit-identical, it is one rounded
+// product), except for the start state whose v is the float32 product (dtype flow).
+#pragma once
+#include "lmc_rng.hpp"
+#include "lmc_targets.hpp"
+
+namespace lmc {
+
+// ---- status bits (per chain) ------------------------------------------------------------------
+constexpr int kStatusBadInitialEnergy = 1;   // base_hmc.py:145-148 -> ValueError on the host
+constexpr int kStatusNanLogbern = 2;         // math.py:23-24 -> FloatingPointError on the host
+
+// ---- per-draw statistic slots -------------------------------------------------------------------
+enum StatF64 : int {
+    kSfStepSize = 0,      // exp(log_step) AFTER the update (nuts.py/hmc.py "step_size")
+    kSfStepSizeBar = 1,
+    kSfAccept = 2,        // mean_tree_accept (NUTS) / accept (HMC)
+    kSfEnergyError = 3,
+    kSfEnergy = 4,
+    kSfMaxEnergyError = 5,  // NUTS max_energy_error / HMC path_length
+    kSfModelLogp = 6,
+    kNumStatF64 = 7
+};
+enum StatI32 : int { kSiDepth = 0 /* HMC: n_steps */, kSiTreeSize = 1 /* leapfrogs */, kNumStatI32 = 2 };
+enum StatU8 : int { kSbDiverging = 0, kSbTune = 1, kSbAccepted = 2, kNumStatU8 = 3 };
+enum Counter : int { kCtMaxTreedepth = 0, kCtDivsSample = 1, kCtSamplesAfterTune = 2, kCtLeapfrogs = 3, kNumCounters = 4 };
+
+struct ChainArrays {
+    int chains, d, dpad;
+    // persistent state
+    double* q;            // [C][dpad]
+    float* var;           // [C][dpad]
+    float* inv_std;       // [C][dpad]
+    double* wmean;        // [2][C][dpad]   Welford means (slot wsel = foreground)
+    double* wraw;         // [2][C][dpad]
+    double* wsum;         // [C][2]
+    int* wsel;            // [C]
+    int* n_samples;       // [C]
+    double* da;           // [C][4] log_step, log_bar, hbar, mu
+    int* da_count;        // [C]
+    int* iter_count;      // [C]
+    uint32_t* mt;         // [C][624]
+    int* rng_pos;         // [C]
+    int* rng_has_gauss;   // [C]
+    double* rng_gauss;    // [C]
+    int* status;          // [C]
+    long long* counters;  // [C][kNumCounters]
+    double* scratch;      // [C][scratch_stride]
+    long long scratch_stride;
+    // outputs (row = iteration index relative to the engine's reserved capacity)
+    double* trace;        // [C][cap][d] or nullptr
+    double* stat_f64;     // [kNumStatF64][C][cap]
+    int* stat_i32;        // [kNumStatI32][C][cap]
+    unsigned char* stat_u8;  // [kNumStatU8][C][cap]
+    long long cap;
+};
+
+struct SamplerParams {
+    int kind;             // 0 NUTS, 1 HMC
+    int momentum_f32;     // 1: QuadPotentialDiagAdapt (float32 draw), 0: QuadPotentialDiag (float64 draw)
+    int adapt_mass;       // 1: Welford updates during tuning (DiagAdapt)
+    int adapt_step_size;
+    double target_accept, emax, gamma, k, t0;
+    int max_treedepth, early_max_treedepth;
+    double path_length;
+    int max_steps;
+    int window;           // adaptation_window (101)
+    long long n_tune;     // iterations with index < n_tune are tuning iterations
+    long long iter_begin; // global index of the first iteration of this launch
+    int n_iters;
+    int nlds;             // subtree levels kept in LDS (>= 1)
+    int lds_doubles;      // dynamic LDS size in doubles
+};
+
+// ---- numpy scalar helpers ------------------------------------------------------------------------
+__device__ __forceinline__ double np_logaddexp(double x, double y) {   // npy_logaddexp
+    if (x == y) return first_f64(x + 0.693147180559945309417232121458176568);
+    const double t = x - y;
+    if (t > 0) return first_f64(x + log1p(exp(-t)));
+    if (t <= 0) return first_f64(y + log1p(exp(t)));
+    return t;
+}
+__device__ __forceinline__ double log1mexp(double x) {   // math.py:28-35
+    return (x < 0.683) ? log(-expm1(-x)) : log1p(-exp(-x));
+}
+
+// ---- vector <-> memory (blocked layout, 8*NS contiguous bytes per lane) ---------------------------
+template <int NS>
+__device__ __forceinline__ void vload(const double* base, double (&x)[NS]) {
+    const double* p = base + lane_id() * NS;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) x[s] = p[s];
+}
+template <int NS>
+__device__ __forceinline__ void vstore(double* base, const double (&x)[NS]) {
+    double* p = base + lane_id() * NS;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) p[s] = x[s];
+}
+template <int NS>
+__device__ __forceinline__ void vcopy(double (&dst)[NS], const double (&src)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) dst[s] = src[s];
+}
+
+// partial (per-lane) dot of a with var (.) b, i.e. numpy's a.dot(velocity(b))
+template <int NS>
+__device__ __forceinline__ double pdot_v(const double (&a)[NS], const float (&var)[NS], const double (&b)[NS]) {
+    double acc = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc = __builtin_fma(a[s], static_cast<double>(var[s]) * b[s], acc);
+    return acc;
+}
+// same with the float32 velocity of a float32 momentum (the start state): v = f32(var * f32(b))
+template <int NS>
+__device__ __forceinline__ double pdot_v32(const double (&a)[NS], const float (&var)[NS], const double (&b)[NS]) {
+    double acc = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        acc = __builtin_fma(a[s], static_cast<double>(var[s] * static_cast<float>(b[s])), acc);
+    return acc;
+}
+
+// ---- leapfrog (integration.py:100-121) -------------------------------------------------------------
+// In/out: q, p, g. Out: energy, logp. Every elementwise operation is the same rounded IEEE
+// operation as numpy's (TU built with -ffp-contract=off); only the two reductions differ in order.
+template <int NS, class Target>
+__device__ __forceinline__ void leapfrog(const Target& tgt, const float (&var)[NS], double eps,
+                                         double (&q)[NS], double (&p)[NS], double (&g)[NS],
+                                         double& energy, double& logp) {
+    const double dt = 0.5 * eps;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        p[s] = p[s] + dt * g[s];
+        const double v = static_cast<double>(var[s]) * p[s];
+        q[s] = q[s] + eps * v;
+    }
+    logp = first_f64(tgt.logp_grad(q, g));
+    double part = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        p[s] = p[s] + dt * g[s];
+        const double v = static_cast<double>(var[s]) * p[s];
+        part = __builtin_fma(p[s], v, part);
+    }
+    energy = first_f64(0.5 * wave_sum(part) - logp);
+}
+
+// ---- subtree stack -----------------------------------------------------------------------------------
+// Level j < nlds lives in LDS, deeper levels in the chain's HBM scratch row. Level 0 holds {p, q},
+// level j > 0 holds {lp, rp, psum, prop q}; per-level scalars live in registers (lane j).
+struct TreeStack {
+    double* lds;        // this wave's LDS region
+    double* glb;        // this chain's scratch row (levels >= nlds)
+    int nlds;
+    int dpad;
+    __device__ __forceinline__ double* level(int j) const {
+        if (j < nlds) return lds + (j == 0 ? 0 : (2 + 4 * (j - 1)) * dpad);
+        return glb + static_cast<long long>(j - nlds) * 4 * dpad;
+    }
+};
+
+struct LevelScalars {   // lane j holds level j
+    double ls, lwas, pe, plogp;
+    __device__ __forceinline__ void put(int j, double a, double b, double c, double d) {
+        if (lane_id() == j) { ls = a; lwas = b; pe = c; plogp = d; }
+    }
+    __device__ __forceinline__ void get(int j, double& a, double& b, double& c, double& d) const {
+        a = readlane_f64(ls, j); b = readlane_f64(lwas, j); c = readlane_f64(pe, j); d = readlane_f64(plogp, j);
+    }
+};
+
+struct TransitionOut {
+    double accept;         // mean_tree_accept / HMC accept
+    double energy, energy_error, max_energy_error, model_logp;
+    int depth;             // NUTS depth / HMC n_steps
+    int n_leapfrog;        // NUTS tree_size / HMC n_steps
+    int diverging;
+    int exhausted;         // NUTS: loop ran to max_treedepth without turning/diverging
+    int accepted;          // HMC
+    int nan_logbern;
+};
+
+// ---- NUTS transition -----------------------------------------------------------------------------------
+// q0/p0/g0: start state (p0 float32-valued when momentum_f32). On return q holds the proposal.
+template <int NS, class Target>
+__device__ inline void nuts_transition(const Target& tgt, const float (&var)[NS], RngState& rng,
+                                       const TreeStack& stk, double (&q)[NS], const double (&p0)[NS],
+                                       const double (&g0)[NS], double e0, double logp0, double step_size,
+                                       double emax, int max_depth, bool momentum_f32, TransitionOut& out) {
+    // trajectory ends + running totals (registers)
+    double Lq[NS], Lp[NS], Lg[NS], Rq[NS], Rp[NS], Rg[NS], psum[NS], propq[NS];
+    vcopy(Lq, q); vcopy(Lp, p0); vcopy(Lg, g0);
+    vcopy(Rq, q); vcopy(Rp, p0); vcopy(Rg, g0);
+    vcopy(psum, p0); vcopy(propq, q);
+    bool l_start = momentum_f32, r_start = momentum_f32;   // end still is the float32 start state
+    double prop_e = e0, prop_logp = logp0;
+    double log_size = 0.0, lwas = -INFINITY, max_de = 0.0;
+    int depth = 0, n_leap = 0;
+    bool diverging = false, turning = false, exhausted = true, nan_lb = false;
+    LevelScalars lsc = {0.0, 0.0, 0.0, 0.0};
+
+    for (int dd = 0; dd < max_depth; ++dd) {
+        const bool right = rng_uniform(rng) < 0.5;   // log(U) < log(.5), nuts.py:213
+        const double eps = right ? step_size : -step_size;
+        double cq[NS], cp[NS], cg[NS];
+        if (right) { vcopy(cq, Rq); vcopy(cp, Rp); vcopy(cg, Rg); }
+        else       { vcopy(cq, Lq); vcopy(cp, Lp); vcopy(cg, Lg); }
+
+        // in-flight node t (registers)
+        double tlp[NS], trp[NS], tps[NS], tq[NS];
+        double tls = 0.0, tlwas = 0.0, tpe = 0.0, tplogp = 0.0;
+        const int n_leaves = 1 << depth;
+        for (int i = 0; i < n_leaves; ++i) {
+            double energy, logp;
+            leapfrog<NS>(tgt, var, eps, cq, cp, cg, energy, logp);
+            ++n_leap;
+            double de = first_f64(energy - e0);
+            if (isnan(de)) de = INFINITY;
+            if (fabs(de) > fabs(max_de)) max_de = de;
+            if (!(fabs(de) < emax)) { diverging = true; break; }   // nuts.py:358,370-375
+            vcopy(tlp, cp); vcopy(trp, cp); vcopy(tps, cp); vcopy(tq, cq);
+            tls = -de; tlwas = first_f64(-de + fmin(0.0, -de)); tpe = energy; tplogp = logp;
+            int j = 0;
+            while ((i >> j) & 1) {   // t closes a right child: merge stack[j] (a, earlier) with t (b)
+                double alp[NS], arp[NS], aps[NS], aq[NS];
+                double als, alwas, ape, aplogp;
+                const double* lv = stk.level(j);
+                if (j == 0) {
+                    vload<NS>(lv, alp); vcopy(arp, alp); vcopy(aps, alp);
+                    vload<NS>(lv + stk.dpad, aq);
+                } else {
+                    vload<NS>(lv, alp); vload<NS>(lv + stk.dpad, arp);
+                    vload<NS>(lv + 2 * stk.dpad, aps); vload<NS>(lv + 3 * stk.dpad, aq);
+                }
+                lsc.get(j, als, alwas, ape, aplogp);
+                double ps[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) ps[s] = aps[s] + tps[s];
+                bool turn;
+                if (j > 0) {   // nuts.py:389-396
+                    double p1[NS], p2[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) { p1[s] = aps[s] + tlp[s]; p2[s] = arp[s] + tps[s]; }
+                    double dots[6] = {pdot_v<NS>(ps, var, alp), pdot_v<NS>(ps, var, trp),
+                                      pdot_v<NS>(p1, var, alp), pdot_v<NS>(p1, var, tlp),
+                                      pdot_v<NS>(p2, var, arp), pdot_v<NS>(p2, var, trp)};
+                    wave_sum_n<6>(dots);
+                    turn = (dots[0] <= 0) | (dots[1] <= 0) | (dots[2] <= 0) | (dots[3] <= 0) |
+                           (dots[4] <= 0) | (dots[5] <= 0);
+                } else {
+                    double dots[2] = {pdot_v<NS>(ps, var, alp), pdot_v<NS>(ps, var, trp)};
+                    wave_sum_n<2>(dots);
+                    turn = (dots[0] <= 0) | (dots[1] <= 0);
+                }
+                const double ls = np_logaddexp(als, tls);
+                const double lw = np_logaddexp(alwas, tlwas);
+                const double lp_sel = first_f64(tls - ls);
+                if (isnan(lp_sel)) nan_lb = true;
+                const bool take_b = first_f64(log(rng_uniform(rng))) < lp_sel;   // nuts.py:404, drawn even if turning
+                // merged node: left end from a, right end from b(t)
+                vcopy(tlp, alp); vcopy(tps, ps);
+                if (!take_b) { vcopy(tq, aq); tpe = ape; tplogp = aplogp; }
+                tls = ls; tlwas = lw;
+                ++j;
+                if (turn) { turning = true; break; }
+            }
+            if (turning) break;
+            if (i + 1 < n_leaves) {   // park t at level j (the last leaf's cascade result stays in registers)
+                double* lv = stk.level(j);
+                if (j == 0) {
+                    vstore<NS>(lv, tps); vstore<NS>(lv + stk.dpad, tq);
+                } else {
+                    vstore<NS>(lv, tlp); vstore<NS>(lv + stk.dpad, trp);
+                    vstore<NS>(lv + 2 * stk.dpad, tps); vstore<NS>(lv + 3 * stk.dpad, tq);
+                }
+                lsc.put(j, tls, tlwas, tpe, tplogp);
+                wave_sync();
+            }
+        }
+        ++depth;   // nuts.py:315
+        if (diverging || turning) { exhausted = false; break; }
+
+        // ---- accepted subtree t: merge into the trajectory (nuts.py:321-340)
+        const double sel = first_f64(tls - log_size);
+        if (isnan(sel)) nan_lb = true;
+        if (first_f64(log(rng_uniform(rng))) < sel) { vcopy(propq, tq); prop_e = tpe; prop_logp = tplogp; }
+        log_size = np_logaddexp(log_size, tls);
+        lwas = np_logaddexp(lwas, tlwas);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {   // in place; float32 storage when the start momentum is float32
+            const double t = psum[s] + tps[s];
+            psum[s] = momentum_f32 ? static_cast<double>(static_cast<float>(t)) : t;
+        }
+        double dots[6];
+        if (right) {
+            // old right end (p, v) is needed for the second extra check
+            double p1[NS], p2[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { p1[s] = psum[s] + tlp[s]; p2[s] = Rp[s] + tps[s]; }
+            dots[2] = l_start ? pdot_v32<NS>(p1, var, Lp) : pdot_v<NS>(p1, var, Lp);
+            dots[3] = pdot_v<NS>(p1, var, tlp);
+            dots[4] = r_start ? pdot_v32<NS>(p2, var, Rp) : pdot_v<NS>(p2, var, Rp);
+            dots[5] = pdot_v<NS>(p2, var, trp);
+            vcopy(Rq, cq); vcopy(Rp, cp); vcopy(Rg, cg); r_start = false;
+        } else {
+            double p1[NS], p2[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { p1[s] = tps[s] + Lp[s]; p2[s] = tlp[s] + psum[s]; }
+            dots[2] = pdot_v<NS>(p1, var, trp);
+            dots[3] = l_start ? pdot_v32<NS>(p1, var, Lp) : pdot_v<NS>(p1, var, Lp);
+            dots[4] = pdot_v<NS>(p2, var, tlp);
+            dots[5] = r_start ? pdot_v32<NS>(p2, var, Rp) : pdot_v<NS>(p2, var, Rp);
+            vcopy(Lq, cq); vcopy(Lp, cp); vcopy(Lg, cg); l_start = false;
+        }
+        dots[0] = l_start ? pdot_v32<NS>(psum, var, Lp) : pdot_v<NS>(psum, var, Lp);
+        dots[1] = r_start ? pdot_v32<NS>(psum, var, Rp) : pdot_v<NS>(psum, var, Rp);
+        wave_sum_n<6>(dots);
+        if ((dots[0] <= 0) | (dots[1] <= 0) | (dots[2] <= 0) | (dots[3] <= 0) | (dots[4] <= 0) | (dots[5] <= 0)) {
+            turning = true; exhausted = false; break;
+        }
+    }
+
+    double mean_accept = 0.0;
+    if (log_size > 0) mean_accept = first_f64(exp(lwas - (log_size + log1mexp(log_size))));   // nuts.py:421-425
+    vcopy(q, propq);
+    out.accept = mean_accept;
+    out.energy = prop_e;
+    out.energy_error = first_f64(prop_e - e0);
+    out.max_energy_error = max_de;
+    out.model_logp = prop_logp;
+    out.depth = depth;
+    out.n_leapfrog = n_leap;
+    out.diverging = diverging;
+    out.exhausted = exhausted;
+    out.accepted = 0;
+    out.nan_logbern = nan_lb;
+}
+
+// ---- HMC transition (hmc.py:140-182) -------------------------------------------------------------------
+template <int NS, class Target>
+__device__ inline void hmc_transition(const Target& tgt, const float (&var)[NS], RngState& rng,
+                                      double (&q)[NS], const double (&p0)[NS], const double (&g0)[NS],
+                                      double e0, double logp0, double step_size, double emax,
+                                      double path_length, int max_steps, TransitionOut& out) {
+    const double plen = first_f64(rng_uniform(rng) * path_length);
+    int n_steps = static_cast<int>(plen / step_size);
+    n_steps = n_steps < 1 ? 1 : n_steps;
+    n_steps = n_steps > max_steps ? max_steps : n_steps;
+    double cq[NS], cp[NS], cg[NS];
+    vcopy(cq, q); vcopy(cp, p0); vcopy(cg, g0);
+    double energy = e0, logp = logp0;
+    for (int i = 0; i < n_steps; ++i) leapfrog<NS>(tgt, var, step_size, cq, cp, cg, energy, logp);
+    bool diverging = !isfinite(energy);
+    double de = first_f64(e0 - energy);
+    if (isnan(de)) de = -INFINITY;
+    if (fabs(de) > emax) diverging = true;
+    const double accept = first_f64(fmin(1.0, exp(de)));
+    bool accepted = false;
+    if (!diverging) {
+        const double u = rng_uniform(rng);
+        if (!(u >= accept)) { accepted = true; vcopy(q, cq); }
+    }
+    out.accept = accept;
+    out.energy = energy;
+    out.energy_error = de;
+    out.max_energy_error = plen;   // slot shared with path_length
+    out.model_logp = logp;
+    out.depth = n_steps;
+    out.n_leapfrog = n_steps;
+    out.diverging = diverging;
+    out.exhausted = 0;
+    out.accepted = accepted;
+    out.nan_logbern = 0;
+}
+
+// ---- the iteration kernel: n_iters x _astep for every chain, no host round trips ------------------------
+// Occupancy target per vector width (waves per SIMD; the VGPR budget is 512 / waves): the
+// per-chain state is register resident, so wider chains trade occupancy for registers.
+constexpr int run_waves_per_simd(int ns) { return ns <= 1 ? 4 : ns == 2 ? 3 : ns == 4 ? 2 : 1; }
+
+template <int NS, template <int> class TargetT>
+__global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainArrays A, SamplerParams P, const double* tparams) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int c = blockIdx.x;
+    const int lane = lane_id();
+    const int d = A.d, dpad = A.dpad;
+    const long long row = static_cast<long long>(c) * dpad;
+
+    if (A.status[c] & kStatusBadInitialEnergy) return;   // chain already aborted (ValueError on host)
+
+    TargetT<NS> tgt;
+    tgt.init(tparams, d);
+
+    // ---- load persistent chain state
+    double q[NS];
+    float var[NS], inv_std[NS];
+    vload<NS>(A.q + row, q);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        var[s] = A.var[row + lane * NS + s];
+        inv_std[s] = A.inv_std[row + lane * NS + s];
+    }
+    RngState rng;
+    rng.mt = A.mt + static_cast<long long>(c) * kMtN;
+    rng.pos = first_i32(A.rng_pos[c]);
+    rng.has_gauss = first_i32(A.rng_has_gauss[c]);
+    rng.gauss = first_f64(A.rng_gauss[c]);
+    double log_step = first_f64(A.da[c * 4 + 0]);
+    double log_bar = first_f64(A.da[c * 4 + 1]);
+    double hbar = first_f64(A.da[c * 4 + 2]);
+    const double mu = first_f64(A.da[c * 4 + 3]);
+    int da_count = first_i32(A.da_count[c]);
+    int iter_count = first_i32(A.iter_count[c]);
+    int n_samples = first_i32(A.n_samples[c]);
+    int wsel = first_i32(A.wsel[c]);
+    double wsum_f = first_f64(A.wsum[c * 2 + wsel]);
+    double wsum_b = first_f64(A.wsum[c * 2 + (1 - wsel)]);
+    long long ct_maxdepth = 0, ct_divs = 0, ct_after = 0, ct_leap = 0;
+    int status = 0;
+
+    TreeStack stk;
+    stk.lds = lds;
+    stk.glb = A.scratch + static_cast<long long>(c) * A.scratch_stride;
+    stk.nlds = P.nlds;
+    stk.dpad = dpad;
+    const long long plane = static_cast<long long>(A.chains) * dpad;
+
+    for (int it = 0; it < P.n_iters; ++it) {
+        const long long git = P.iter_begin + it;
+        const bool tune = git < P.n_tune;
+
+        // ---- momentum draw (quadpotential.py:221-224 / :374-376)
+        rng_normals(rng, d, lds);   // level-0 LDS region doubles as the normals buffer (stack is empty)
+        double p0[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int e = lane * NS + s;
+            const double z = (e < d) ? lds[e] : 0.0;
+            p0[s] = P.momentum_f32 ? static_cast<double>(inv_std[s] * static_cast<float>(z))
+                                   : z * static_cast<double>(inv_std[s]);
+        }
+        wave_sync();
+
+        // ---- start state (integration.py:52-66)
+        double g0[NS];
+        const double logp0 = first_f64(tgt.logp_grad(q, g0));
+        double e0;
+        if (P.momentum_f32) {   // float32 velocity, float32 kinetic energy
+            double part = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const float pf = static_cast<float>(p0[s]);
+                part = __builtin_fma(static_cast<double>(pf), static_cast<double>(var[s] * pf), part);
+            }
+            const float kin = 0.5f * static_cast<float>(wave_sum(part));
+            e0 = first_f64(static_cast<double>(kin) - logp0);
+        } else {
+            e0 = first_f64(0.5 * wave_sum(pdot_v<NS>(p0, var, p0)) - logp0);
+        }
+        if (!isfinite(e0)) {   // base_hmc.py:145-148: the reference raises; the chain stops here
+            status |= kStatusBadInitialEnergy;
+            break;
+        }
+
+        // ---- step size for this iteration (base_hmc.py:151-153)
+        const bool adapt_step = tune && P.adapt_step_size;
+        const double step_size = first_f64(adapt_step ? exp(log_step) : exp(log_bar));
+
+        TransitionOut out;
+        if (P.kind == 0) {
+            const int md = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
+            nuts_transition<NS>(tgt, var, rng, stk, q, p0, g0, e0, logp0, step_size, P.emax, md,
+                                P.momentum_f32 != 0, out);
+            if (out.exhausted && !tune) ++ct_maxdepth;
+        } else {
+            hmc_transition<NS>(tgt, var, rng, q, p0, g0, e0, logp0, step_size, P.emax, P.path_length,
+                               P.max_steps, out);
+        }
+        if (out.nan_logbern) status |= kStatusNanLogbern;
+        ct_leap += out.n_leapfrog;
+
+        // ---- dual averaging (step_sizes.py:71-92)
+        if (adapt_step) {
+            const double w = 1.0 / (static_cast<double>(da_count) + P.t0);
+            hbar = first_f64((1.0 - w) * hbar + w * (P.target_accept - out.accept));
+            log_step = first_f64(mu - hbar * sqrt(static_cast<double>(da_count)) / P.gamma);
+            const double mk = pow(static_cast<double>(da_count), -P.k);
+            log_bar = first_f64(mk * log_step + (1.0 - mk) * log_bar);
+            ++da_count;
+        }
+
+        // ---- diagonal mass adaptation (quadpotential.py:231-245, :324-340)
+        if (tune && P.adapt_mass) {
+            double* fm = A.wmean + wsel * plane + row;
+            double* fr = A.wraw + wsel * plane + row;
+            double* bm = A.wmean + (1 - wsel) * plane + row;
+            double* br = A.wraw + (1 - wsel) * plane + row;
+            wsum_f += 1.0;
+            wsum_b += 1.0;
+            const double prop_f = first_f64(1.0 / wsum_f), prop_b = first_f64(1.0 / wsum_b);
+            double m[NS], r[NS];
+            vload<NS>(fm, m); vload<NS>(fr, r);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double od = q[s] - m[s];
+                m[s] = m[s] + prop_f * od;
+                const double nd = q[s] - m[s];
+                r[s] = r[s] + 1.0 * od * nd;
+                const int e = lane * NS + s;
+                if (e < d) {
+                    var[s] = static_cast<float>(r[s] / wsum_f);
+                    const float sd = sqrtf(var[s]);
+                    inv_std[s] = 1.0f / sd;
+                }
+            }
+            vstore<NS>(fm, m); vstore<NS>(fr, r);
+            vload<NS>(bm, m); vload<NS>(br, r);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double od = q[s] - m[s];
+                m[s] = m[s] + prop_b * od;
+                const double nd = q[s] - m[s];
+                r[s] = r[s] + 1.0 * od * nd;
+            }
+            if (n_samples > 0 && n_samples % P.window == 0) {   // background becomes foreground
+                vstore<NS>(bm, m); vstore<NS>(br, r);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { m[s] = 0.0; r[s] = 0.0; }
+                vstore<NS>(fm, m); vstore<NS>(fr, r);             // old foreground = fresh background
+                wsum_f = wsum_b;
+                wsum_b = 0.0;
+                wsel = 1 - wsel;
+            } else {
+                vstore<NS>(bm, m); vstore<NS>(br, r);
+            }
+            ++n_samples;
+        }
+
+        // ---- bookkeeping (base_hmc.py:164-190)
+        if (out.diverging && !tune) ++ct_divs;
+        ++iter_count;
+        if (!tune) ++ct_after;
+
+        // ---- outputs: draw row + stats
+        const long long orow = static_cast<long long>(c) * A.cap + git;
+        if (A.trace != nullptr) {
+            double* tr = A.trace + orow * d;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int e = lane * NS + s;
+                if (e < d) tr[e] = q[s];
+            }
+        }
+        if (lane == 0) {
+            const long long fs = static_cast<long long>(A.chains) * A.cap;
+            A.stat_f64[kSfStepSize * fs + orow] = exp(log_step);
+            A.stat_f64[kSfStepSizeBar * fs + orow] = exp(log_bar);
+            A.stat_f64[kSfAccept * fs + orow] = out.accept;
+            A.stat_f64[kSfEnergyError * fs + orow] = out.energy_error;
+            A.stat_f64[kSfEnergy * fs + orow] = out.energy;
+            A.stat_f64[kSfMaxEnergyError * fs + orow] = out.max_energy_error;
+            A.stat_f64[kSfModelLogp * fs + orow] = out.model_logp;
+            A.stat_i32[kSiDepth * fs + orow] = out.depth;
+            A.stat_i32[kSiTreeSize * fs + orow] = out.n_leapfrog;
+            A.stat_u8[kSbDiverging * fs + orow] = static_cast<unsigned char>(out.diverging);
+            A.stat_u8[kSbTune * fs + orow] = static_cast<unsigned char>(tune);
+            A.stat_u8[kSbAccepted * fs + orow] = static_cast<unsigned char>(out.accepted);
+        }
+    }
+
+    // ---- store persistent chain state
+    vstore<NS>(A.q + row, q);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        A.var[row + lane * NS + s] = var[s];
+        A.inv_std[row + lane * NS + s] = inv_std[s];
+    }
+    if (lane == 0) {
+        A.rng_pos[c] = rng.pos;
+        A.rng_has_gauss[c] = rng.has_gauss;
+        A.rng_gauss[c] = rng.gauss;
+        A.da[c * 4 + 0] = log_step;
+        A.da[c * 4 + 1] = log_bar;
+        A.da[c * 4 + 2] = hbar;
+        A.da_count[c] = da_count;
+        A.iter_count[c] = iter_count;
+        A.n_samples[c] = n_samples;
+        A.wsel[c] = wsel;
+        A.wsum[c * 2 + wsel] = wsum_f;
+        A.wsum[c * 2 + (1 - wsel)] = wsum_b;
+        A.status[c] |= status;
+        A.counters[c * kNumCounters + kCtMaxTreedepth] += ct_maxdepth;
+        A.counters[c * kNumCounters + kCtDivsSample] += ct_divs;
+        A.counters[c * kNumCounters + kCtSamplesAfterTune] += ct_after;
+        A.counters[c * kNumCounters + kCtLeapfrogs] += ct_leap;
+    }
+}
+
+}  // namespace lmc

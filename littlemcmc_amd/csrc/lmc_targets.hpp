@@ -1,0 +1,148 @@
+// Device log-densities: the plug-in `logp_dlogp_func(q) -> (logp, dlogp)` of the reference
+// (/root/reference/littlemcmc/integration.py:40,62,115) as a __device__ functor that is inlined
+// into the leapfrog of the transition kernel.
+//
+// Contract (the "lane-distributed" form of the plug-in):
+//   template <int NS> struct Target {
+//       __device__ void init(const double* params, int d);          // once per kernel, per wave
+//       __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const;
+//   };
+// Lane l owns elements e = l*NS + s, s < NS; elements with e >= d are padding: they arrive as 0
+// and MUST be returned as 0 in g. The return value (logp) must be wave-uniform; use
+// lmc::wave_sum() for reductions and lmc::from_lane_below/above() for neighbours.
+// The CPU statements of the same densities are in oracle/targets.py (same operation order).
+#pragma once
+#include "lmc_wave.hpp"
+
+namespace lmc {
+
+enum TargetFamily : int {
+    kStdNormal = 0,
+    kDiagGaussian = 1,
+    kAR1 = 2,
+    kFunnel = 3,
+    kNormal1D = 4,
+    kUser = 5,
+};
+
+// logp = -1/2 sum q^2 ; g = -q
+template <int NS>
+struct StdNormalTarget {
+    __device__ void init(const double*, int) {}
+    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            part = __builtin_fma(q[s], q[s], part);
+            g[s] = -q[s];
+        }
+        return -0.5 * wave_sum(part);
+    }
+};
+
+// g = -(prec*q) ; logp = 1/2 q.g  (params = prec[d])
+template <int NS>
+struct DiagGaussianTarget {
+    double prec[NS];
+    __device__ void init(const double* params, int d) {
+        const int lane = lane_id();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int e = lane * NS + s;
+            prec[s] = (e < d) ? params[e] : 0.0;
+        }
+    }
+    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            g[s] = -(prec[s] * q[s]);
+            part = __builtin_fma(q[s], g[s], part);
+        }
+        return 0.5 * wave_sum(part);
+    }
+};
+
+// AR(1): (Pq)_i = (diag_i q_i + off q_{i-1}) + off q_{i+1}; g = -Pq; logp = 1/2 q.g
+// params = {c_end, c_mid, off}
+template <int NS>
+struct AR1Target {
+    double c_end, c_mid, off;
+    int d;
+    __device__ void init(const double* params, int d_) {
+        c_end = params[0];
+        c_mid = params[1];
+        off = params[2];
+        d = d_;
+    }
+    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
+        const int lane = lane_id();
+        const double below = from_lane_below(q[NS - 1]);   // element e-1 of this lane's first slot
+        const double above = from_lane_above(q[0]);        // element e+1 of this lane's last slot
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int e = lane * NS + s;
+            const double prev = (s == 0) ? below : q[s - 1];
+            const double next = (s == NS - 1) ? above : q[s + 1];
+            const double diag = (e == 0 || e == d - 1) ? c_end : c_mid;
+            double pq = diag * q[s];
+            if (e > 0) pq = pq + off * prev;
+            if (e < d - 1) pq = pq + off * next;
+            g[s] = (e < d) ? -pq : 0.0;
+            part = __builtin_fma(q[s], g[s], part);
+        }
+        return 0.5 * wave_sum(part);
+    }
+};
+
+// Neal's funnel: v = q_0, x = q_{1..d-1}
+template <int NS>
+struct FunnelTarget {
+    int d;
+    __device__ void init(const double*, int d_) { d = d_; }
+    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
+        const int lane = lane_id();
+        const double v = readlane_f64(q[0], 0);
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int e = lane * NS + s;
+            if (e > 0) part = __builtin_fma(q[s], q[s], part);
+        }
+        const double ssum = wave_sum(part);
+        const double ev = exp(-v);
+        const double hes = 0.5 * ev * ssum;
+        const double dm1 = static_cast<double>(d - 1);
+        const double logp = -(v * v) / 18.0 - 0.5 * dm1 * v - hes;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int e = lane * NS + s;
+            g[s] = (e == 0) ? (-v / 9.0 - 0.5 * dm1 + hes) : ((e < d) ? -(ev * q[s]) : 0.0);
+        }
+        return logp;
+    }
+};
+
+// The reference's own test target (/root/reference/tests/test_utils.py:19-28), d == 1:
+// logp = -z^2/2 - log(scale sqrt(2 pi)), z = (x-loc)/scale ; dlogp = -(x-loc)/scale (sic).
+// params = {loc, scale}
+template <int NS>
+struct Normal1DTarget {
+    double loc, scale, lognorm;
+    __device__ void init(const double* params, int) {
+        loc = params[0];
+        scale = params[1];
+        lognorm = log(scale * sqrt(2.0 * 3.141592653589793));
+    }
+    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
+        const int lane = lane_id();
+        const double x = readlane_f64(q[0], 0);
+        const double z = (x - loc) / scale;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) g[s] = (lane == 0 && s == 0) ? -(x - loc) / scale : 0.0;
+        return -0.5 * z * z - lognorm;
+    }
+};
+
+}  // namespace lmc

@@ -1,0 +1,211 @@
+"""Thin object wrapper over the C ABI handle (include/lmc_hip.h): one Engine == one GPU == one
+block of chains, each chain a wavefront. Host arrays in, host arrays out; the zero-copy device
+pointers are exposed for consumers that keep results in HBM (bench.py, diagnostics)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+class Engine:
+    def __init__(self, target, chains, kind="nuts", potential="diag_adapt", device=0, lib_path=None,
+                 target_accept=0.8, Emax=1000.0, adapt_step_size=True, step_scale=0.25, gamma=0.05, k=0.75,
+                 t0=10, path_length=2.0, max_treedepth=10, early_max_treedepth=8, max_steps=1024,
+                 adaptation_window=101, lds_levels=0):
+        self._lib = _abi.load(lib_path or getattr(target, "lib_path", None))
+        self._h = C.c_void_p()
+        self.target = target
+        self.chains = int(chains)
+        self.dim = int(target.d)
+        self.kind = kind
+        cfg = _abi.Config()
+        self._lib.lmc_config_defaults(C.byref(cfg), self.chains, self.dim)
+        cfg.device = int(device)
+        cfg.kind = {"nuts": _abi.KIND_NUTS, "hmc": _abi.KIND_HMC}[kind]
+        cfg.target_family = int(target.family)
+        cfg.potential = {"diag_adapt": _abi.POT_DIAG_ADAPT, "diag": _abi.POT_DIAG}[potential]
+        cfg.adapt_step_size = int(bool(adapt_step_size))
+        cfg.target_accept = float(target_accept)
+        cfg.emax = float(Emax)
+        cfg.step_scale = float(step_scale)
+        cfg.gamma = float(gamma)
+        cfg.k = float(k)
+        cfg.t0 = float(t0)
+        cfg.max_treedepth = int(max_treedepth)
+        cfg.early_max_treedepth = int(early_max_treedepth)
+        cfg.path_length = float(path_length)
+        cfg.max_steps = int(max_steps)
+        cfg.adaptation_window = int(adaptation_window)
+        cfg.lds_levels = int(lds_levels)
+        self.cfg = cfg
+        h = C.c_void_p()
+        self._check(self._lib.lmc_engine_create(C.byref(cfg), C.byref(h)), handle=None)
+        self._h = h
+        params = np.ascontiguousarray(target.params, dtype=np.float64)
+        self._check(self._lib.lmc_engine_set_target_params(self._h, _abi.ptr(params), params.size))
+        self.capacity = 0
+        self.keep_trace = False
+
+    # ---- plumbing ---------------------------------------------------------------------------------
+    def _check(self, rc, handle=True):
+        if rc != _abi.OK:
+            msg = self._lib.lmc_last_error(self._h if handle else None)
+            raise _abi.HipLibraryError("liblmc_hip error %d: %s" % (rc, (msg or b"?").decode()))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.lmc_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, stream_handle):
+        self._check(self._lib.lmc_engine_set_stream(self._h, C.c_void_p(int(stream_handle) if stream_handle else 0)))
+
+    def synchronize(self):
+        self._check(self._lib.lmc_engine_synchronize(self._h))
+
+    # ---- state --------------------------------------------------------------------------------------
+    def set_potential(self, initial_mean, initial_diag, initial_weight=10.0):
+        diag = np.ascontiguousarray(initial_diag, dtype=np.float64)
+        per_chain = int(diag.ndim == 2)
+        mean = None if initial_mean is None else np.ascontiguousarray(
+            np.broadcast_to(np.asarray(initial_mean, dtype=np.float64), diag.shape))
+        self._check(self._lib.lmc_engine_set_potential(self._h, _abi.ptr(mean), _abi.ptr(diag),
+                                                       float(initial_weight), per_chain))
+
+    def seed(self, seeds):
+        s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64) & 0xFFFFFFFF, dtype=np.uint32)
+        assert s.shape == (self.chains,)
+        self._check(self._lib.lmc_engine_seed(self._h, _abi.ptr(s)))
+
+    def set_rng_state(self, chain, state):
+        """state: the tuple of np.random.get_state() ('MT19937', key[624], pos, has_gauss, gauss)."""
+        key = np.ascontiguousarray(state[1], dtype=np.uint32)
+        self._check(self._lib.lmc_engine_set_rng_state(self._h, int(chain), _abi.ptr(key), int(state[2]),
+                                                       int(state[3]), float(state[4])))
+
+    def get_rng_state(self, chain):
+        key = np.zeros(624, dtype=np.uint32)
+        pos, hg, g = C.c_int32(), C.c_int32(), C.c_double()
+        self._check(self._lib.lmc_engine_get_rng_state(self._h, int(chain), _abi.ptr(key), C.byref(pos),
+                                                       C.byref(hg), C.byref(g)))
+        return ("MT19937", key, int(pos.value), int(hg.value), float(g.value))
+
+    def set_position(self, q):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        self._check(self._lib.lmc_engine_set_position(self._h, _abi.ptr(q), int(q.ndim == 2)))
+
+    def get_position(self):
+        q = np.empty((self.chains, self.dim))
+        self._check(self._lib.lmc_engine_get_position(self._h, _abi.ptr(q)))
+        return q
+
+    def reset_tuning(self):
+        self._check(self._lib.lmc_engine_reset_tuning(self._h))
+
+    def set_dual_average(self, log_step, log_bar, hbar=0.0, count=1):
+        self._check(self._lib.lmc_engine_set_dual_average(self._h, float(log_step), float(log_bar), float(hbar),
+                                                          int(count)))
+
+    # ---- sampling -----------------------------------------------------------------------------------
+    def reserve(self, capacity, keep_trace=True):
+        self._check(self._lib.lmc_engine_reserve(self._h, int(capacity), int(bool(keep_trace))))
+        self.capacity = int(capacity)
+        self.keep_trace = bool(keep_trace)
+
+    def run(self, n_tune, iter_begin, n_iters):
+        self._check(self._lib.lmc_engine_run(self._h, int(n_tune), int(iter_begin), int(n_iters)))
+
+    def trace(self, iter_begin=0, n_iters=None):
+        n = self.capacity - iter_begin if n_iters is None else n_iters
+        out = np.empty((self.chains, n, self.dim))
+        self._check(self._lib.lmc_engine_get_trace(self._h, _abi.ptr(out), int(iter_begin), int(n)))
+        return out
+
+    def stat_f64(self, stat, iter_begin=0, n_iters=None):
+        n = self.capacity - iter_begin if n_iters is None else n_iters
+        out = np.empty((self.chains, n))
+        self._check(self._lib.lmc_engine_get_stat_f64(self._h, int(stat), _abi.ptr(out), int(iter_begin), int(n)))
+        return out
+
+    def stat_i32(self, stat, iter_begin=0, n_iters=None):
+        n = self.capacity - iter_begin if n_iters is None else n_iters
+        out = np.empty((self.chains, n), dtype=np.int32)
+        self._check(self._lib.lmc_engine_get_stat_i32(self._h, int(stat), _abi.ptr(out), int(iter_begin), int(n)))
+        return out
+
+    def stat_u8(self, stat, iter_begin=0, n_iters=None):
+        n = self.capacity - iter_begin if n_iters is None else n_iters
+        out = np.empty((self.chains, n), dtype=np.uint8)
+        self._check(self._lib.lmc_engine_get_stat_u8(self._h, int(stat), _abi.ptr(out), int(iter_begin), int(n)))
+        return out
+
+    def trace_device_ptr(self):
+        return self._lib.lmc_engine_trace_device_ptr(self._h)
+
+    def adapt_state(self):
+        var = np.empty((self.chains, self.dim), dtype=np.float32)
+        da = np.empty((self.chains, 4))
+        cnt = np.empty(self.chains, dtype=np.int32)
+        ns = np.empty(self.chains, dtype=np.int32)
+        self._check(self._lib.lmc_engine_get_adapt_state(self._h, _abi.ptr(var), _abi.ptr(da), _abi.ptr(cnt),
+                                                         _abi.ptr(ns)))
+        return {"var": var, "log_step": da[:, 0], "log_bar": da[:, 1], "hbar": da[:, 2], "mu": da[:, 3],
+                "count": cnt, "n_samples": ns}
+
+    def status(self):
+        st = np.empty(self.chains, dtype=np.int32)
+        self._check(self._lib.lmc_engine_get_status(self._h, _abi.ptr(st)))
+        return st
+
+    def counters(self):
+        ct = np.empty((self.chains, _abi.NUM_COUNTERS), dtype=np.int64)
+        self._check(self._lib.lmc_engine_get_counters(self._h, _abi.ptr(ct)))
+        return ct
+
+    # ---- unit entry points --------------------------------------------------------------------------
+    def trajectory(self, q0, p0, eps, n_fwd, n_back=0, p0_is_f32=None):
+        q0 = np.ascontiguousarray(np.broadcast_to(np.asarray(q0, dtype=np.float64), (self.chains, self.dim)))
+        if p0_is_f32 is None:
+            p0_is_f32 = np.asarray(p0).dtype == np.float32
+        p0 = np.ascontiguousarray(np.broadcast_to(np.asarray(p0, dtype=np.float64), (self.chains, self.dim)))
+        ns = n_fwd + n_back + 1
+        out = {k: np.empty((self.chains, ns, self.dim)) for k in ("q", "p", "v", "g")}
+        out["energy"] = np.empty((self.chains, ns))
+        out["logp"] = np.empty((self.chains, ns))
+        self._check(self._lib.lmc_engine_trajectory(
+            self._h, _abi.ptr(q0), _abi.ptr(p0), int(bool(p0_is_f32)), float(eps), int(n_fwd), int(n_back),
+            _abi.ptr(out["q"]), _abi.ptr(out["p"]), _abi.ptr(out["v"]), _abi.ptr(out["g"]),
+            _abi.ptr(out["energy"]), _abi.ptr(out["logp"])))
+        return out
+
+    def logp_dlogp(self, q):
+        q = np.ascontiguousarray(np.broadcast_to(np.asarray(q, dtype=np.float64), (self.chains, self.dim)))
+        logp = np.empty(self.chains)
+        grad = np.empty((self.chains, self.dim))
+        self._check(self._lib.lmc_engine_logp_dlogp(self._h, _abi.ptr(q), _abi.ptr(logp), _abi.ptr(grad)))
+        return logp, grad
+
+    def rng_draw(self, ops):
+        ops = np.ascontiguousarray(ops, dtype=np.int32)
+        total = int(np.abs(ops).sum())
+        out = np.empty((self.chains, total))
+        self._check(self._lib.lmc_engine_rng_draw(self._h, _abi.ptr(ops), ops.size, _abi.ptr(out)))
+        return out
+
+    def draw_momentum(self):
+        out = np.empty((self.chains, self.dim))
+        self._check(self._lib.lmc_engine_draw_momentum(self._h, _abi.ptr(out)))
+        return out

@@ -1,0 +1,223 @@
+"""Mass matrices (potentials) -- host-side mirror of /root/reference/littlemcmc/quadpotential.py
+for the diagonal family, which is the one on the GPU hot path.
+
+The objects keep the reference's constructor signatures and protocol (``velocity``, ``energy``,
+``velocity_energy``, ``random``, ``update``, ``reset``; quadpotential.py:93-140) but hold no
+numerics of their own: every method is a call into liblmc_hip.so (a one-chain engine). ``random()``
+consumes the *global* legacy numpy stream exactly like the reference does -- the MT19937 state
+is handed to the device and back -- so ``np.random.seed(...)`` keeps its meaning.
+
+Dense potentials (QuadPotentialFull / FullInv / FullAdapt, quadpotential.py:390-615) are
+outside the hot-path scope and raise NotImplementedError.
+"""
+import numpy as np
+
+from . import targets as _targets
+
+__all__ = [
+    "quad_potential",
+    "QuadPotentialDiag",
+    "QuadPotentialFull",
+    "QuadPotentialFullInv",
+    "QuadPotentialDiagAdapt",
+    "QuadPotentialFullAdapt",
+    "PositiveDefiniteError",
+]
+
+
+class PositiveDefiniteError(ValueError):
+    """quadpotential.py:80-90."""
+
+    def __init__(self, msg, idx):
+        super().__init__(msg)
+        self.idx = idx
+        self.msg = msg
+
+    def __str__(self):
+        return "Scaling is not positive definite: %s. Check indexes %s." % (self.msg, self.idx)
+
+
+def partial_check_positive_definite(C):
+    """quadpotential.py:68-77."""
+    d = C if C.ndim == 1 else np.diag(C)
+    (i,) = np.nonzero(np.logical_or(np.isnan(d), d <= 0))
+    if len(i):
+        raise PositiveDefiniteError("Simple check failed. Diagonal contains negatives", i)
+
+
+def quad_potential(C, is_cov):
+    """quadpotential.py:33-65: build a potential from a scaling vector (diagonal) or matrix."""
+    C = np.asarray(C)
+    partial_check_positive_definite(C)
+    if C.ndim == 1:
+        return QuadPotentialDiag(C if is_cov else 1.0 / C)
+    if is_cov:
+        return QuadPotentialFull(C)
+    return QuadPotentialFullInv(C)
+
+
+class QuadPotential:
+    """Protocol base (quadpotential.py:93-140). Numerics live on the device."""
+
+    _engine_kind = None  # "diag_adapt" | "diag"
+
+    def __init__(self, n):
+        self._n = int(n)
+        self._engine = None      # engine this potential is bound to (a step's, or a private one)
+        self._own_engine = False
+
+    # -- engine plumbing ------------------------------------------------------------------------
+    def _bind(self, engine):
+        """Attach to the one-chain engine of a step method and load the initial values into it."""
+        self._engine = engine
+        self._own_engine = False
+        self._push_initial(engine)
+
+    def _eng(self):
+        if self._engine is None:
+            from .engine import Engine
+
+            self._engine = Engine(_targets.StdNormal(self._n), chains=1, potential=self._engine_kind)
+            self._own_engine = True
+            self._push_initial(self._engine)
+        return self._engine
+
+    def _push_initial(self, engine):
+        raise NotImplementedError
+
+    def _pull(self, engine, chain=0):
+        """Refresh the host-visible attributes from the device state of ``chain``."""
+        st = engine.adapt_state()
+        self._var = st["var"][chain].copy()
+        self._stds = np.sqrt(self._var)
+        self._inv_stds = (1.0 / self._stds).astype(np.float32)
+        self._n_samples = int(st["n_samples"][chain])
+
+    def _state0(self, x):
+        """compute_state(q=0, p=x) under a standard-normal target: v = M^-1 x, energy = x.v/2."""
+        eng = self._eng()
+        if eng.target.family != _targets.StdNormal.family:
+            # bound to a step with another target: kinetic part = energy + logp(0)
+            out = eng.trajectory(np.zeros(self._n), x, 0.0, 0, 0)
+            return out["v"][0, 0], out["energy"][0, 0] + out["logp"][0, 0]
+        out = eng.trajectory(np.zeros(self._n), x, 0.0, 0, 0)
+        return out["v"][0, 0], out["energy"][0, 0]
+
+    # -- protocol -------------------------------------------------------------------------------
+    def velocity(self, x, out=None):
+        v, _ = self._state0(np.asarray(x))
+        if out is not None:
+            out[:] = v
+            return out
+        return v
+
+    def energy(self, x, velocity=None):
+        _, e = self._state0(np.asarray(x))
+        return e
+
+    def velocity_energy(self, x, v_out):
+        v, e = self._state0(np.asarray(x))
+        v_out[:] = v
+        return e
+
+    def random(self):
+        """Momentum draw from the global legacy numpy stream, generated on the device."""
+        eng = self._eng()
+        eng.set_rng_state(0, np.random.get_state())
+        p = eng.draw_momentum()[0]
+        np.random.set_state(eng.get_rng_state(0))
+        return p.astype(np.float32) if self._engine_kind == "diag_adapt" else p
+
+    def update(self, sample, grad, tune):
+        raise NotImplementedError(
+            "mass-matrix adaptation runs inside the sampling kernel (per tuning iteration); it is not a "
+            "separate host call in littlemcmc_amd")
+
+    def raise_ok(self, vmap=None):
+        return None
+
+    def reset(self):
+        if self._engine is not None:
+            self._push_initial(self._engine)
+
+
+class QuadPotentialDiagAdapt(QuadPotential):
+    """quadpotential.py:148-291: float32 diagonal adapted from the tuning draws' variance."""
+
+    _engine_kind = "diag_adapt"
+
+    def __init__(self, n, initial_mean, initial_diag=None, initial_weight=0, adaptation_window=101,
+                 adaptation_window_multiplier=1, dtype=None):
+        initial_mean = np.asarray(initial_mean)
+        if initial_diag is not None:
+            initial_diag = np.asarray(initial_diag)
+            if initial_diag.ndim != 1:
+                raise ValueError("Initial diagonal must be one-dimensional.")
+        if initial_mean.ndim != 1:
+            raise ValueError("Initial mean must be one-dimensional.")
+        if initial_diag is not None and len(initial_diag) != n:
+            raise ValueError("Wrong shape for initial_diag: expected %s got %s" % (n, len(initial_diag)))
+        if len(initial_mean) != n:
+            raise ValueError("Wrong shape for initial_mean: expected %s got %s" % (n, len(initial_mean)))
+        if dtype not in (None, "float32", np.float32):
+            raise NotImplementedError("the device mass matrix is float32, like the reference's default")
+        if adaptation_window_multiplier != 1:
+            raise NotImplementedError("adaptation_window_multiplier != 1 is not implemented on the device")
+        super().__init__(n)
+        self.dtype = "float32"
+        if initial_diag is None:  # quadpotential.py:178-180
+            initial_diag = np.ones(n, dtype="float32")
+            initial_weight = 1
+        self._initial_mean = np.array(initial_mean, dtype="d")
+        self._initial_diag = initial_diag.astype("float32")
+        self._initial_weight = initial_weight
+        self.adaptation_window = int(adaptation_window)
+        self.adaptation_window_multiplier = float(adaptation_window_multiplier)
+        self._var = np.array(self._initial_diag, copy=True)
+        self._stds = np.sqrt(self._initial_diag)
+        self._inv_stds = 1.0 / self._stds
+        self._n_samples = 0
+
+    def _push_initial(self, engine):
+        engine.set_potential(self._initial_mean, self._initial_diag.astype("d"), float(self._initial_weight))
+        self._var = np.array(self._initial_diag, copy=True)
+        self._stds = np.sqrt(self._initial_diag)
+        self._inv_stds = 1.0 / self._stds
+        self._n_samples = 0
+
+
+class QuadPotentialDiag(QuadPotential):
+    """quadpotential.py:346-387: fixed float32 diagonal (covariance), float64 momentum draw."""
+
+    _engine_kind = "diag"
+
+    def __init__(self, v, dtype=None):
+        v = np.asarray(v)
+        if dtype not in (None, "float32", np.float32):
+            raise NotImplementedError("the device mass matrix is float32, like the reference's default")
+        super().__init__(v.shape[0])
+        self.dtype = "float32"
+        self.v = v.astype("float32")
+        self.s = self.v ** 0.5
+        self.inv_s = 1.0 / self.s
+        self._n_samples = 0
+
+    def _push_initial(self, engine):
+        engine.set_potential(None, self.v.astype("d"), 0.0)
+
+    def _pull(self, engine, chain=0):
+        pass
+
+
+def _dense_out_of_scope(name):
+    def __init__(self, *a, **k):
+        raise NotImplementedError(
+            "%s (dense mass matrix) is outside the GPU hot path of this build; use the diagonal "
+            "potentials (SURVEY.md section 8f-3)" % name)
+
+    return type(name, (QuadPotential,), {"__init__": __init__})
+
+
+QuadPotentialFull = _dense_out_of_scope("QuadPotentialFull")
+QuadPotentialFullInv = _dense_out_of_scope("QuadPotentialFullInv")
+QuadPotentialFullAdapt = _dense_out_of_scope("QuadPotentialFullAdapt")

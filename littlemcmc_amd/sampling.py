@@ -1,0 +1,151 @@
+"""``sample`` / ``init_nuts`` -- the driver boundary of /root/reference/littlemcmc/sampling.py.
+
+Same call signature, same seed derivation, same start-point logic, same return layout
+(``trace[chains, draws, ndim]``, ``stats[name][chains, draws, 1]`` cast to ``step.stats_dtypes``;
+sampling.py:207-220). What changed is everything underneath: instead of one Python loop per chain
+(sampling.py:331-521) or one OS process per chain (parallel_sampling.py), all chains run as
+wavefronts of one HIP kernel (csrc/lmc_sampler.hpp) and the host only slices the run into a few
+launches. ``cores``, ``mp_ctx`` and ``pickle_backend`` are accepted and ignored.
+"""
+import logging
+import os
+from collections.abc import Iterable
+
+import numpy as np
+
+from . import _abi
+from .base_hmc import raise_for_status
+from .nuts import NUTS
+from .quadpotential import QuadPotentialDiagAdapt
+from .targets import require_device_target
+
+_log = logging.getLogger("littlemcmc_amd")
+
+
+def _derive_seeds(random_seed, chains):
+    """sampling.py:131-138: per-chain seeds from an int (global legacy stream) or a list."""
+    if random_seed is None or isinstance(random_seed, (int, np.integer)):
+        if random_seed is not None:
+            np.random.seed(int(random_seed))
+        return [int(np.random.randint(2 ** 30)) for _ in range(chains)]
+    if isinstance(random_seed, Iterable):
+        seeds = [int(s) for s in random_seed]
+        if len(seeds) < chains:
+            raise ValueError("random_seed list is shorter than the number of chains")
+        return seeds[:chains]
+    raise TypeError("Invalid value for `random_seed`. Must be tuple, list or int")
+
+
+def init_nuts(logp_dlogp_func, model_ndim=None, init="auto", random_seed=None, size=None, **kwargs):
+    """Set up start point and NUTS sampler (sampling.py:524-605). Diagonal modes only."""
+    if model_ndim is None:
+        model_ndim = size if size is not None else getattr(logp_dlogp_func, "d", None)
+    require_device_target(logp_dlogp_func, model_ndim)
+    if not isinstance(init, str):
+        raise TypeError("init must be a string.")
+    init = init.lower()
+    if init == "auto":
+        init = "jitter+adapt_diag"
+    _log.info("Initializing NUTS using {}...".format(init))
+    if random_seed is not None:   # sampling.py:574-576
+        random_seed = int(np.atleast_1d(random_seed)[0])
+        np.random.seed(random_seed)
+    if init == "adapt_diag":
+        start = np.zeros(model_ndim)
+    elif init == "jitter+adapt_diag":
+        start = 2 * np.random.rand(model_ndim) - 1
+    elif init in ("adapt_full", "jitter+adapt_full"):
+        raise NotImplementedError(
+            "init=%r needs a dense mass matrix, which is outside the GPU hot path of this build "
+            "(SURVEY.md section 8f-3); use 'adapt_diag' or 'jitter+adapt_diag'" % init)
+    else:
+        raise ValueError("Unknown initializer: {}.".format(init))
+    potential = QuadPotentialDiagAdapt(model_ndim, start, np.ones(model_ndim), 10)
+    step = NUTS(logp_dlogp_func=logp_dlogp_func, model_ndim=model_ndim, potential=potential, **kwargs)
+    return start, step
+
+
+def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, init="auto", chains=None,
+           cores=None, start=None, progressbar=True, random_seed=None, discard_tuned_samples=True,
+           chain_idx=0, callback=None, mp_ctx=None, pickle_backend="pickle", size=None, device=0,
+           launch_iters=None, return_engine=False, **kwargs):
+    """Draw samples with many chains on one MI355X (reference signature: sampling.py:35-53).
+
+    Extra keywords: ``size`` (alias of ``model_ndim``), ``device`` (HIP ordinal), ``launch_iters``
+    (iterations per kernel launch; default: the whole run in at most a few launches),
+    ``return_engine`` (also return the live Engine, e.g. to read device pointers).
+    """
+    if model_ndim is None:
+        model_ndim = size if size is not None else getattr(logp_dlogp_func, "d", None)
+    target = require_device_target(logp_dlogp_func, model_ndim)
+    if cores is None:
+        cores = min(4, os.cpu_count() or 1)
+    if chains is None:
+        chains = max(2, cores)
+    seeds = _derive_seeds(random_seed, chains)
+
+    if draws == 0:
+        _log.warning("Tuning was enabled throughout the whole trace.")
+    elif draws < 500:
+        _log.warning("Only {} samples in chain.".format(draws))
+
+    if step is None or start is None:   # sampling.py:148-159 (always builds a NUTS for the start point)
+        start_, step_ = init_nuts(target, model_ndim, init=init, random_seed=seeds, **kwargs)
+        if step is None:
+            step = step_
+        if start is None:
+            start = start_
+    start = np.asarray(start, dtype="d")
+    if start.ndim == 1:   # same start for every chain (sampling.py:163-164)
+        starts = np.broadcast_to(start, (chains, model_ndim))
+    else:
+        starts = start
+        if starts.shape != (chains, model_ndim):
+            raise ValueError("start must have shape (model_ndim,) or (chains, model_ndim)")
+
+    n_total = int(tune) + int(draws)
+    eng = step._make_engine(chains, device=device)
+    try:
+        eng.seed(seeds)                       # np.random.seed(random_seed[i]) per chain (sampling.py:496-497)
+        eng.set_position(np.ascontiguousarray(starts))
+        eng.reset_tuning()                    # step.reset_tuning(); iter_count = 0 (sampling.py:503-509)
+        eng.reserve(max(n_total, 1), keep_trace=True)
+        per_launch = int(launch_iters) if launch_iters else max(1, min(n_total, 250))
+        it = 0
+        while it < n_total:
+            n = min(per_launch, n_total - it)
+            eng.run(tune, it, n)
+            it += n
+        eng.synchronize()
+        raise_for_status(eng.status())
+
+        lo = int(tune) if discard_tuned_samples else 0   # sampling.py:473-476
+        n_out = n_total - lo
+        if n_out > 0:
+            trace = eng.trace(lo, n_out)
+            raw = step._stats_from_engine(eng, lo, n_out)
+            stats = {name: raw[name][:, :, None].astype(dtype) for name, dtype in step.stats_dtypes[0].items()}
+        else:
+            trace = np.zeros((chains, 0, model_ndim))
+            stats = {name: np.zeros((chains, 0, 1), dtype=dtype) for name, dtype in step.stats_dtypes[0].items()}
+
+        # leave the step object as the reference's sequential driver leaves it: state of the LAST chain
+        step.tune = False if n_total > 0 else step.tune
+        step.iter_count = n_total
+        step.step_adapt._pull(eng, chains - 1)
+        step.potential._pull(eng, chains - 1)
+        ct = eng.counters()
+        step._samples_after_tune += int(ct[:, _abi.CT_SAMPLES_AFTER_TUNE].sum())
+        step._num_divs_sample += int(ct[:, _abi.CT_DIVS_AFTER_TUNE].sum())
+        if hasattr(step, "_reached_max_treedepth"):
+            step._reached_max_treedepth += int(ct[:, _abi.CT_REACHED_MAX_TREEDEPTH].sum())
+        if draws > 0:
+            tail = eng.stat_f64(_abi.STAT_ACCEPT, int(tune), int(draws))
+            step.step_adapt._tuned_stats = list(tail[chains - 1])
+    except Exception:
+        eng.close()
+        raise
+    if return_engine:
+        return trace, stats, eng
+    eng.close()
+    return trace, stats

@@ -1,0 +1,147 @@
+"""Device log-densities: what ``logp_dlogp_func`` is in this framework.
+
+The reference takes any Python callable ``q -> (logp, dlogp)`` and calls it once per leapfrog
+step (/root/reference/littlemcmc/integration.py:40,62,115). On the GPU the callable is a
+``__device__`` functor compiled into the transition kernel (littlemcmc_amd/csrc/lmc_targets.hpp).
+The objects here name such a functor plus its parameters; they are ALSO callable with the
+reference's signature -- the call evaluates the device functor on the GPU for one point -- so
+they can be passed wherever the reference expects ``logp_dlogp_func``.
+
+A plain Python callable cannot run inside a HIP kernel; passing one raises ``TypeError`` (there is
+no CPU fallback). Arbitrary densities are supported through :class:`UserTarget`, which compiles a
+user-supplied HIP snippet into a private build of the library.
+"""
+import hashlib
+import os
+
+import numpy as np
+
+from . import _abi, _build
+
+
+class DeviceTarget:
+    """Base: a device functor family + its parameter vector."""
+
+    family = None
+    lib_path = None  # default library
+
+    def __init__(self, d, params=()):
+        self.d = int(d)
+        self.params = np.ascontiguousarray(params, dtype=np.float64)
+        self._eval_engine = None
+
+    # reference plug-in signature, evaluated on the GPU
+    def __call__(self, q):
+        from .engine import Engine
+
+        if self._eval_engine is None:
+            self._eval_engine = Engine(self, chains=1)
+        logp, grad = self._eval_engine.logp_dlogp(np.asarray(q, dtype=np.float64).reshape(1, self.d))
+        return self._wrap_logp(logp[0]), grad[0]
+
+    def _wrap_logp(self, logp):
+        return np.float64(logp)
+
+    def __getstate__(self):  # picklable like the reference requires (docs/tutorials/quickstart.rst:42-46)
+        st = dict(self.__dict__)
+        st["_eval_engine"] = None
+        return st
+
+
+class StdNormal(DeviceTarget):
+    """logp = -1/2 sum q^2."""
+
+    family = _abi.TARGET_STD_NORMAL
+
+    def __init__(self, d):
+        super().__init__(d)
+
+
+class DiagGaussian(DeviceTarget):
+    """Independent Gaussian with precisions ``prec`` (1/sigma^2)."""
+
+    family = _abi.TARGET_DIAG_GAUSSIAN
+
+    def __init__(self, prec):
+        prec = np.ascontiguousarray(prec, dtype=np.float64)
+        super().__init__(prec.shape[0], prec)
+
+    @classmethod
+    def ill_conditioned(cls, d, kappa=1e4):
+        i = np.arange(d, dtype=np.float64)
+        return cls(1.0 / (kappa ** (i / max(d - 1, 1))))
+
+
+class AR1(DeviceTarget):
+    """Stationary AR(1) Gaussian with unit marginal variances (tridiagonal precision)."""
+
+    family = _abi.TARGET_AR1
+
+    def __init__(self, d, rho=0.9):
+        c = 1.0 / (1.0 - rho * rho)
+        super().__init__(d, [c, (1.0 + rho * rho) * c, -rho * c])
+        self.rho = float(rho)
+
+
+class Funnel(DeviceTarget):
+    """Neal's funnel: q_0 ~ N(0, 9), q_i | q_0 ~ N(0, exp(q_0))."""
+
+    family = _abi.TARGET_FUNNEL
+
+    def __init__(self, d):
+        super().__init__(d)
+
+
+class Normal1D(DeviceTarget):
+    """The reference's 1-D test target (tests/test_utils.py:19-28): logp has shape (1,)."""
+
+    family = _abi.TARGET_NORMAL1D
+
+    def __init__(self, loc=0.0, scale=1.0):
+        super().__init__(1, [loc, scale])
+
+    def _wrap_logp(self, logp):
+        return np.array([logp])
+
+
+class UserTarget(DeviceTarget):
+    """A user-written device log-density, compiled with hipcc and linked into the kernels.
+
+    ``source`` must define, in namespace ``lmc``::
+
+        template <int NS> struct UserTarget {
+            __device__ void init(const double* params, int d);
+            __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const;
+        };
+
+    following the lane-distributed contract documented in csrc/lmc_targets.hpp. The library is
+    rebuilt once per distinct source (cached by content hash next to the package).
+    """
+
+    family = _abi.TARGET_USER
+
+    def __init__(self, d, source, params=()):
+        super().__init__(d, params)
+        self.source = source
+        digest = hashlib.sha256(source.encode()).hexdigest()[:16]
+        cache = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_user_targets")
+        os.makedirs(cache, exist_ok=True)
+        header = os.path.join(cache, "user_%s.hpp" % digest)
+        lib = os.path.join(cache, "liblmc_hip_user_%s.so" % digest)
+        if not os.path.exists(lib):
+            with open(header, "w") as fh:
+                fh.write(source)
+            _build.build(out=lib, extra_flags=["-DLMC_USER_TARGET_HEADER=\"%s\"" % header], force=True)
+        self.lib_path = lib
+
+
+def require_device_target(logp_dlogp_func, model_ndim=None):
+    """The product path runs the density inside HIP kernels: reject anything else, loudly."""
+    if not isinstance(logp_dlogp_func, DeviceTarget):
+        raise TypeError(
+            "littlemcmc_amd runs logp_dlogp_func inside the GPU leapfrog kernel: pass a "
+            "littlemcmc_amd.targets.DeviceTarget (StdNormal, DiagGaussian, AR1, Funnel, Normal1D or a "
+            "UserTarget built from a HIP snippet), not %r. There is no CPU fallback." % (logp_dlogp_func,))
+    if model_ndim is not None and int(model_ndim) != logp_dlogp_func.d:
+        raise ValueError("model_ndim=%s does not match the target's dimension %d" % (model_ndim, logp_dlogp_func.d))
+    return logp_dlogp_func
