@@ -51,6 +51,14 @@ extern "C" {
 #define LMC_TARGET_NORMAL1D 4        /* params: {loc, scale}; dim must be 1 */
 #define LMC_TARGET_USER 5
 
+/* Summation order of the float32 kinetic energy of the start state, 0.5f * sdot(p, v)
+ * (integration.py:63-64 with float32 operands -> numpy -> OpenBLAS cblas_sdot). The value feeds the
+ * accept statistic and, through dual averaging, every later step size, so same-seed parity beyond
+ * ~1e-6 needs the host BLAS's rounding. NATIVE: exact products summed in float64, rounded once. */
+#define LMC_SDOT_NATIVE 0
+#define LMC_SDOT_OPENBLAS_SKYLAKEX 1   /* OpenBLAS 0.3.29 sdot_k_SKYLAKEX (AVX-512 hosts); default */
+#define LMC_SDOT_OPENBLAS_HASWELL 2    /* OpenBLAS 0.3.29 sdot_k_HASWELL (AVX2 hosts) */
+
 /* per-chain status bits (lmc_engine_get_status) */
 #define LMC_STATUS_BAD_INITIAL_ENERGY 1   /* base_hmc.py:145-148 (ValueError in the reference) */
 #define LMC_STATUS_NAN_LOGBERN 2          /* math.py:23-24 (FloatingPointError in the reference) */
@@ -106,6 +114,7 @@ typedef struct lmc_config {
     int32_t max_steps;            /* 1024 (HMC) */
     int32_t adaptation_window;    /* 101 (quadpotential.py:156) */
     int32_t lds_levels;           /* subtree-stack levels kept in LDS; 0 = choose automatically */
+    int32_t start_energy_sdot;    /* LMC_SDOT_*: summation order of the float32 start-state kinetic energy */
 } lmc_config;
 
 /* Fill *cfg with the reference's defaults for the given shape. */

@@ -18,6 +18,7 @@ KIND_NUTS, KIND_HMC = 0, 1
 POT_DIAG_ADAPT, POT_DIAG = 0, 1
 TARGET_STD_NORMAL, TARGET_DIAG_GAUSSIAN, TARGET_AR1, TARGET_FUNNEL, TARGET_NORMAL1D, TARGET_USER = range(6)
 STATUS_BAD_INITIAL_ENERGY, STATUS_NAN_LOGBERN = 1, 2
+SDOT_NATIVE, SDOT_OPENBLAS_SKYLAKEX, SDOT_OPENBLAS_HASWELL = 0, 1, 2
 (STAT_STEP_SIZE, STAT_STEP_SIZE_BAR, STAT_ACCEPT, STAT_ENERGY_ERROR, STAT_ENERGY, STAT_MAX_ENERGY_ERROR,
  STAT_MODEL_LOGP) = range(7)
 STAT_DEPTH, STAT_TREE_SIZE = 0, 1
@@ -37,7 +38,7 @@ class Config(C.Structure):
         ("gamma", C.c_double), ("k", C.c_double), ("t0", C.c_double),
         ("max_treedepth", C.c_int32), ("early_max_treedepth", C.c_int32),
         ("path_length", C.c_double), ("max_steps", C.c_int32), ("adaptation_window", C.c_int32),
-        ("lds_levels", C.c_int32),
+        ("lds_levels", C.c_int32), ("start_energy_sdot", C.c_int32),
     ]
 
 

@@ -122,8 +122,8 @@ __global__ __launch_bounds__(64) void logp_kernel(ChainArrays A, const double* t
 // compute_state + n_fwd steps (+eps) + n_back steps (-eps); all states written out.
 template <int NS, template <int> class TargetT>
 __global__ __launch_bounds__(64) void trajectory_kernel(ChainArrays A, const double* tparams, const double* q0,
-                                                        const double* p0, int p0_is_f32, double eps, int n_fwd,
-                                                        int n_back, double* oq, double* op, double* ov,
+                                                        const double* p0, int p0_is_f32, int sdot_mode, double eps,
+                                                        int n_fwd, int n_back, double* oq, double* op, double* ov,
                                                         double* og, double* oe, double* ol) {
     const int c = blockIdx.x;
     const int lane = lane_id();
@@ -145,15 +145,14 @@ __global__ __launch_bounds__(64) void trajectory_kernel(ChainArrays A, const dou
     double energy;
     double v[NS];
     if (p0_is_f32) {
-        double part = 0.0;
+        extern __shared__ __attribute__((aligned(16))) double lds[];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const float pf = static_cast<float>(p[s]);
-            const float vf = var[s] * pf;
-            v[s] = static_cast<double>(vf);
-            part = __builtin_fma(static_cast<double>(pf), static_cast<double>(vf), part);
+            p[s] = static_cast<double>(static_cast<float>(p[s]));
+            v[s] = static_cast<double>(var[s] * static_cast<float>(p[s]));
         }
-        energy = static_cast<double>(0.5f * static_cast<float>(wave_sum(part))) - logp;
+        const float kin = start_kinetic_f32<NS>(p, var, d, sdot_mode, reinterpret_cast<float*>(lds), A.dpad);
+        energy = static_cast<double>(kin) - logp;
     } else {
 #pragma unroll
         for (int s = 0; s < NS; ++s) v[s] = static_cast<double>(var[s]) * p[s];
@@ -372,6 +371,7 @@ void lmc_config_defaults(lmc_config* cfg, int32_t chains, int32_t dim) {
     cfg->max_steps = 1024;
     cfg->adaptation_window = 101;
     cfg->lds_levels = 0;
+    cfg->start_energy_sdot = LMC_SDOT_OPENBLAS_SKYLAKEX;
 }
 
 static int launch_reset(lmc_engine* e, int reset_step, int reset_mass) {
@@ -401,6 +401,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         return fail(nullptr, LMC_ERR_INVALID, "LMC_TARGET_NORMAL1D requires dim == 1");
     if (cfg->kind != LMC_KIND_NUTS && cfg->kind != LMC_KIND_HMC)
         return fail(nullptr, LMC_ERR_INVALID, "unknown step kind %d", cfg->kind);
+    if (cfg->start_energy_sdot < LMC_SDOT_NATIVE || cfg->start_energy_sdot > LMC_SDOT_OPENBLAS_HASWELL)
+        return fail(nullptr, LMC_ERR_INVALID, "unknown start_energy_sdot mode %d", cfg->start_energy_sdot);
     if (cfg->max_treedepth < 1 || cfg->max_treedepth > 20 || cfg->early_max_treedepth < 1 ||
         cfg->early_max_treedepth > 20)
         return fail(nullptr, LMC_ERR_INVALID, "max_treedepth must be in [1, 20]");
@@ -701,6 +703,7 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
     P.n_iters = n_iters;
     P.nlds = e->nlds;
     P.lds_doubles = e->lds_bytes / 8;
+    P.sdot_mode = e->cfg.start_energy_sdot;
     const dim3 grid(e->cfg.chains), block(64);
 #define RUN_CALL(T) \
     LMC_NS_SWITCH(e, e->ns, hipLaunchKernelGGL((run_kernel<NS, T>), grid, block, e->lds_bytes, e->stream, e->A, P, e->tparams))
@@ -813,8 +816,8 @@ int lmc_engine_trajectory(lmc_engine* e, const double* q0, const double* p0, int
     HIP_TRY(e, hipMemcpyAsync(dp0.p, p0, C * d * sizeof(double), hipMemcpyDefault, e->stream));
     const dim3 grid(e->cfg.chains), block(64);
 #define TRAJ_CALL(T)                                                                                          \
-    LMC_NS_SWITCH(e, e->ns, hipLaunchKernelGGL((trajectory_kernel<NS, T>), grid, block, 0, e->stream, e->A,   \
-                                               e->tparams, dq0.p, dp0.p, p0_is_f32, eps, n_fwd, n_back, oq.p, \
+    LMC_NS_SWITCH(e, e->ns, hipLaunchKernelGGL((trajectory_kernel<NS, T>), grid, block, e->dpad * 8, e->stream, e->A,   \
+                                               e->tparams, dq0.p, dp0.p, p0_is_f32, e->cfg.start_energy_sdot, eps, n_fwd, n_back, oq.p, \
                                                op.p, ov.p, og.p, oe.p, ol.p))
     LMC_FAMILY_SWITCH(e, e->cfg.target_family, TRAJ_CALL)
 #undef TRAJ_CALL

@@ -87,6 +87,7 @@ struct SamplerParams {
     int n_iters;
     int nlds;             // subtree levels kept in LDS (>= 1)
     int lds_doubles;      // dynamic LDS size in doubles
+    int sdot_mode;        // SdotMode for the float32 start-state kinetic energy
 };
 
 // ---- numpy scalar helpers ------------------------------------------------------------------------
@@ -136,6 +137,90 @@ __device__ __forceinline__ double pdot_v32(const double (&a)[NS], const float (&
     for (int s = 0; s < NS; ++s)
         acc = __builtin_fma(a[s], static_cast<double>(var[s] * static_cast<float>(b[s])), acc);
     return acc;
+}
+
+// ---- float32 start-state kinetic energy: 0.5f * sdot(p, v) --------------------------------------------
+// The reference computes the start state's kinetic energy with numpy's float32 dot, i.e. OpenBLAS
+// cblas_sdot (integration.py:63-64 -> quadpotential.py:210-214). Its value feeds every energy error of
+// the iteration, the accept statistic and through dual averaging the next step size, so a chain only
+// tracks the reference beyond ~1e-6 if this one number is rounded the same way. The two modes below
+// restate the summation order of OpenBLAS 0.3.29's sdot_k_SKYLAKEX / sdot_k_HASWELL (unit stride; read
+// off the shipped binary numpy 2.2.6 links against -- see DESIGN.md "float32 start energy"):
+//   n1 = n & ~31 elements in SIMD accumulators with fused multiply-add, consolidated in a fixed order,
+//   the n - n1 tail as float32 products accumulated sequentially in DOUBLE, result = f32(tail + f64(simd)).
+// kSdotNative sums the exact float32 products in float64 (wave butterfly) and rounds once.
+enum SdotMode : int { kSdotNative = 0, kSdotOpenblasSkylakeX = 1, kSdotOpenblasHaswell = 2 };
+
+// x, y: float32 vectors staged in LDS (n elements each). Wave-uniform result.
+__device__ inline float sdot_openblas(const float* x, const float* y, int n, int mode) {
+    const int lane = lane_id();
+    const int n1 = n & ~31;
+    float simd = 0.0f;
+    if (n1) {
+        if (mode == kSdotOpenblasSkylakeX) {
+            const int n64 = n1 & ~63;
+            float acc = 0.0f;                                  // zmm k = lane/16, element lane%16
+            for (int b = 0; b < n64; b += 64) acc = __builtin_fmaf(x[b + lane], y[b + lane], acc);
+            float a = acc + __shfl_down(acc, 8, 64);           // fold 512 -> 256: valid on lanes 16k+m, m<8
+            if (n1 > n64) {                                    // one trailing 32-block on ymm accumulators
+                const int k = lane >> 4, m = lane & 15;
+                if (m < 8) a = __builtin_fmaf(x[n64 + 8 * k + m], y[n64 + 8 * k + m], a);
+            }
+            float sv = a + __shfl(a, (lane & 7) + 16, 64);     // ((A0 + A1) + A2) + A3 on lanes m<8
+            sv = sv + __shfl(a, (lane & 7) + 32, 64);
+            sv = sv + __shfl(a, (lane & 7) + 48, 64);
+            const float h = sv + __shfl_down(sv, 4, 64);       // low half + high half, lanes m<4
+            const float h0 = __shfl(h, 0, 64), h1 = __shfl(h, 1, 64), h2 = __shfl(h, 2, 64), h3 = __shfl(h, 3, 64);
+            simd = (h0 + h1) + (h2 + h3);                      // two vhaddps
+        } else {
+            float acc = 0.0f;                                  // ymm k = lane/8 (lanes < 32)
+            if (lane < 32)
+                for (int b = 0; b < n1; b += 32) acc = __builtin_fmaf(x[b + lane], y[b + lane], acc);
+            const float hk = acc + __shfl_down(acc, 4, 64);    // H_k[m] on lanes 8k+m, m<4
+            const int m = lane & 3;
+            const float s01 = __shfl(hk, m, 64) + __shfl(hk, 8 + m, 64);
+            const float s23 = __shfl(hk, 16 + m, 64) + __shfl(hk, 24 + m, 64);
+            const float sv = s01 + s23;
+            const float h0 = __shfl(sv, 0, 64), h1 = __shfl(sv, 1, 64), h2 = __shfl(sv, 2, 64), h3 = __shfl(sv, 3, 64);
+            simd = (h0 + h1) + (h2 + h3);
+        }
+    }
+    // tail: float32 products, sequential double accumulation from 0, then + simd
+    const int nt = n - n1;                                     // < 32
+    double prod = 0.0;
+    if (lane < nt) prod = static_cast<double>(x[n1 + lane] * y[n1 + lane]);
+    double tail = 0.0;
+    for (int t = 0; t < nt; ++t) tail = tail + readlane_f64(prod, t);
+    const double tot = tail + static_cast<double>(simd);
+    return __builtin_bit_cast(float, first_u32(__builtin_bit_cast(uint32_t, static_cast<float>(tot))));
+}
+
+// 0.5f * p.dot(v) for the float32 start state; p, v float32-valued. scratch: >= 2*dpad floats of LDS.
+template <int NS>
+__device__ inline float start_kinetic_f32(const double (&p0)[NS], const float (&var)[NS], int d, int mode,
+                                          float* scratch, int dpad) {
+    if (mode == kSdotNative) {
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float pf = static_cast<float>(p0[s]);
+            part = __builtin_fma(static_cast<double>(pf), static_cast<double>(var[s] * pf), part);
+        }
+        return 0.5f * static_cast<float>(wave_sum(part));
+    }
+    const int lane = lane_id();
+    float* x = scratch;
+    float* y = scratch + dpad;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float pf = static_cast<float>(p0[s]);
+        x[lane * NS + s] = pf;
+        y[lane * NS + s] = var[s] * pf;
+    }
+    wave_sync();
+    const float dot = sdot_openblas(x, y, d, mode);
+    wave_sync();
+    return 0.5f * dot;
 }
 
 // ---- leapfrog (integration.py:100-121) -------------------------------------------------------------
@@ -463,14 +548,8 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
         double g0[NS];
         const double logp0 = first_f64(tgt.logp_grad(q, g0));
         double e0;
-        if (P.momentum_f32) {   // float32 velocity, float32 kinetic energy
-            double part = 0.0;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const float pf = static_cast<float>(p0[s]);
-                part = __builtin_fma(static_cast<double>(pf), static_cast<double>(var[s] * pf), part);
-            }
-            const float kin = 0.5f * static_cast<float>(wave_sum(part));
+        if (P.momentum_f32) {   // float32 velocity, float32 kinetic energy (BLAS-order faithful)
+            const float kin = start_kinetic_f32<NS>(p0, var, d, P.sdot_mode, reinterpret_cast<float*>(lds), dpad);
             e0 = first_f64(static_cast<double>(kin) - logp0);
         } else {
             e0 = first_f64(0.5 * wave_sum(pdot_v<NS>(p0, var, p0)) - logp0);

@@ -7,12 +7,16 @@ import numpy as np
 
 from . import _abi
 
+# Rounding of the float32 start-state kinetic energy: "auto" = match this host's numpy/BLAS
+# (_blas_probe.py), or "skylakex" / "haswell" / "native" (include/lmc_hip.h: LMC_SDOT_*).
+DEFAULT_SDOT = "auto"
+
 
 class Engine:
     def __init__(self, target, chains, kind="nuts", potential="diag_adapt", device=0, lib_path=None,
                  target_accept=0.8, Emax=1000.0, adapt_step_size=True, step_scale=0.25, gamma=0.05, k=0.75,
                  t0=10, path_length=2.0, max_treedepth=10, early_max_treedepth=8, max_steps=1024,
-                 adaptation_window=101, lds_levels=0):
+                 adaptation_window=101, lds_levels=0, sdot=None):
         self._lib = _abi.load(lib_path or getattr(target, "lib_path", None))
         self._h = C.c_void_p()
         self.target = target
@@ -38,6 +42,14 @@ class Engine:
         cfg.max_steps = int(max_steps)
         cfg.adaptation_window = int(adaptation_window)
         cfg.lds_levels = int(lds_levels)
+        if sdot is None:
+            sdot = DEFAULT_SDOT
+        if sdot == "auto":   # float32 start-energy rounding of the host's numpy (see _blas_probe.py)
+            from ._blas_probe import detect_sdot_mode
+
+            sdot = detect_sdot_mode()
+        cfg.start_energy_sdot = {"native": _abi.SDOT_NATIVE, "skylakex": _abi.SDOT_OPENBLAS_SKYLAKEX,
+                                 "haswell": _abi.SDOT_OPENBLAS_HASWELL}.get(sdot, sdot)
         self.cfg = cfg
         h = C.c_void_p()
         self._check(self._lib.lmc_engine_create(C.byref(cfg), C.byref(h)), handle=None)

@@ -68,7 +68,11 @@ def assert_chain_matches(got_q, got_stats, want_q, want_stats, margins, label=""
         if name in INT_STATS:
             np.testing.assert_array_equal(g, w, err_msg="%s %s" % (label, name))
         else:
-            # energies carry the float32 start-energy difference (absolute ~1e-5 at d~100)
-            np.testing.assert_allclose(g, w, rtol=1e-6, atol=5e-5, err_msg="%s %s" % (label, name))
+            # energies carry the float32 start-energy rounding: a few float32 ulps of the kinetic energy
+            scale = 1.0
+            if "energy" in want_stats:
+                scale = 1.0 + np.abs(np.ravel(want_stats["energy"])[:upto])
+            assert np.all(np.abs(g - w) <= 1e-6 * np.abs(w) + 2e-6 * scale), "%s %s: max abs diff %g" % (
+                label, name, np.max(np.abs(g - w)))
     np.testing.assert_allclose(got_q[:upto], want_q[:upto], rtol=RTOL_Q, atol=1e-9, err_msg="%s q" % label)
     return upto

@@ -74,7 +74,7 @@ def test_leapfrog_golden(golden_dir):
         d = int(g[k + "d"])
         tgt = device_target(g[k + "family"], d, g[k + "params"])
         adapt = str(g[k + "pot"]) == "adapt"
-        with lmc.Engine(tgt, chains=2, potential="diag_adapt" if adapt else "diag") as eng:
+        with lmc.Engine(tgt, chains=2, potential="diag_adapt" if adapt else "diag", sdot="skylakex") as eng:
             eng.set_potential(np.zeros(d), g[k + "var"].astype("d"), 10.0)
             n, eps = int(g[k + "n"]), float(g[k + "eps"])
             out = eng.trajectory(g[k + "q"][0], g[k + "p"][0], eps, n, n, p0_is_f32=adapt)
@@ -84,7 +84,8 @@ def test_leapfrog_golden(golden_dir):
                                                err_msg="%s%s" % (k, name))
                 # energies: start state is a float32 kinetic energy in the adapt case
                 np.testing.assert_allclose(out["energy"][c][1:], g[k + "energy"][1:], rtol=1e-12, atol=1e-12)
-                np.testing.assert_allclose(out["energy"][c][0], g[k + "energy"][0], rtol=1e-6 if adapt else 1e-12)
+                # ... rounded like the capture host's BLAS (sdot_k_SKYLAKEX): agrees to the last float32 bit
+                np.testing.assert_allclose(out["energy"][c][0], g[k + "energy"][0], rtol=1e-13, atol=1e-13)
                 np.testing.assert_allclose(out["logp"][c], g[k + "logp"], rtol=1e-12, atol=1e-13)
                 # reversibility (reference tests/test_hmc.py:23-40, rtol 1e-5)
                 np.testing.assert_allclose(out["q"][c][-1], out["q"][c][0], rtol=1e-5, atol=1e-12)
@@ -110,3 +111,46 @@ def test_logp_dlogp_matches_oracle_targets():
         l1, g1 = tgt(q[0])
         np.testing.assert_allclose(l1, f(q[0])[0], rtol=1e-12, atol=1e-12)
         assert g1.shape == (d,)
+
+
+@pytest.mark.parametrize("mode", ["skylakex", "haswell"])
+def test_start_energy_float32_blas_order(mode):
+    """0.5f * sdot(p, v) of the start state: device == numpy emulation of the OpenBLAS kernel, bit for bit,
+    for every length class (pure tail, 32-block, 64-blocks + 32-block + tail)."""
+    from littlemcmc_amd import _abi
+    from littlemcmc_amd._blas_probe import emulate_sdot
+
+    rs = np.random.RandomState(11)
+    code = {"skylakex": _abi.SDOT_OPENBLAS_SKYLAKEX, "haswell": _abi.SDOT_OPENBLAS_HASWELL}[mode]
+    for d in [1, 2, 3, 10, 31, 32, 33, 63, 64, 65, 96, 100, 127, 128, 129, 200, 256, 257, 1000, 1024]:
+        chains = 3
+        with lmc.Engine(T.StdNormal(d), chains=chains, sdot=mode) as eng:
+            var = (0.5 + rs.rand(d))
+            eng.set_potential(np.zeros(d), var, 10.0)
+            p = rs.randn(chains, d).astype(np.float32)
+            out = eng.trajectory(np.zeros((chains, d)), p.astype("d"), 0.1, 0, 0, p0_is_f32=True)
+            for c in range(chains):
+                v = var.astype(np.float32) * p[c]
+                want = np.float32(0.5) * emulate_sdot(p[c], v, code)
+                assert out["energy"][c, 0] == np.float64(want), (mode, d, out["energy"][c, 0], want)
+                np.testing.assert_array_equal(out["v"][c, 0], v.astype("d"))
+
+
+def test_start_energy_matches_host_numpy_when_detected():
+    """With sdot="auto" the device start energy equals this host's float32 numpy dot (the reference's
+    arithmetic on this box) whenever the probe recognises the BLAS kernel."""
+    from littlemcmc_amd._blas_probe import detect_sdot_mode, emulate_sdot
+
+    mode = detect_sdot_mode()
+    rs = np.random.RandomState(5)
+    x = rs.randn(200).astype(np.float32)
+    y = rs.randn(200).astype(np.float32)
+    if emulate_sdot(x, y, mode) != np.dot(x, y):
+        pytest.skip("host BLAS sdot order not recognised; device uses the SkylakeX order")
+    d = 128
+    with lmc.Engine(T.StdNormal(d), chains=4) as eng:
+        p = rs.randn(4, d).astype(np.float32)
+        out = eng.trajectory(np.zeros((4, d)), p.astype("d"), 0.1, 0, 0, p0_is_f32=True)
+        for c in range(4):
+            want = 0.5 * p[c].dot(np.ones(d, np.float32) * p[c])
+            assert out["energy"][c, 0] == np.float64(want)
