@@ -185,6 +185,27 @@ int64_t lmc_engine_capacity(lmc_engine* e);
  * Any pointer may be NULL. */
 int lmc_engine_get_adapt_state(lmc_engine* e, float* var, double* dual_avg, int32_t* da_count,
                                int32_t* n_samples);
+/* Full adaptation state of every chain, for checkpoint/resume and for per-iteration parity tests
+ * (the reference has no such call: its state is the Python step object, base_hmc.py:192-200).
+ * Every pointer may be NULL (skipped). Shapes: vectors [chains][dim], scalars [chains].
+ * set(): inv_std is re-derived from var exactly as quadpotential.py:226-229 does (float32 sqrt, 1/x). */
+typedef struct lmc_chain_state {
+    float* var;             /* potential._var */
+    double* fore_mean;      /* potential._foreground_var.mean */
+    double* fore_raw_var;   /* potential._foreground_var.raw_var */
+    double* back_mean;      /* potential._background_var.mean */
+    double* back_raw_var;   /* potential._background_var.raw_var */
+    double* fore_w_sum;     /* potential._foreground_var.w_sum */
+    double* back_w_sum;     /* potential._background_var.w_sum */
+    int32_t* n_samples;     /* potential._n_samples */
+    double* log_step;       /* step_adapt._log_step */
+    double* log_bar;        /* step_adapt._log_bar */
+    double* hbar;           /* step_adapt._hbar */
+    int32_t* da_count;      /* step_adapt._count */
+    int32_t* iter_count;    /* step.iter_count */
+} lmc_chain_state;
+int lmc_engine_get_chain_state(lmc_engine* e, const lmc_chain_state* dst);
+int lmc_engine_set_chain_state(lmc_engine* e, const lmc_chain_state* src);
 int lmc_engine_get_status(lmc_engine* e, int32_t* status);
 int lmc_engine_get_counters(lmc_engine* e, int64_t* counters);
 

@@ -43,6 +43,19 @@ class Config(C.Structure):
 
 
 _P = C.c_void_p
+
+
+class ChainState(C.Structure):
+    """struct lmc_chain_state (include/lmc_hip.h): pointers, NULL = skip."""
+
+    FIELDS = (("var", np.float32, True), ("fore_mean", np.float64, True), ("fore_raw_var", np.float64, True),
+              ("back_mean", np.float64, True), ("back_raw_var", np.float64, True), ("fore_w_sum", np.float64, False),
+              ("back_w_sum", np.float64, False), ("n_samples", np.int32, False), ("log_step", np.float64, False),
+              ("log_bar", np.float64, False), ("hbar", np.float64, False), ("da_count", np.int32, False),
+              ("iter_count", np.int32, False))
+    _fields_ = [(name, C.c_void_p) for name, _dt, _vec in FIELDS]
+
+
 _SIGNATURES = {
     # name: (restype, [argtypes])
     "lmc_config_defaults": (None, [C.POINTER(Config), C.c_int32, C.c_int32]),
@@ -73,6 +86,8 @@ _SIGNATURES = {
     "lmc_engine_stat_f64_device_ptr": (_P, [_P]),
     "lmc_engine_capacity": (C.c_int64, [_P]),
     "lmc_engine_get_adapt_state": (C.c_int, [_P, _P, _P, _P, _P]),
+    "lmc_engine_get_chain_state": (C.c_int, [_P, C.POINTER(ChainState)]),
+    "lmc_engine_set_chain_state": (C.c_int, [_P, C.POINTER(ChainState)]),
     "lmc_engine_get_status": (C.c_int, [_P, _P]),
     "lmc_engine_get_counters": (C.c_int, [_P, _P]),
     "lmc_engine_trajectory": (C.c_int, [_P, _P, _P, C.c_int32, C.c_double, C.c_int32, C.c_int32,

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -227,6 +228,15 @@ __global__ void set_da_kernel(ChainArrays A, double log_step, double log_bar, do
     A.da[c * 4 + 1] = log_bar;
     A.da[c * 4 + 2] = hbar;
     A.da_count[c] = count;
+}
+
+// After lmc_engine_set_chain_state(): inv_std = 1 / sqrt(var) in float32 (quadpotential.py:226-229).
+__global__ void derive_inv_std_kernel(ChainArrays A) {
+    const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const long long n = static_cast<long long>(A.chains) * A.dpad;
+    if (idx >= n) return;
+    const float sd = sqrtf(A.var[idx]);
+    A.inv_std[idx] = 1.0f / sd;
 }
 
 }  // namespace lmc
@@ -798,6 +808,79 @@ int lmc_engine_get_counters(lmc_engine* e, int64_t* counters) {
                          hipMemcpyDefault));
     return LMC_OK;
 }
+
+// ---- full chain state (checkpoint / resume / per-iteration parity) ---------------------------------------
+static int copy_vec_rows(lmc_engine* e, void* user, void* dev, size_t elem, bool to_user) {
+    const size_t C = e->cfg.chains, d = e->cfg.dim, dp = e->dpad;
+    if (to_user)
+        HIP_TRY(e, hipMemcpy2D(user, d * elem, dev, dp * elem, d * elem, C, hipMemcpyDefault));
+    else
+        HIP_TRY(e, hipMemcpy2D(dev, dp * elem, user, d * elem, d * elem, C, hipMemcpyDefault));
+    return LMC_OK;
+}
+
+static int chain_state_xfer(lmc_engine* e, const lmc_chain_state* st, bool to_user) {
+    if (!e || !st) return fail(e, LMC_ERR_INVALID, "null argument");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    ChainArrays& A = e->A;
+    const size_t C = e->cfg.chains;
+    const size_t plane = C * static_cast<size_t>(e->dpad);
+    std::vector<int> wsel(C);
+    HIP_TRY(e, hipMemcpy(wsel.data(), A.wsel, C * sizeof(int), hipMemcpyDeviceToHost));
+    int rc;
+    if (!to_user) {   // canonical layout on load: slot 0 = foreground for every chain
+        std::fill(wsel.begin(), wsel.end(), 0);
+        if (st->fore_mean || st->fore_raw_var || st->back_mean || st->back_raw_var || st->fore_w_sum || st->back_w_sum) {
+            if (!(st->fore_mean && st->fore_raw_var && st->back_mean && st->back_raw_var && st->fore_w_sum && st->back_w_sum))
+                return fail(e, LMC_ERR_INVALID, "the Welford fields must be set together");
+            HIP_TRY(e, hipMemcpy(A.wsel, wsel.data(), C * sizeof(int), hipMemcpyHostToDevice));
+        }
+    } else {
+        for (size_t c = 1; c < C; ++c)
+            if (wsel[c] != wsel[0]) {   // chains switch windows in lockstep (same n_samples); guard anyway
+                return fail(e, LMC_ERR_STATE, "chains are in different adaptation windows; read state per launch boundary");
+            }
+    }
+    const int f = wsel[0], b = 1 - wsel[0];
+    if (st->var && (rc = copy_vec_rows(e, st->var, A.var, sizeof(float), to_user)) != LMC_OK) return rc;
+    if (st->fore_mean && (rc = copy_vec_rows(e, st->fore_mean, A.wmean + f * plane, sizeof(double), to_user)) != LMC_OK) return rc;
+    if (st->fore_raw_var && (rc = copy_vec_rows(e, st->fore_raw_var, A.wraw + f * plane, sizeof(double), to_user)) != LMC_OK) return rc;
+    if (st->back_mean && (rc = copy_vec_rows(e, st->back_mean, A.wmean + b * plane, sizeof(double), to_user)) != LMC_OK) return rc;
+    if (st->back_raw_var && (rc = copy_vec_rows(e, st->back_raw_var, A.wraw + b * plane, sizeof(double), to_user)) != LMC_OK) return rc;
+    auto strided = [&](double* user, double* dev, int stride, int off) -> int {   // [C] <-> dev[c*stride+off]
+        if (!user) return LMC_OK;
+        if (to_user)
+            HIP_TRY(e, hipMemcpy2D(user, sizeof(double), dev + off, stride * sizeof(double), sizeof(double), C, hipMemcpyDefault));
+        else
+            HIP_TRY(e, hipMemcpy2D(dev + off, stride * sizeof(double), user, sizeof(double), sizeof(double), C, hipMemcpyDefault));
+        return LMC_OK;
+    };
+    if ((rc = strided(st->fore_w_sum, A.wsum, 2, f)) != LMC_OK) return rc;
+    if ((rc = strided(st->back_w_sum, A.wsum, 2, b)) != LMC_OK) return rc;
+    if ((rc = strided(st->log_step, A.da, 4, 0)) != LMC_OK) return rc;
+    if ((rc = strided(st->log_bar, A.da, 4, 1)) != LMC_OK) return rc;
+    if ((rc = strided(st->hbar, A.da, 4, 2)) != LMC_OK) return rc;
+    auto ints = [&](int32_t* user, int* dev) -> int {
+        if (!user) return LMC_OK;
+        if (to_user) HIP_TRY(e, hipMemcpy(user, dev, C * sizeof(int), hipMemcpyDefault));
+        else HIP_TRY(e, hipMemcpy(dev, user, C * sizeof(int), hipMemcpyDefault));
+        return LMC_OK;
+    };
+    if ((rc = ints(st->n_samples, A.n_samples)) != LMC_OK) return rc;
+    if ((rc = ints(st->da_count, A.da_count)) != LMC_OK) return rc;
+    if ((rc = ints(st->iter_count, A.iter_count)) != LMC_OK) return rc;
+    if (!to_user && st->var) {
+        const long long n = static_cast<long long>(C) * e->dpad;
+        hipLaunchKernelGGL(derive_inv_std_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, e->stream, e->A);
+        HIP_TRY(e, hipGetLastError());
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+    }
+    return LMC_OK;
+}
+
+int lmc_engine_get_chain_state(lmc_engine* e, const lmc_chain_state* dst) { return chain_state_xfer(e, dst, true); }
+int lmc_engine_set_chain_state(lmc_engine* e, const lmc_chain_state* src) { return chain_state_xfer(e, src, false); }
 
 // ---- unit entry points -----------------------------------------------------------------------------------
 int lmc_engine_trajectory(lmc_engine* e, const double* q0, const double* p0, int32_t p0_is_f32, double eps,

@@ -177,6 +177,28 @@ class Engine:
         return {"var": var, "log_step": da[:, 0], "log_bar": da[:, 1], "hbar": da[:, 2], "mu": da[:, 3],
                 "count": cnt, "n_samples": ns}
 
+    def get_chain_state(self):
+        """Full adaptation state of every chain as a dict of host arrays (checkpoint)."""
+        st = _abi.ChainState()
+        out = {}
+        for name, dt, vec in _abi.ChainState.FIELDS:
+            out[name] = np.empty((self.chains, self.dim) if vec else (self.chains,), dtype=dt)
+            setattr(st, name, out[name].ctypes.data)
+        self._check(self._lib.lmc_engine_get_chain_state(self._h, C.byref(st)))
+        return out
+
+    def set_chain_state(self, state):
+        """Restore (a subset of) the fields returned by get_chain_state(); arrays are [chains, dim] / [chains]."""
+        st = _abi.ChainState()
+        keep = []
+        for name, dt, vec in _abi.ChainState.FIELDS:
+            if name in state and state[name] is not None:
+                shape = (self.chains, self.dim) if vec else (self.chains,)
+                a = np.ascontiguousarray(np.broadcast_to(np.asarray(state[name], dtype=dt), shape))
+                keep.append(a)
+                setattr(st, name, a.ctypes.data)
+        self._check(self._lib.lmc_engine_set_chain_state(self._h, C.byref(st)))
+
     def status(self):
         st = np.empty(self.chains, dtype=np.int32)
         self._check(self._lib.lmc_engine_get_status(self._h, _abi.ptr(st)))

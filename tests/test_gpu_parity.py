@@ -119,4 +119,45 @@ def test_e2e_golden_through_sample_api(golden_dir, name):
         want = {n_: g["stat_" + n_][c, :, 0] for n_ in stats}
         verified += assert_chain_matches(trace[c], got, g["trace"][c], want, margins[c, :, 0],
                                          label="%s chain %d" % (name, c))
-    assert verified >= 0.75 * chains * (tune + draws), "%s: only %d iterations verified" % (name, verified)
+    # whole tuned chains are chaotic (see test_every_iteration_of_the_golden_runs): require a solid prefix
+    assert verified >= chains * min(40, tune + draws), "%s: only %d iterations verified" % (name, verified)
+
+
+@pytest.mark.parametrize("name", E2E)
+def test_every_iteration_of_the_golden_runs(golden_dir, name):
+    """Tuning makes a chain exponentially sensitive to 1-ulp differences (dual averaging feeds the accept
+    statistic back into the step size), so whole tuned chains can only track the reference for a few dozen
+    iterations. Here every iteration of the golden configurations -- tuning and sampling, both sides of the
+    adaptation-window switches (101, 202) and of the early-treedepth boundary -- is replayed on the device from
+    the oracle's exact pre-iteration state and must reproduce the oracle's iteration: integer stats exactly,
+    positions / energies / adaptation state to 1e-10."""
+    from tests._gpu_util import oracle_chain_snapshots, replay_iterations_on_device
+
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    d, chains, tune, draws = int(g["d"]), int(g["chains"]), int(g["tune"]), int(g["draws"])
+    kw = kwargs_from(g)
+    fam = str(g["family"])
+    f = OT.DiagGaussian(g["params"]) if fam == "diag_gaussian" else OT.make(fam, d)
+    tgt = device_target(fam, d, g["params"])
+    seeds = [int(s) for s in g["seeds"]]
+    start = g["start"]
+    total_checked = total_fragile = 0
+    for c in range(min(chains, 2)):
+        if str(g["kind"]) == "hmc":
+            ostep = orc.Step(f, d, kind="hmc", **kw)
+            step = lmc.HamiltonianMC(tgt, d, **kw)
+        else:
+            _s, ostep = orc.init_nuts(f, d, seeds=seeds, **kw)
+            _s2, step = lmc.init_nuts(tgt, d, random_seed=seeds, **kw)
+            np.testing.assert_array_equal(_s, _s2)
+            np.testing.assert_array_equal(_s, start)
+        snaps, outs = oracle_chain_snapshots(ostep, start, seeds[c], tune, draws)
+        # the oracle chain IS the golden chain on the capture host; elsewhere (other BLAS) allow drift
+        same = np.allclose(np.array([o["q"] for o in outs]), g["trace"][c], rtol=1e-9, atol=1e-12)
+        checked, fragile = replay_iterations_on_device(step, snaps, outs, label="%s chain %d" % (name, c))
+        total_checked += checked
+        total_fragile += fragile
+        if same:
+            np.testing.assert_array_equal(np.array([o["stats"]["diverging"] for o in outs]),
+                                          g["stat_diverging"][c, :, 0])
+    assert total_checked >= 0.99 * (min(chains, 2) * (tune + draws)), (total_checked, total_fragile)
