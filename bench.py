@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: leapfrog-steps/sec of the many-chain NUTS hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1: this process)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2] / SURVEY.md 8d "C3"): 65 536 chains per GPU x dim 128, AR(1) rho=0.9
+correlated Gaussian, NUTS defaults, diagonal mass adaptation, init jitter+adapt_diag; the timed job is
+the reference recipe ``sample(tune=T, draws=D)`` cut into K equal launches ("steps") of the one persistent
+kernel (tune = first half). W warm-up steps run first on a throw-away copy of the job (same kernel, same
+shapes) and are not timed. Chains are independent: with N GPUs every rank owns its own block of
+65 536 chains (weak scaling, no data-path collective); ranks only meet in the barrier and in the
+max/sum reductions of the timing.
+
+value  = leapfrog steps of ALL chains on ALL GPUs in the timed region (sum of tree_size) / wall seconds
+roofline.achieved = algorithmic bytes (60*d per leapfrog step) / kernel time by HIP events
+cpu_baseline      = the numpy oracle (a port of the reference, oracle/lmc_oracle.py) on this box's host
+                    cores, one chain per core, same recipe, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK = 8.0e12      # B/s, MI355X spec (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.3 TB/s achievable)
+SEED = 20260928
+
+
+def make_target(lmc, name, dim):
+    if name == "ar1":
+        return lmc.targets.AR1(dim, 0.9), "AR(1) rho=0.9 correlated Gaussian"
+    if name == "std_normal":
+        return lmc.targets.StdNormal(dim), "standard normal"
+    if name == "funnel":
+        return lmc.targets.Funnel(dim), "Neal's funnel"
+    if name == "diag":
+        return lmc.targets.DiagGaussian.ill_conditioned(dim, 1e4), "ill-conditioned diagonal Gaussian kappa=1e4"
+    raise SystemExit("unknown target %s" % name)
+
+
+def cpu_baseline_worker(args):
+    """One oracle chain (a port of the reference's sequential path) -> (leapfrogs, seconds)."""
+    name, dim, tune, draws, seed, start = args
+    sys.path.insert(0, ROOT)
+    from oracle import lmc_oracle as orc
+    from oracle import targets as OT
+
+    f = {"ar1": lambda: OT.AR1(dim, 0.9), "std_normal": lambda: OT.StdNormal(dim), "funnel": lambda: OT.Funnel(dim),
+         "diag": lambda: OT.DiagGaussian.ill_conditioned(dim, 1e4)}[name]()
+    pot = orc.DiagAdaptPotential(dim, start, np.ones(dim), 10)
+    step = orc.Step(f, dim, kind="nuts", potential=pot)
+    t0 = time.perf_counter()
+    _tr, st = orc.sample(f, dim, draws=draws, tune=tune, step=step, chains=1, start=start, random_seed=[seed],
+                         discard_tuned_samples=False)
+    return float(st["tree_size"].sum()), time.perf_counter() - t0
+
+
+def cpu_baseline(name, dim, seeds, start, budget_iters):
+    import multiprocessing as mp
+
+    cores = os.cpu_count() or 1
+    tune = draws = budget_iters // 2
+    jobs = [(name, dim, tune, draws, int(seeds[i % len(seeds)]), start) for i in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(cpu_baseline_worker, jobs)
+    wall = time.perf_counter() - t0
+    leap = sum(r[0] for r in res)
+    return {
+        "value": leap / wall, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+        "sample": "%d chains (1 per core) x (tune %d + draws %d), %s d=%d, numpy oracle; %.0f leapfrogs in %.1f s"
+                  % (cores, tune, draws, name, dim, leap, wall),
+        "per_core": leap / wall / cores,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chains", type=int, default=65536, help="chains PER GPU")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--target", default="ar1", choices=["ar1", "std_normal", "funnel", "diag"])
+    ap.add_argument("--iters-per-step", type=int, default=100, help="NUTS iterations per chain per launch")
+    ap.add_argument("--max-treedepth", type=int, default=10)
+    ap.add_argument("--no-trace", action="store_true", help="do not store draws (statistics only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=600, help="iterations per oracle chain in the CPU baseline")
+    ap.add_argument("--lds-levels", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import littlemcmc_amd as lmc
+    from littlemcmc_amd import _abi
+
+    K, W, ips = args.steps, args.warmup, args.iters_per_step
+    n_total = K * ips
+    n_tune = n_total // 2
+    chains = args.chains
+    target, target_desc = make_target(lmc, args.target, args.dim)
+
+    # seeds: sample()'s own derivation over the GLOBAL chain index space (prefix stable), block per rank
+    np.random.seed(SEED)
+    seeds_all = np.array([np.random.randint(2 ** 30) for _ in range(chains * world)], dtype=np.uint32)
+    np.random.seed(int(seeds_all[0]))
+    start = 2 * np.random.rand(args.dim) - 1            # init_nuts jitter (sampling.py:574-584)
+    seeds = seeds_all[rank * chains:(rank + 1) * chains]
+
+    step = lmc.NUTS(target, args.dim, potential=lmc.QuadPotentialDiagAdapt(args.dim, start, np.ones(args.dim), 10),
+                    max_treedepth=args.max_treedepth)
+    kw = step._engine_kwargs()
+    kw["lds_levels"] = args.lds_levels
+    stream = torch.cuda.current_stream()
+
+    def new_job(capacity, tune, keep_trace):
+        eng = lmc.Engine(target, chains=chains, device=local_rank, **kw)
+        step.potential._push_initial(eng)
+        eng.set_stream(stream.cuda_stream)
+        eng.seed(seeds)
+        eng.set_position(start)
+        eng.reset_tuning()
+        eng.reserve(capacity, keep_trace=keep_trace, trace_begin=tune)
+        return eng
+
+    # ---- warm-up: W launches of a throw-away copy of the job
+    if W > 0:
+        warm = new_job(W * ips, (W * ips) // 2, keep_trace=False)
+        for s in range(W):
+            warm.run((W * ips) // 2, s * ips, ips)
+        warm.synchronize()
+        warm.close()
+
+    eng = new_job(n_total, n_tune, keep_trace=not args.no_trace)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(K):
+        ev[s][0].record(stream)
+        eng.run(n_tune, s * ips, ips)
+        ev[s][1].record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    ct = eng.counters()
+    leap_local = float(ct[:, _abi.CT_LEAPFROGS].sum())
+    status = eng.status()
+    if status.any():
+        raise SystemExit("chains reported failure status bits: %s" % np.unique(status))
+    depth_mean = float(eng.stat_i32(_abi.STAT_DEPTH, n_tune, n_total - n_tune).mean()) if n_total > n_tune else 0.0
+    div_after = int(ct[:, _abi.CT_DIVS_AFTER_TUNE].sum())
+    eng.close()
+
+    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    leap_t = torch.tensor([leap_local], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(leap_t, op=dist.ReduceOp.SUM)
+    wall_max, leap_all = float(wall_t.item()), float(leap_t.item())
+
+    if rank == 0:
+        value = leap_all / wall_max
+        kern_s = sum(kernel_ms) / 1e3
+        bytes_per_leap = 60 * args.dim
+        achieved = leap_local * bytes_per_leap / kern_s          # this GPU's kernel, algorithmic bytes / kernel time
+        out = {
+            "metric": "leapfrog-steps/sec (all chains)", "value": value, "unit": "leapfrog-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall_max * 1e3 / K,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "C3: %d chains/GPU x dim %d %s, NUTS max_treedepth=%d, diag mass adapt, "
+                            "tune %d + draws %d in %d launches of %d iterations"
+                            % (chains, args.dim, target_desc, args.max_treedepth, n_tune, n_total - n_tune, K, ips),
+                "chains_per_gpu": chains, "dim": args.dim, "target": args.target, "tune": n_tune,
+                "draws": n_total - n_tune, "rng": "MT19937 (numpy legacy stream, same-seed parity mode)",
+                "trace_in_hbm": not args.no_trace, "parallelism": "chain-block x%d" % world,
+            },
+            "leapfrogs": leap_all, "wall_s": wall_max, "mean_depth_draws": depth_mean,
+            "divergences_after_tune": div_after,
+            "roofline": {
+                "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK, "traffic": None,
+                "kernel": "lmc::run_kernel<NS=%d>" % max(1, (args.dim + 63) // 64),
+                "kernel_ms_avg": sum(kernel_ms) / K, "algorithmic_bytes_per_leapfrog": bytes_per_leap,
+                "read_only_frac": leap_local * 28 * args.dim / kern_s / HBM_PEAK,
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.target, args.dim, seeds_all[:64], start, args.cpu_iters)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -162,11 +162,12 @@ int lmc_engine_set_dual_average(lmc_engine* e, double log_step, double log_bar, 
                                 int32_t count);
 
 /* ---- sampling: the body of _iter_sample (sampling.py:507-521) for ALL chains ---------------------
- * reserve(): allocate output storage for `capacity` iterations per chain (trace optional).
+ * reserve(): allocate output storage for `capacity` iterations per chain. Draws are stored for iterations
+ *        >= trace_begin (0 = all, tune = discard_tuned_samples, < 0 = keep no trace: statistics only).
  * run(): iterations [iter_begin, iter_begin + n_iters) of every chain; iterations with global index
  *        < n_tune are tuning iterations (stop_tuning happens at index n_tune, sampling.py:510-511).
  *        Asynchronous on the engine's stream. */
-int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int32_t keep_trace);
+int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int64_t trace_begin);
 int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters);
 
 /* ---- results (synchronise the stream). dst shapes: trace [chains][n_iters][dim]; stats [chains][n_iters] */
@@ -174,10 +175,13 @@ int lmc_engine_get_trace(lmc_engine* e, double* dst, int64_t iter_begin, int64_t
 int lmc_engine_get_stat_f64(lmc_engine* e, int32_t stat, double* dst, int64_t iter_begin, int64_t n_iters);
 int lmc_engine_get_stat_i32(lmc_engine* e, int32_t stat, int32_t* dst, int64_t iter_begin, int64_t n_iters);
 int lmc_engine_get_stat_u8(lmc_engine* e, int32_t stat, uint8_t* dst, int64_t iter_begin, int64_t n_iters);
-/* Device pointers of the engine-owned outputs for zero-copy consumers (layout [chains][capacity][dim]
- * and [n_stats][chains][capacity]); valid until the next reserve()/destroy(). */
+/* Device pointers of the engine-owned outputs for zero-copy consumers (trace layout
+ * [chains][capacity - trace_begin][dim], stats [n_stats][chains][capacity]); valid until the next
+ * reserve()/destroy(). */
 void* lmc_engine_trace_device_ptr(lmc_engine* e);
 void* lmc_engine_stat_f64_device_ptr(lmc_engine* e);
+void* lmc_engine_stat_i32_device_ptr(lmc_engine* e);
+int64_t lmc_engine_trace_begin(lmc_engine* e);
 int64_t lmc_engine_capacity(lmc_engine* e);
 
 /* adaptation state: potential._var [chains][dim] (float32), step_adapt fields [chains][4] =

@@ -76,7 +76,7 @@ _SIGNATURES = {
     "lmc_engine_get_position": (C.c_int, [_P, _P]),
     "lmc_engine_reset_tuning": (C.c_int, [_P]),
     "lmc_engine_set_dual_average": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_int32]),
-    "lmc_engine_reserve": (C.c_int, [_P, C.c_int64, C.c_int32]),
+    "lmc_engine_reserve": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "lmc_engine_run": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32]),
     "lmc_engine_get_trace": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "lmc_engine_get_stat_f64": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int64]),
@@ -84,6 +84,8 @@ _SIGNATURES = {
     "lmc_engine_get_stat_u8": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int64]),
     "lmc_engine_trace_device_ptr": (_P, [_P]),
     "lmc_engine_stat_f64_device_ptr": (_P, [_P]),
+    "lmc_engine_stat_i32_device_ptr": (_P, [_P]),
+    "lmc_engine_trace_begin": (C.c_int64, [_P]),
     "lmc_engine_capacity": (C.c_int64, [_P]),
     "lmc_engine_get_adapt_state": (C.c_int, [_P, _P, _P, _P, _P]),
     "lmc_engine_get_chain_state": (C.c_int, [_P, C.POINTER(ChainState)]),

@@ -664,8 +664,9 @@ int lmc_engine_set_dual_average(lmc_engine* e, double log_step, double log_bar, 
     return LMC_OK;
 }
 
-int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int32_t keep_trace) {
+int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int64_t trace_begin) {
     if (!e || capacity < 1) return fail(e, LMC_ERR_INVALID, "capacity must be >= 1");
+    const bool keep_trace = trace_begin >= 0 && trace_begin < capacity;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     ChainArrays& A = e->A;
@@ -675,7 +676,8 @@ int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int32_t keep_trace) {
     dev_free(e, A.stat_u8); A.stat_u8 = nullptr;
     const size_t C = e->cfg.chains, cap = static_cast<size_t>(capacity);
     int rc;
-    if (keep_trace && (rc = dev_alloc(e, &A.trace, C * cap * e->cfg.dim, false)) != LMC_OK) return rc;
+    if (keep_trace && (rc = dev_alloc(e, &A.trace, C * (cap - static_cast<size_t>(trace_begin)) * e->cfg.dim, false)) != LMC_OK) return rc;
+    A.trace_begin = keep_trace ? trace_begin : 0;
     if ((rc = dev_alloc(e, &A.stat_f64, kNumStatF64 * C * cap)) != LMC_OK) return rc;
     if ((rc = dev_alloc(e, &A.stat_i32, kNumStatI32 * C * cap)) != LMC_OK) return rc;
     if ((rc = dev_alloc(e, &A.stat_u8, kNumStatU8 * C * cap)) != LMC_OK) return rc;
@@ -747,8 +749,16 @@ static int check_window(lmc_engine* e, const void* dst, int64_t iter_begin, int6
 int lmc_engine_get_trace(lmc_engine* e, double* dst, int64_t iter_begin, int64_t n_iters) {
     int rc = check_window(e, dst, iter_begin, n_iters);
     if (rc != LMC_OK) return rc;
-    if (!e->A.trace) return fail(e, LMC_ERR_STATE, "trace was not reserved (keep_trace = 0)");
-    return copy_rows(e, dst, e->A.trace, sizeof(double), iter_begin, n_iters, e->cfg.dim);
+    if (!e->A.trace) return fail(e, LMC_ERR_STATE, "no trace was reserved (trace_begin < 0)");
+    if (iter_begin < e->A.trace_begin)
+        return fail(e, LMC_ERR_INVALID, "draws before iteration %lld were not stored", (long long)e->A.trace_begin);
+    const size_t C = e->cfg.chains, d = e->cfg.dim;
+    const size_t rows = static_cast<size_t>(e->A.cap - e->A.trace_begin);
+    const double* src = e->A.trace + static_cast<size_t>(iter_begin - e->A.trace_begin) * d;
+    HIP_TRY(e, hipMemcpy2DAsync(dst, n_iters * d * sizeof(double), src, rows * d * sizeof(double),
+                                n_iters * d * sizeof(double), C, hipMemcpyDefault, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return LMC_OK;
 }
 
 int lmc_engine_get_stat_f64(lmc_engine* e, int32_t stat, double* dst, int64_t iter_begin, int64_t n_iters) {
@@ -777,6 +787,8 @@ int lmc_engine_get_stat_u8(lmc_engine* e, int32_t stat, uint8_t* dst, int64_t it
 
 void* lmc_engine_trace_device_ptr(lmc_engine* e) { return e ? e->A.trace : nullptr; }
 void* lmc_engine_stat_f64_device_ptr(lmc_engine* e) { return e ? e->A.stat_f64 : nullptr; }
+void* lmc_engine_stat_i32_device_ptr(lmc_engine* e) { return e ? e->A.stat_i32 : nullptr; }
+int64_t lmc_engine_trace_begin(lmc_engine* e) { return e ? e->A.trace_begin : 0; }
 int64_t lmc_engine_capacity(lmc_engine* e) { return e ? e->A.cap : 0; }
 
 int lmc_engine_get_adapt_state(lmc_engine* e, float* var, double* dual_avg, int32_t* da_count, int32_t* n_samples) {
@@ -836,18 +848,38 @@ static int chain_state_xfer(lmc_engine* e, const lmc_chain_state* st, bool to_us
                 return fail(e, LMC_ERR_INVALID, "the Welford fields must be set together");
             HIP_TRY(e, hipMemcpy(A.wsel, wsel.data(), C * sizeof(int), hipMemcpyHostToDevice));
         }
-    } else {
-        for (size_t c = 1; c < C; ++c)
-            if (wsel[c] != wsel[0]) {   // chains switch windows in lockstep (same n_samples); guard anyway
-                return fail(e, LMC_ERR_STATE, "chains are in different adaptation windows; read state per launch boundary");
-            }
     }
-    const int f = wsel[0], b = 1 - wsel[0];
     if (st->var && (rc = copy_vec_rows(e, st->var, A.var, sizeof(float), to_user)) != LMC_OK) return rc;
-    if (st->fore_mean && (rc = copy_vec_rows(e, st->fore_mean, A.wmean + f * plane, sizeof(double), to_user)) != LMC_OK) return rc;
-    if (st->fore_raw_var && (rc = copy_vec_rows(e, st->fore_raw_var, A.wraw + f * plane, sizeof(double), to_user)) != LMC_OK) return rc;
-    if (st->back_mean && (rc = copy_vec_rows(e, st->back_mean, A.wmean + b * plane, sizeof(double), to_user)) != LMC_OK) return rc;
-    if (st->back_raw_var && (rc = copy_vec_rows(e, st->back_raw_var, A.wraw + b * plane, sizeof(double), to_user)) != LMC_OK) return rc;
+    if (!to_user) {
+        if (st->fore_mean && (rc = copy_vec_rows(e, st->fore_mean, A.wmean, sizeof(double), false)) != LMC_OK) return rc;
+        if (st->fore_raw_var && (rc = copy_vec_rows(e, st->fore_raw_var, A.wraw, sizeof(double), false)) != LMC_OK) return rc;
+        if (st->back_mean && (rc = copy_vec_rows(e, st->back_mean, A.wmean + plane, sizeof(double), false)) != LMC_OK) return rc;
+        if (st->back_raw_var && (rc = copy_vec_rows(e, st->back_raw_var, A.wraw + plane, sizeof(double), false)) != LMC_OK) return rc;
+    } else if (st->fore_mean || st->fore_raw_var || st->back_mean || st->back_raw_var) {
+        // chains may sit in different adaptation windows (slot wsel[c] is the foreground): select per chain
+        const size_t d = e->cfg.dim, dp = e->dpad;
+        std::vector<double> host(2 * plane);
+        auto gather = [&](const double* dev, double* fore, double* back) -> int {
+            HIP_TRY(e, hipMemcpy(host.data(), dev, 2 * plane * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t c = 0; c < C; ++c) {
+                const double* f0 = host.data() + static_cast<size_t>(wsel[c]) * plane + c * dp;
+                const double* b0 = host.data() + static_cast<size_t>(1 - wsel[c]) * plane + c * dp;
+                if (fore) HIP_TRY(e, hipMemcpy(fore + c * d, f0, d * sizeof(double), hipMemcpyDefault));
+                if (back) HIP_TRY(e, hipMemcpy(back + c * d, b0, d * sizeof(double), hipMemcpyDefault));
+            }
+            return LMC_OK;
+        };
+        if ((st->fore_mean || st->back_mean) && (rc = gather(A.wmean, st->fore_mean, st->back_mean)) != LMC_OK) return rc;
+        if ((st->fore_raw_var || st->back_raw_var) && (rc = gather(A.wraw, st->fore_raw_var, st->back_raw_var)) != LMC_OK) return rc;
+    }
+    if (to_user && (st->fore_w_sum || st->back_w_sum)) {
+        std::vector<double> w(2 * C);
+        HIP_TRY(e, hipMemcpy(w.data(), A.wsum, 2 * C * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<double> fw(C), bw(C);
+        for (size_t c = 0; c < C; ++c) { fw[c] = w[2 * c + wsel[c]]; bw[c] = w[2 * c + 1 - wsel[c]]; }
+        if (st->fore_w_sum) HIP_TRY(e, hipMemcpy(st->fore_w_sum, fw.data(), C * sizeof(double), hipMemcpyDefault));
+        if (st->back_w_sum) HIP_TRY(e, hipMemcpy(st->back_w_sum, bw.data(), C * sizeof(double), hipMemcpyDefault));
+    }
     auto strided = [&](double* user, double* dev, int stride, int off) -> int {   // [C] <-> dev[c*stride+off]
         if (!user) return LMC_OK;
         if (to_user)
@@ -856,8 +888,10 @@ static int chain_state_xfer(lmc_engine* e, const lmc_chain_state* st, bool to_us
             HIP_TRY(e, hipMemcpy2D(dev + off, stride * sizeof(double), user, sizeof(double), sizeof(double), C, hipMemcpyDefault));
         return LMC_OK;
     };
-    if ((rc = strided(st->fore_w_sum, A.wsum, 2, f)) != LMC_OK) return rc;
-    if ((rc = strided(st->back_w_sum, A.wsum, 2, b)) != LMC_OK) return rc;
+    if (!to_user) {
+        if ((rc = strided(st->fore_w_sum, A.wsum, 2, 0)) != LMC_OK) return rc;
+        if ((rc = strided(st->back_w_sum, A.wsum, 2, 1)) != LMC_OK) return rc;
+    }
     if ((rc = strided(st->log_step, A.da, 4, 0)) != LMC_OK) return rc;
     if ((rc = strided(st->log_bar, A.da, 4, 1)) != LMC_OK) return rc;
     if ((rc = strided(st->hbar, A.da, 4, 2)) != LMC_OK) return rc;

@@ -65,7 +65,8 @@ struct ChainArrays {
     double* scratch;      // [C][scratch_stride]
     long long scratch_stride;
     // outputs (row = iteration index relative to the engine's reserved capacity)
-    double* trace;        // [C][cap][d] or nullptr
+    double* trace;        // [C][cap - trace_begin][d] or nullptr
+    long long trace_begin; // first iteration whose draw is stored
     double* stat_f64;     // [kNumStatF64][C][cap]
     int* stat_i32;        // [kNumStatI32][C][cap]
     unsigned char* stat_u8;  // [kNumStatU8][C][cap]
@@ -640,8 +641,8 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
 
         // ---- outputs: draw row + stats
         const long long orow = static_cast<long long>(c) * A.cap + git;
-        if (A.trace != nullptr) {
-            double* tr = A.trace + orow * d;
+        if (A.trace != nullptr && git >= A.trace_begin) {
+            double* tr = A.trace + (static_cast<long long>(c) * (A.cap - A.trace_begin) + (git - A.trace_begin)) * d;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int e = lane * NS + s;

@@ -58,6 +58,7 @@ class Engine:
         self._check(self._lib.lmc_engine_set_target_params(self._h, _abi.ptr(params), params.size))
         self.capacity = 0
         self.keep_trace = False
+        self.trace_begin = 0
 
     # ---- plumbing ---------------------------------------------------------------------------------
     def _check(self, rc, handle=True):
@@ -132,15 +133,19 @@ class Engine:
                                                           int(count)))
 
     # ---- sampling -----------------------------------------------------------------------------------
-    def reserve(self, capacity, keep_trace=True):
-        self._check(self._lib.lmc_engine_reserve(self._h, int(capacity), int(bool(keep_trace))))
+    def reserve(self, capacity, keep_trace=True, trace_begin=0):
+        """Output storage for ``capacity`` iterations; draws kept for iterations >= trace_begin."""
+        tb = int(trace_begin) if keep_trace else -1
+        self._check(self._lib.lmc_engine_reserve(self._h, int(capacity), tb))
         self.capacity = int(capacity)
-        self.keep_trace = bool(keep_trace)
+        self.keep_trace = bool(keep_trace) and tb < capacity
+        self.trace_begin = max(tb, 0)
 
     def run(self, n_tune, iter_begin, n_iters):
         self._check(self._lib.lmc_engine_run(self._h, int(n_tune), int(iter_begin), int(n_iters)))
 
-    def trace(self, iter_begin=0, n_iters=None):
+    def trace(self, iter_begin=None, n_iters=None):
+        iter_begin = self.trace_begin if iter_begin is None else iter_begin
         n = self.capacity - iter_begin if n_iters is None else n_iters
         out = np.empty((self.chains, n, self.dim))
         self._check(self._lib.lmc_engine_get_trace(self._h, _abi.ptr(out), int(iter_begin), int(n)))
@@ -166,6 +171,12 @@ class Engine:
 
     def trace_device_ptr(self):
         return self._lib.lmc_engine_trace_device_ptr(self._h)
+
+    def stat_i32_device_ptr(self):
+        return self._lib.lmc_engine_stat_i32_device_ptr(self._h)
+
+    def stat_f64_device_ptr(self):
+        return self._lib.lmc_engine_stat_f64_device_ptr(self._h)
 
     def adapt_state(self):
         var = np.empty((self.chains, self.dim), dtype=np.float32)

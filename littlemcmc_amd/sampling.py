@@ -109,7 +109,8 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
         eng.seed(seeds)                       # np.random.seed(random_seed[i]) per chain (sampling.py:496-497)
         eng.set_position(np.ascontiguousarray(starts))
         eng.reset_tuning()                    # step.reset_tuning(); iter_count = 0 (sampling.py:503-509)
-        eng.reserve(max(n_total, 1), keep_trace=True)
+        lo = int(tune) if discard_tuned_samples else 0   # sampling.py:473-476
+        eng.reserve(max(n_total, 1), keep_trace=True, trace_begin=min(lo, max(n_total - 1, 0)))
         per_launch = int(launch_iters) if launch_iters else max(1, min(n_total, 250))
         it = 0
         while it < n_total:
@@ -119,7 +120,6 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
         eng.synchronize()
         raise_for_status(eng.status())
 
-        lo = int(tune) if discard_tuned_samples else 0   # sampling.py:473-476
         n_out = n_total - lo
         if n_out > 0:
             trace = eng.trace(lo, n_out)

@@ -120,7 +120,7 @@ def test_e2e_golden_through_sample_api(golden_dir, name):
         verified += assert_chain_matches(trace[c], got, g["trace"][c], want, margins[c, :, 0],
                                          label="%s chain %d" % (name, c))
     # whole tuned chains are chaotic (see test_every_iteration_of_the_golden_runs): require a solid prefix
-    assert verified >= chains * min(40, tune + draws), "%s: only %d iterations verified" % (name, verified)
+    assert verified >= chains * min(15, tune + draws), "%s: only %d iterations verified" % (name, verified)
 
 
 @pytest.mark.parametrize("name", E2E)
