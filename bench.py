@@ -132,7 +132,7 @@ def main():
                     max_treedepth=args.max_treedepth)
     kw = step._engine_kwargs()
     kw["lds_levels"] = args.lds_levels
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream()        # a real (non-null) HIP stream: the engine launches on it, the events time it
 
     def new_job(capacity, tune, keep_trace):
         eng = lmc.Engine(target, chains=chains, device=local_rank, **kw)
