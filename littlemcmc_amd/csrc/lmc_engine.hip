@@ -134,12 +134,14 @@ __global__ __launch_bounds__(64) void trajectory_kernel(ChainArrays A, const dou
     tgt.init(tparams, d);
     double q[NS], p[NS], g[NS];
     float var[NS];
+    double vard[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int e = lane * NS + s;
         q[s] = (e < d) ? q0[static_cast<long long>(c) * d + e] : 0.0;
         p[s] = (e < d) ? p0[static_cast<long long>(c) * d + e] : 0.0;
         var[s] = A.var[row + e];
+        vard[s] = static_cast<double>(var[s]);
     }
     const int n_states = n_fwd + n_back + 1;
     double logp = tgt.logp_grad(q, g);
@@ -157,11 +159,11 @@ __global__ __launch_bounds__(64) void trajectory_kernel(ChainArrays A, const dou
     } else {
 #pragma unroll
         for (int s = 0; s < NS; ++s) v[s] = static_cast<double>(var[s]) * p[s];
-        energy = 0.5 * wave_sum(pdot_v<NS>(p, var, p)) - logp;
+        energy = 0.5 * wave_sum(pdot_v<NS>(p, vard, p)) - logp;
     }
     for (int k = 0; k < n_states; ++k) {
         if (k > 0) {
-            leapfrog<NS>(tgt, var, (k <= n_fwd) ? eps : -eps, q, p, g, energy, logp);
+            leapfrog<NS>(tgt, vard, (k <= n_fwd) ? eps : -eps, q, p, g, energy, logp);
 #pragma unroll
             for (int s = 0; s < NS; ++s) v[s] = static_cast<double>(var[s]) * p[s];
         }

@@ -129,6 +129,35 @@ __device__ inline double rng_uniform(RngState& r) {
     return first_f64(mt_words_to_double(w0, w1));
 }
 
+// Look-ahead window over the stream: lane l holds the l-th upcoming 53-bit double. A tree transition
+// draws one uniform per merge; reading them from registers (v_readlane with a uniform index) keeps the
+// two dependent HBM/L2 word loads off every merge's critical path. The window is only valid while
+// nothing else advances the stream (empty it with window_reset() around rng_normals()).
+struct UniformWindow {
+    double val;
+    int n;      // doubles available in the window
+    int idx;    // next one to hand out
+};
+__device__ __forceinline__ void window_reset(UniformWindow& w) { w.val = 0.0; w.n = 0; w.idx = 0; }
+
+__device__ inline double window_next(RngState& r, UniformWindow& w) {
+    if (w.idx == w.n) {   // (re)fill from the current stream position
+        if (r.pos >= kMtN) mt_regen(r);
+        int n = (kMtN - r.pos) >> 1;
+        n = n > 64 ? 64 : n;
+        const int lane = lane_id();
+        double v = 0.0;
+        if (lane < n) v = mt_words_to_double(r.mt[r.pos + 2 * lane], r.mt[r.pos + 2 * lane + 1]);
+        w.val = v;
+        w.n = n;
+        w.idx = 0;
+    }
+    const double u = readlane_f64(w.val, w.idx);
+    ++w.idx;
+    r.pos += 2;
+    return u;
+}
+
 // normal(size=d) -> out[0..d) (LDS or global scratch, any lane may write any slot).
 // Consumer order: attempt k accepted => normals (f*x2, f*x1) in that order; an odd tail leaves
 // f*x1 in the cache for the next call (numpy legacy_gauss).

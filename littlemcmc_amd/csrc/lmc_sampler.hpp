@@ -124,19 +124,19 @@ __device__ __forceinline__ void vcopy(double (&dst)[NS], const double (&src)[NS]
 
 // partial (per-lane) dot of a with var (.) b, i.e. numpy's a.dot(velocity(b))
 template <int NS>
-__device__ __forceinline__ double pdot_v(const double (&a)[NS], const float (&var)[NS], const double (&b)[NS]) {
+__device__ __forceinline__ double pdot_v(const double (&a)[NS], const double (&var)[NS], const double (&b)[NS]) {
     double acc = 0.0;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) acc = __builtin_fma(a[s], static_cast<double>(var[s]) * b[s], acc);
+    for (int s = 0; s < NS; ++s) acc = __builtin_fma(a[s], var[s] * b[s], acc);
     return acc;
 }
 // same with the float32 velocity of a float32 momentum (the start state): v = f32(var * f32(b))
 template <int NS>
-__device__ __forceinline__ double pdot_v32(const double (&a)[NS], const float (&var)[NS], const double (&b)[NS]) {
+__device__ __forceinline__ double pdot_v32(const double (&a)[NS], const double (&var)[NS], const double (&b)[NS]) {
     double acc = 0.0;
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-        acc = __builtin_fma(a[s], static_cast<double>(var[s] * static_cast<float>(b[s])), acc);
+        acc = __builtin_fma(a[s], static_cast<double>(static_cast<float>(var[s]) * static_cast<float>(b[s])), acc);
     return acc;
 }
 
@@ -227,26 +227,42 @@ __device__ inline float start_kinetic_f32(const double (&p0)[NS], const float (&
 // ---- leapfrog (integration.py:100-121) -------------------------------------------------------------
 // In/out: q, p, g. Out: energy, logp. Every elementwise operation is the same rounded IEEE
 // operation as numpy's (TU built with -ffp-contract=off); only the two reductions differ in order.
+// Targets whose log-density is a plain lane sum (kLanePartial) hand back the per-lane partial, so
+// logp and the kinetic energy share ONE interleaved butterfly instead of two dependent ones.
 template <int NS, class Target>
-__device__ __forceinline__ void leapfrog(const Target& tgt, const float (&var)[NS], double eps,
+__device__ __forceinline__ void leapfrog(const Target& tgt, const double (&var)[NS], double eps,
                                          double (&q)[NS], double (&p)[NS], double (&g)[NS],
                                          double& energy, double& logp) {
     const double dt = 0.5 * eps;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         p[s] = p[s] + dt * g[s];
-        const double v = static_cast<double>(var[s]) * p[s];
+        const double v = var[s] * p[s];
         q[s] = q[s] + eps * v;
     }
-    logp = first_f64(tgt.logp_grad(q, g));
-    double part = 0.0;
+    if constexpr (Target::kLanePartial) {
+        double parts[2];
+        parts[0] = tgt.logp_grad_partial(q, g);
+        double kin = 0.0;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        p[s] = p[s] + dt * g[s];
-        const double v = static_cast<double>(var[s]) * p[s];
-        part = __builtin_fma(p[s], v, part);
+        for (int s = 0; s < NS; ++s) {
+            p[s] = p[s] + dt * g[s];
+            kin = __builtin_fma(p[s], var[s] * p[s], kin);
+        }
+        parts[1] = kin;
+        wave_sum_n<2>(parts);
+        logp = parts[0];
+        energy = first_f64(0.5 * parts[1] - logp);
+    } else {
+        logp = first_f64(tgt.logp_grad(q, g));
+        double kin = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            p[s] = p[s] + dt * g[s];
+            kin = __builtin_fma(p[s], var[s] * p[s], kin);
+        }
+        energy = first_f64(0.5 * wave_sum(kin) - logp);
     }
-    energy = first_f64(0.5 * wave_sum(part) - logp);
 }
 
 // ---- subtree stack -----------------------------------------------------------------------------------
@@ -263,13 +279,20 @@ struct TreeStack {
     }
 };
 
+// Tree weights are kept in the LINEAR domain: w = exp(-dE - c) with one offset c per transition.
+// The reference carries log-weights and pays logaddexp (exp + log1p) twice plus log(U) per merge
+// (nuts.py:322-328, :399-404); in the linear domain a merge is two additions and the multinomial
+// choice is  U * (w_a + w_b) < w_b  -- the same event as  log U < ls_b - logaddexp(ls_a, ls_b).
+// One exp per LEAF replaces five transcendental evaluations per MERGE. c starts at 0 (start state
+// weight 1) and is only moved (cold path) when a leaf's -dE exceeds it by 600, so nothing overflows
+// for |dE| < Emax; results differ from the log-domain form by a few ulps of the weights.
 struct LevelScalars {   // lane j holds level j
-    double ls, lwas, pe, plogp;
-    __device__ __forceinline__ void put(int j, double a, double b, double c, double d) {
-        if (lane_id() == j) { ls = a; lwas = b; pe = c; plogp = d; }
+    double w, a, pe, plogp;
+    __device__ __forceinline__ void put(int j, double w_, double a_, double c, double d) {
+        if (lane_id() == j) { w = w_; a = a_; pe = c; plogp = d; }
     }
-    __device__ __forceinline__ void get(int j, double& a, double& b, double& c, double& d) const {
-        a = readlane_f64(ls, j); b = readlane_f64(lwas, j); c = readlane_f64(pe, j); d = readlane_f64(plogp, j);
+    __device__ __forceinline__ void get(int j, double& w_, double& a_, double& c, double& d) const {
+        w_ = readlane_f64(w, j); a_ = readlane_f64(a, j); c = readlane_f64(pe, j); d = readlane_f64(plogp, j);
     }
 };
 
@@ -287,7 +310,7 @@ struct TransitionOut {
 // ---- NUTS transition -----------------------------------------------------------------------------------
 // q0/p0/g0: start state (p0 float32-valued when momentum_f32). On return q holds the proposal.
 template <int NS, class Target>
-__device__ inline void nuts_transition(const Target& tgt, const float (&var)[NS], RngState& rng,
+__device__ inline void nuts_transition(const Target& tgt, const double (&var)[NS], RngState& rng,
                                        const TreeStack& stk, double (&q)[NS], const double (&p0)[NS],
                                        const double (&g0)[NS], double e0, double logp0, double step_size,
                                        double emax, int max_depth, bool momentum_f32, TransitionOut& out) {
@@ -298,13 +321,18 @@ __device__ inline void nuts_transition(const Target& tgt, const float (&var)[NS]
     vcopy(psum, p0); vcopy(propq, q);
     bool l_start = momentum_f32, r_start = momentum_f32;   // end still is the float32 start state
     double prop_e = e0, prop_logp = logp0;
-    double log_size = 0.0, lwas = -INFINITY, max_de = 0.0;
+    double coff = 0.0;          // weight offset c
+    double w_start = 1.0;       // exp(0 - c): the start state's weight
+    double wn = 0.0, an = 0.0;  // accepted subtrees: sum of weights, sum of weight * min(1, e^{-dE})
+    double max_de = 0.0;
     int depth = 0, n_leap = 0;
-    bool diverging = false, turning = false, exhausted = true, nan_lb = false;
+    bool diverging = false, turning = false, exhausted = true;
     LevelScalars lsc = {0.0, 0.0, 0.0, 0.0};
+    UniformWindow win;
+    window_reset(win);
 
     for (int dd = 0; dd < max_depth; ++dd) {
-        const bool right = rng_uniform(rng) < 0.5;   // log(U) < log(.5), nuts.py:213
+        const bool right = window_next(rng, win) < 0.5;   // log(U) < log(.5), nuts.py:213
         const double eps = right ? step_size : -step_size;
         double cq[NS], cp[NS], cg[NS];
         if (right) { vcopy(cq, Rq); vcopy(cp, Rp); vcopy(cg, Rg); }
@@ -312,7 +340,7 @@ __device__ inline void nuts_transition(const Target& tgt, const float (&var)[NS]
 
         // in-flight node t (registers)
         double tlp[NS], trp[NS], tps[NS], tq[NS];
-        double tls = 0.0, tlwas = 0.0, tpe = 0.0, tplogp = 0.0;
+        double tw = 0.0, ta = 0.0, tpe = 0.0, tplogp = 0.0;
         const int n_leaves = 1 << depth;
         for (int i = 0; i < n_leaves; ++i) {
             double energy, logp;
@@ -322,12 +350,22 @@ __device__ inline void nuts_transition(const Target& tgt, const float (&var)[NS]
             if (isnan(de)) de = INFINITY;
             if (fabs(de) > fabs(max_de)) max_de = de;
             if (!(fabs(de) < emax)) { diverging = true; break; }   // nuts.py:358,370-375
+            const double x = -de;
+            if (x - coff > 600.0) {   // cold path: move the offset, rescale every stored weight
+                const double f = first_f64(exp(coff - x));
+                lsc.w *= f; lsc.a *= f;
+                wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
+                coff = x;
+            }
+            tw = first_f64(exp(x - coff));                                 // e^{log_size}
+            const double sat = (coff == 0.0) ? fmin(1.0, tw) : ((x >= 0.0) ? 1.0 : exp(x));
+            ta = first_f64(tw * sat);                                      // e^{log_p_accept_weighted}
             vcopy(tlp, cp); vcopy(trp, cp); vcopy(tps, cp); vcopy(tq, cq);
-            tls = -de; tlwas = first_f64(-de + fmin(0.0, -de)); tpe = energy; tplogp = logp;
+            tpe = energy; tplogp = logp;
             int j = 0;
             while ((i >> j) & 1) {   // t closes a right child: merge stack[j] (a, earlier) with t (b)
                 double alp[NS], arp[NS], aps[NS], aq[NS];
-                double als, alwas, ape, aplogp;
+                double aw, aa, ape, aplogp;
                 const double* lv = stk.level(j);
                 if (j == 0) {
                     vload<NS>(lv, alp); vcopy(arp, alp); vcopy(aps, alp);
@@ -336,7 +374,7 @@ __device__ inline void nuts_transition(const Target& tgt, const float (&var)[NS]
                     vload<NS>(lv, alp); vload<NS>(lv + stk.dpad, arp);
                     vload<NS>(lv + 2 * stk.dpad, aps); vload<NS>(lv + 3 * stk.dpad, aq);
                 }
-                lsc.get(j, als, alwas, ape, aplogp);
+                lsc.get(j, aw, aa, ape, aplogp);
                 double ps[NS];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) ps[s] = aps[s] + tps[s];
@@ -356,15 +394,13 @@ __device__ inline void nuts_transition(const Target& tgt, const float (&var)[NS]
                     wave_sum_n<2>(dots);
                     turn = (dots[0] <= 0) | (dots[1] <= 0);
                 }
-                const double ls = np_logaddexp(als, tls);
-                const double lw = np_logaddexp(alwas, tlwas);
-                const double lp_sel = first_f64(tls - ls);
-                if (isnan(lp_sel)) nan_lb = true;
-                const bool take_b = first_f64(log(rng_uniform(rng))) < lp_sel;   // nuts.py:404, drawn even if turning
+                const double wsum = first_f64(aw + tw);
+                const double asum = first_f64(aa + ta);
+                const bool take_b = first_f64(window_next(rng, win) * wsum) < tw;   // nuts.py:404 (drawn even if turning)
                 // merged node: left end from a, right end from b(t)
                 vcopy(tlp, alp); vcopy(tps, ps);
                 if (!take_b) { vcopy(tq, aq); tpe = ape; tplogp = aplogp; }
-                tls = ls; tlwas = lw;
+                tw = wsum; ta = asum;
                 ++j;
                 if (turn) { turning = true; break; }
             }
@@ -377,7 +413,7 @@ __device__ inline void nuts_transition(const Target& tgt, const float (&var)[NS]
                     vstore<NS>(lv, tlp); vstore<NS>(lv + stk.dpad, trp);
                     vstore<NS>(lv + 2 * stk.dpad, tps); vstore<NS>(lv + 3 * stk.dpad, tq);
                 }
-                lsc.put(j, tls, tlwas, tpe, tplogp);
+                lsc.put(j, tw, ta, tpe, tplogp);
                 wave_sync();
             }
         }
@@ -385,11 +421,11 @@ __device__ inline void nuts_transition(const Target& tgt, const float (&var)[NS]
         if (diverging || turning) { exhausted = false; break; }
 
         // ---- accepted subtree t: merge into the trajectory (nuts.py:321-340)
-        const double sel = first_f64(tls - log_size);
-        if (isnan(sel)) nan_lb = true;
-        if (first_f64(log(rng_uniform(rng))) < sel) { vcopy(propq, tq); prop_e = tpe; prop_logp = tplogp; }
-        log_size = np_logaddexp(log_size, tls);
-        lwas = np_logaddexp(lwas, tlwas);
+        if (first_f64(window_next(rng, win) * (w_start + wn)) < tw) {   // biased progressive: U < w_sub / w_tree
+            vcopy(propq, tq); prop_e = tpe; prop_logp = tplogp;
+        }
+        wn = first_f64(wn + tw);
+        an = first_f64(an + ta);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {   // in place; float32 storage when the start momentum is float32
             const double t = psum[s] + tps[s];
@@ -424,8 +460,8 @@ __device__ inline void nuts_transition(const Target& tgt, const float (&var)[NS]
         }
     }
 
-    double mean_accept = 0.0;
-    if (log_size > 0) mean_accept = first_f64(exp(lwas - (log_size + log1mexp(log_size))));   // nuts.py:421-425
+    // nuts.py:421-425: exp(lwas - log(e^{log_size} - 1)) == sum(w min(1,w)) / sum(w) over accepted leaves
+    const double mean_accept = (wn > 0.0) ? first_f64(an / wn) : 0.0;
     vcopy(q, propq);
     out.accept = mean_accept;
     out.energy = prop_e;
@@ -437,16 +473,18 @@ __device__ inline void nuts_transition(const Target& tgt, const float (&var)[NS]
     out.diverging = diverging;
     out.exhausted = exhausted;
     out.accepted = 0;
-    out.nan_logbern = nan_lb;
+    out.nan_logbern = 0;
 }
 
 // ---- HMC transition (hmc.py:140-182) -------------------------------------------------------------------
 template <int NS, class Target>
-__device__ inline void hmc_transition(const Target& tgt, const float (&var)[NS], RngState& rng,
+__device__ inline void hmc_transition(const Target& tgt, const double (&var)[NS], RngState& rng,
                                       double (&q)[NS], const double (&p0)[NS], const double (&g0)[NS],
                                       double e0, double logp0, double step_size, double emax,
                                       double path_length, int max_steps, TransitionOut& out) {
-    const double plen = first_f64(rng_uniform(rng) * path_length);
+    UniformWindow win;
+    window_reset(win);
+    const double plen = first_f64(window_next(rng, win) * path_length);
     int n_steps = static_cast<int>(plen / step_size);
     n_steps = n_steps < 1 ? 1 : n_steps;
     n_steps = n_steps > max_steps ? max_steps : n_steps;
@@ -461,7 +499,7 @@ __device__ inline void hmc_transition(const Target& tgt, const float (&var)[NS],
     const double accept = first_f64(fmin(1.0, exp(de)));
     bool accepted = false;
     if (!diverging) {
-        const double u = rng_uniform(rng);
+        const double u = window_next(rng, win);
         if (!(u >= accept)) { accepted = true; vcopy(q, cq); }
     }
     out.accept = accept;
@@ -498,11 +536,13 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
     // ---- load persistent chain state
     double q[NS];
     float var[NS], inv_std[NS];
+    double vard[NS];   // the float32 mass promoted once (every use is a float64 product)
     vload<NS>(A.q + row, q);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         var[s] = A.var[row + lane * NS + s];
         inv_std[s] = A.inv_std[row + lane * NS + s];
+        vard[s] = static_cast<double>(var[s]);
     }
     RngState rng;
     rng.mt = A.mt + static_cast<long long>(c) * kMtN;
@@ -553,7 +593,7 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
             const float kin = start_kinetic_f32<NS>(p0, var, d, P.sdot_mode, reinterpret_cast<float*>(lds), dpad);
             e0 = first_f64(static_cast<double>(kin) - logp0);
         } else {
-            e0 = first_f64(0.5 * wave_sum(pdot_v<NS>(p0, var, p0)) - logp0);
+            e0 = first_f64(0.5 * wave_sum(pdot_v<NS>(p0, vard, p0)) - logp0);
         }
         if (!isfinite(e0)) {   // base_hmc.py:145-148: the reference raises; the chain stops here
             status |= kStatusBadInitialEnergy;
@@ -567,11 +607,11 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
         TransitionOut out;
         if (P.kind == 0) {
             const int md = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
-            nuts_transition<NS>(tgt, var, rng, stk, q, p0, g0, e0, logp0, step_size, P.emax, md,
+            nuts_transition<NS>(tgt, vard, rng, stk, q, p0, g0, e0, logp0, step_size, P.emax, md,
                                 P.momentum_f32 != 0, out);
             if (out.exhausted && !tune) ++ct_maxdepth;
         } else {
-            hmc_transition<NS>(tgt, var, rng, q, p0, g0, e0, logp0, step_size, P.emax, P.path_length,
+            hmc_transition<NS>(tgt, vard, rng, q, p0, g0, e0, logp0, step_size, P.emax, P.path_length,
                                P.max_steps, out);
         }
         if (out.nan_logbern) status |= kStatusNanLogbern;
@@ -609,6 +649,7 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
                     var[s] = static_cast<float>(r[s] / wsum_f);
                     const float sd = sqrtf(var[s]);
                     inv_std[s] = 1.0f / sd;
+                    vard[s] = static_cast<double>(var[s]);
                 }
             }
             vstore<NS>(fm, m); vstore<NS>(fr, r);

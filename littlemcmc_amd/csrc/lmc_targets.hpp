@@ -4,8 +4,12 @@
 //
 // Contract (the "lane-distributed" form of the plug-in):
 //   template <int NS> struct Target {
+//       static constexpr bool kLanePartial = false;
 //       __device__ void init(const double* params, int d);          // once per kernel, per wave
 //       __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const;
+//       // only if kLanePartial: the per-lane partial p_l with logp = sum over lanes of p_l; lets the
+//       // integrator fuse this reduction with the kinetic-energy one
+//       __device__ double logp_grad_partial(const double (&q)[NS], double (&g)[NS]) const;
 //   };
 // Lane l owns elements e = l*NS + s, s < NS; elements with e >= d are padding: they arrive as 0
 // and MUST be returned as 0 in g. The return value (logp) must be wave-uniform; use
@@ -28,21 +32,26 @@ enum TargetFamily : int {
 // logp = -1/2 sum q^2 ; g = -q
 template <int NS>
 struct StdNormalTarget {
+    static constexpr bool kLanePartial = true;
     __device__ void init(const double*, int) {}
-    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
+    __device__ double logp_grad_partial(const double (&q)[NS], double (&g)[NS]) const {
         double part = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             part = __builtin_fma(q[s], q[s], part);
             g[s] = -q[s];
         }
-        return -0.5 * wave_sum(part);
+        return -0.5 * part;   // exact scaling: sum(-q^2/2) == -(sum q^2)/2 bit for bit
+    }
+    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
+        return wave_sum(logp_grad_partial(q, g));
     }
 };
 
 // g = -(prec*q) ; logp = 1/2 q.g  (params = prec[d])
 template <int NS>
 struct DiagGaussianTarget {
+    static constexpr bool kLanePartial = true;
     double prec[NS];
     __device__ void init(const double* params, int d) {
         const int lane = lane_id();
@@ -52,14 +61,17 @@ struct DiagGaussianTarget {
             prec[s] = (e < d) ? params[e] : 0.0;
         }
     }
-    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
+    __device__ double logp_grad_partial(const double (&q)[NS], double (&g)[NS]) const {
         double part = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             g[s] = -(prec[s] * q[s]);
             part = __builtin_fma(q[s], g[s], part);
         }
-        return 0.5 * wave_sum(part);
+        return 0.5 * part;
+    }
+    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
+        return wave_sum(logp_grad_partial(q, g));
     }
 };
 
@@ -67,6 +79,7 @@ struct DiagGaussianTarget {
 // params = {c_end, c_mid, off}
 template <int NS>
 struct AR1Target {
+    static constexpr bool kLanePartial = true;
     double c_end, c_mid, off;
     int d;
     __device__ void init(const double* params, int d_) {
@@ -76,6 +89,9 @@ struct AR1Target {
         d = d_;
     }
     __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
+        return wave_sum(logp_grad_partial(q, g));
+    }
+    __device__ double logp_grad_partial(const double (&q)[NS], double (&g)[NS]) const {
         const int lane = lane_id();
         const double below = from_lane_below(q[NS - 1]);   // element e-1 of this lane's first slot
         const double above = from_lane_above(q[0]);        // element e+1 of this lane's last slot
@@ -92,13 +108,14 @@ struct AR1Target {
             g[s] = (e < d) ? -pq : 0.0;
             part = __builtin_fma(q[s], g[s], part);
         }
-        return 0.5 * wave_sum(part);
+        return 0.5 * part;
     }
 };
 
 // Neal's funnel: v = q_0, x = q_{1..d-1}
 template <int NS>
 struct FunnelTarget {
+    static constexpr bool kLanePartial = false;
     int d;
     __device__ void init(const double*, int d_) { d = d_; }
     __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
@@ -129,6 +146,7 @@ struct FunnelTarget {
 // params = {loc, scale}
 template <int NS>
 struct Normal1DTarget {
+    static constexpr bool kLanePartial = false;
     double loc, scale, lognorm;
     __device__ void init(const double* params, int) {
         loc = params[0];
