@@ -259,6 +259,7 @@ struct lmc_engine {
     float* init_diag = nullptr;    // [C][dpad]
     double init_weight = 10.0;
     bool potential_set = false;
+    double* da_tables = nullptr;   // [2][da_table_len]: sqrt(count), count ** -k
     double initial_step = 0.0;
     std::vector<void*> allocs;
     std::string err;
@@ -486,6 +487,20 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     TRY_ALLOC(dev_alloc(e, &e->init_mean, C * dp));
     TRY_ALLOC(dev_alloc(e, &e->init_diag, C * dp));
     TRY_ALLOC(dev_alloc(e, &e->tparams, 8));
+    {   // dual-averaging tables: sqrt(count), count ** -k with the HOST libm (step_sizes.py:88-89)
+        const int len = 16384;
+        std::vector<double> tab(2 * static_cast<size_t>(len));
+        for (int i = 0; i < len; ++i) {
+            tab[i] = std::sqrt(static_cast<double>(i));
+            tab[len + i] = i > 0 ? std::pow(static_cast<double>(i), -cfg->k) : 0.0;
+        }
+        TRY_ALLOC(dev_alloc(e, &e->da_tables, tab.size(), false));
+        hipError_t ce = hipMemcpy(e->da_tables, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (ce != hipSuccess) return bail(fail(nullptr, LMC_ERR_HIP, "da tables: %s", hipGetErrorString(ce)));
+        A.da_sqrt = e->da_tables;
+        A.da_mk = e->da_tables + len;
+        A.da_table_len = len;
+    }
 #undef TRY_ALLOC
     // default potential of BaseHMC (base_hmc.py:109-113): QuadPotentialDiagAdapt(d, zeros, ones, 10)
     {

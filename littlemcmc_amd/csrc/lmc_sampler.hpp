@@ -54,6 +54,9 @@ struct ChainArrays {
     int* wsel;            // [C]
     int* n_samples;       // [C]
     double* da;           // [C][4] log_step, log_bar, hbar, mu
+    const double* da_sqrt; // [da_table_len] sqrt(count)        (host libm)
+    const double* da_mk;   // [da_table_len] count ** -k        (host libm)
+    int da_table_len;
     int* da_count;        // [C]
     int* iter_count;      // [C]
     uint32_t* mt;         // [C][624]
@@ -241,18 +244,16 @@ __device__ __forceinline__ void leapfrog(const Target& tgt, const double (&var)[
         q[s] = q[s] + eps * v;
     }
     if constexpr (Target::kLanePartial) {
-        double parts[2];
-        parts[0] = tgt.logp_grad_partial(q, g);
+        double lp = tgt.logp_grad_partial(q, g);
         double kin = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             p[s] = p[s] + dt * g[s];
             kin = __builtin_fma(p[s], var[s] * p[s], kin);
         }
-        parts[1] = kin;
-        wave_sum_n<2>(parts);
-        logp = parts[0];
-        energy = first_f64(0.5 * parts[1] - logp);
+        wave_sum2(lp, kin);
+        logp = lp;
+        energy = first_f64(0.5 * kin - logp);
     } else {
         logp = first_f64(tgt.logp_grad(q, g));
         double kin = 0.0;
@@ -352,13 +353,13 @@ __device__ inline void nuts_transition(const Target& tgt, const double (&var)[NS
             if (!(fabs(de) < emax)) { diverging = true; break; }   // nuts.py:358,370-375
             const double x = -de;
             if (x - coff > 600.0) {   // cold path: move the offset, rescale every stored weight
-                const double f = first_f64(exp(coff - x));
+                const double f = exp_uniform(coff - x);
                 lsc.w *= f; lsc.a *= f;
                 wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
                 coff = x;
             }
-            tw = first_f64(exp(x - coff));                                 // e^{log_size}
-            const double sat = (coff == 0.0) ? fmin(1.0, tw) : ((x >= 0.0) ? 1.0 : exp(x));
+            tw = exp_uniform(x - coff);                                    // e^{log_size}
+            const double sat = (coff == 0.0) ? fmin(1.0, tw) : ((x >= 0.0) ? 1.0 : exp_uniform(x));
             ta = first_f64(tw * sat);                                      // e^{log_p_accept_weighted}
             vcopy(tlp, cp); vcopy(trp, cp); vcopy(tps, cp); vcopy(tq, cq);
             tpe = energy; tplogp = logp;
@@ -383,16 +384,12 @@ __device__ inline void nuts_transition(const Target& tgt, const double (&var)[NS
                     double p1[NS], p2[NS];
 #pragma unroll
                     for (int s = 0; s < NS; ++s) { p1[s] = aps[s] + tlp[s]; p2[s] = arp[s] + tps[s]; }
-                    double dots[6] = {pdot_v<NS>(ps, var, alp), pdot_v<NS>(ps, var, trp),
-                                      pdot_v<NS>(p1, var, alp), pdot_v<NS>(p1, var, tlp),
-                                      pdot_v<NS>(p2, var, arp), pdot_v<NS>(p2, var, trp)};
-                    wave_sum_n<6>(dots);
-                    turn = (dots[0] <= 0) | (dots[1] <= 0) | (dots[2] <= 0) | (dots[3] <= 0) |
-                           (dots[4] <= 0) | (dots[5] <= 0);
+                    const double dots[6] = {pdot_v<NS>(ps, var, alp), pdot_v<NS>(ps, var, trp),
+                                            pdot_v<NS>(p1, var, alp), pdot_v<NS>(p1, var, tlp),
+                                            pdot_v<NS>(p2, var, arp), pdot_v<NS>(p2, var, trp)};
+                    turn = any_sum_nonpositive6(dots);
                 } else {
-                    double dots[2] = {pdot_v<NS>(ps, var, alp), pdot_v<NS>(ps, var, trp)};
-                    wave_sum_n<2>(dots);
-                    turn = (dots[0] <= 0) | (dots[1] <= 0);
+                    turn = any_sum_nonpositive2(pdot_v<NS>(ps, var, alp), pdot_v<NS>(ps, var, trp));
                 }
                 const double wsum = first_f64(aw + tw);
                 const double asum = first_f64(aa + ta);
@@ -454,10 +451,7 @@ __device__ inline void nuts_transition(const Target& tgt, const double (&var)[NS
         }
         dots[0] = l_start ? pdot_v32<NS>(psum, var, Lp) : pdot_v<NS>(psum, var, Lp);
         dots[1] = r_start ? pdot_v32<NS>(psum, var, Rp) : pdot_v<NS>(psum, var, Rp);
-        wave_sum_n<6>(dots);
-        if ((dots[0] <= 0) | (dots[1] <= 0) | (dots[2] <= 0) | (dots[3] <= 0) | (dots[4] <= 0) | (dots[5] <= 0)) {
-            turning = true; exhausted = false; break;
-        }
+        if (any_sum_nonpositive6(dots)) { turning = true; exhausted = false; break; }
     }
 
     // nuts.py:421-425: exp(lwas - log(e^{log_size} - 1)) == sum(w min(1,w)) / sum(w) over accepted leaves
@@ -496,7 +490,7 @@ __device__ inline void hmc_transition(const Target& tgt, const double (&var)[NS]
     double de = first_f64(e0 - energy);
     if (isnan(de)) de = -INFINITY;
     if (fabs(de) > emax) diverging = true;
-    const double accept = first_f64(fmin(1.0, exp(de)));
+    const double accept = first_f64(fmin(1.0, exp_uniform(de)));
     bool accepted = false;
     if (!diverging) {
         const double u = window_next(rng, win);
@@ -518,7 +512,18 @@ __device__ inline void hmc_transition(const Target& tgt, const double (&var)[NS]
 // ---- the iteration kernel: n_iters x _astep for every chain, no host round trips ------------------------
 // Occupancy target per vector width (waves per SIMD; the VGPR budget is 512 / waves): the
 // per-chain state is register resident, so wider chains trade occupancy for registers.
-constexpr int run_waves_per_simd(int ns) { return ns <= 1 ? 4 : ns == 2 ? 3 : ns == 4 ? 2 : 1; }
+#ifndef LMC_WAVES_NS1
+#define LMC_WAVES_NS1 4
+#endif
+#ifndef LMC_WAVES_NS2
+#define LMC_WAVES_NS2 3
+#endif
+#ifndef LMC_WAVES_NS4
+#define LMC_WAVES_NS4 2
+#endif
+constexpr int run_waves_per_simd(int ns) {
+    return ns <= 1 ? LMC_WAVES_NS1 : ns == 2 ? LMC_WAVES_NS2 : ns == 4 ? LMC_WAVES_NS4 : 1;
+}
 
 template <int NS, template <int> class TargetT>
 __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainArrays A, SamplerParams P, const double* tparams) {
@@ -554,6 +559,7 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
     double hbar = first_f64(A.da[c * 4 + 2]);
     const double mu = first_f64(A.da[c * 4 + 3]);
     int da_count = first_i32(A.da_count[c]);
+    double step_now = exp_uniform(log_step), step_bar_now = exp_uniform(log_bar);
     int iter_count = first_i32(A.iter_count[c]);
     int n_samples = first_i32(A.n_samples[c]);
     int wsel = first_i32(A.wsel[c]);
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
 
         // ---- step size for this iteration (base_hmc.py:151-153)
         const bool adapt_step = tune && P.adapt_step_size;
-        const double step_size = first_f64(adapt_step ? exp(log_step) : exp(log_bar));
+        const double step_size = adapt_step ? step_now : step_bar_now;   // exp(log_step) / exp(log_bar)
 
         TransitionOut out;
         if (P.kind == 0) {
@@ -621,10 +627,21 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
         if (adapt_step) {
             const double w = 1.0 / (static_cast<double>(da_count) + P.t0);
             hbar = first_f64((1.0 - w) * hbar + w * (P.target_accept - out.accept));
-            log_step = first_f64(mu - hbar * sqrt(static_cast<double>(da_count)) / P.gamma);
-            const double mk = pow(static_cast<double>(da_count), -P.k);
+            // sqrt(count) and count ** -k come from host-built tables (glibc sqrt/pow: the very values the
+            // reference's Python floats get); the device pow is only the fallback beyond the table
+            double sq, mk;
+            if (da_count < A.da_table_len) {
+                sq = first_f64(A.da_sqrt[da_count]);
+                mk = first_f64(A.da_mk[da_count]);
+            } else {
+                sq = sqrt(static_cast<double>(da_count));
+                mk = pow(static_cast<double>(da_count), -P.k);
+            }
+            log_step = first_f64(mu - hbar * sq / P.gamma);
             log_bar = first_f64(mk * log_step + (1.0 - mk) * log_bar);
             ++da_count;
+            step_now = exp_uniform(log_step);
+            step_bar_now = exp_uniform(log_bar);
         }
 
         // ---- diagonal mass adaptation (quadpotential.py:231-245, :324-340)
@@ -692,8 +709,8 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
         }
         if (lane == 0) {
             const long long fs = static_cast<long long>(A.chains) * A.cap;
-            A.stat_f64[kSfStepSize * fs + orow] = exp(log_step);
-            A.stat_f64[kSfStepSizeBar * fs + orow] = exp(log_bar);
+            A.stat_f64[kSfStepSize * fs + orow] = step_now;
+            A.stat_f64[kSfStepSizeBar * fs + orow] = step_bar_now;
             A.stat_f64[kSfAccept * fs + orow] = out.accept;
             A.stat_f64[kSfEnergyError * fs + orow] = out.energy_error;
             A.stat_f64[kSfEnergy * fs + orow] = out.energy;

@@ -32,24 +32,27 @@ __device__ __forceinline__ uint32_t first_u32(uint32_t x) {
 }
 
 // ---- DPP data movement (VALU cross-lane, no LDS traffic) ---------------------------------------
-// dpp_ctrl encodings (GFX9): row_shr:n = 0x110+n, wave_rol:1 = 0x134, wave_ror:1 = 0x13C,
-// row_bcast:15 = 0x142, row_bcast:31 = 0x143. Lanes with no source (or masked rows) receive 0.
-template <int CTRL, int ROW_MASK>
+// dpp_ctrl encodings (GFX9): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+// bound_ctrl:1 with full row/bank masks: lanes without a source lane read 0, so no "old" register has
+// to be zeroed first (that would be one extra VALU move per DPP move).
+template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
 // Sum over the 64 lanes; result is wave-uniform (read from lane 63 into SGPRs).
 // Hillis-Steele inside each 16-lane row (row_shr 1,2,4,8), then row_bcast 15 / 31 across rows.
 __device__ __forceinline__ double wave_sum(double x) {
-    x += dpp_f64<0x111, 0xf>(x);
-    x += dpp_f64<0x112, 0xf>(x);
-    x += dpp_f64<0x114, 0xf>(x);
-    x += dpp_f64<0x118, 0xf>(x);
-    x += dpp_f64<0x142, 0xa>(x);
-    x += dpp_f64<0x143, 0xc>(x);
+    // rows get extra cross terms from the unmasked broadcasts, but lane 63 ends up with exactly
+    // R3 + R2 + (R1 + R0): row_bcast:15 adds R_{k-1} to row k, row_bcast:31 adds lane 31 (R1 + R0) to rows 2,3
+    x += dpp_f64<0x111>(x);
+    x += dpp_f64<0x112>(x);
+    x += dpp_f64<0x114>(x);
+    x += dpp_f64<0x118>(x);
+    x += dpp_f64<0x142>(x);
+    x += dpp_f64<0x143>(x);
     return readlane_f64(x, 63);
 }
 
@@ -58,19 +61,123 @@ __device__ __forceinline__ double wave_sum(double x) {
 template <int N>
 __device__ __forceinline__ void wave_sum_n(double (&x)[N]) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x111, 0xf>(x[i]);
+    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x111>(x[i]);
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x112, 0xf>(x[i]);
+    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x112>(x[i]);
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x114, 0xf>(x[i]);
+    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x114>(x[i]);
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x118, 0xf>(x[i]);
+    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x118>(x[i]);
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x142, 0xa>(x[i]);
+    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x142>(x[i]);
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x143, 0xc>(x[i]);
+    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x143>(x[i]);
 #pragma unroll
     for (int i = 0; i < N; ++i) x[i] = readlane_f64(x[i], 63);
+}
+
+// ---- transposed multi-value reductions (gfx950 v_permlane32_swap / v_permlane16_swap) ------------------
+// Reducing K values with K independent butterflies costs K * 6 stages. Swapping halves instead lets ONE
+// add serve two values: after v_permlane32_swap(a, b) the registers hold [a_lo | b_lo] and [a_hi | b_hi],
+// so their sum carries a's partial sums in lanes 0-31 and b's in lanes 32-63; v_permlane16_swap does the
+// same for 16-lane rows. Each step halves the number of live registers; the remaining intra-row scan
+// (row_shr 1,2,4,8) runs once for up to four values.
+__device__ __forceinline__ double swap32_add(double a, double b) {   // [a_lo + a_hi | b_lo + b_hi]
+    const auto lo = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(__double2loint(a)),
+                                                     static_cast<unsigned>(__double2loint(b)), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(__double2hiint(a)),
+                                                     static_cast<unsigned>(__double2hiint(b)), false, false);
+    return __hiloint2double(static_cast<int>(hi[0]), static_cast<int>(lo[0])) +
+           __hiloint2double(static_cast<int>(hi[1]), static_cast<int>(lo[1]));
+}
+__device__ __forceinline__ double swap16_add(double a, double b) {   // rows [a0+a1, b0+b1, a2+a3, b2+b3]
+    const auto lo = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(__double2loint(a)),
+                                                     static_cast<unsigned>(__double2loint(b)), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(__double2hiint(a)),
+                                                     static_cast<unsigned>(__double2hiint(b)), false, false);
+    return __hiloint2double(static_cast<int>(hi[0]), static_cast<int>(lo[0])) +
+           __hiloint2double(static_cast<int>(hi[1]), static_cast<int>(lo[1]));
+}
+__device__ __forceinline__ double row_scan(double x) {   // lane 15 of every 16-lane row = row total
+    x += dpp_f64<0x111>(x);
+    x += dpp_f64<0x112>(x);
+    x += dpp_f64<0x114>(x);
+    x += dpp_f64<0x118>(x);
+    return x;
+}
+
+// Two sums for the price of ~one: a <- sum(a), b <- sum(b), both wave-uniform.
+__device__ __forceinline__ void wave_sum2(double& a, double& b) {
+    double x = swap32_add(a, b);           // lanes 0-31: a partials, lanes 32-63: b partials
+    x = row_scan(x);
+    x += dpp_f64<0x142>(x);                // row_bcast:15: lane 31 = R0 + R1 = sum(a), lane 63 = R2 + R3 = sum(b)
+    a = readlane_f64(x, 31);
+    b = readlane_f64(x, 63);
+}
+
+// U-turn tests: true if ANY of the given dot products (per-lane partials in d[]) is <= 0.
+__device__ __forceinline__ bool any_sum_nonpositive2(double d0, double d1) {
+    double x = swap32_add(d0, d1);
+    x = row_scan(x);
+    x += dpp_f64<0x142>(x);
+    const unsigned long long m = __ballot(x <= 0.0);
+    return (m & ((1ull << 31) | (1ull << 63))) != 0ull;
+}
+__device__ __forceinline__ bool any_sum_nonpositive6(const double (&d)[6]) {
+    const double x01 = swap32_add(d[0], d[1]);
+    const double x23 = swap32_add(d[2], d[3]);
+    const double x45 = swap32_add(d[4], d[5]);
+    double y = swap16_add(x01, x23);       // rows: d0, d2, d1, d3 (16 partials each)
+    double z = swap16_add(x45, 0.0);       // rows: d4, 0, d5, 0
+    y = row_scan(y);
+    z = row_scan(z);
+    const unsigned long long my = __ballot(y <= 0.0);
+    const unsigned long long mz = __ballot(z <= 0.0);
+    const unsigned long long rows = (1ull << 15) | (1ull << 31) | (1ull << 47) | (1ull << 63);
+    return ((my & rows) | (mz & ((1ull << 15) | (1ull << 47)))) != 0ull;
+}
+
+// ---- cheap exp for wave-uniform arguments ---------------------------------------------------------------
+// The OCML exp spends half of its ~50 VALU instructions moving polynomial constants into VGPRs. Here the
+// constants are produced by the scalar unit (s_mov, free next to a saturated vector pipe) and feed the FMAs
+// as SGPR operands. Cody-Waite reduction by ln2 (hi/lo), degree-13 Taylor polynomial on |r| <= ln2/2
+// (truncation 4e-18 relative), ldexp. |error| < ~1.5 ulp; arguments are clamped to [-800, 800].
+template <unsigned long long BITS>
+__device__ __forceinline__ double sgpr_const() {
+    unsigned lo, hi;
+    asm("s_mov_b32 %0, %1" : "=s"(lo) : "i"(static_cast<unsigned>(BITS & 0xffffffffull)));
+    asm("s_mov_b32 %0, %1" : "=s"(hi) : "i"(static_cast<unsigned>(BITS >> 32)));
+    return __hiloint2double(static_cast<int>(hi), static_cast<int>(lo));
+}
+#define LMC_SC(x) (::lmc::sgpr_const<__builtin_bit_cast(unsigned long long, static_cast<double>(x))>())
+
+// p * r + c with c taken straight from an SGPR pair (VOP3 form; hipcc would pick v_fmac and copy c first)
+__device__ __forceinline__ double fma_sgpr_addend(double p, double r, double c) {
+    double out;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(out) : "v"(p), "v"(r), "s"(c));
+    return out;
+}
+
+__device__ __forceinline__ double exp_uniform(double x) {
+    double xv = fmin(fmax(x, -800.0), 800.0);
+    asm volatile("" : "+v"(xv));                       // keep the argument in a VGPR: one SGPR operand per VALU op
+    const double kf = rint(xv * LMC_SC(1.4426950408889634074));
+    double r = __builtin_fma(-kf, LMC_SC(6.93147180369123816490e-01), xv);
+    r = __builtin_fma(-kf, LMC_SC(1.90821492927058770002e-10), r);
+    double p = fma_sgpr_addend(r, LMC_SC(1.0 / 6227020800.0), LMC_SC(1.0 / 479001600.0));
+    p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 39916800.0));
+    p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 3628800.0));
+    p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 362880.0));
+    p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 40320.0));
+    p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 5040.0));
+    p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 720.0));
+    p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 120.0));
+    p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 24.0));
+    p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 6.0));
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return first_f64(ldexp(p, static_cast<int>(kf)));
 }
 
 // Neighbour exchange for banded targets: value held by lane-1 / lane+1 (0 at the wave edge).
