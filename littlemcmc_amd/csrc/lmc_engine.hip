@@ -455,7 +455,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     if (nlds < 1) nlds = 1;
     e->nlds = nlds;
     e->lds_bytes = (2 + 4 * (nlds - 1)) * e->dpad * 8;
-    if (e->lds_bytes > 64 * 1024) return bail(fail(nullptr, LMC_ERR_INVALID, "lds_levels too large"));
+    if (e->lds_bytes > 160 * 1024) return bail(fail(nullptr, LMC_ERR_INVALID, "lds_levels too large"));
 
     const size_t C = cfg->chains, dp = e->dpad;
     ChainArrays& A = e->A;
@@ -734,8 +734,13 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
     P.lds_doubles = e->lds_bytes / 8;
     P.sdot_mode = e->cfg.start_energy_sdot;
     const dim3 grid(e->cfg.chains), block(64);
-#define RUN_CALL(T) \
-    LMC_NS_SWITCH(e, e->ns, hipLaunchKernelGGL((run_kernel<NS, T>), grid, block, e->lds_bytes, e->stream, e->A, P, e->tparams))
+#define RUN_CALL(T)                                                                                           \
+    LMC_NS_SWITCH(e, e->ns, {                                                                                 \
+        if (e->lds_bytes > 64 * 1024)                                                                         \
+            HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NS, T>),                 \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));        \
+        hipLaunchKernelGGL((run_kernel<NS, T>), grid, block, e->lds_bytes, e->stream, e->A, P, e->tparams);   \
+    })
     LMC_FAMILY_SWITCH(e, e->cfg.target_family, RUN_CALL)
 #undef RUN_CALL
     HIP_TRY(e, hipGetLastError());
