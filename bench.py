@@ -49,6 +49,12 @@ def cpu_baseline_worker(args):
     """One oracle chain (a port of the reference's sequential path) -> (leapfrogs, seconds)."""
     name, dim, tune, draws, seed, start = args
     sys.path.insert(0, ROOT)
+    try:   # one BLAS thread per chain process: the reference's chain-per-process model, no oversubscription
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(1)
+    except Exception:
+        pass
     from oracle import lmc_oracle as orc
     from oracle import targets as OT
 
@@ -93,7 +99,7 @@ def main():
     ap.add_argument("--max-treedepth", type=int, default=10)
     ap.add_argument("--no-trace", action="store_true", help="do not store draws (statistics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=600, help="iterations per oracle chain in the CPU baseline")
+    ap.add_argument("--cpu-iters", type=int, default=400, help="iterations per oracle chain in the CPU baseline")
     ap.add_argument("--lds-levels", type=int, default=0)
     args = ap.parse_args()
 

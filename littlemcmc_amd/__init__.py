@@ -5,7 +5,7 @@ liblmc_hip.so (HIP, gfx950); importing the package does not need a GPU, using it
 
 __version__ = "0.1.0"
 
-from . import targets
+from . import diagnostics, distributed, targets
 from .engine import Engine
 from .hmc import HamiltonianMC
 from .nuts import NUTS
@@ -22,5 +22,5 @@ from .sampling import init_nuts, sample
 __all__ = [
     "sample", "init_nuts", "HamiltonianMC", "NUTS", "quad_potential", "QuadPotentialDiag",
     "QuadPotentialFull", "QuadPotentialFullInv", "QuadPotentialDiagAdapt", "QuadPotentialFullAdapt",
-    "Engine", "targets",
+    "Engine", "targets", "diagnostics", "distributed",
 ]

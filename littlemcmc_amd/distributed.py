@@ -1,0 +1,66 @@
+"""Multi-GPU: one process per GPU, contiguous chain blocks, no collective on the sampling path.
+
+Chains are independent: rank r of W owns chains [r*C/W, (r+1)*C/W) together with
+that slice of the prefix-stable per-chain seed list (sampling.py:131-136), samples them on its own MI355X
+through the ordinary ``sample()`` path, and only the end-of-run diagnostics meet in one all-reduce of
+per-dimension sufficient statistics (diagnostics.py) -- RCCL over xGMI when the process group is "nccl",
+gloo in the CPU tests. Launch with ``python -m torch.distributed.run --nproc-per-node N ...``.
+"""
+import os
+
+import numpy as np
+
+
+def chain_block(total_chains, rank, world):
+    """Contiguous block [lo, hi) of rank ``rank``; blocks differ by at most one chain."""
+    base, rem = divmod(int(total_chains), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def global_seeds(random_seed, total_chains):
+    """Per-chain seeds over the GLOBAL chain index space, identical on every rank (sampling.py:131-136)."""
+    from .sampling import _derive_seeds
+
+    return _derive_seeds(random_seed, total_chains)
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def sample_distributed(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, chains=None, random_seed=None,
+                       start=None, group=None, diagnostics=True, **kwargs):
+    """``sample()`` for a job of ``chains`` chains spread over the ranks of the current process group.
+
+    Returns (trace, stats, diag): this rank's block of the trace/stats (same layouts as ``sample``) and, if
+    requested, R-hat/ESS over ALL chains of ALL ranks. With the same ``random_seed`` the union of the blocks
+    equals a single-GPU run of ``chains`` chains, chain for chain.
+    """
+    import torch.distributed as dist
+
+    from .sampling import init_nuts, sample
+
+    rank, world, local_rank = env_rank_world()
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    seeds = global_seeds(random_seed, chains)
+    lo, hi = chain_block(chains, rank, world)
+    if start is None and kwargs.get("step") is None:
+        # init_nuts must see the GLOBAL first seed so every rank jitters from the same start (sampling.py:574-584)
+        start, step = init_nuts(logp_dlogp_func, model_ndim, init=kwargs.pop("init", "auto"), random_seed=seeds,
+                                **{k: v for k, v in kwargs.items() if k not in ("device", "launch_iters")})
+        kwargs = {k: v for k, v in kwargs.items() if k in ("device", "launch_iters")}
+        kwargs["step"] = step
+    kwargs.setdefault("device", local_rank)
+    trace, stats, eng = sample(logp_dlogp_func, model_ndim, draws=draws, tune=tune, chains=hi - lo,
+                               random_seed=seeds[lo:hi], start=start, return_engine=True, **kwargs)
+    diag = None
+    if diagnostics:
+        from . import diagnostics as dg
+
+        x = dg.trace_tensor(eng)
+        diag = dg.summarize(x, group=group)
+        diag = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in diag.items()}
+    eng.close()
+    return trace, stats, diag

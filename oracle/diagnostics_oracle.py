@@ -1,0 +1,49 @@
+"""Plain-numpy restatement of littlemcmc_amd/diagnostics.py (split R-hat, Geyer multi-chain ESS).
+
+TEST INFRASTRUCTURE ONLY. The reference has no diagnostics: parity UNPINNED against
+the reference; this file pins the device/torch implementation against a direct, loop-level statement of the
+Stan reference-manual formulas."""
+import numpy as np
+
+
+def split(x):
+    c, n, d = x.shape
+    h = n // 2
+    return np.concatenate([x[:, :h], x[:, n - h:]], axis=0)
+
+
+def rhat_ess(x, do_split=True):
+    if do_split:
+        x = split(x)
+    m, n, d = x.shape
+    rhat = np.zeros(d)
+    ess = np.zeros(d)
+    for j in range(d):
+        y = x[:, :, j]
+        means = y.mean(axis=1)
+        acov = np.zeros((m, n))
+        for c in range(m):
+            z = y[c] - means[c]
+            for t in range(n):
+                acov[c, t] = np.dot(z[: n - t], z[t:]) / n
+        chain_var = acov[:, 0] * n / (n - 1.0)
+        w = chain_var.mean()
+        b_over_n = means.var(ddof=1) if m > 1 else 0.0
+        var_plus = w * (n - 1.0) / n + b_over_n
+        rhat[j] = np.sqrt(var_plus / w)
+        rho = 1.0 - (w - acov.mean(axis=0) * n / (n - 1.0)) / var_plus
+        rho[0] = 1.0
+        tau = -1.0
+        prev = np.inf
+        t = 0
+        while t + 1 < n:
+            p = rho[t] + rho[t + 1]
+            if p <= 0:
+                break
+            p = min(p, prev)
+            prev = p
+            tau += 2.0 * p
+            t += 2
+        tau = max(tau, 1.0 / np.log10(max(m * n, 10.0)))
+        ess[j] = m * n / tau
+    return rhat, ess

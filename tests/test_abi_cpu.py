@@ -1,0 +1,139 @@
+"""No-GPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol declared in
+include/lmc_hip.h, constants agree between header and binding, host-side argument handling mirrors the
+reference's errors, and the product path fails loudly (no CPU fallback) when there is no device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import littlemcmc_amd as lmc
+from littlemcmc_amd import _abi
+from littlemcmc_amd import targets as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "lmc_hip.h")).read()
+
+
+def declared_functions():
+    names = re.findall(r"^\s*(?:const\s+char\*|int32_t|int64_t|int|void\*?|void)\s+(lmc_\w+)\s*\(", HEADER, re.M)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_abi.LIB_PATH)
+    fns = declared_functions()
+    assert len(fns) >= 35
+    for name in fns:
+        assert hasattr(lib, name), "liblmc_hip.so does not export %s" % name
+    assert sorted(_abi.EXPORTED_SYMBOLS) == fns, set(fns) ^ set(_abi.EXPORTED_SYMBOLS)
+
+
+def test_header_constants_match_binding():
+    consts = dict(re.findall(r"#define\s+(LMC_\w+)\s+(\d+)", HEADER))
+    assert int(consts["LMC_ABI_VERSION"]) == _abi.ABI_VERSION == _abi.load().lmc_abi_version()
+    for name in ("KIND_NUTS", "KIND_HMC", "POT_DIAG_ADAPT", "POT_DIAG", "TARGET_STD_NORMAL", "TARGET_DIAG_GAUSSIAN",
+                 "TARGET_AR1", "TARGET_FUNNEL", "TARGET_NORMAL1D", "TARGET_USER", "STAT_STEP_SIZE", "STAT_ACCEPT",
+                 "STAT_MODEL_LOGP", "STAT_DEPTH", "STAT_TREE_SIZE", "STAT_DIVERGING", "STAT_TUNE", "STAT_ACCEPTED",
+                 "CT_LEAPFROGS", "NUM_COUNTERS", "SDOT_NATIVE", "SDOT_OPENBLAS_SKYLAKEX", "SDOT_OPENBLAS_HASWELL",
+                 "STATUS_BAD_INITIAL_ENERGY", "STATUS_NAN_LOGBERN"):
+        assert int(consts["LMC_" + name]) == getattr(_abi, name), name
+
+
+def test_config_struct_layout_and_defaults():
+    lib = _abi.load()
+    cfg = _abi.Config()
+    lib.lmc_config_defaults(ctypes.byref(cfg), 7, 13)
+    assert (cfg.chains, cfg.dim, cfg.abi_version) == (7, 13, _abi.ABI_VERSION)
+    # reference defaults: nuts.py:110-120, hmc.py:67-68, quadpotential.py:156
+    assert (cfg.target_accept, cfg.emax, cfg.step_scale, cfg.gamma, cfg.k, cfg.t0) == (0.8, 1000.0, 0.25, 0.05, 0.75, 10.0)
+    assert (cfg.max_treedepth, cfg.early_max_treedepth, cfg.max_steps, cfg.adaptation_window) == (10, 8, 1024, 101)
+    assert cfg.path_length == 2.0 and cfg.start_energy_sdot == _abi.SDOT_OPENBLAS_SKYLAKEX
+    fields = re.findall(r"^\s+(?:int32_t|double)\s+(\w+);", HEADER[HEADER.index("typedef struct lmc_config"):], re.M)
+    assert [f for f, _ in _abi.Config._fields_] == fields[: len(_abi.Config._fields_)]
+
+
+def test_built_in_targets_present_user_absent():
+    lib = _abi.load()
+    assert [lib.lmc_has_target(i) for i in range(6)] == [1, 1, 1, 1, 1, 0]
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_abi.HipLibraryError, match="no HIP device"):
+        lmc.Engine(T.StdNormal(4), chains=2)
+    with pytest.raises(_abi.HipLibraryError):
+        lmc.sample(T.StdNormal(4), 4, draws=3, tune=3, chains=2, random_seed=1)
+
+
+def test_plain_python_callable_is_rejected():
+    f = lambda q: (-0.5 * np.dot(q, q), -q)   # noqa: E731
+    with pytest.raises(TypeError, match="DeviceTarget"):
+        lmc.NUTS(f, 3)
+    with pytest.raises(TypeError, match="DeviceTarget"):
+        lmc.sample(f, 3)
+    with pytest.raises(ValueError, match="model_ndim"):
+        lmc.NUTS(T.StdNormal(4), 5)
+
+
+def test_reference_argument_errors():
+    tgt = T.StdNormal(3)
+    with pytest.raises(ValueError, match="both"):     # base_hmc.py:115-116
+        lmc.NUTS(tgt, 3, scaling=np.ones(3), potential=lmc.QuadPotentialDiag(np.ones(3)))
+    with pytest.raises(TypeError, match="string"):    # sampling.py:563-564
+        lmc.init_nuts(tgt, 3, init=3)
+    with pytest.raises(ValueError, match="Unknown initializer"):   # sampling.py:599
+        lmc.init_nuts(tgt, 3, init="nope")
+    with pytest.raises(NotImplementedError):          # dense mass matrices: out of scope
+        lmc.init_nuts(tgt, 3, init="adapt_full")
+    from littlemcmc_amd.quadpotential import PositiveDefiniteError
+
+    with pytest.raises(PositiveDefiniteError):        # tests/test_quadpotential.py:21-24
+        lmc.quad_potential(np.array([0, 2, 3]), True)
+    with pytest.raises(TypeError):                    # sampling.py:138
+        from littlemcmc_amd.sampling import _derive_seeds
+        _derive_seeds(1.5, 2)
+
+
+def test_seed_derivation_and_start_match_golden(golden_dir):
+    from littlemcmc_amd.sampling import _derive_seeds
+
+    g = np.load(os.path.join(golden_dir, "seeds.npz"))
+    for chains in (2, 4, 64):
+        seeds = _derive_seeds(20260928, chains)
+        np.testing.assert_array_equal(seeds, g["seeds_%d" % chains])
+        start, step = lmc.init_nuts(T.StdNormal(7), 7, random_seed=seeds)
+        np.testing.assert_array_equal(start, g["jitter_%d" % chains])
+        assert isinstance(step, lmc.NUTS) and isinstance(step.potential, lmc.QuadPotentialDiagAdapt)
+        assert step.potential._initial_weight == 10 and step.step_size == 0.25 / 7 ** 0.25
+
+
+def test_stats_dtypes_match_reference_tables():
+    # nuts.py:87-101, hmc.py:36-50
+    assert list(lmc.NUTS.stats_dtypes[0]) == ["depth", "step_size", "tune", "mean_tree_accept", "step_size_bar",
+                                              "tree_size", "diverging", "energy_error", "energy",
+                                              "max_energy_error", "model_logp"]
+    assert lmc.NUTS.stats_dtypes[0]["depth"] == np.int64 and lmc.NUTS.stats_dtypes[0]["tree_size"] == np.float64
+    assert list(lmc.HamiltonianMC.stats_dtypes[0]) == ["step_size", "n_steps", "tune", "step_size_bar", "accept",
+                                                       "diverging", "energy_error", "energy", "path_length",
+                                                       "accepted", "model_logp"]
+
+
+def test_blas_probe_emulation_matches_numpy_here():
+    """The float32 dot emulation used to pick the device's start-energy rounding is exact on the capture host."""
+    from littlemcmc_amd._blas_probe import detect_sdot_mode, emulate_sdot
+
+    mode = detect_sdot_mode()
+    rs = np.random.RandomState(0)
+    hits = total = 0
+    for n in (1, 5, 31, 32, 33, 64, 100, 128, 257, 1000):
+        x, y = rs.randn(n).astype("f4"), rs.randn(n).astype("f4")
+        hits += int(emulate_sdot(x, y, mode) == np.dot(x, y))
+        total += 1
+    if mode == _abi.SDOT_OPENBLAS_SKYLAKEX and hits < total:
+        pytest.skip("host BLAS is not one of the two restated OpenBLAS kernels")
+    assert hits == total

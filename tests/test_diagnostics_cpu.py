@@ -1,0 +1,96 @@
+"""Diagnostics (split R-hat / ESS) vs the numpy restatement, and the multi-rank reduction over gloo
+(world_size 2, CPU) -- the only collective of the multi-GPU path."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from littlemcmc_amd import diagnostics as dg
+from littlemcmc_amd.distributed import chain_block
+from oracle import diagnostics_oracle as odg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def ar1_chains(chains, n, d, rho, seed):
+    rs = np.random.RandomState(seed)
+    x = np.zeros((chains, n, d))
+    x[:, 0] = rs.randn(chains, d)
+    for t in range(1, n):
+        x[:, t] = rho * x[:, t - 1] + np.sqrt(1 - rho ** 2) * rs.randn(chains, d)
+    return x + np.linspace(-1, 1, d)
+
+
+@pytest.mark.parametrize("rho", [0.0, 0.6, -0.4])
+def test_rhat_ess_match_numpy_restatement(rho):
+    x = ar1_chains(6, 80, 3, rho, 1)
+    got = dg.summarize(torch.from_numpy(x))
+    rhat, ess = odg.rhat_ess(x)
+    np.testing.assert_allclose(got["rhat"].numpy(), rhat, rtol=1e-10)
+    np.testing.assert_allclose(got["ess"].numpy(), ess, rtol=1e-8)
+
+
+def test_ess_recovers_known_autocorrelation_time():
+    rho = 0.5
+    x = ar1_chains(256, 400, 2, rho, 3)
+    got = dg.summarize(torch.from_numpy(x))
+    want = 256 * 400 * (1 - rho) / (1 + rho)
+    assert np.all(np.abs(got["ess"].numpy() / want - 1) < 0.1)
+    assert np.all(np.abs(got["rhat"].numpy() - 1) < 0.01)
+
+
+def test_chunking_does_not_change_the_statistics():
+    x = torch.from_numpy(ar1_chains(10, 64, 4, 0.3, 5))
+    a = dg.summarize(x, chunk=3)
+    b = dg.summarize(x, chunk=1000)
+    np.testing.assert_allclose(a["ess"].numpy(), b["ess"].numpy(), rtol=1e-12)
+
+
+def test_chain_blocks_partition_the_chains():
+    for total, world in [(65536, 8), (10, 3), (7, 8), (4096, 1)]:
+        blocks = [chain_block(total, r, world) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == total
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in blocks]
+        assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from littlemcmc_amd import diagnostics as dg
+from littlemcmc_amd.distributed import chain_block, global_seeds
+from tests.test_diagnostics_cpu import ar1_chains
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+x = ar1_chains(12, 90, 3, 0.5, 7)                    # the WHOLE job, identical on both ranks
+lo, hi = chain_block(12, rank, world)
+got = dg.summarize(torch.from_numpy(x[lo:hi]))       # each rank only sees its block
+ref = dg.summarize(torch.from_numpy(x), group=dist.new_group([rank]))   # single-rank reduction of everything
+np.testing.assert_allclose(got["ess"].numpy(), ref["ess"].numpy(), rtol=1e-10)
+np.testing.assert_allclose(got["rhat"].numpy(), ref["rhat"].numpy(), rtol=1e-12)
+assert got["n_chains"] == 24.0
+seeds = global_seeds(20260928, 12)
+assert seeds[:4] == global_seeds(20260928, 4)          # prefix stable: blocks do not depend on the job size
+out = [None] * world
+dist.all_gather_object(out, seeds[lo:hi])
+assert sum(out, []) == seeds
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_rank_gloo_reduction_equals_single_process(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+        assert "ok" in o

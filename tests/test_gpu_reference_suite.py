@@ -1,0 +1,160 @@
+"""-m gpu: the reference's own test-suite (/root/reference/tests/test_hmc.py, test_quadpotential.py diagonal
+cases, test_sampling.py), re-read against littlemcmc_amd: same calls, same assertions, device arithmetic."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+import littlemcmc_amd as lmc
+from littlemcmc_amd import quadpotential
+from littlemcmc_amd.targets import Normal1D
+
+pytestmark = pytest.mark.gpu
+
+logp_dlogp_func = Normal1D()   # tests/test_utils.py:19-28
+
+
+# ---- tests/test_hmc.py -------------------------------------------------------------------------------
+def test_leapfrog_reversible():
+    np.random.seed(42)
+    model_ndim = 1
+    scaling = np.random.rand(model_ndim)
+    step = lmc.HamiltonianMC(logp_dlogp_func=logp_dlogp_func, model_ndim=model_ndim, scaling=scaling)
+    p = step.potential.random()
+    q = np.random.randn(model_ndim)
+    start = step.integrator.compute_state(p, q)
+    for epsilon in [0.01, 0.1]:
+        for n_steps in [1, 2, 3, 4, 20]:
+            state = start
+            for _ in range(n_steps):
+                state = step.integrator.step(epsilon, state)
+            for _ in range(n_steps):
+                state = step.integrator.step(-epsilon, state)
+            npt.assert_allclose(state.q, start.q, rtol=1e-5)
+            npt.assert_allclose(state.p, start.p, rtol=1e-5)
+
+
+def test_nuts_tuning():
+    model_ndim = 1
+    step = lmc.NUTS(logp_dlogp_func=logp_dlogp_func, model_ndim=model_ndim)
+    trace, stats = lmc.sample(logp_dlogp_func, model_ndim, 5, 5, step=step, chains=1, cores=1)
+    assert not step.tune
+
+
+# ---- tests/test_quadpotential.py (diagonal cases) -----------------------------------------------------
+def test_elemwise_energy():
+    scaling = np.array([1, 2, 3])
+    x = np.ones_like(scaling)
+    pot = quadpotential.quad_potential(scaling, True)
+    npt.assert_allclose(pot.energy(x), 0.5 * scaling.sum())
+
+
+def test_equal_diag():
+    np.random.seed(42)
+    for _ in range(3):
+        diag = np.random.rand(5)
+        x = np.random.randn(5)
+        pots = [quadpotential.quad_potential(diag, False), quadpotential.quad_potential(1.0 / diag, True)]
+        v = np.diag(1.0 / diag).dot(x)
+        e = x.dot(np.diag(1.0 / diag).dot(x)) / 2
+        for pot in pots:
+            npt.assert_allclose(pot.velocity(x), v, rtol=1e-6)
+            npt.assert_allclose(pot.energy(x), e, rtol=1e-6)
+
+
+def test_random_diag():
+    d = np.arange(10) + 1
+    np.random.seed(42)
+    pots = [quadpotential.quad_potential(d, True), quadpotential.quad_potential(1.0 / d, False)]
+    for pot in pots:
+        vals = np.array([pot.random() for _ in range(1000)])
+        npt.assert_allclose(vals.std(0), np.sqrt(1.0 / d), atol=0.1)
+
+
+def test_random_consumes_the_global_numpy_stream():
+    """potential.random() draws from np.random like the reference (quadpotential.py:221-224, :374-376)."""
+    pot = quadpotential.QuadPotentialDiagAdapt(5, np.zeros(5), np.full(5, 4.0), 10)
+    np.random.seed(7)
+    got = pot.random()
+    np.random.seed(7)
+    want = (1.0 / np.sqrt(np.full(5, 4.0, dtype="f4"))) * np.random.normal(size=5).astype("f4")
+    assert got.dtype == np.float32
+    npt.assert_array_equal(got, want)
+    npt.assert_array_equal(np.random.normal(size=3), np.random.RandomState(7).normal(size=8)[5:])
+
+
+# ---- tests/test_sampling.py ------------------------------------------------------------------------------
+@pytest.mark.parametrize("method", ["adapt_diag", "jitter+adapt_diag"])
+def test_init_nuts(method):
+    start, step = lmc.init_nuts(logp_dlogp_func=logp_dlogp_func, model_ndim=1, init=method)
+    assert isinstance(start, np.ndarray) and len(start) == 1 and isinstance(step, lmc.NUTS)
+
+
+@pytest.mark.parametrize("cls", [lmc.HamiltonianMC, lmc.NUTS])
+def test_sampling_runs(cls):
+    model_ndim, draws, tune, chains = 1, 3, 1, 2
+    step = cls(logp_dlogp_func=logp_dlogp_func, model_ndim=model_ndim)
+    trace, stats = lmc.sample(logp_dlogp_func, model_ndim, draws, tune, step=step, chains=chains, cores=1)
+    assert trace.shape == (chains, draws, model_ndim)
+    assert all(stats[name].shape == (chains, draws, model_ndim) for name in step.stats_dtypes[0])
+    assert all(stats[name].dtype == dt for name, dt in step.stats_dtypes[0].items())
+
+
+def test_multiprocess_sampling_runs():
+    step = lmc.NUTS(logp_dlogp_func=logp_dlogp_func, model_ndim=1)
+    trace, stats = lmc.sample(logp_dlogp_func, 1, 1, 1, step=step, chains=4, cores=4)
+    assert np.var(trace) > 0   # the reference's cores=4 path returns the start point here; we do not
+
+
+@pytest.mark.parametrize("cls", [lmc.HamiltonianMC, lmc.NUTS])
+def test_recovers_1d_normal(cls):
+    step = cls(logp_dlogp_func=logp_dlogp_func, model_ndim=1)
+    trace, stats = lmc.sample(logp_dlogp_func, 1, 1000, 1000, step=step, chains=1, cores=1)
+    assert np.allclose(np.mean(trace), 0, atol=1)
+    assert np.allclose(np.std(trace), 1, atol=1)
+    # much tighter than the reference asks: 1000 draws of a unit normal
+    assert abs(np.mean(trace)) < 0.2 and abs(np.std(trace) - 1) < 0.2
+
+
+def test_samples_not_all_same():
+    trace, stats = lmc.sample(logp_dlogp_func, 1, 50, 10, chains=1, cores=1)
+    assert np.var(trace) > 0
+
+
+def test_reset_tuning():
+    model_ndim, draws, tune, chains = 1, 2, 50, 2
+    start, step = lmc.init_nuts(logp_dlogp_func=logp_dlogp_func, model_ndim=1)
+    lmc.sample(logp_dlogp_func, model_ndim, draws=draws, tune=tune, chains=chains, step=step, start=start, cores=1)
+    assert step.potential._n_samples == tune
+    assert step.step_adapt._count == tune + 1
+
+
+# ---- step-method protocol (_astep) with the global numpy stream ----------------------------------------------
+def test_astep_protocol_matches_oracle():
+    from oracle import lmc_oracle as orc
+    from oracle import targets as OT
+
+    d = 6
+    step = lmc.NUTS(lmc.targets.StdNormal(d), d)
+    ostep = orc.Step(OT.StdNormal(d), d, kind="nuts")
+    np.random.seed(99)
+    rng = np.random.RandomState(99)
+    q = oq = np.full(d, 0.3)
+    for i in range(12):
+        q, st = step._astep(q)
+        oq, ost = ostep.astep(oq, rng)
+        assert st[0]["depth"] == ost["depth"] and st[0]["tree_size"] == ost["tree_size"]
+        npt.assert_allclose(q, oq, rtol=1e-9, atol=1e-12)
+        npt.assert_allclose(st[0]["step_size"], ost["step_size"], rtol=1e-10)
+    assert step.iter_count == 12 and step.potential._n_samples == 12 and step.step_adapt._count == 13
+    assert np.random.get_state()[2] == rng.get_state()[2]      # the global stream advanced identically
+    step.stop_tuning()
+    q, st = step._astep(q)
+    assert st[0]["tune"] is np.False_ or not st[0]["tune"]
+
+
+def test_bad_initial_energy_raises_value_error():
+    step = lmc.NUTS(lmc.targets.StdNormal(2), 2)
+    with pytest.raises(ValueError, match="Bad initial energy"):
+        step._astep(np.array([np.inf, 0.0]))
+    with pytest.raises(ValueError, match="Bad initial energy"):
+        lmc.sample(lmc.targets.StdNormal(2), 2, draws=2, tune=2, chains=3, start=np.array([np.nan, 0.0]), random_seed=1)

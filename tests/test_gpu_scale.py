@@ -1,0 +1,133 @@
+"""-m gpu: BASELINE.json-size runs checked through size-independent properties: posterior moments,
+tree invariants, chain-block prefix stability (the multi-GPU partition), checkpoint/resume idempotence,
+launch-slicing invariance, divergence-heavy ragged trees."""
+import numpy as np
+import pytest
+
+import littlemcmc_amd as lmc
+from littlemcmc_amd import _abi
+from littlemcmc_amd import targets as T
+
+pytestmark = pytest.mark.gpu
+
+
+def tree_invariants(stats, max_treedepth):
+    depth = stats["depth"][..., 0]
+    size = stats["tree_size"][..., 0]
+    div = stats["diverging"][..., 0]
+    assert depth.min() >= 1 and depth.max() <= max_treedepth
+    # a tree of depth k holds 2^k - 1 leapfrogs unless its last doubling stopped early (turn/divergence inside)
+    assert np.all(size <= 2.0 ** depth - 1)
+    assert np.all(size >= 2.0 ** (depth - 1))
+    assert np.all(np.isfinite(stats["energy"])) and np.all(stats["mean_tree_accept"] >= 0)
+    assert np.all(stats["mean_tree_accept"][~div[..., None]] <= 1 + 1e-12)
+    return depth, size, div
+
+
+def test_c2_4096_chains_dim64_std_normal_moments():
+    """configs[1]: 4096 chains, dim 64 standard normal, NUTS max_treedepth=10."""
+    d, chains, tune, draws = 64, 4096, 300, 200
+    trace, stats = lmc.sample(T.StdNormal(d), d, draws=draws, tune=tune, chains=chains, random_seed=20260928,
+                              max_treedepth=10)
+    assert trace.shape == (chains, draws, d)
+    tree_invariants(stats, 10)
+    # 4096 x 200 draws per dimension: moments to ~3e-3; per-chain statistics pooled
+    assert np.abs(trace.mean(axis=(0, 1))).max() < 5e-3
+    assert np.abs(trace.var(axis=(0, 1)) - 1).max() < 1e-2
+    assert abs(stats["mean_tree_accept"].mean() - 0.8) < 0.05        # dual averaging hit its target
+    assert stats["diverging"].sum() == 0
+    assert np.median(stats["depth"]) == 3                           # depth 3, 7 leapfrogs per draw
+
+
+def test_chain_block_prefix_stability_and_launch_slicing():
+    """The first K chains of a big run equal a K-chain run (what makes chain-block partitioning across
+    GPUs exact), and cutting a run into launches of any length does not change a single bit."""
+    d, tune, draws = 16, 60, 20
+    tgt = T.AR1(d, 0.9)
+    seeds = lmc.distributed.global_seeds(7, 96)
+    start, step = lmc.init_nuts(tgt, d, random_seed=seeds)
+    full, sfull = lmc.sample(tgt, d, draws=draws, tune=tune, chains=96, random_seed=seeds, start=start, step=step,
+                             launch_iters=1000)
+    lo, hi = lmc.distributed.chain_block(96, 1, 3)
+    _s, step2 = lmc.init_nuts(tgt, d, random_seed=seeds)
+    part, spart = lmc.sample(tgt, d, draws=draws, tune=tune, chains=hi - lo, random_seed=seeds[lo:hi], start=start,
+                             step=step2, launch_iters=7)
+    np.testing.assert_array_equal(part, full[lo:hi])
+    for k in sfull:
+        np.testing.assert_array_equal(spart[k], sfull[k][lo:hi])
+
+
+def test_checkpoint_resume_is_bit_identical():
+    d, chains = 32, 64
+    tgt = T.StdNormal(d)
+    seeds = list(range(100, 100 + chains))
+
+    def fresh():
+        step = lmc.NUTS(tgt, d)
+        eng = step._make_engine(chains)
+        eng.seed(seeds)
+        eng.set_position(np.full(d, 0.2))
+        eng.reset_tuning()
+        return eng
+
+    a = fresh()
+    a.reserve(80)
+    a.run(50, 0, 80)
+    want = a.trace()
+    b = fresh()
+    b.reserve(80)
+    b.run(50, 0, 30)
+    ckpt = b.get_chain_state()
+    pos = b.get_position()
+    rng = [b.get_rng_state(c) for c in range(chains)]
+    part1 = b.trace(0, 30)
+    b.close()
+    c = fresh()
+    c.set_chain_state(ckpt)
+    c.set_position(pos)
+    for i, st in enumerate(rng):
+        c.set_rng_state(i, st)
+    c.reserve(80)
+    c.run(50, 30, 50)
+    np.testing.assert_array_equal(np.concatenate([part1, c.trace(30, 50)], axis=1), want)
+    a.close()
+    c.close()
+
+
+def test_c5_funnel_divergences_and_ragged_trees():
+    """configs[4] shape at test size: Neal's funnel d=256, max_treedepth=12: divergence-heavy, ragged."""
+    d, chains, tune, draws = 256, 512, 200, 100
+    trace, stats = lmc.sample(T.Funnel(d), d, draws=draws, tune=tune, chains=chains, random_seed=3, max_treedepth=12)
+    depth, size, div = tree_invariants(stats, 12)
+    assert div.sum() > 0                        # the funnel neck diverges
+    assert depth.max() > depth.min()            # ragged trees across chains
+    assert np.isfinite(trace).all()
+    v = trace[..., 0]
+    assert abs(v.mean()) < 1.5 and 0.5 < v.std() < 4.0      # q_0 ~ N(0, 3^2) roughly explored
+
+
+def test_c4_ill_conditioned_dim1000_mass_adaptation():
+    """configs[3] shape at test size: d=1000 diagonal Gaussian, kappa=1e4: the adapted mass matrix must
+    learn the scales (var_i ~ sigma_i^2) and the draws must have the right variances."""
+    d, chains, tune, draws = 1000, 128, 400, 100
+    tgt = T.DiagGaussian.ill_conditioned(d, 1e4)
+    trace, stats, eng = lmc.sample(tgt, d, draws=draws, tune=tune, chains=chains, random_seed=11, return_engine=True)
+    var = eng.adapt_state()["var"]
+    eng.close()
+    sigma2 = 1.0 / tgt.params
+    ratio = np.median(var / sigma2, axis=0)
+    assert 0.5 < np.median(ratio) < 1.5
+    pooled = trace.var(axis=(0, 1)) / sigma2
+    assert 0.8 < np.median(pooled) < 1.2
+    tree_invariants(stats, 10)
+
+
+def test_hmc_c1_four_chains():
+    """configs[0]: 4 chains, dim 10 standard normal, HamiltonianMC path_length=2.0."""
+    d = 10
+    step = lmc.HamiltonianMC(T.StdNormal(d), d, path_length=2.0)
+    trace, stats = lmc.sample(T.StdNormal(d), d, draws=1000, tune=1000, step=step, chains=4, cores=4,
+                              random_seed=20260928)
+    assert trace.shape == (4, 1000, d)
+    assert np.abs(trace.mean(axis=(0, 1))).max() < 0.15 and np.abs(trace.var(axis=(0, 1)) - 1).max() < 0.25
+    assert np.all(stats["n_steps"] >= 1) and stats["accepted"].mean() > 0.5
