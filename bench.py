@@ -68,10 +68,28 @@ def cpu_baseline_worker(args):
     return float(st["tree_size"].sum()), time.perf_counter() - t0
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p_))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(name, dim, seeds, start, budget_iters):
     import multiprocessing as mp
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     tune = draws = budget_iters // 2
     jobs = [(name, dim, tune, draws, int(seeds[i % len(seeds)]), start) for i in range(cores)]
     t0 = time.perf_counter()
@@ -99,7 +117,8 @@ def main():
     ap.add_argument("--max-treedepth", type=int, default=10)
     ap.add_argument("--no-trace", action="store_true", help="do not store draws (statistics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=400, help="iterations per oracle chain in the CPU baseline")
+    ap.add_argument("--no-ess", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2000, help="iterations per oracle chain in the CPU baseline")
     ap.add_argument("--lds-levels", type=int, default=0)
     args = ap.parse_args()
 
@@ -183,6 +202,23 @@ def main():
         raise SystemExit("chains reported failure status bits: %s" % np.unique(status))
     depth_mean = float(eng.stat_i32(_abi.STAT_DEPTH, n_tune, n_total - n_tune).mean()) if n_total > n_tune else 0.0
     div_after = int(ct[:, _abi.CT_DIVS_AFTER_TUNE].sum())
+
+    # ---- ESS/sec (the second half of BASELINE.json's metric): split-R-hat / Geyer ESS of the post-warm-up
+    #      draws, computed where they live (HBM) and reduced across ranks with ONE all-reduce (RCCL) of
+    #      per-dimension sufficient statistics -- the only collective of the multi-GPU path.
+    ess = None
+    if not args.no_trace and not args.no_ess and n_total - n_tune >= 8:
+        from littlemcmc_amd import diagnostics as dg
+
+        t_ess = time.perf_counter()
+        diag = dg.summarize(dg.trace_tensor(eng), chunk=1024)
+        torch.cuda.synchronize()
+        draw_steps = [s for s in range(K) if s * ips >= n_tune]
+        draw_s = sum(kernel_ms[s] for s in draw_steps) / 1e3
+        e = diag["ess"]
+        ess = {"min": float(e.min()), "median": float(e.median()), "rhat_max": float(diag["rhat"].max()),
+               "draw_seconds_this_rank": draw_s, "chains_total": diag["n_chains"] / 2, "draws": n_total - n_tune,
+               "diagnostics_seconds": time.perf_counter() - t_ess}
     eng.close()
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
@@ -211,6 +247,12 @@ def main():
                 "trace_in_hbm": not args.no_trace, "parallelism": "chain-block x%d" % world,
             },
             "leapfrogs": leap_all, "wall_s": wall_max, "mean_depth_draws": depth_mean,
+            "ess_per_sec": None if ess is None else {
+                "min": ess["min"] / ess["draw_seconds_this_rank"], "median": ess["median"] / ess["draw_seconds_this_rank"],
+                "ess_min": ess["min"], "ess_median": ess["median"], "rhat_max": ess["rhat_max"],
+                "definition": "multi-chain split-R-hat / Geyer ESS over all %d chains x %d post-warm-up draws, "
+                              "divided by the post-warm-up kernel time" % (int(ess["chains_total"]), ess["draws"]),
+                "diagnostics_seconds": ess["diagnostics_seconds"]},
             "divergences_after_tune": div_after,
             "roofline": {
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

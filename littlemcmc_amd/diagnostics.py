@@ -99,9 +99,15 @@ def finalize(stats):
 
 def summarize(x, split=True, max_lag=None, group=None, chunk=2048):
     """x[chains, draws, d] (this rank's chain block) -> dict(rhat[d], ess[d], mean[d], var[d]) over ALL ranks."""
-    if split:
-        x = split_chains(x)
-    return finalize(all_reduce_stats(local_sufficient_stats(x, max_lag=max_lag, chunk=chunk), group=group))
+    if split:   # the halves are views; sufficient statistics add over chains, so no concatenated copy is made
+        n = x.shape[1]
+        h = n // 2
+        a = local_sufficient_stats(x[:, :h], max_lag=max_lag, chunk=chunk)
+        b = local_sufficient_stats(x[:, n - h:], max_lag=max_lag, chunk=chunk)
+        stats = {k: (a[k] + b[k] if k != "n_draws" else a[k]) for k in a}
+    else:
+        stats = local_sufficient_stats(x, max_lag=max_lag, chunk=chunk)
+    return finalize(all_reduce_stats(stats, group=group))
 
 
 class _DevicePtr:
