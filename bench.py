@@ -233,6 +233,14 @@ def main():
         kern_s = sum(kernel_ms) / 1e3
         bytes_per_leap = 60 * args.dim
         achieved = leap_local * bytes_per_leap / kern_s          # this GPU's kernel, algorithmic bytes / kernel time
+        traffic, traffic_src = None, None
+        try:   # HBM bytes per launch from the committed PMC profile of this same workload (not measurable in-process)
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("%s:%d" % (args.target, args.dim))
+            if tr:
+                traffic = tr["hbm_bytes_per_leapfrog"] * leap_local / K
+                traffic_src = tr["source"]
+        except Exception:
+            pass
         out = {
             "metric": "leapfrog-steps/sec (all chains)", "value": value, "unit": "leapfrog-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall_max * 1e3 / K,
@@ -256,7 +264,8 @@ def main():
             "divergences_after_tune": div_after,
             "roofline": {
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": None,
+                "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "B per launch", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": leap_local * bytes_per_leap / K,
                 "kernel": "lmc::run_kernel<NS=%d>" % max(1, (args.dim + 63) // 64),
                 "kernel_ms_avg": sum(kernel_ms) / K, "algorithmic_bytes_per_leapfrog": bytes_per_leap,
                 "read_only_frac": leap_local * 28 * args.dim / kern_s / HBM_PEAK,
