@@ -411,7 +411,7 @@ __device__ inline void nuts_transition(const Target& tgt, const double (&var)[NS
                     vstore<NS>(lv + 2 * stk.dpad, tps); vstore<NS>(lv + 3 * stk.dpad, tq);
                 }
                 lsc.put(j, tw, ta, tpe, tplogp);
-                wave_sync();
+                // no fence: every lane reads back exactly the slice it wrote (same-thread program order)
             }
         }
         ++depth;   // nuts.py:315

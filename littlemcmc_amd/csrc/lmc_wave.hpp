@@ -181,14 +181,10 @@ __device__ __forceinline__ double exp_uniform(double x) {
 }
 
 // Neighbour exchange for banded targets: value held by lane-1 / lane+1 (0 at the wave edge).
-__device__ __forceinline__ double from_lane_below(double x) {  // lane l receives lane l-1
-    const double y = __shfl_up(x, 1, 64);
-    return lane_id() == 0 ? 0.0 : y;
-}
-__device__ __forceinline__ double from_lane_above(double x) {  // lane l receives lane l+1
-    const double y = __shfl_down(x, 1, 64);
-    return lane_id() == 63 ? 0.0 : y;
-}
+// DPP wave_shr:1 / wave_shl:1 (GFX9 whole-wave shifts, 0x138 / 0x130) with bound_ctrl: two VALU moves per
+// double, no LDS crossbar round trip.
+__device__ __forceinline__ double from_lane_below(double x) { return dpp_f64<0x138>(x); }  // lane l <- lane l-1
+__device__ __forceinline__ double from_lane_above(double x) { return dpp_f64<0x130>(x); }  // lane l <- lane l+1
 
 // Order same-wave accesses to LDS / global scratch that cross lanes (writer lane != reader lane).
 __device__ __forceinline__ void wave_sync() {
