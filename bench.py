@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--no-ess", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2000, help="iterations per oracle chain in the CPU baseline")
     ap.add_argument("--lds-levels", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend (nccl = RCCL; gloo only to exercise the multi-rank path on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -132,10 +134,16 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    if args.backend == "gloo":          # test mode: several ranks may share one GPU
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     import littlemcmc_amd as lmc
     from littlemcmc_amd import _abi
@@ -211,7 +219,7 @@ def main():
         from littlemcmc_amd import diagnostics as dg
 
         t_ess = time.perf_counter()
-        diag = dg.summarize(dg.trace_tensor(eng), chunk=1024)
+        diag = dg.summarize(dg.trace_tensor(eng), chunk=1024, reduce_device=red_dev)
         torch.cuda.synchronize()
         draw_steps = [s for s in range(K) if s * ips >= n_tune]
         draw_s = sum(kernel_ms[s] for s in draw_steps) / 1e3
@@ -221,8 +229,8 @@ def main():
                "diagnostics_seconds": time.perf_counter() - t_ess}
     eng.close()
 
-    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-    leap_t = torch.tensor([leap_local], dtype=torch.float64, device="cuda")
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=red_dev)
+    leap_t = torch.tensor([leap_local], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(leap_t, op=dist.ReduceOp.SUM)
@@ -271,7 +279,7 @@ def main():
                 "read_only_frac": leap_local * 28 * args.dim / kern_s / HBM_PEAK,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.target, args.dim, seeds_all[:64], start, args.cpu_iters)
         print(json.dumps(out))
     if world > 1:

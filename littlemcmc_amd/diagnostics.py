@@ -54,17 +54,19 @@ def local_sufficient_stats(x, max_lag=None, chunk=2048):
     return out
 
 
-def all_reduce_stats(stats, group=None):
-    """Sum the sufficient statistics over ranks (RCCL on GPUs, gloo on CPU). n_draws must agree."""
+def all_reduce_stats(stats, group=None, reduce_device=None):
+    """Sum the sufficient statistics over ranks (RCCL on GPUs, gloo on CPU). n_draws must agree.
+    ``reduce_device``: where the collective runs (default: where the statistics live)."""
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return stats
     out = dict(stats)
     for k in ("n_chains", "sum_mean", "sum_mean_sq", "sum_var", "sum_acov"):
-        t = stats[k].clone()
+        home = stats[k].device
+        t = stats[k].clone() if reduce_device is None else stats[k].to(reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        out[k] = t
+        out[k] = t.to(home)
     return out
 
 
@@ -97,7 +99,7 @@ def finalize(stats):
     return {"rhat": rhat, "ess": ess, "mean": gmean, "var": var_plus, "n_chains": m, "n_draws": n}
 
 
-def summarize(x, split=True, max_lag=None, group=None, chunk=2048):
+def summarize(x, split=True, max_lag=None, group=None, chunk=2048, reduce_device=None):
     """x[chains, draws, d] (this rank's chain block) -> dict(rhat[d], ess[d], mean[d], var[d]) over ALL ranks."""
     if split:   # the halves are views; sufficient statistics add over chains, so no concatenated copy is made
         n = x.shape[1]
@@ -107,7 +109,7 @@ def summarize(x, split=True, max_lag=None, group=None, chunk=2048):
         stats = {k: (a[k] + b[k] if k != "n_draws" else a[k]) for k in a}
     else:
         stats = local_sufficient_stats(x, max_lag=max_lag, chunk=chunk)
-    return finalize(all_reduce_stats(stats, group=group))
+    return finalize(all_reduce_stats(stats, group=group, reduce_device=reduce_device))
 
 
 class _DevicePtr:
