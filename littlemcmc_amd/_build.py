@@ -43,7 +43,7 @@ def build(out=None, extra_flags=(), force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-o", out, os.path.join(CSRC, "lmc_engine.hip")]
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", CSRC] + list(extra_flags) + ["-o", out, os.path.join(CSRC, "lmc_engine.hip")]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -320,6 +320,14 @@ static void dev_free(lmc_engine* e, void* p) {
 #define LMC_USER_CASE(KERNEL_CALL)
 #endif
 
+#if defined(LMC_USER_TARGET_HEADER) && defined(LMC_ONLY_USER)
+// JIT build around a user density: instantiate the kernels for that family only (seconds, not a minute)
+#define LMC_FAMILY_SWITCH(e, family, KERNEL_CALL)                                       \
+    switch (family) {                                                                   \
+        LMC_USER_CASE(KERNEL_CALL)                                                      \
+        default: return fail(e, LMC_ERR_INVALID, "target family %d is not in this build", family); \
+    }
+#else
 #define LMC_FAMILY_SWITCH(e, family, KERNEL_CALL)                                       \
     switch (family) {                                                                   \
         case LMC_TARGET_STD_NORMAL: { KERNEL_CALL(StdNormalTarget); } break;            \
@@ -330,6 +338,7 @@ static void dev_free(lmc_engine* e, void* p) {
         LMC_USER_CASE(KERNEL_CALL)                                                      \
         default: return fail(e, LMC_ERR_INVALID, "unknown target family %d", family);   \
     }
+#endif
 
 template <class T>
 struct DevBuf {   // RAII staging buffer: device copy of a host-or-device array
@@ -350,7 +359,9 @@ extern "C" {
 int32_t lmc_abi_version(void) { return LMC_ABI_VERSION; }
 
 int32_t lmc_has_target(int32_t family) {
+#if !(defined(LMC_USER_TARGET_HEADER) && defined(LMC_ONLY_USER))
     if (family >= LMC_TARGET_STD_NORMAL && family <= LMC_TARGET_NORMAL1D) return 1;
+#endif
 #ifdef LMC_USER_TARGET_HEADER
     if (family == LMC_TARGET_USER) return 1;
 #endif

@@ -131,7 +131,7 @@ class UserTarget(DeviceTarget):
         if not os.path.exists(lib):
             with open(header, "w") as fh:
                 fh.write(source)
-            _build.build(out=lib, extra_flags=["-DLMC_USER_TARGET_HEADER=\"%s\"" % header], force=True)
+            _build.build(out=lib, extra_flags=["-DLMC_USER_TARGET_HEADER=\"%s\"" % header, "-DLMC_ONLY_USER"], force=True)
         self.lib_path = lib
 
 

@@ -158,3 +158,52 @@ def test_bad_initial_energy_raises_value_error():
         step._astep(np.array([np.inf, 0.0]))
     with pytest.raises(ValueError, match="Bad initial energy"):
         lmc.sample(lmc.targets.StdNormal(2), 2, draws=2, tune=2, chains=3, start=np.array([np.nan, 0.0]), random_seed=1)
+
+
+# ---- a user-written device log-density, compiled at run time and linked into the kernels -------------------
+USER_SRC = r"""
+#include "lmc_wave.hpp"
+namespace lmc {
+// independent Gaussians with means mu (params) and unit variance: logp = -1/2 sum (q - mu)^2
+template <int NS>
+struct UserTarget {
+    static constexpr bool kLanePartial = true;
+    double mu[NS];
+    __device__ void init(const double* params, int d) {
+        for (int s = 0; s < NS; ++s) { const int e = lane_id() * NS + s; mu[s] = (e < d) ? params[e] : 0.0; }
+    }
+    __device__ double logp_grad_partial(const double (&q)[NS], double (&g)[NS]) const {
+        double part = 0.0;
+        for (int s = 0; s < NS; ++s) { const double z = q[s] - mu[s]; g[s] = -z; part = __builtin_fma(z, z, part); }
+        return -0.5 * part;
+    }
+    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const { return wave_sum(logp_grad_partial(q, g)); }
+};
+}  // namespace lmc
+"""
+
+
+def test_user_target_is_compiled_and_sampled():
+    import shutil
+
+    if shutil.which("hipcc") is None and not __import__("os").path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available on this box")
+    d = 70
+    mu = np.linspace(-2.0, 3.0, d)
+    tgt = lmc.targets.UserTarget(d, USER_SRC, params=mu)
+    q = np.random.RandomState(0).randn(d)
+    logp, grad = tgt(q)                                     # reference plug-in signature, evaluated on the GPU
+    npt.assert_allclose(logp, -0.5 * np.sum((q - mu) ** 2), rtol=1e-13)
+    npt.assert_allclose(grad, -(q - mu), rtol=1e-15, atol=1e-15)
+    trace, stats = lmc.sample(tgt, d, draws=300, tune=300, chains=256, random_seed=5)
+    npt.assert_allclose(trace.mean(axis=(0, 1)), mu, atol=0.03)
+    npt.assert_allclose(trace.var(axis=(0, 1)), 1.0, atol=0.05)
+    # same chain as the oracle driven by the numpy statement of the same density
+    from oracle import lmc_oracle as orc
+
+    f = lambda x: (-0.5 * np.dot(x - mu, x - mu), -(x - mu))   # noqa: E731
+    ot, ost = orc.sample(f, d, draws=5, tune=25, chains=2, random_seed=5, discard_tuned_samples=False)
+    gt, gst = lmc.sample(tgt, d, draws=5, tune=25, chains=2, random_seed=5, discard_tuned_samples=False)
+    n = 15
+    npt.assert_array_equal(gst["depth"][:, :n], ost["depth"][:, :n])
+    npt.assert_allclose(gt[:, :n], ot[:, :n], rtol=1e-6, atol=1e-8)
