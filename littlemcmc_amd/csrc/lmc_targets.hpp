@@ -80,32 +80,34 @@ struct DiagGaussianTarget {
 template <int NS>
 struct AR1Target {
     static constexpr bool kLanePartial = true;
-    double c_end, c_mid, off;
-    int d;
-    __device__ void init(const double* params, int d_) {
-        c_end = params[0];
-        c_mid = params[1];
-        off = params[2];
-        d = d_;
+    // per-lane coefficient slices, fixed for the whole kernel: diagonal, coupling to e-1 and to e+1.
+    // Boundary / padding elements simply carry a 0 coefficient, so the hot loop has no selects.
+    double diag[NS], lo[NS], hi[NS];
+    __device__ void init(const double* params, int d) {
+        const double c_end = params[0], c_mid = params[1], off = params[2];
+        const int lane = lane_id();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int e = lane * NS + s;
+            diag[s] = (e >= d) ? 0.0 : ((e == 0 || e == d - 1) ? c_end : c_mid);
+            lo[s] = (e > 0 && e < d) ? off : 0.0;
+            hi[s] = (e < d - 1) ? off : 0.0;
+        }
     }
     __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
         return wave_sum(logp_grad_partial(q, g));
     }
     __device__ double logp_grad_partial(const double (&q)[NS], double (&g)[NS]) const {
-        const int lane = lane_id();
         const double below = from_lane_below(q[NS - 1]);   // element e-1 of this lane's first slot
         const double above = from_lane_above(q[0]);        // element e+1 of this lane's last slot
         double part = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const int e = lane * NS + s;
             const double prev = (s == 0) ? below : q[s - 1];
             const double next = (s == NS - 1) ? above : q[s + 1];
-            const double diag = (e == 0 || e == d - 1) ? c_end : c_mid;
-            double pq = diag * q[s];
-            if (e > 0) pq = pq + off * prev;
-            if (e < d - 1) pq = pq + off * next;
-            g[s] = (e < d) ? -pq : 0.0;
+            // (diag q + off q_{e-1}) + off q_{e+1}; a zero coefficient adds +0.0, which leaves the sum unchanged
+            const double pq = (diag[s] * q[s] + lo[s] * prev) + hi[s] * next;
+            g[s] = -pq;
             part = __builtin_fma(q[s], g[s], part);
         }
         return 0.5 * part;
