@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64) void seed_kernel(ChainArrays A, const uint32_t*
 }
 
 __global__ __launch_bounds__(64) void rng_draw_kernel(ChainArrays A, const int* ops, int n_ops, double* out,
-                                                      long long out_stride) {
+                                                      long long out_stride, double* stage, long long stage_stride) {
     const int c = blockIdx.x;
     const int lane = lane_id();
     RngState r;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void rng_draw_kernel(ChainArrays A, const int* 
     for (int k = 0; k < n_ops; ++k) {
         const int op = ops[k];
         if (op > 0) {
-            rng_normals(r, op, o);
+            rng_normals(r, op, o, stage + static_cast<long long>(c) * stage_stride);
             o += op;
         } else {
             for (int i = 0; i < -op; ++i) {
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void momentum_kernel(ChainArrays A, int momentu
     r.pos = first_i32(A.rng_pos[c]);
     r.has_gauss = first_i32(A.rng_has_gauss[c]);
     r.gauss = first_f64(A.rng_gauss[c]);
-    rng_normals(r, d, lds);
+    rng_normals(r, d, lds, lds + A.dpad);
     const long long row = static_cast<long long>(c) * A.dpad;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -1006,14 +1006,18 @@ int lmc_engine_rng_draw(lmc_engine* e, const int32_t* ops, int32_t n_ops, double
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     std::vector<int32_t> hops(n_ops);
     HIP_TRY(e, hipMemcpy(hops.data(), ops, n_ops * sizeof(int32_t), hipMemcpyDefault));
-    long long total = 0;
-    for (int32_t op : hops) total += op > 0 ? op : -op;
+    long long total = 0, biggest = 2;
+    for (int32_t op : hops) {
+        total += op > 0 ? op : -op;
+        if (op > biggest) biggest = op;
+    }
+    biggest += 2;
     const size_t C = e->cfg.chains;
     DevBuf<int> dops;
-    DevBuf<double> dout;
-    HIP_TRY(e, dops.alloc(n_ops)); HIP_TRY(e, dout.alloc(C * total));
+    DevBuf<double> dout, dstage;
+    HIP_TRY(e, dops.alloc(n_ops)); HIP_TRY(e, dout.alloc(C * total)); HIP_TRY(e, dstage.alloc(C * biggest));
     HIP_TRY(e, hipMemcpyAsync(dops.p, hops.data(), n_ops * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(rng_draw_kernel, dim3(e->cfg.chains), dim3(64), 0, e->stream, e->A, dops.p, n_ops, dout.p, total);
+    hipLaunchKernelGGL(rng_draw_kernel, dim3(e->cfg.chains), dim3(64), 0, e->stream, e->A, dops.p, n_ops, dout.p, total, dstage.p, biggest);
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, hipMemcpyAsync(out, dout.p, C * total * sizeof(double), hipMemcpyDefault, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -1028,7 +1032,7 @@ int lmc_engine_draw_momentum(lmc_engine* e, double* out) {
     HIP_TRY(e, dout.alloc(C * d));
     const int f32 = e->cfg.potential == LMC_POT_DIAG_ADAPT;
     const dim3 grid(e->cfg.chains), block(64);
-    const int lds = e->dpad * 8;
+    const int lds = 2 * e->dpad * 8;
     LMC_NS_SWITCH(e, e->ns, hipLaunchKernelGGL((momentum_kernel<NS>), grid, block, lds, e->stream, e->A, f32, dout.p))
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, hipMemcpyAsync(out, dout.p, C * d * sizeof(double), hipMemcpyDefault, e->stream));

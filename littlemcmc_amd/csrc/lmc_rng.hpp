@@ -161,7 +161,12 @@ __device__ inline double window_next(RngState& r, UniformWindow& w) {
 // normal(size=d) -> out[0..d) (LDS or global scratch, any lane may write any slot).
 // Consumer order: attempt k accepted => normals (f*x2, f*x1) in that order; an odd tail leaves
 // f*x1 in the cache for the next call (numpy legacy_gauss).
-__device__ inline void rng_normals(RngState& r, int d, double* out) {
+// Two phases so that the expensive part (log, divide, sqrt: ~150 VALU) runs once per 64 ACCEPTED pairs
+// instead of once per 64 attempts: (1) scan attempts 64 at a time -- temper four words, form (x1, x2),
+// test r2 -- and compact the accepted (x1, x2) pairs in stream order into `stage` (room for d doubles);
+// (2) one lane per accepted pair computes f = sqrt(-2 log(r2) / r2) and writes both variates.
+// The stream position advances by exactly the words the sequential algorithm consumes.
+__device__ inline void rng_normals(RngState& r, int d, double* out, double* stage) {
     const int lane = lane_id();
     int produced = 0;
     if (r.has_gauss && d > 0) {
@@ -170,63 +175,65 @@ __device__ inline void rng_normals(RngState& r, int d, double* out) {
         r.gauss = 0.0;
         produced = 1;
     }
-    while (produced < d) {
+    const int need_pairs = (d - produced + 1) >> 1;
+    int have = 0;
+    while (have < need_pairs) {
         const int avail = (kMtN - r.pos) >> 2;   // whole attempts left in this generation
         if (avail == 0) {                         // 0 or 2 words left: one attempt across the twist
             const double x1 = 2.0 * rng_uniform(r) - 1.0;
             const double x2 = 2.0 * rng_uniform(r) - 1.0;
             const double r2 = x1 * x1 + x2 * x2;
             if (r2 > 0.0 && r2 < 1.0) {
-                const double f = sqrt(-2.0 * log(r2) / r2);
-                if (lane == 0) out[produced] = f * x2;
-                if (produced + 1 < d) {
-                    if (lane == 0) out[produced + 1] = f * x1;
-                } else {
-                    r.gauss = first_f64(f * x1);
-                    r.has_gauss = 1;
-                }
-                produced += 2;
+                if (lane == 0) { stage[2 * have] = x1; stage[2 * have + 1] = x2; }
+                ++have;
             }
             continue;
         }
         const int n_att = avail < 64 ? avail : 64;
-        const int need_pairs = (d - produced + 1) >> 1;
         bool acc = false;
-        double x1 = 0.0, x2 = 0.0, r2 = 1.0;
+        double x1 = 0.0, x2 = 0.0;
         if (lane < n_att) {
             const uint32_t* w = r.mt + r.pos + 4 * lane;
             x1 = 2.0 * mt_words_to_double(w[0], w[1]) - 1.0;
             x2 = 2.0 * mt_words_to_double(w[2], w[3]) - 1.0;
-            r2 = x1 * x1 + x2 * x2;
+            const double r2 = x1 * x1 + x2 * x2;
             acc = (r2 > 0.0) && (r2 < 1.0);
         }
         unsigned long long mask = __ballot(acc);
         const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        int rank = __popcll(mask & below);
+        const int rank = __popcll(mask & below);
         int consumed = n_att;
-        if (__popcll(mask) >= need_pairs) {
-            const unsigned long long lastm = __ballot(acc && rank == need_pairs - 1);
+        const int want = need_pairs - have;
+        if (__popcll(mask) >= want) {             // the want-th accepted attempt ends the call
+            const unsigned long long lastm = __ballot(acc && rank == want - 1);
             const int last = __ffsll(static_cast<long long>(lastm)) - 1;
             consumed = last + 1;
             mask &= (last == 63) ? ~0ull : ((1ull << (last + 1)) - 1ull);
         }
-        const bool mine = acc && ((mask >> lane) & 1ull);
+        if (acc && ((mask >> lane) & 1ull)) {
+            stage[2 * (have + rank)] = x1;
+            stage[2 * (have + rank) + 1] = x2;
+        }
+        have += __popcll(mask);
+        r.pos += 4 * consumed;
+    }
+    wave_sync();
+    for (int base = 0; base < need_pairs; base += 64) {
+        const int pi = base + lane;
         double g1 = 0.0;
-        if (mine) {
+        if (pi < need_pairs) {
+            const double x1 = stage[2 * pi], x2 = stage[2 * pi + 1];
+            const double r2 = x1 * x1 + x2 * x2;
             const double f = sqrt(-2.0 * log(r2) / r2);
-            const int idx = produced + 2 * rank;
+            const int idx = produced + 2 * pi;
             out[idx] = f * x2;
             g1 = f * x1;
             if (idx + 1 < d) out[idx + 1] = g1;
         }
-        const int got = 2 * __popcll(mask);
-        if (produced + got > d) {   // odd tail: the last accepted attempt's second variate is cached
-            const int last = 63 - __clzll(static_cast<long long>(mask));
-            r.gauss = readlane_f64(g1, last);
+        if (base + 64 >= need_pairs && produced + 2 * need_pairs > d) {   // odd tail: cache the last second variate
+            r.gauss = readlane_f64(g1, need_pairs - 1 - base);
             r.has_gauss = 1;
         }
-        produced += got;
-        r.pos += 4 * consumed;
     }
     wave_sync();
 }

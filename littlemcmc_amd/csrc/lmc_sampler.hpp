@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
         const bool tune = git < P.n_tune;
 
         // ---- momentum draw (quadpotential.py:221-224 / :374-376)
-        rng_normals(rng, d, lds);   // level-0 LDS region doubles as the normals buffer (stack is empty)
+        rng_normals(rng, d, lds, lds + dpad);   // the level-0 LDS region (2*dpad doubles) = normals + staging
         double p0[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
