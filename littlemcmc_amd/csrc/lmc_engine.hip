@@ -460,7 +460,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     int nlds = cfg->lds_levels;
     if (nlds <= 0) {
         nlds = 1;
-        while (nlds < max_levels && (2 + 4 * nlds) * e->dpad * 8 <= 10240) ++nlds;
+        while (nlds < max_levels && (2 + 4 * nlds) * e->dpad * 8 <= 10240) ++nlds;   // + 2.5 KiB RNG state -> 12 waves/CU
     }
     if (nlds > max_levels) nlds = max_levels;
     if (nlds < 1) nlds = 1;
@@ -744,13 +744,14 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
     P.nlds = e->nlds;
     P.lds_doubles = e->lds_bytes / 8;
     P.sdot_mode = e->cfg.start_energy_sdot;
+    const int run_lds = e->lds_bytes + 2560;   // subtree stack + MT19937 state
     const dim3 grid(e->cfg.chains), block(64);
 #define RUN_CALL(T)                                                                                           \
     LMC_NS_SWITCH(e, e->ns, {                                                                                 \
-        if (e->lds_bytes > 64 * 1024)                                                                         \
+        if (run_lds > 64 * 1024)                                                                              \
             HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NS, T>),                 \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));        \
-        hipLaunchKernelGGL((run_kernel<NS, T>), grid, block, e->lds_bytes, e->stream, e->A, P, e->tparams);   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));             \
+        hipLaunchKernelGGL((run_kernel<NS, T>), grid, block, run_lds, e->stream, e->A, P, e->tparams);        \
     })
     LMC_FAMILY_SWITCH(e, e->cfg.target_family, RUN_CALL)
 #undef RUN_CALL

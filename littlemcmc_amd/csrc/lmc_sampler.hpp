@@ -90,7 +90,7 @@ struct SamplerParams {
     long long iter_begin; // global index of the first iteration of this launch
     int n_iters;
     int nlds;             // subtree levels kept in LDS (>= 1)
-    int lds_doubles;      // dynamic LDS size in doubles
+    int lds_doubles;      // LDS doubles used by the subtree stack; the MT19937 state (624 words) follows
     int sdot_mode;        // SdotMode for the float32 start-state kinetic energy
 };
 
@@ -549,8 +549,14 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
         inv_std[s] = A.inv_std[row + lane * NS + s];
         vard[s] = static_cast<double>(var[s]);
     }
+    // The MT19937 state lives in LDS for the whole launch (2.5 KB per wave, behind the subtree stack): the
+    // momentum draw, the uniform window and the twist then cost LDS latency instead of HBM/L2 round trips.
     RngState rng;
-    rng.mt = A.mt + static_cast<long long>(c) * kMtN;
+    uint32_t* mt_glb = A.mt + static_cast<long long>(c) * kMtN;
+    uint32_t* mt_lds = reinterpret_cast<uint32_t*>(lds + P.lds_doubles);
+    for (int i = lane; i < kMtN; i += 64) mt_lds[i] = mt_glb[i];
+    wave_sync();
+    rng.mt = mt_lds;
     rng.pos = first_i32(A.rng_pos[c]);
     rng.has_gauss = first_i32(A.rng_has_gauss[c]);
     rng.gauss = first_f64(A.rng_gauss[c]);
@@ -725,6 +731,8 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
     }
 
     // ---- store persistent chain state
+    wave_sync();
+    for (int i = lane; i < kMtN; i += 64) mt_glb[i] = mt_lds[i];
     vstore<NS>(A.q + row, q);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
