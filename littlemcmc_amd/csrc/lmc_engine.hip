@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -103,15 +104,16 @@ __global__ __launch_bounds__(64) void logp_kernel(ChainArrays A, const double* t
     const int c = blockIdx.x;
     const int lane = lane_id();
     const int d = A.d;
+    Team<1> tm{nullptr, 0};
     TargetT<NS> tgt;
-    tgt.init(tparams, d);
+    tgt.init(tm, tparams, d);
     double q[NS], g[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int e = lane * NS + s;
         q[s] = (e < d) ? qin[static_cast<long long>(c) * d + e] : 0.0;
     }
-    const double logp = tgt.logp_grad(q, g);
+    const double logp = tgt.logp_grad(tm, q, g);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int e = lane * NS + s;
@@ -130,8 +132,9 @@ __global__ __launch_bounds__(64) void trajectory_kernel(ChainArrays A, const dou
     const int lane = lane_id();
     const int d = A.d;
     const long long row = static_cast<long long>(c) * A.dpad;
+    Team<1> tm{nullptr, 0};
     TargetT<NS> tgt;
-    tgt.init(tparams, d);
+    tgt.init(tm, tparams, d);
     double q[NS], p[NS], g[NS];
     float var[NS];
     double vard[NS];
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(64) void trajectory_kernel(ChainArrays A, const dou
         vard[s] = static_cast<double>(var[s]);
     }
     const int n_states = n_fwd + n_back + 1;
-    double logp = tgt.logp_grad(q, g);
+    double logp = tgt.logp_grad(tm, q, g);
     double energy;
     double v[NS];
     if (p0_is_f32) {
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(64) void trajectory_kernel(ChainArrays A, const dou
             p[s] = static_cast<double>(static_cast<float>(p[s]));
             v[s] = static_cast<double>(var[s] * static_cast<float>(p[s]));
         }
-        const float kin = start_kinetic_f32<NS>(p, var, d, sdot_mode, reinterpret_cast<float*>(lds), A.dpad);
+        const float kin = start_kinetic_f32<NS>(tm, p, var, d, sdot_mode, reinterpret_cast<float*>(lds), A.dpad);
         energy = static_cast<double>(kin) - logp;
     } else {
 #pragma unroll
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(64) void trajectory_kernel(ChainArrays A, const dou
     }
     for (int k = 0; k < n_states; ++k) {
         if (k > 0) {
-            leapfrog<NS>(tgt, vard, (k <= n_fwd) ? eps : -eps, q, p, g, energy, logp);
+            leapfrog<NS>(tm, tgt, vard, (k <= n_fwd) ? eps : -eps, q, p, g, energy, logp);
 #pragma unroll
             for (int s = 0; s < NS; ++s) v[s] = static_cast<double>(var[s]) * p[s];
         }
@@ -250,7 +253,8 @@ static thread_local std::string g_last_error;
 
 struct lmc_engine {
     lmc_config cfg;
-    int ns = 0, dpad = 0, nlds = 1, lds_bytes = 0;
+    int ns = 0, dpad = 0, nlds = 1, lds_bytes = 0;   // ns: vector width of the W = 1 unit kernels (dpad = 64 * ns)
+    int run_ns = 0, run_w = 1;                       // shape of the sampling kernel: dpad = 64 * run_ns * run_w
     hipStream_t own_stream = nullptr, stream = nullptr;
     ChainArrays A;
     double* tparams = nullptr;
@@ -442,6 +446,15 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     e->cfg = *cfg;
     e->ns = ns_for_dim(cfg->dim);
     e->dpad = 64 * e->ns;
+    // sampling kernel: one wave per chain up to 128 elements, then 2 or 4 waves per chain
+    if (e->ns <= 2) { e->run_ns = e->ns; e->run_w = 1; }
+    else if (e->ns == 4) { e->run_ns = 4; e->run_w = 1; }
+    else if (e->ns == 8) { e->run_ns = 4; e->run_w = 2; }
+    else { e->run_ns = 4; e->run_w = 4; }
+    if (const char* shape = std::getenv("LMC_RUN_SHAPE")) {   // tuning knob: "ns,w" with 64*ns*w == dpad
+        int a = 0, b = 0;
+        if (std::sscanf(shape, "%d,%d", &a, &b) == 2 && 64 * a * b == e->dpad) { e->run_ns = a; e->run_w = b; }
+    }
     e->initial_step = cfg->step_scale / std::pow(static_cast<double>(cfg->dim), 0.25);   // base_hmc.py:102
 
     auto bail = [&](int rc) {
@@ -460,7 +473,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     int nlds = cfg->lds_levels;
     if (nlds <= 0) {
         nlds = 1;
-        while (nlds < max_levels && (2 + 4 * nlds) * e->dpad * 8 <= 10240) ++nlds;   // + 2.5 KiB RNG state -> 12 waves/CU
+        while (nlds < max_levels && (2 + 4 * nlds) * e->dpad * 8 <= 10240 * e->run_w) ++nlds;   // ~10 KiB per wave + RNG state -> 12 waves/CU
     }
     if (nlds > max_levels) nlds = max_levels;
     if (nlds < 1) nlds = 1;
@@ -744,17 +757,28 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
     P.nlds = e->nlds;
     P.lds_doubles = e->lds_bytes / 8;
     P.sdot_mode = e->cfg.start_energy_sdot;
-    const int run_lds = e->lds_bytes + 2560;   // subtree stack + MT19937 state
-    const dim3 grid(e->cfg.chains), block(64);
-#define RUN_CALL(T)                                                                                           \
-    LMC_NS_SWITCH(e, e->ns, {                                                                                 \
-        if (run_lds > 64 * 1024)                                                                              \
-            HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NS, T>),                 \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));             \
-        hipLaunchKernelGGL((run_kernel<NS, T>), grid, block, run_lds, e->stream, e->A, P, e->tparams);        \
-    })
+    const int run_lds = e->lds_bytes + lds_tail_doubles(e->run_w) * 8;   // subtree stack + MT19937 + team exchange
+    const dim3 grid(e->cfg.chains), block(64 * e->run_w);
+#define RUN_ONE(NSV, WV, T)                                                                                    \
+    {                                                                                                          \
+        if (run_lds > 64 * 1024)                                                                               \
+            HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NSV, WV, T>),             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));              \
+        hipLaunchKernelGGL((run_kernel<NSV, WV, T>), grid, block, run_lds, e->stream, e->A, P, e->tparams);    \
+    }
+#define RUN_CALL(T)                                                                                            \
+    {                                                                                                          \
+        const int shape = e->run_ns * 10 + e->run_w;                                                           \
+        if (shape == 11) RUN_ONE(1, 1, T)                                                                      \
+        else if (shape == 21) RUN_ONE(2, 1, T)                                                                 \
+        else if (shape == 41) RUN_ONE(4, 1, T)                                                                 \
+        else if (shape == 42) RUN_ONE(4, 2, T)                                                                 \
+        else if (shape == 44) RUN_ONE(4, 4, T)                                                                 \
+        else return fail(e, LMC_ERR_INVALID, "unsupported kernel shape ns=%d w=%d", e->run_ns, e->run_w);      \
+    }
     LMC_FAMILY_SWITCH(e, e->cfg.target_family, RUN_CALL)
 #undef RUN_CALL
+#undef RUN_ONE
     HIP_TRY(e, hipGetLastError());
     return LMC_OK;
 }

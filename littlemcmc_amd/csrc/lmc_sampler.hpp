@@ -20,6 +20,7 @@
 #pragma once
 #include "lmc_rng.hpp"
 #include "lmc_targets.hpp"
+#include "lmc_team.hpp"
 
 namespace lmc {
 
@@ -94,28 +95,16 @@ struct SamplerParams {
     int sdot_mode;        // SdotMode for the float32 start-state kinetic energy
 };
 
-// ---- numpy scalar helpers ------------------------------------------------------------------------
-__device__ __forceinline__ double np_logaddexp(double x, double y) {   // npy_logaddexp
-    if (x == y) return first_f64(x + 0.693147180559945309417232121458176568);
-    const double t = x - y;
-    if (t > 0) return first_f64(x + log1p(exp(-t)));
-    if (t <= 0) return first_f64(y + log1p(exp(t)));
-    return t;
-}
-__device__ __forceinline__ double log1mexp(double x) {   // math.py:28-35
-    return (x < 0.683) ? log(-expm1(-x)) : log1p(-exp(-x));
-}
-
-// ---- vector <-> memory (blocked layout, 8*NS contiguous bytes per lane) ---------------------------
+// ---- vector <-> memory (blocked layout, 8*NS contiguous bytes per thread of the team) -----------------
 template <int NS>
 __device__ __forceinline__ void vload(const double* base, double (&x)[NS]) {
-    const double* p = base + lane_id() * NS;
+    const double* p = base + static_cast<int>(threadIdx.x) * NS;
 #pragma unroll
     for (int s = 0; s < NS; ++s) x[s] = p[s];
 }
 template <int NS>
 __device__ __forceinline__ void vstore(double* base, const double (&x)[NS]) {
-    double* p = base + lane_id() * NS;
+    double* p = base + static_cast<int>(threadIdx.x) * NS;
 #pragma unroll
     for (int s = 0; s < NS; ++s) p[s] = x[s];
 }
@@ -200,8 +189,9 @@ __device__ inline float sdot_openblas(const float* x, const float* y, int n, int
 }
 
 // 0.5f * p.dot(v) for the float32 start state; p, v float32-valued. scratch: >= 2*dpad floats of LDS.
-template <int NS>
-__device__ inline float start_kinetic_f32(const double (&p0)[NS], const float (&var)[NS], int d, int mode,
+// With W > 1 every wave evaluates the same staged vectors redundantly (same value everywhere).
+template <int NS, class TeamT>
+__device__ inline float start_kinetic_f32(TeamT& tm, const double (&p0)[NS], const float (&var)[NS], int d, int mode,
                                           float* scratch, int dpad) {
     if (mode == kSdotNative) {
         double part = 0.0;
@@ -210,21 +200,60 @@ __device__ inline float start_kinetic_f32(const double (&p0)[NS], const float (&
             const float pf = static_cast<float>(p0[s]);
             part = __builtin_fma(static_cast<double>(pf), static_cast<double>(var[s] * pf), part);
         }
-        return 0.5f * static_cast<float>(wave_sum(part));
+        return 0.5f * static_cast<float>(tm.sum(part));
     }
-    const int lane = lane_id();
+    const int t = tm.tid();
     float* x = scratch;
     float* y = scratch + dpad;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const float pf = static_cast<float>(p0[s]);
-        x[lane * NS + s] = pf;
-        y[lane * NS + s] = var[s] * pf;
+        x[t * NS + s] = pf;
+        y[t * NS + s] = var[s] * pf;
     }
-    wave_sync();
+    tm.sync();
     const float dot = sdot_openblas(x, y, d, mode);
-    wave_sync();
+    tm.sync();
     return 0.5f * dot;
+}
+
+// ---- team-wide RNG access ---------------------------------------------------------------------------------
+// The MT19937 state is shared by the team (LDS); every wave keeps identical copies of the scalar stream state.
+// A twist is done by wave 0 between two barriers; normal(size=d) is produced by wave 0 and its stream state
+// re-broadcast through LDS.
+template <class TeamT>
+__device__ inline double team_uniform(TeamT& tm, RngState& r, UniformWindow& w) {
+    if constexpr (TeamT::kWaves == 1) {
+        return window_next(r, w);
+    } else {
+        if (w.idx == w.n && r.pos >= kMtN) {
+            tm.sync();                       // every wave has finished reading the old generation
+            if (tm.wave() == 0) mt_regen(r);
+            tm.sync();
+            r.pos = 0;
+        }
+        return window_next(r, w);
+    }
+}
+template <class TeamT>
+__device__ inline void team_normals(TeamT& tm, RngState& r, int d, double* out, double* stage, double* bcast) {
+    if constexpr (TeamT::kWaves == 1) {
+        rng_normals(r, d, out, stage);
+    } else {
+        tm.sync();
+        if (tm.wave() == 0) {
+            rng_normals(r, d, out, stage);
+            if (lane_id() == 0) {
+                bcast[0] = static_cast<double>(r.pos);
+                bcast[1] = static_cast<double>(r.has_gauss);
+                bcast[2] = r.gauss;
+            }
+        }
+        tm.sync();
+        r.pos = first_i32(static_cast<int>(bcast[0]));
+        r.has_gauss = first_i32(static_cast<int>(bcast[1]));
+        r.gauss = first_f64(bcast[2]);
+    }
 }
 
 // ---- leapfrog (integration.py:100-121) -------------------------------------------------------------
@@ -232,8 +261,8 @@ __device__ inline float start_kinetic_f32(const double (&p0)[NS], const float (&
 // operation as numpy's (TU built with -ffp-contract=off); only the two reductions differ in order.
 // Targets whose log-density is a plain lane sum (kLanePartial) hand back the per-lane partial, so
 // logp and the kinetic energy share ONE interleaved butterfly instead of two dependent ones.
-template <int NS, class Target>
-__device__ __forceinline__ void leapfrog(const Target& tgt, const double (&var)[NS], double eps,
+template <int NS, class Target, class TeamT>
+__device__ __forceinline__ void leapfrog(TeamT& tm, const Target& tgt, const double (&var)[NS], double eps,
                                          double (&q)[NS], double (&p)[NS], double (&g)[NS],
                                          double& energy, double& logp) {
     const double dt = 0.5 * eps;
@@ -244,25 +273,25 @@ __device__ __forceinline__ void leapfrog(const Target& tgt, const double (&var)[
         q[s] = q[s] + eps * v;
     }
     if constexpr (Target::kLanePartial) {
-        double lp = tgt.logp_grad_partial(q, g);
+        double lp = tgt.logp_grad_partial(tm, q, g);
         double kin = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             p[s] = p[s] + dt * g[s];
             kin = __builtin_fma(p[s], var[s] * p[s], kin);
         }
-        wave_sum2(lp, kin);
+        tm.sum2(lp, kin);
         logp = lp;
         energy = first_f64(0.5 * kin - logp);
     } else {
-        logp = first_f64(tgt.logp_grad(q, g));
+        logp = first_f64(tgt.logp_grad(tm, q, g));
         double kin = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             p[s] = p[s] + dt * g[s];
             kin = __builtin_fma(p[s], var[s] * p[s], kin);
         }
-        energy = first_f64(0.5 * wave_sum(kin) - logp);
+        energy = first_f64(0.5 * tm.sum(kin) - logp);
     }
 }
 
@@ -310,8 +339,8 @@ struct TransitionOut {
 
 // ---- NUTS transition -----------------------------------------------------------------------------------
 // q0/p0/g0: start state (p0 float32-valued when momentum_f32). On return q holds the proposal.
-template <int NS, class Target>
-__device__ inline void nuts_transition(const Target& tgt, const double (&var)[NS], RngState& rng,
+template <int NS, class Target, class TeamT>
+__device__ inline void nuts_transition(TeamT& tm, const Target& tgt, const double (&var)[NS], RngState& rng,
                                        const TreeStack& stk, double (&q)[NS], const double (&p0)[NS],
                                        const double (&g0)[NS], double e0, double logp0, double step_size,
                                        double emax, int max_depth, bool momentum_f32, TransitionOut& out) {
@@ -333,7 +362,7 @@ __device__ inline void nuts_transition(const Target& tgt, const double (&var)[NS
     window_reset(win);
 
     for (int dd = 0; dd < max_depth; ++dd) {
-        const bool right = window_next(rng, win) < 0.5;   // log(U) < log(.5), nuts.py:213
+        const bool right = team_uniform(tm, rng, win) < 0.5;   // log(U) < log(.5), nuts.py:213
         const double eps = right ? step_size : -step_size;
         double cq[NS], cp[NS], cg[NS];
         if (right) { vcopy(cq, Rq); vcopy(cp, Rp); vcopy(cg, Rg); }
@@ -345,7 +374,7 @@ __device__ inline void nuts_transition(const Target& tgt, const double (&var)[NS
         const int n_leaves = 1 << depth;
         for (int i = 0; i < n_leaves; ++i) {
             double energy, logp;
-            leapfrog<NS>(tgt, var, eps, cq, cp, cg, energy, logp);
+            leapfrog<NS>(tm, tgt, var, eps, cq, cp, cg, energy, logp);
             ++n_leap;
             double de = first_f64(energy - e0);
             if (isnan(de)) de = INFINITY;
@@ -384,16 +413,16 @@ __device__ inline void nuts_transition(const Target& tgt, const double (&var)[NS
                     double p1[NS], p2[NS];
 #pragma unroll
                     for (int s = 0; s < NS; ++s) { p1[s] = aps[s] + tlp[s]; p2[s] = arp[s] + tps[s]; }
-                    const double dots[6] = {pdot_v<NS>(ps, var, alp), pdot_v<NS>(ps, var, trp),
-                                            pdot_v<NS>(p1, var, alp), pdot_v<NS>(p1, var, tlp),
-                                            pdot_v<NS>(p2, var, arp), pdot_v<NS>(p2, var, trp)};
-                    turn = any_sum_nonpositive6(dots);
+                    double dots[6] = {pdot_v<NS>(ps, var, alp), pdot_v<NS>(ps, var, trp),
+                                      pdot_v<NS>(p1, var, alp), pdot_v<NS>(p1, var, tlp),
+                                      pdot_v<NS>(p2, var, arp), pdot_v<NS>(p2, var, trp)};
+                    turn = tm.any_nonpositive6(dots);
                 } else {
-                    turn = any_sum_nonpositive2(pdot_v<NS>(ps, var, alp), pdot_v<NS>(ps, var, trp));
+                    turn = tm.any_nonpositive2(pdot_v<NS>(ps, var, alp), pdot_v<NS>(ps, var, trp));
                 }
                 const double wsum = first_f64(aw + tw);
                 const double asum = first_f64(aa + ta);
-                const bool take_b = first_f64(window_next(rng, win) * wsum) < tw;   // nuts.py:404 (drawn even if turning)
+                const bool take_b = first_f64(team_uniform(tm, rng, win) * wsum) < tw;   // nuts.py:404 (drawn even if turning)
                 // merged node: left end from a, right end from b(t)
                 vcopy(tlp, alp); vcopy(tps, ps);
                 if (!take_b) { vcopy(tq, aq); tpe = ape; tplogp = aplogp; }
@@ -418,7 +447,7 @@ __device__ inline void nuts_transition(const Target& tgt, const double (&var)[NS
         if (diverging || turning) { exhausted = false; break; }
 
         // ---- accepted subtree t: merge into the trajectory (nuts.py:321-340)
-        if (first_f64(window_next(rng, win) * (w_start + wn)) < tw) {   // biased progressive: U < w_sub / w_tree
+        if (first_f64(team_uniform(tm, rng, win) * (w_start + wn)) < tw) {   // biased progressive: U < w_sub / w_tree
             vcopy(propq, tq); prop_e = tpe; prop_logp = tplogp;
         }
         wn = first_f64(wn + tw);
@@ -451,7 +480,7 @@ __device__ inline void nuts_transition(const Target& tgt, const double (&var)[NS
         }
         dots[0] = l_start ? pdot_v32<NS>(psum, var, Lp) : pdot_v<NS>(psum, var, Lp);
         dots[1] = r_start ? pdot_v32<NS>(psum, var, Rp) : pdot_v<NS>(psum, var, Rp);
-        if (any_sum_nonpositive6(dots)) { turning = true; exhausted = false; break; }
+        if (tm.any_nonpositive6(dots)) { turning = true; exhausted = false; break; }
     }
 
     // nuts.py:421-425: exp(lwas - log(e^{log_size} - 1)) == sum(w min(1,w)) / sum(w) over accepted leaves
@@ -471,21 +500,21 @@ __device__ inline void nuts_transition(const Target& tgt, const double (&var)[NS
 }
 
 // ---- HMC transition (hmc.py:140-182) -------------------------------------------------------------------
-template <int NS, class Target>
-__device__ inline void hmc_transition(const Target& tgt, const double (&var)[NS], RngState& rng,
+template <int NS, class Target, class TeamT>
+__device__ inline void hmc_transition(TeamT& tm, const Target& tgt, const double (&var)[NS], RngState& rng,
                                       double (&q)[NS], const double (&p0)[NS], const double (&g0)[NS],
                                       double e0, double logp0, double step_size, double emax,
                                       double path_length, int max_steps, TransitionOut& out) {
     UniformWindow win;
     window_reset(win);
-    const double plen = first_f64(window_next(rng, win) * path_length);
+    const double plen = first_f64(team_uniform(tm, rng, win) * path_length);
     int n_steps = static_cast<int>(plen / step_size);
     n_steps = n_steps < 1 ? 1 : n_steps;
     n_steps = n_steps > max_steps ? max_steps : n_steps;
     double cq[NS], cp[NS], cg[NS];
     vcopy(cq, q); vcopy(cp, p0); vcopy(cg, g0);
     double energy = e0, logp = logp0;
-    for (int i = 0; i < n_steps; ++i) leapfrog<NS>(tgt, var, step_size, cq, cp, cg, energy, logp);
+    for (int i = 0; i < n_steps; ++i) leapfrog<NS>(tm, tgt, var, step_size, cq, cp, cg, energy, logp);
     bool diverging = !isfinite(energy);
     double de = first_f64(e0 - energy);
     if (isnan(de)) de = -INFINITY;
@@ -493,7 +522,7 @@ __device__ inline void hmc_transition(const Target& tgt, const double (&var)[NS]
     const double accept = first_f64(fmin(1.0, exp_uniform(de)));
     bool accepted = false;
     if (!diverging) {
-        const double u = window_next(rng, win);
+        const double u = team_uniform(tm, rng, win);
         if (!(u >= accept)) { accepted = true; vcopy(q, cq); }
     }
     out.accept = accept;
@@ -510,8 +539,9 @@ __device__ inline void hmc_transition(const Target& tgt, const double (&var)[NS]
 }
 
 // ---- the iteration kernel: n_iters x _astep for every chain, no host round trips ------------------------
-// Occupancy target per vector width (waves per SIMD; the VGPR budget is 512 / waves): the
-// per-chain state is register resident, so wider chains trade occupancy for registers.
+// Occupancy target per vector width (waves per SIMD; the VGPR budget is 512 / waves): the per-chain state
+// is register resident, so wider per-thread slices trade occupancy for registers. Chains longer than
+// 128 elements are spread over W waves (dpad = 64 * NS * W) instead of growing NS further.
 #ifndef LMC_WAVES_NS1
 #define LMC_WAVES_NS1 4
 #endif
@@ -524,19 +554,26 @@ __device__ inline void hmc_transition(const Target& tgt, const double (&var)[NS]
 constexpr int run_waves_per_simd(int ns) {
     return ns <= 1 ? LMC_WAVES_NS1 : ns == 2 ? LMC_WAVES_NS2 : ns == 4 ? LMC_WAVES_NS4 : 1;
 }
+// LDS carve (doubles) behind the subtree stack: MT19937 state (624 words), team exchange area, RNG re-broadcast
+constexpr int kLdsMtDoubles = 320;
+constexpr int lds_tail_doubles(int w) { return w == 1 ? kLdsMtDoubles : kLdsMtDoubles + 2 * w * kTeamSlots + 4; }
 
-template <int NS, template <int> class TargetT>
-__global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainArrays A, SamplerParams P, const double* tparams) {
+template <int NS, int W, template <int> class TargetT>
+__global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(ChainArrays A, SamplerParams P, const double* tparams) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int c = blockIdx.x;
-    const int lane = lane_id();
     const int d = A.d, dpad = A.dpad;
     const long long row = static_cast<long long>(c) * dpad;
+    Team<W> tm;
+    tm.xbuf = lds + P.lds_doubles + kLdsMtDoubles;
+    tm.parity = 0;
+    double* rng_bcast = tm.xbuf + 2 * W * kTeamSlots;
+    const int tid = tm.tid();
 
     if (A.status[c] & kStatusBadInitialEnergy) return;   // chain already aborted (ValueError on host)
 
     TargetT<NS> tgt;
-    tgt.init(tparams, d);
+    tgt.init(tm, tparams, d);
 
     // ---- load persistent chain state
     double q[NS];
@@ -545,8 +582,8 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
     vload<NS>(A.q + row, q);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        var[s] = A.var[row + lane * NS + s];
-        inv_std[s] = A.inv_std[row + lane * NS + s];
+        var[s] = A.var[row + tid * NS + s];
+        inv_std[s] = A.inv_std[row + tid * NS + s];
         vard[s] = static_cast<double>(var[s]);
     }
     // The MT19937 state lives in LDS for the whole launch (2.5 KB per wave, behind the subtree stack): the
@@ -554,8 +591,8 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
     RngState rng;
     uint32_t* mt_glb = A.mt + static_cast<long long>(c) * kMtN;
     uint32_t* mt_lds = reinterpret_cast<uint32_t*>(lds + P.lds_doubles);
-    for (int i = lane; i < kMtN; i += 64) mt_lds[i] = mt_glb[i];
-    wave_sync();
+    for (int i = tid; i < kMtN; i += 64 * W) mt_lds[i] = mt_glb[i];
+    tm.sync();
     rng.mt = mt_lds;
     rng.pos = first_i32(A.rng_pos[c]);
     rng.has_gauss = first_i32(A.rng_has_gauss[c]);
@@ -586,26 +623,26 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
         const bool tune = git < P.n_tune;
 
         // ---- momentum draw (quadpotential.py:221-224 / :374-376)
-        rng_normals(rng, d, lds, lds + dpad);   // the level-0 LDS region (2*dpad doubles) = normals + staging
+        team_normals(tm, rng, d, lds, lds + dpad, rng_bcast);   // level-0 LDS region (2*dpad doubles) = normals + staging
         double p0[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const int e = lane * NS + s;
+            const int e = tid * NS + s;
             const double z = (e < d) ? lds[e] : 0.0;
             p0[s] = P.momentum_f32 ? static_cast<double>(inv_std[s] * static_cast<float>(z))
                                    : z * static_cast<double>(inv_std[s]);
         }
-        wave_sync();
+        tm.sync();
 
         // ---- start state (integration.py:52-66)
         double g0[NS];
-        const double logp0 = first_f64(tgt.logp_grad(q, g0));
+        const double logp0 = first_f64(tgt.logp_grad(tm, q, g0));
         double e0;
         if (P.momentum_f32) {   // float32 velocity, float32 kinetic energy (BLAS-order faithful)
-            const float kin = start_kinetic_f32<NS>(p0, var, d, P.sdot_mode, reinterpret_cast<float*>(lds), dpad);
+            const float kin = start_kinetic_f32<NS>(tm, p0, var, d, P.sdot_mode, reinterpret_cast<float*>(lds), dpad);
             e0 = first_f64(static_cast<double>(kin) - logp0);
         } else {
-            e0 = first_f64(0.5 * wave_sum(pdot_v<NS>(p0, vard, p0)) - logp0);
+            e0 = first_f64(0.5 * tm.sum(pdot_v<NS>(p0, vard, p0)) - logp0);
         }
         if (!isfinite(e0)) {   // base_hmc.py:145-148: the reference raises; the chain stops here
             status |= kStatusBadInitialEnergy;
@@ -619,11 +656,11 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
         TransitionOut out;
         if (P.kind == 0) {
             const int md = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
-            nuts_transition<NS>(tgt, vard, rng, stk, q, p0, g0, e0, logp0, step_size, P.emax, md,
+            nuts_transition<NS>(tm, tgt, vard, rng, stk, q, p0, g0, e0, logp0, step_size, P.emax, md,
                                 P.momentum_f32 != 0, out);
             if (out.exhausted && !tune) ++ct_maxdepth;
         } else {
-            hmc_transition<NS>(tgt, vard, rng, q, p0, g0, e0, logp0, step_size, P.emax, P.path_length,
+            hmc_transition<NS>(tm, tgt, vard, rng, q, p0, g0, e0, logp0, step_size, P.emax, P.path_length,
                                P.max_steps, out);
         }
         if (out.nan_logbern) status |= kStatusNanLogbern;
@@ -667,7 +704,7 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
                 m[s] = m[s] + prop_f * od;
                 const double nd = q[s] - m[s];
                 r[s] = r[s] + 1.0 * od * nd;
-                const int e = lane * NS + s;
+                const int e = tid * NS + s;
                 if (e < d) {
                     var[s] = static_cast<float>(r[s] / wsum_f);
                     const float sd = sqrtf(var[s]);
@@ -709,11 +746,11 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
             double* tr = A.trace + (static_cast<long long>(c) * (A.cap - A.trace_begin) + (git - A.trace_begin)) * d;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                const int e = lane * NS + s;
+                const int e = tid * NS + s;
                 if (e < d) tr[e] = q[s];
             }
         }
-        if (lane == 0) {
+        if (tid == 0) {
             const long long fs = static_cast<long long>(A.chains) * A.cap;
             A.stat_f64[kSfStepSize * fs + orow] = step_now;
             A.stat_f64[kSfStepSizeBar * fs + orow] = step_bar_now;
@@ -731,15 +768,15 @@ __global__ __launch_bounds__(64, run_waves_per_simd(NS)) void run_kernel(ChainAr
     }
 
     // ---- store persistent chain state
-    wave_sync();
-    for (int i = lane; i < kMtN; i += 64) mt_glb[i] = mt_lds[i];
+    tm.sync();
+    for (int i = tid; i < kMtN; i += 64 * W) mt_glb[i] = mt_lds[i];
     vstore<NS>(A.q + row, q);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        A.var[row + lane * NS + s] = var[s];
-        A.inv_std[row + lane * NS + s] = inv_std[s];
+        A.var[row + tid * NS + s] = var[s];
+        A.inv_std[row + tid * NS + s] = inv_std[s];
     }
-    if (lane == 0) {
+    if (tid == 0) {
         A.rng_pos[c] = rng.pos;
         A.rng_has_gauss[c] = rng.has_gauss;
         A.rng_gauss[c] = rng.gauss;

@@ -2,21 +2,22 @@
 // (/root/reference/littlemcmc/integration.py:40,62,115) as a __device__ functor that is inlined
 // into the leapfrog of the transition kernel.
 //
-// Contract (the "lane-distributed" form of the plug-in):
+// Contract (the "thread-distributed" form of the plug-in). A chain is owned by a team of 64*W threads
+// (lmc_team.hpp; W = 1 for d <= 128); thread t = tm.tid() owns elements e = t*NS + s, s < NS. Elements with
+// e >= d are padding: they arrive as 0 and MUST be returned as 0 in g.
 //   template <int NS> struct Target {
-//       static constexpr bool kLanePartial = false;
-//       __device__ void init(const double* params, int d);          // once per kernel, per wave
-//       __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const;
-//       // only if kLanePartial: the per-lane partial p_l with logp = sum over lanes of p_l; lets the
-//       // integrator fuse this reduction with the kinetic-energy one
-//       __device__ double logp_grad_partial(const double (&q)[NS], double (&g)[NS]) const;
+//       static constexpr bool kLanePartial = ...;
+//       template <class Team> __device__ void init(Team& tm, const double* params, int d);   // once per kernel
+//       // logp must be team-uniform: reduce with tm.sum(); neighbours with tm.neighbours(); thread 0's value
+//       // with tm.bcast0()
+//       template <class Team> __device__ double logp_grad(Team& tm, const double (&q)[NS], double (&g)[NS]) const;
+//       // only if kLanePartial: the per-thread partial p_t with logp = sum_t p_t; lets the integrator fuse this
+//       // reduction with the kinetic-energy one
+//       template <class Team> __device__ double logp_grad_partial(Team& tm, const double (&q)[NS], double (&g)[NS]) const;
 //   };
-// Lane l owns elements e = l*NS + s, s < NS; elements with e >= d are padding: they arrive as 0
-// and MUST be returned as 0 in g. The return value (logp) must be wave-uniform; use
-// lmc::wave_sum() for reductions and lmc::from_lane_below/above() for neighbours.
 // The CPU statements of the same densities are in oracle/targets.py (same operation order).
 #pragma once
-#include "lmc_wave.hpp"
+#include "lmc_team.hpp"
 
 namespace lmc {
 
@@ -33,8 +34,10 @@ enum TargetFamily : int {
 template <int NS>
 struct StdNormalTarget {
     static constexpr bool kLanePartial = true;
-    __device__ void init(const double*, int) {}
-    __device__ double logp_grad_partial(const double (&q)[NS], double (&g)[NS]) const {
+    template <class Team>
+    __device__ void init(Team&, const double*, int) {}
+    template <class Team>
+    __device__ double logp_grad_partial(Team&, const double (&q)[NS], double (&g)[NS]) const {
         double part = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -43,8 +46,9 @@ struct StdNormalTarget {
         }
         return -0.5 * part;   // exact scaling: sum(-q^2/2) == -(sum q^2)/2 bit for bit
     }
-    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
-        return wave_sum(logp_grad_partial(q, g));
+    template <class Team>
+    __device__ double logp_grad(Team& tm, const double (&q)[NS], double (&g)[NS]) const {
+        return tm.sum(logp_grad_partial(tm, q, g));
     }
 };
 
@@ -53,15 +57,16 @@ template <int NS>
 struct DiagGaussianTarget {
     static constexpr bool kLanePartial = true;
     double prec[NS];
-    __device__ void init(const double* params, int d) {
-        const int lane = lane_id();
+    template <class Team>
+    __device__ void init(Team& tm, const double* params, int d) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const int e = lane * NS + s;
+            const int e = tm.tid() * NS + s;
             prec[s] = (e < d) ? params[e] : 0.0;
         }
     }
-    __device__ double logp_grad_partial(const double (&q)[NS], double (&g)[NS]) const {
+    template <class Team>
+    __device__ double logp_grad_partial(Team&, const double (&q)[NS], double (&g)[NS]) const {
         double part = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -70,8 +75,9 @@ struct DiagGaussianTarget {
         }
         return 0.5 * part;
     }
-    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
-        return wave_sum(logp_grad_partial(q, g));
+    template <class Team>
+    __device__ double logp_grad(Team& tm, const double (&q)[NS], double (&g)[NS]) const {
+        return tm.sum(logp_grad_partial(tm, q, g));
     }
 };
 
@@ -80,26 +86,28 @@ struct DiagGaussianTarget {
 template <int NS>
 struct AR1Target {
     static constexpr bool kLanePartial = true;
-    // per-lane coefficient slices, fixed for the whole kernel: diagonal, coupling to e-1 and to e+1.
+    // per-thread coefficient slices, fixed for the whole kernel: diagonal, coupling to e-1 and to e+1.
     // Boundary / padding elements simply carry a 0 coefficient, so the hot loop has no selects.
     double diag[NS], lo[NS], hi[NS];
-    __device__ void init(const double* params, int d) {
+    template <class Team>
+    __device__ void init(Team& tm, const double* params, int d) {
         const double c_end = params[0], c_mid = params[1], off = params[2];
-        const int lane = lane_id();
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const int e = lane * NS + s;
+            const int e = tm.tid() * NS + s;
             diag[s] = (e >= d) ? 0.0 : ((e == 0 || e == d - 1) ? c_end : c_mid);
             lo[s] = (e > 0 && e < d) ? off : 0.0;
             hi[s] = (e < d - 1) ? off : 0.0;
         }
     }
-    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
-        return wave_sum(logp_grad_partial(q, g));
+    template <class Team>
+    __device__ double logp_grad(Team& tm, const double (&q)[NS], double (&g)[NS]) const {
+        return tm.sum(logp_grad_partial(tm, q, g));
     }
-    __device__ double logp_grad_partial(const double (&q)[NS], double (&g)[NS]) const {
-        const double below = from_lane_below(q[NS - 1]);   // element e-1 of this lane's first slot
-        const double above = from_lane_above(q[0]);        // element e+1 of this lane's last slot
+    template <class Team>
+    __device__ double logp_grad_partial(Team& tm, const double (&q)[NS], double (&g)[NS]) const {
+        double below, above;   // element e-1 of this thread's first slot, e+1 of its last slot
+        tm.neighbours(q[NS - 1], q[0], below, above);
         double part = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -119,24 +127,26 @@ template <int NS>
 struct FunnelTarget {
     static constexpr bool kLanePartial = false;
     int d;
-    __device__ void init(const double*, int d_) { d = d_; }
-    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
-        const int lane = lane_id();
-        const double v = readlane_f64(q[0], 0);
+    template <class Team>
+    __device__ void init(Team&, const double*, int d_) { d = d_; }
+    template <class Team>
+    __device__ double logp_grad(Team& tm, const double (&q)[NS], double (&g)[NS]) const {
+        const int t = tm.tid();
+        const double v = tm.bcast0(q[0]);
         double part = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const int e = lane * NS + s;
+            const int e = t * NS + s;
             if (e > 0) part = __builtin_fma(q[s], q[s], part);
         }
-        const double ssum = wave_sum(part);
+        const double ssum = tm.sum(part);
         const double ev = exp(-v);
         const double hes = 0.5 * ev * ssum;
         const double dm1 = static_cast<double>(d - 1);
         const double logp = -(v * v) / 18.0 - 0.5 * dm1 * v - hes;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const int e = lane * NS + s;
+            const int e = t * NS + s;
             g[s] = (e == 0) ? (-v / 9.0 - 0.5 * dm1 + hes) : ((e < d) ? -(ev * q[s]) : 0.0);
         }
         return logp;
@@ -150,17 +160,18 @@ template <int NS>
 struct Normal1DTarget {
     static constexpr bool kLanePartial = false;
     double loc, scale, lognorm;
-    __device__ void init(const double* params, int) {
+    template <class Team>
+    __device__ void init(Team&, const double* params, int) {
         loc = params[0];
         scale = params[1];
         lognorm = log(scale * sqrt(2.0 * 3.141592653589793));
     }
-    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const {
-        const int lane = lane_id();
-        const double x = readlane_f64(q[0], 0);
+    template <class Team>
+    __device__ double logp_grad(Team& tm, const double (&q)[NS], double (&g)[NS]) const {
+        const double x = tm.bcast0(q[0]);
         const double z = (x - loc) / scale;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) g[s] = (lane == 0 && s == 0) ? -(x - loc) / scale : 0.0;
+        for (int s = 0; s < NS; ++s) g[s] = (tm.tid() == 0 && s == 0) ? -(x - loc) / scale : 0.0;
         return -0.5 * z * z - lognorm;
     }
 };

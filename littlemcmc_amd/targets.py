@@ -110,11 +110,12 @@ class UserTarget(DeviceTarget):
     ``source`` must define, in namespace ``lmc``::
 
         template <int NS> struct UserTarget {
-            __device__ void init(const double* params, int d);
-            __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const;
+            static constexpr bool kLanePartial = false;
+            template <class Team> __device__ void init(Team& tm, const double* params, int d);
+            template <class Team> __device__ double logp_grad(Team& tm, const double (&q)[NS], double (&g)[NS]) const;
         };
 
-    following the lane-distributed contract documented in csrc/lmc_targets.hpp. The library is
+    following the thread-distributed contract documented in csrc/lmc_targets.hpp. The library is
     rebuilt once per distinct source (cached by content hash next to the package).
     """
 

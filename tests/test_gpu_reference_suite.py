@@ -162,22 +162,27 @@ def test_bad_initial_energy_raises_value_error():
 
 # ---- a user-written device log-density, compiled at run time and linked into the kernels -------------------
 USER_SRC = r"""
-#include "lmc_wave.hpp"
+#include "lmc_team.hpp"
 namespace lmc {
 // independent Gaussians with means mu (params) and unit variance: logp = -1/2 sum (q - mu)^2
 template <int NS>
 struct UserTarget {
     static constexpr bool kLanePartial = true;
     double mu[NS];
-    __device__ void init(const double* params, int d) {
-        for (int s = 0; s < NS; ++s) { const int e = lane_id() * NS + s; mu[s] = (e < d) ? params[e] : 0.0; }
+    template <class Team>
+    __device__ void init(Team& tm, const double* params, int d) {
+        for (int s = 0; s < NS; ++s) { const int e = tm.tid() * NS + s; mu[s] = (e < d) ? params[e] : 0.0; }
     }
-    __device__ double logp_grad_partial(const double (&q)[NS], double (&g)[NS]) const {
+    template <class Team>
+    __device__ double logp_grad_partial(Team&, const double (&q)[NS], double (&g)[NS]) const {
         double part = 0.0;
         for (int s = 0; s < NS; ++s) { const double z = q[s] - mu[s]; g[s] = -z; part = __builtin_fma(z, z, part); }
         return -0.5 * part;
     }
-    __device__ double logp_grad(const double (&q)[NS], double (&g)[NS]) const { return wave_sum(logp_grad_partial(q, g)); }
+    template <class Team>
+    __device__ double logp_grad(Team& tm, const double (&q)[NS], double (&g)[NS]) const {
+        return tm.sum(logp_grad_partial(tm, q, g));
+    }
 };
 }  // namespace lmc
 """
