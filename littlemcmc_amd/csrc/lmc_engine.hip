@@ -470,10 +470,16 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     // subtree-stack levels in LDS: as many as fit in ~10 KiB per wave (16 waves/CU), at least one
     const int max_levels = (cfg->max_treedepth > cfg->early_max_treedepth ? cfg->max_treedepth
                                                                           : cfg->early_max_treedepth);
+    // LDS per block: subtree-stack levels + tail (RNG state, team exchange). Keep as many stack levels in LDS
+    // as fit WITHOUT lowering the occupancy the register budget allows (160 KiB per CU; allocation granule
+    // taken as 1280 B -- measured: 12 800 B per wave keeps 12 waves/CU, 12 960 B does not).
     int nlds = cfg->lds_levels;
     if (nlds <= 0) {
+        const int waves_per_cu = 4 * run_waves_per_simd(e->run_ns);
+        const int blocks_per_cu = waves_per_cu / e->run_w > 0 ? waves_per_cu / e->run_w : 1;
+        const long budget = (163840L / blocks_per_cu) / 1280 * 1280 - lds_tail_doubles(e->run_w) * 8L;
         nlds = 1;
-        while (nlds < max_levels && (2 + 4 * nlds) * e->dpad * 8 <= 10240 * e->run_w) ++nlds;   // ~10 KiB per wave + RNG state -> 12 waves/CU
+        while (nlds < max_levels && (2L + 4 * nlds) * e->dpad * 8 <= budget) ++nlds;
     }
     if (nlds > max_levels) nlds = max_levels;
     if (nlds < 1) nlds = 1;
