@@ -299,15 +299,65 @@ __device__ __forceinline__ void leapfrog(TeamT& tm, const Target& tgt, const dou
 // Level j < nlds lives in LDS, deeper levels in the chain's HBM scratch row. Level 0 holds {p, q},
 // level j > 0 holds {lp, rp, psum, prop q}; per-level scalars live in registers (lane j).
 struct TreeStack {
-    double* lds;        // this wave's LDS region
+    double* lds;        // this team's LDS region
     double* glb;        // this chain's scratch row (levels >= nlds)
     int nlds;
     int dpad;
-    __device__ __forceinline__ double* level(int j) const {
-        if (j < nlds) return lds + (j == 0 ? 0 : (2 + 4 * (j - 1)) * dpad);
-        return glb + static_cast<long long>(j - nlds) * 4 * dpad;
-    }
+    __device__ __forceinline__ int lds_offset(int j) const { return (j == 0 ? 0 : (2 + 4 * (j - 1)) * dpad); }
+    __device__ __forceinline__ long long glb_offset(int j) const { return static_cast<long long>(j - nlds) * 4 * dpad; }
 };
+
+// Stack traffic with explicit address spaces: ds_read/ds_write_b128 for the LDS levels, global_load/store for
+// the spilled ones (a generic pointer would make every access a flat_* instruction that checks the aperture
+// and ties up both the LDS and the vector-memory counters).
+typedef __attribute__((address_space(3))) double lds_double;
+typedef __attribute__((address_space(1))) double glb_double;
+template <int NS, class PTR>
+__device__ __forceinline__ void vload_as(PTR base, double (&x)[NS]) {
+    PTR p = base + static_cast<int>(threadIdx.x) * NS;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) x[s] = p[s];
+}
+template <int NS, class PTR>
+__device__ __forceinline__ void vstore_as(PTR base, const double (&x)[NS]) {
+    PTR p = base + static_cast<int>(threadIdx.x) * NS;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) p[s] = x[s];
+}
+// level 0 holds {p, q}; level j > 0 holds {lp, rp, psum, prop q}
+template <int NS>
+__device__ __forceinline__ void stack_load(const TreeStack& stk, int j, double (&lp)[NS], double (&rp)[NS],
+                                           double (&ps)[NS], double (&pq)[NS]) {
+    const int dp = stk.dpad;
+    if (j < stk.nlds) {
+        lds_double* b = (lds_double*)(stk.lds) + stk.lds_offset(j);
+        if (j == 0) {
+            vload_as<NS>(b, lp); vload_as<NS>(b + dp, pq);
+        } else {
+            vload_as<NS>(b, lp); vload_as<NS>(b + dp, rp); vload_as<NS>(b + 2 * dp, ps); vload_as<NS>(b + 3 * dp, pq);
+        }
+    } else {
+        glb_double* b = (glb_double*)(stk.glb) + stk.glb_offset(j);
+        vload_as<NS>(b, lp); vload_as<NS>(b + dp, rp); vload_as<NS>(b + 2 * dp, ps); vload_as<NS>(b + 3 * dp, pq);
+    }
+    if (j == 0) { vcopy(rp, lp); vcopy(ps, lp); }
+}
+template <int NS>
+__device__ __forceinline__ void stack_store(const TreeStack& stk, int j, const double (&lp)[NS], const double (&rp)[NS],
+                                            const double (&ps)[NS], const double (&pq)[NS]) {
+    const int dp = stk.dpad;
+    if (j < stk.nlds) {
+        lds_double* b = (lds_double*)(stk.lds) + stk.lds_offset(j);
+        if (j == 0) {
+            vstore_as<NS>(b, ps); vstore_as<NS>(b + dp, pq);
+        } else {
+            vstore_as<NS>(b, lp); vstore_as<NS>(b + dp, rp); vstore_as<NS>(b + 2 * dp, ps); vstore_as<NS>(b + 3 * dp, pq);
+        }
+    } else {
+        glb_double* b = (glb_double*)(stk.glb) + stk.glb_offset(j);
+        vstore_as<NS>(b, lp); vstore_as<NS>(b + dp, rp); vstore_as<NS>(b + 2 * dp, ps); vstore_as<NS>(b + 3 * dp, pq);
+    }
+}
 
 // Tree weights are kept in the LINEAR domain: w = exp(-dE - c) with one offset c per transition.
 // The reference carries log-weights and pays logaddexp (exp + log1p) twice plus log(U) per merge
@@ -396,14 +446,7 @@ __device__ inline void nuts_transition(TeamT& tm, const Target& tgt, const doubl
             while ((i >> j) & 1) {   // t closes a right child: merge stack[j] (a, earlier) with t (b)
                 double alp[NS], arp[NS], aps[NS], aq[NS];
                 double aw, aa, ape, aplogp;
-                const double* lv = stk.level(j);
-                if (j == 0) {
-                    vload<NS>(lv, alp); vcopy(arp, alp); vcopy(aps, alp);
-                    vload<NS>(lv + stk.dpad, aq);
-                } else {
-                    vload<NS>(lv, alp); vload<NS>(lv + stk.dpad, arp);
-                    vload<NS>(lv + 2 * stk.dpad, aps); vload<NS>(lv + 3 * stk.dpad, aq);
-                }
+                stack_load<NS>(stk, j, alp, arp, aps, aq);
                 lsc.get(j, aw, aa, ape, aplogp);
                 double ps[NS];
 #pragma unroll
@@ -432,13 +475,7 @@ __device__ inline void nuts_transition(TeamT& tm, const Target& tgt, const doubl
             }
             if (turning) break;
             if (i + 1 < n_leaves) {   // park t at level j (the last leaf's cascade result stays in registers)
-                double* lv = stk.level(j);
-                if (j == 0) {
-                    vstore<NS>(lv, tps); vstore<NS>(lv + stk.dpad, tq);
-                } else {
-                    vstore<NS>(lv, tlp); vstore<NS>(lv + stk.dpad, trp);
-                    vstore<NS>(lv + 2 * stk.dpad, tps); vstore<NS>(lv + 3 * stk.dpad, tq);
-                }
+                stack_store<NS>(stk, j, tlp, trp, tps, tq);
                 lsc.put(j, tw, ta, tpe, tplogp);
                 // no fence: every lane reads back exactly the slice it wrote (same-thread program order)
             }
