@@ -161,3 +161,23 @@ def test_every_iteration_of_the_golden_runs(golden_dir, name):
             np.testing.assert_array_equal(np.array([o["stats"]["diverging"] for o in outs]),
                                           g["stat_diverging"][c, :, 0])
     assert total_checked >= 0.99 * (min(chains, 2) * (tune + draws)), (total_checked, total_fragile)
+
+
+@pytest.mark.parametrize("family,d,kw", [("ar1", 200, {}), ("ar1", 300, {}), ("funnel", 600, {"max_treedepth": 9}),
+                                           ("diag_gaussian", 1000, {}), ("std_normal", 129, {})])
+def test_every_iteration_replay_on_wide_and_multi_wave_shapes(family, d, kw):
+    """The kernel shapes beyond one-wave NS<=2 -- NS=4 (d<=256) and teams of 2 / 4 wavefronts per chain
+    (d<=512 / d<=1024, LDS exchange + barrier per reduction) -- replayed iteration by iteration against the
+    oracle exactly like the golden configurations."""
+    from tests._gpu_util import oracle_chain_snapshots, replay_iterations_on_device
+
+    f = OT.make(family, d)
+    tgt = device_target(family, d, f.params())
+    seeds = orc.derive_seeds(4321, 2)
+    tune, draws = 45, 10
+    _s, ostep = orc.init_nuts(f, d, seeds=seeds, **kw)
+    start, step = lmc.init_nuts(tgt, d, random_seed=seeds, **kw)
+    np.testing.assert_array_equal(_s, start)
+    snaps, outs = oracle_chain_snapshots(ostep, start, seeds[1], tune, draws)
+    checked, fragile = replay_iterations_on_device(step, snaps, outs, label="%s d=%d" % (family, d))
+    assert checked >= tune + draws - 1, (checked, fragile)
