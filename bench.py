@@ -167,14 +167,14 @@ def main():
     kw["lds_levels"] = args.lds_levels
     stream = torch.cuda.Stream()        # a real (non-null) HIP stream: the engine launches on it, the events time it
 
-    def new_job(capacity, tune, keep_trace):
+    def new_job(capacity, trace_from, keep_trace):
         eng = lmc.Engine(target, chains=chains, device=local_rank, **kw)
         step.potential._push_initial(eng)
         eng.set_stream(stream.cuda_stream)
         eng.seed(seeds)
         eng.set_position(start)
         eng.reset_tuning()
-        eng.reserve(capacity, keep_trace=keep_trace, trace_begin=tune)
+        eng.reserve(capacity, keep_trace=keep_trace, trace_begin=trace_from)
         return eng
 
     # ---- warm-up: W launches of a throw-away copy of the job
@@ -185,7 +185,15 @@ def main():
         warm.synchronize()
         warm.close()
 
-    eng = new_job(n_total, n_tune, keep_trace=not args.no_trace)
+    # draws stay in HBM; if the requested job is longer than the memory allows, keep the most recent draws only
+    trace_begin = n_tune
+    if not args.no_trace:
+        free_b, _tot = torch.cuda.mem_get_info()
+        per_draw = chains * args.dim * 8
+        fit = int(0.6 * free_b // per_draw)
+        if n_total - n_tune > fit:
+            trace_begin = n_total - max(fit, 1)
+    eng = new_job(n_total, trace_begin, keep_trace=not args.no_trace)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     torch.cuda.synchronize()
     if world > 1:
@@ -208,7 +216,8 @@ def main():
     status = eng.status()
     if status.any():
         raise SystemExit("chains reported failure status bits: %s" % np.unique(status))
-    depth_mean = float(eng.stat_i32(_abi.STAT_DEPTH, n_tune, n_total - n_tune).mean()) if n_total > n_tune else 0.0
+    depth_mean = float(eng.stat_i32(_abi.STAT_DEPTH, n_total - min(ips, n_total - n_tune), min(ips, n_total - n_tune)).mean()) \
+        if n_total > n_tune else 0.0
     div_after = int(ct[:, _abi.CT_DIVS_AFTER_TUNE].sum())
 
     # ---- ESS/sec (the second half of BASELINE.json's metric): split-R-hat / Geyer ESS of the post-warm-up
@@ -221,11 +230,11 @@ def main():
         t_ess = time.perf_counter()
         diag = dg.summarize(dg.trace_tensor(eng), chunk=1024, reduce_device=red_dev)
         torch.cuda.synchronize()
-        draw_steps = [s for s in range(K) if s * ips >= n_tune]
+        draw_steps = [s for s in range(K) if s * ips >= trace_begin]
         draw_s = sum(kernel_ms[s] for s in draw_steps) / 1e3
         e = diag["ess"]
         ess = {"min": float(e.min()), "median": float(e.median()), "rhat_max": float(diag["rhat"].max()),
-               "draw_seconds_this_rank": draw_s, "chains_total": diag["n_chains"] / 2, "draws": n_total - n_tune,
+               "draw_seconds_this_rank": draw_s, "chains_total": diag["n_chains"] / 2, "draws": n_total - trace_begin,
                "diagnostics_seconds": time.perf_counter() - t_ess}
     eng.close()
 
