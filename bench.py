@@ -286,6 +286,9 @@ def main():
                 "kernel": "lmc::run_kernel<NS=%d>" % max(1, (args.dim + 63) // 64),
                 "kernel_ms_avg": sum(kernel_ms) / K, "algorithmic_bytes_per_leapfrog": bytes_per_leap,
                 "read_only_frac": leap_local * 28 * args.dim / kern_s / HBM_PEAK,
+                "limiter": "measured: VALU issue (f64 at 16 lanes/clk), ~220 VALU instr per leapfrog at ~90% issue "
+                           "utilisation with 3 waves/SIMD; the trajectory lives in registers/LDS, so HBM traffic is "
+                           "a few % of the algorithmic bytes and frac can exceed 1 (profiles/, DESIGN.md section 6)",
             },
         }
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
