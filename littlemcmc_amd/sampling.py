@@ -95,6 +95,10 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
             step = step_
         if start is None:
             start = start_
+    if isinstance(start, (list, tuple)):   # one start point per chain (sampling.py:161-164 accepts a list)
+        if len(start) != chains:
+            raise ValueError("start list must have one entry per chain")
+        start = np.stack([np.asarray(x, dtype="d") for x in start])
     start = np.asarray(start, dtype="d")
     if start.ndim == 1:   # same start for every chain (sampling.py:163-164)
         starts = np.broadcast_to(start, (chains, model_ndim))

@@ -212,3 +212,44 @@ def test_user_target_is_compiled_and_sampled():
     n = 15
     npt.assert_array_equal(gst["depth"][:, :n], ost["depth"][:, :n])
     npt.assert_allclose(gt[:, :n], ot[:, :n], rtol=1e-6, atol=1e-8)
+
+
+# ---- driver extras: per-chain starts, seed lists, kwargs forwarding, warnings -------------------
+def test_sample_driver_extras():
+    d = 4
+    tgt = lmc.targets.StdNormal(d)
+    starts = [np.full(d, float(i)) for i in range(3)]
+    seeds = [11, 22, 33]
+    tr, st = lmc.sample(tgt, d, draws=5, tune=0, chains=3, start=starts, random_seed=seeds,
+                        discard_tuned_samples=False, step=lmc.NUTS(tgt, d, adapt_step_size=False))
+    # a list of seeds is used verbatim, chain by chain; a chain is a function of (seed, start) only
+    tr1, st1 = lmc.sample(tgt, d, draws=5, tune=0, chains=1, start=[starts[2]], random_seed=[33],
+                          discard_tuned_samples=False, step=lmc.NUTS(tgt, d, adapt_step_size=False))
+    npt.assert_array_equal(tr[2], tr1[0])
+    # **kwargs reach the NUTS constructor (sampling.py:149-155): a depth cap is honoured
+    tr2, st2 = lmc.sample(tgt, d, draws=30, tune=30, chains=2, random_seed=5, max_treedepth=2, early_max_treedepth=2)
+    assert st2["depth"].max() <= 2
+    # size= is an alias of model_ndim (north_star's spelling)
+    tr3, _ = lmc.sample(tgt, size=d, draws=3, tune=3, chains=2, random_seed=5)
+    assert tr3.shape == (2, 3, d)
+
+
+def test_warnings_follow_the_reference():
+    from littlemcmc_amd.report import WarningType
+
+    # divergences after tuning -> DIVERGENCES warning (base_hmc.py:207-227); funnel with a large fixed step size
+    d = 8
+    tgt = lmc.targets.Funnel(d)
+    step = lmc.NUTS(tgt, d, adapt_step_size=False, step_scale=6.0)
+    lmc.sample(tgt, d, draws=60, tune=5, chains=4, step=step, random_seed=3)
+    kinds = [w.kind for w in step.warnings()]
+    assert WarningType.DIVERGENCES in kinds
+    assert step._num_divs_sample > 0 and step._samples_after_tune == 4 * 60
+    # max tree depth reached in > 5 % of the draws -> TREEDEPTH warning (nuts.py:226-239)
+    tgt2 = lmc.targets.StdNormal(16)
+    step2 = lmc.NUTS(tgt2, 16, adapt_step_size=False, step_scale=0.02, max_treedepth=3)
+    lmc.sample(tgt2, 16, draws=40, tune=0, chains=2, step=step2, random_seed=4)
+    assert WarningType.TREEDEPTH in [w.kind for w in step2.warnings()]
+    assert step2._reached_max_treedepth > 0
+    # acceptance far from target -> BAD_ACCEPTANCE (step_sizes.py:101-121)
+    assert WarningType.BAD_ACCEPTANCE in [w.kind for w in step2.warnings()]
