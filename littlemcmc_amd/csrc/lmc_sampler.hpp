@@ -437,7 +437,7 @@ __device__ inline void nuts_transition(TeamT& tm, const Target& tgt, const doubl
                 wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
                 coff = x;
             }
-            tw = exp_uniform(x - coff);                                    // e^{log_size}
+            tw = exp_uniform_fast(x - coff);                               // e^{log_size}; x - coff <= 600
             const double sat = (coff == 0.0) ? fmin(1.0, tw) : ((x >= 0.0) ? 1.0 : exp_uniform(x));
             ta = first_f64(tw * sat);                                      // e^{log_p_accept_weighted}
             vcopy(tlp, cp); vcopy(trp, cp); vcopy(tps, cp); vcopy(tq, cq);
