@@ -282,7 +282,7 @@ __device__ __forceinline__ void leapfrog(TeamT& tm, const Target& tgt, const dou
         }
         tm.sum2(lp, kin);
         logp = lp;
-        energy = first_f64(0.5 * kin - logp);
+        energy = 0.5 * kin - logp;   // wave-uniform, VGPR resident
     } else {
         logp = first_f64(tgt.logp_grad(tm, q, g));
         double kin = 0.0;
@@ -291,7 +291,7 @@ __device__ __forceinline__ void leapfrog(TeamT& tm, const Target& tgt, const dou
             p[s] = p[s] + dt * g[s];
             kin = __builtin_fma(p[s], var[s] * p[s], kin);
         }
-        energy = first_f64(0.5 * tm.sum(kin) - logp);
+        energy = 0.5 * tm.sum(kin) - logp;
     }
 }
 
@@ -439,7 +439,7 @@ __device__ inline void nuts_transition(TeamT& tm, const Target& tgt, const doubl
             }
             tw = exp_uniform_fast(x - coff);                               // e^{log_size}; x - coff <= 600
             const double sat = (coff == 0.0) ? fmin(1.0, tw) : ((x >= 0.0) ? 1.0 : exp_uniform(x));
-            ta = first_f64(tw * sat);                                      // e^{log_p_accept_weighted}
+            ta = tw * sat;                                                 // e^{log_p_accept_weighted}
             vcopy(tlp, cp); vcopy(trp, cp); vcopy(tps, cp); vcopy(tq, cq);
             tpe = energy; tplogp = logp;
             int j = 0;
@@ -463,9 +463,9 @@ __device__ inline void nuts_transition(TeamT& tm, const Target& tgt, const doubl
                 } else {
                     turn = tm.any_nonpositive2(pdot_v<NS>(ps, var, alp), pdot_v<NS>(ps, var, trp));
                 }
-                const double wsum = first_f64(aw + tw);
-                const double asum = first_f64(aa + ta);
-                const bool take_b = first_f64(team_uniform(tm, rng, win) * wsum) < tw;   // nuts.py:404 (drawn even if turning)
+                const double wsum = aw + tw;
+                const double asum = aa + ta;
+                const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < tw);   // nuts.py:404 (drawn even if turning)
                 // merged node: left end from a, right end from b(t)
                 vcopy(tlp, alp); vcopy(tps, ps);
                 if (!take_b) { vcopy(tq, aq); tpe = ape; tplogp = aplogp; }
@@ -484,7 +484,7 @@ __device__ inline void nuts_transition(TeamT& tm, const Target& tgt, const doubl
         if (diverging || turning) { exhausted = false; break; }
 
         // ---- accepted subtree t: merge into the trajectory (nuts.py:321-340)
-        if (first_f64(team_uniform(tm, rng, win) * (w_start + wn)) < tw) {   // biased progressive: U < w_sub / w_tree
+        if (uniform_true(team_uniform(tm, rng, win) * (w_start + wn) < tw)) {   // biased progressive: U < w_sub / w_tree
             vcopy(propq, tq); prop_e = tpe; prop_logp = tplogp;
         }
         wn = first_f64(wn + tw);

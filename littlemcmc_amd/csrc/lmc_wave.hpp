@@ -216,8 +216,12 @@ __device__ __forceinline__ double exp_uniform_fast(double x) {
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    return first_f64(ldexp(p * t, ki >> 6));
+    return ldexp(p * t, ki >> 6);   // wave-uniform value left in a VGPR pair (callers add to / compare with it)
 }
+
+// Uniform predicate from a comparison whose operands are wave-uniform but VGPR-resident: all lanes agree, so
+// the ballot is either 0 or exec. One v_cmp + scalar test; tells the compiler the branch is uniform.
+__device__ __forceinline__ bool uniform_true(bool lane_pred) { return __ballot(lane_pred) != 0ull; }
 
 // Neighbour exchange for banded targets: value held by lane-1 / lane+1 (0 at the wave edge).
 // DPP wave_shr:1 / wave_shl:1 (GFX9 whole-wave shifts, 0x138 / 0x130) with bound_ctrl: two VALU moves per
