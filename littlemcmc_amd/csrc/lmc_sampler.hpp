@@ -1,4 +1,4 @@
-// The hot path as device code: one chain per wavefront, whole iterations on the GPU.
+// The hot path as device code: one chain per wavefront (or per team of wavefronts), whole iterations on the GPU.
 //
 //   leapfrog        <- /root/reference/littlemcmc/integration.py:52-66,100-121  (+ quadpotential.py:206-219)
 //   momentum draw   <- quadpotential.py:221-224 (float32) / :374-376 (float64)
@@ -8,15 +8,16 @@
 //   mass adaptation <- quadpotential.py:226-245, :294-340
 //   iteration body  <- base_hmc.py:140-190 (_astep)
 //
-// Storage plan per chain (wave):
-//   registers : current state (q,p,g), trajectory ends L/R (q,p,g), p_sum, proposal q, the
-//               in-flight subtree node (lp, rp, psum, prop q), float32 mass (var, inv_std),
-//               per-level subtree scalars (lane j holds level j)
-//   LDS       : subtree stack levels [0, nlds)   (level 0 = {p, q}; level j>0 = {lp, rp, psum, prop q})
-//   HBM       : subtree stack levels >= nlds (per-chain scratch rows, L2 resident while hot),
-//               MT19937 state, Welford accumulators, persistent chain state, trace/stat outputs
-// Velocities are never stored: v = var (.) p is recomputed (bit-identical, it is one rounded
-// product), except for the start state whose v is the float32 product (dtype flow).
+// Storage plan per chain:
+//   registers : current state (q,p,g), trajectory ends L/R (q,p,g), p_sum, proposal q, the in-flight subtree
+//               node (lp, rp, psum, prop q + weights), float32 mass (var, inv_std) and its float64 promotion,
+//               per-level subtree scalars (lane j holds level j), the uniform look-ahead window
+//   LDS       : subtree stack levels [0, nlds) (level 0 = {p, q}; level j>0 = {lp, rp, psum, prop q}), the chain's
+//               MT19937 state for the duration of the launch, the team exchange area (W > 1)
+//   HBM       : subtree stack levels >= nlds (per-chain scratch rows, L2 resident while hot), Welford
+//               accumulators, persistent chain state between launches, trace / stat outputs
+// Velocities are never stored: v = var (.) p is recomputed (bit-identical, it is one rounded product), except
+// for the start state whose v is the float32 product (dtype flow).
 #pragma once
 #include "lmc_rng.hpp"
 #include "lmc_targets.hpp"

@@ -56,26 +56,6 @@ __device__ __forceinline__ double wave_sum(double x) {
     return readlane_f64(x, 63);
 }
 
-// N independent sums in one pass (the six U-turn dot products of a tree merge): the DPP
-// chains are independent, so the scheduler interleaves them and hides the DPP latency.
-template <int N>
-__device__ __forceinline__ void wave_sum_n(double (&x)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x111>(x[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x112>(x[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x114>(x[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x118>(x[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x142>(x[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) x[i] += dpp_f64<0x143>(x[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = readlane_f64(x[i], 63);
-}
-
 // ---- transposed multi-value reductions (gfx950 v_permlane32_swap / v_permlane16_swap) ------------------
 // Reducing K values with K independent butterflies costs K * 6 stages. Swapping halves instead lets ONE
 // add serve two values: after v_permlane32_swap(a, b) the registers hold [a_lo | b_lo] and [a_hi | b_hi],
