@@ -7,7 +7,7 @@
 Workload (BASELINE.json configs[2] / SURVEY.md 8d "C3"): 65 536 chains per GPU x dim 128, AR(1) rho=0.9
 correlated Gaussian, NUTS defaults, diagonal mass adaptation, init jitter+adapt_diag; the timed job is
 the reference recipe ``sample(tune=T, draws=D)`` cut into K equal launches ("steps") of the one persistent
-kernel (tune = first half). W warm-up steps run first on a throw-away copy of the job (same kernel, same
+kernel (tune = first half; the default K = 20 x 100 iterations is exactly SURVEY 8d's tune=1000, draws=1000). W warm-up steps run first on a throw-away copy of the job (same kernel, same
 shapes) and are not timed. Chains are independent: with N GPUs every rank owns its own block of
 65 536 chains (weak scaling, no data-path collective); ranks only meet in the barrier and in the
 max/sum reductions of the timing.
@@ -110,7 +110,7 @@ def cpu_baseline(name, dim, seeds, start, budget_iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--chains", type=int, default=65536, help="chains PER GPU")
     ap.add_argument("--dim", type=int, default=128)
