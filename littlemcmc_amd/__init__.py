@@ -1,26 +1,24 @@
 """littlemcmc_amd -- MI355X-native many-chain HMC/NUTS engine behind littlemcmc's API.
 
-Export list mirrors /root/reference/littlemcmc/__init__.py:19-29. Numerics live in
-liblmc_hip.so (HIP, gfx950); importing the package does not need a GPU, using it does."""
+The public names are the ones /root/reference/littlemcmc/__init__.py:19-29 exports, plus the GPU-side pieces
+(``targets``, ``Engine``, ``diagnostics``, ``distributed``). Numerics live in liblmc_hip.so (HIP, gfx950);
+importing the package needs no GPU, using it does -- there is no CPU fallback."""
 
 __version__ = "0.1.0"
 
-from . import diagnostics, distributed, targets
+from . import diagnostics, distributed, quadpotential as _qp, targets
 from .engine import Engine
 from .hmc import HamiltonianMC
 from .nuts import NUTS
-from .quadpotential import (
-    QuadPotentialDiag,
-    QuadPotentialDiagAdapt,
-    QuadPotentialFull,
-    QuadPotentialFullAdapt,
-    QuadPotentialFullInv,
-    quad_potential,
-)
 from .sampling import init_nuts, sample
 
-__all__ = [
-    "sample", "init_nuts", "HamiltonianMC", "NUTS", "quad_potential", "QuadPotentialDiag",
-    "QuadPotentialFull", "QuadPotentialFullInv", "QuadPotentialDiagAdapt", "QuadPotentialFullAdapt",
-    "Engine", "targets", "diagnostics", "distributed",
-]
+# mass matrices: the diagonal family runs on the device; the dense classes exist for API completeness and
+# raise NotImplementedError (outside the hot-path scope)
+quad_potential = _qp.quad_potential
+QuadPotentialDiag, QuadPotentialDiagAdapt = _qp.QuadPotentialDiag, _qp.QuadPotentialDiagAdapt
+QuadPotentialFull, QuadPotentialFullInv, QuadPotentialFullAdapt = (
+    _qp.QuadPotentialFull, _qp.QuadPotentialFullInv, _qp.QuadPotentialFullAdapt)
+
+__all__ = ["sample", "init_nuts", "HamiltonianMC", "NUTS", "quad_potential", "QuadPotentialDiag", "QuadPotentialFull",
+           "QuadPotentialFullInv", "QuadPotentialDiagAdapt", "QuadPotentialFullAdapt", "Engine", "targets",
+           "diagnostics", "distributed"]

@@ -1,7 +1,9 @@
-"""Exceptions (/root/reference/littlemcmc/exceptions.py:22)."""
-
-__all__ = ["SamplingError"]
+"""Exception types of the package (reference: /root/reference/littlemcmc/exceptions.py:22 for SamplingError)."""
+from ._abi import HipLibraryError  # noqa: F401  (no-GPU / no-library failures are loud, never a fallback)
 
 
 class SamplingError(RuntimeError):
-    """Error while sampling."""
+    """Raised when sampling cannot proceed."""
+
+
+__all__ = ["SamplingError", "HipLibraryError"]

@@ -1,17 +1,14 @@
-"""Sampler warnings (host-only record types; /root/reference/littlemcmc/report.py:20-37)."""
+"""Host-only record types for sampler warnings.
+
+Mirrors the *interface* of /root/reference/littlemcmc/report.py:20-37 (field names of ``SamplerWarning`` and the
+member names / values of ``WarningType`` are part of the API surface: ``step.warnings()`` returns them)."""
+import collections
 import enum
-from collections import namedtuple
 
-SamplerWarning = namedtuple("SamplerWarning", "kind, message, level, step, exec_info, extra")
+_WARNING_FIELDS = ("kind", "message", "level", "step", "exec_info", "extra")
+SamplerWarning = collections.namedtuple("SamplerWarning", _WARNING_FIELDS)
 
-
-@enum.unique
-class WarningType(enum.Enum):
-    DIVERGENCE = 1
-    TUNING_DIVERGENCE = 2
-    DIVERGENCES = 3
-    TREEDEPTH = 4
-    BAD_PARAMS = 5
-    CONVERGENCE = 6
-    BAD_ACCEPTANCE = 7
-    BAD_ENERGY = 8
+# member order fixes the values 1..8, as in the reference
+_WARNING_KINDS = ("DIVERGENCE TUNING_DIVERGENCE DIVERGENCES TREEDEPTH "   # HMC / NUTS
+                  "BAD_PARAMS CONVERGENCE BAD_ACCEPTANCE BAD_ENERGY")       # sampler parameters / convergence
+WarningType = enum.unique(enum.Enum("WarningType", _WARNING_KINDS.split(), start=1, module=__name__))
