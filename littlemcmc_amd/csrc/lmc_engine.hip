@@ -21,6 +21,14 @@
 
 using namespace lmc;
 
+// hipMemcpy(..., hipMemcpyDefault) on pageable host pointers can leave a stale "last error" behind (pointer-attribute
+// probing); clear it before a launch so that the hipGetLastError() after the launch reports THIS launch only.
+#define LMC_LAUNCH(...)            \
+    do {                           \
+        (void)hipGetLastError();   \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 // ---------------------------------------------------------------------------------------------
 // unit kernels (share the device functions with run_kernel)
 // ---------------------------------------------------------------------------------------------
@@ -408,7 +416,7 @@ static int launch_reset(lmc_engine* e, int reset_step, int reset_mass) {
     const int blocks = static_cast<int>((n + threads - 1) / threads);
     const double log_step0 = std::log(e->initial_step);         // step_sizes.py:51
     const double mu = std::log(10 * e->initial_step);           // step_sizes.py:55
-    hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(threads), 0, e->stream, e->A, e->init_mean, e->init_diag,
+    LMC_LAUNCH(reset_kernel, dim3(blocks), dim3(threads), 0, e->stream, e->A, e->init_mean, e->init_diag,
                        e->init_weight, e->cfg.potential == LMC_POT_DIAG_ADAPT ? 1 : 0, log_step0, mu, reset_step,
                        reset_mass);
     HIP_TRY(e, hipGetLastError());
@@ -630,7 +638,7 @@ int lmc_engine_seed(lmc_engine* e, const uint32_t* seeds) {
     HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&dseeds), e->cfg.chains * sizeof(uint32_t)));
     hipError_t err = hipMemcpyAsync(dseeds, seeds, e->cfg.chains * sizeof(uint32_t), hipMemcpyDefault, e->stream);
     if (err == hipSuccess) {
-        hipLaunchKernelGGL(seed_kernel, dim3(e->cfg.chains), dim3(64), 0, e->stream, e->A, dseeds);
+        LMC_LAUNCH(seed_kernel, dim3(e->cfg.chains), dim3(64), 0, e->stream, e->A, dseeds);
         err = hipGetLastError();
     }
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
@@ -706,7 +714,7 @@ int lmc_engine_set_dual_average(lmc_engine* e, double log_step, double log_bar, 
     if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     const int threads = 256, blocks = (e->cfg.chains + threads - 1) / threads;
-    hipLaunchKernelGGL(set_da_kernel, dim3(blocks), dim3(threads), 0, e->stream, e->A, log_step, log_bar, hbar, count);
+    LMC_LAUNCH(set_da_kernel, dim3(blocks), dim3(threads), 0, e->stream, e->A, log_step, log_bar, hbar, count);
     HIP_TRY(e, hipGetLastError());
     return LMC_OK;
 }
@@ -770,7 +778,7 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
         if (run_lds > 64 * 1024)                                                                               \
             HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NSV, WV, T>),             \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));              \
-        hipLaunchKernelGGL((run_kernel<NSV, WV, T>), grid, block, run_lds, e->stream, e->A, P, e->tparams);    \
+        LMC_LAUNCH((run_kernel<NSV, WV, T>), grid, block, run_lds, e->stream, e->A, P, e->tparams);    \
     }
 #define RUN_CALL(T)                                                                                            \
     {                                                                                                          \
@@ -970,7 +978,7 @@ static int chain_state_xfer(lmc_engine* e, const lmc_chain_state* st, bool to_us
     if ((rc = ints(st->iter_count, A.iter_count)) != LMC_OK) return rc;
     if (!to_user && st->var) {
         const long long n = static_cast<long long>(C) * e->dpad;
-        hipLaunchKernelGGL(derive_inv_std_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, e->stream, e->A);
+        LMC_LAUNCH(derive_inv_std_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, e->stream, e->A);
         HIP_TRY(e, hipGetLastError());
         HIP_TRY(e, hipStreamSynchronize(e->stream));
     }
@@ -997,7 +1005,7 @@ int lmc_engine_trajectory(lmc_engine* e, const double* q0, const double* p0, int
     HIP_TRY(e, hipMemcpyAsync(dp0.p, p0, C * d * sizeof(double), hipMemcpyDefault, e->stream));
     const dim3 grid(e->cfg.chains), block(64);
 #define TRAJ_CALL(T)                                                                                          \
-    LMC_NS_SWITCH(e, e->ns, hipLaunchKernelGGL((trajectory_kernel<NS, T>), grid, block, e->dpad * 8, e->stream, e->A,   \
+    LMC_NS_SWITCH(e, e->ns, LMC_LAUNCH((trajectory_kernel<NS, T>), grid, block, e->dpad * 8, e->stream, e->A,   \
                                                e->tparams, dq0.p, dp0.p, p0_is_f32, e->cfg.start_energy_sdot, eps, n_fwd, n_back, oq.p, \
                                                op.p, ov.p, og.p, oe.p, ol.p))
     LMC_FAMILY_SWITCH(e, e->cfg.target_family, TRAJ_CALL)
@@ -1022,7 +1030,7 @@ int lmc_engine_logp_dlogp(lmc_engine* e, const double* q, double* logp, double* 
     HIP_TRY(e, hipMemcpyAsync(dq.p, q, C * d * sizeof(double), hipMemcpyDefault, e->stream));
     const dim3 grid(e->cfg.chains), block(64);
 #define LOGP_CALL(T) \
-    LMC_NS_SWITCH(e, e->ns, hipLaunchKernelGGL((logp_kernel<NS, T>), grid, block, 0, e->stream, e->A, e->tparams, dq.p, dl.p, dg.p))
+    LMC_NS_SWITCH(e, e->ns, LMC_LAUNCH((logp_kernel<NS, T>), grid, block, 0, e->stream, e->A, e->tparams, dq.p, dl.p, dg.p))
     LMC_FAMILY_SWITCH(e, e->cfg.target_family, LOGP_CALL)
 #undef LOGP_CALL
     HIP_TRY(e, hipGetLastError());
@@ -1048,7 +1056,7 @@ int lmc_engine_rng_draw(lmc_engine* e, const int32_t* ops, int32_t n_ops, double
     DevBuf<double> dout, dstage;
     HIP_TRY(e, dops.alloc(n_ops)); HIP_TRY(e, dout.alloc(C * total)); HIP_TRY(e, dstage.alloc(C * biggest));
     HIP_TRY(e, hipMemcpyAsync(dops.p, hops.data(), n_ops * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(rng_draw_kernel, dim3(e->cfg.chains), dim3(64), 0, e->stream, e->A, dops.p, n_ops, dout.p, total, dstage.p, biggest);
+    LMC_LAUNCH(rng_draw_kernel, dim3(e->cfg.chains), dim3(64), 0, e->stream, e->A, dops.p, n_ops, dout.p, total, dstage.p, biggest);
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, hipMemcpyAsync(out, dout.p, C * total * sizeof(double), hipMemcpyDefault, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -1064,7 +1072,7 @@ int lmc_engine_draw_momentum(lmc_engine* e, double* out) {
     const int f32 = e->cfg.potential == LMC_POT_DIAG_ADAPT;
     const dim3 grid(e->cfg.chains), block(64);
     const int lds = 2 * e->dpad * 8;
-    LMC_NS_SWITCH(e, e->ns, hipLaunchKernelGGL((momentum_kernel<NS>), grid, block, lds, e->stream, e->A, f32, dout.p))
+    LMC_NS_SWITCH(e, e->ns, LMC_LAUNCH((momentum_kernel<NS>), grid, block, lds, e->stream, e->A, f32, dout.p))
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, hipMemcpyAsync(out, dout.p, C * d * sizeof(double), hipMemcpyDefault, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));

@@ -1,0 +1,80 @@
+"""-m gpu: edge cases of the driver / engine boundary: empty outputs, single chain, tune-only and draw-only runs,
+the largest supported dimension, invalid shapes, capacity errors."""
+import numpy as np
+import pytest
+
+import littlemcmc_amd as lmc
+from littlemcmc_amd import _abi
+from littlemcmc_amd import targets as T
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_and_degenerate_runs():
+    d = 3
+    tgt = T.StdNormal(d)
+    # draws = 0 with discard_tuned_samples: empty trace, stats keep their dtypes (sampling.py:141-143 only warns)
+    tr, st = lmc.sample(tgt, d, draws=0, tune=7, chains=2, random_seed=1)
+    assert tr.shape == (2, 0, d) and st["depth"].shape == (2, 0, 1) and st["depth"].dtype == np.int64
+    # tune = 0: no adaptation at all, step size stays at step_scale / d**0.25
+    tr, st = lmc.sample(tgt, d, draws=6, tune=0, chains=1, random_seed=1)
+    assert tr.shape == (1, 6, d) and not st["tune"].any()
+    np.testing.assert_allclose(st["step_size_bar"], 0.25 / d ** 0.25, rtol=1e-12)
+    # one chain, one draw
+    tr, st = lmc.sample(tgt, d, draws=1, tune=1, chains=1, random_seed=1)
+    assert tr.shape == (1, 1, d)
+
+
+def test_largest_dimension_and_beyond():
+    d = 1024
+    tr, st = lmc.sample(T.StdNormal(d), d, draws=3, tune=5, chains=2, random_seed=2)
+    assert tr.shape == (2, 3, d) and np.isfinite(tr).all()
+    with pytest.raises(_abi.HipLibraryError, match="dim > 1024"):
+        lmc.Engine(T.StdNormal(1025), chains=1)
+    with pytest.raises(_abi.HipLibraryError, match="requires dim == 1"):
+        t = T.Normal1D()
+        t.d = 2
+        lmc.Engine(t, chains=1)
+
+
+def test_engine_call_sequence_errors():
+    eng = lmc.Engine(T.StdNormal(4), chains=2)
+    try:
+        with pytest.raises(_abi.HipLibraryError, match="reserve"):
+            eng.run(0, 0, 1)
+        eng.reserve(5, keep_trace=False)
+        with pytest.raises(_abi.HipLibraryError, match="exceed reserved capacity"):
+            eng.run(0, 3, 4)
+        eng.run(2, 0, 5)
+        with pytest.raises(_abi.HipLibraryError, match="no trace"):
+            eng.trace(0, 5)
+        assert eng.stat_i32(_abi.STAT_TREE_SIZE).shape == (2, 5)
+        with pytest.raises(_abi.HipLibraryError, match="positive definite"):
+            eng.set_potential(np.zeros(4), np.array([1.0, 0.0, 1.0, 1.0]), 10.0)
+        dg = lmc.Engine(T.DiagGaussian(np.ones(3)), chains=1)
+        try:
+            with pytest.raises(_abi.HipLibraryError, match="precisions"):
+                dg._check(dg._lib.lmc_engine_set_target_params(dg._h, _abi.ptr(np.ones(2)), 2))
+        finally:
+            dg.close()
+    finally:
+        eng.close()
+
+
+def test_trace_window_and_partial_reads():
+    d, chains = 5, 3
+    eng = lmc.NUTS(T.StdNormal(d), d)._make_engine(chains)
+    try:
+        eng.seed([1, 2, 3])
+        eng.set_position(np.zeros(d))
+        eng.reset_tuning()
+        eng.reserve(20, keep_trace=True, trace_begin=8)
+        eng.run(8, 0, 20)
+        full = eng.trace()
+        assert full.shape == (chains, 12, d)
+        np.testing.assert_array_equal(eng.trace(10, 4), full[:, 2:6])
+        with pytest.raises(_abi.HipLibraryError, match="not stored"):
+            eng.trace(3, 2)
+        np.testing.assert_array_equal(eng.get_position(), full[:, -1])      # the chain's position is its last draw
+    finally:
+        eng.close()
