@@ -78,3 +78,28 @@ def test_trace_window_and_partial_reads():
         np.testing.assert_array_equal(eng.get_position(), full[:, -1])      # the chain's position is its last draw
     finally:
         eng.close()
+
+
+def test_results_do_not_depend_on_where_the_tree_stack_lives():
+    """Subtree-stack levels in LDS or spilled to the HBM scratch row: same bits (AR(1) d=48, depth up to 8)."""
+    d, chains, n = 48, 24, 40
+    tgt = T.AR1(d, 0.95)
+    ref = None
+    for lds_levels in (1, 2, 4, 0):
+        eng = lmc.Engine(tgt, chains=chains, lds_levels=lds_levels)
+        try:
+            eng.set_potential(np.zeros(d), np.ones(d), 10.0)
+            eng.seed(list(range(chains)))
+            eng.set_position(np.full(d, 0.1))
+            eng.reset_tuning()
+            eng.reserve(n)
+            eng.run(25, 0, n)
+            out = (eng.trace(), eng.stat_i32(_abi.STAT_TREE_SIZE), eng.stat_f64(_abi.STAT_ENERGY))
+            assert out[1].max() > 31        # deep enough to reach spilled levels when lds_levels is small
+        finally:
+            eng.close()
+        if ref is None:
+            ref = out
+        else:
+            for a, b in zip(ref, out):
+                np.testing.assert_array_equal(a, b)
