@@ -260,6 +260,15 @@ def main():
                 traffic_src = tr["source"]
         except Exception:
             pass
+        valu_issue = None
+        try:   # the limiter that actually binds (profiles/: VALU issue), as measured by the committed PMC run
+            ps = json.load(open(os.path.join(ROOT, "profiles", "r01_default_pmc_summary.json")))
+            occ = 3 if args.dim > 64 else 4   # waves per SIMD of the instantiation (168 / 128 VGPRs)
+            valu_issue = {"valu_inst_per_leapfrog": ps["per_leapfrog"]["SQ_INSTS_VALU"],
+                          "simd_issue_utilisation": min(1.0, occ * ps["wave_time_split"]["valu_active"]),
+                          "source": "profiles/r01_default_pmc_summary.json (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves per SIMD)"}
+        except Exception:
+            pass
         out = {
             "metric": "leapfrog-steps/sec (all chains)", "value": value, "unit": "leapfrog-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall_max * 1e3 / K,
@@ -288,6 +297,7 @@ def main():
                 "kernel": "lmc::run_kernel<NS=%d>" % max(1, (args.dim + 63) // 64),
                 "kernel_ms_avg": sum(kernel_ms) / K, "algorithmic_bytes_per_leapfrog": bytes_per_leap,
                 "read_only_frac": leap_local * 28 * args.dim / kern_s / HBM_PEAK,
+                "valu_issue": valu_issue,
                 "limiter": "measured: VALU issue (f64 at 16 lanes/clk), ~220 VALU instr per leapfrog at ~90% issue "
                            "utilisation with 3 waves/SIMD; the trajectory lives in registers/LDS, so HBM traffic is "
                            "a few % of the algorithmic bytes and frac can exceed 1 (profiles/, DESIGN.md section 6)",
