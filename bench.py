@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--target", default="ar1", choices=["ar1", "std_normal", "funnel", "diag"])
     ap.add_argument("--iters-per-step", type=int, default=100, help="NUTS iterations per chain per launch")
     ap.add_argument("--max-treedepth", type=int, default=10)
+    ap.add_argument("--kind", default="nuts", choices=["nuts", "hmc"], help="step method (hmc: path_length 2.0)")
     ap.add_argument("--no-trace", action="store_true", help="do not store draws (statistics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
@@ -163,8 +164,11 @@ def main():
     start = 2 * np.random.rand(args.dim) - 1            # init_nuts jitter (sampling.py:574-584)
     seeds = seeds_all[rank * chains:(rank + 1) * chains]
 
-    step = lmc.NUTS(target, args.dim, potential=lmc.QuadPotentialDiagAdapt(args.dim, start, np.ones(args.dim), 10),
-                    max_treedepth=args.max_treedepth)
+    pot = lmc.QuadPotentialDiagAdapt(args.dim, start, np.ones(args.dim), 10)
+    if args.kind == "nuts":
+        step = lmc.NUTS(target, args.dim, potential=pot, max_treedepth=args.max_treedepth)
+    else:
+        step = lmc.HamiltonianMC(target, args.dim, potential=pot, path_length=2.0)
     kw = step._engine_kwargs()
     kw["lds_levels"] = args.lds_levels
     stream = torch.cuda.Stream()        # a real (non-null) HIP stream: the engine launches on it, the events time it
@@ -269,15 +273,15 @@ def main():
                           "source": "profiles/r01_default_pmc_summary.json (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves per SIMD)"}
         except Exception:
             pass
+        method = ("NUTS max_treedepth=%d" % args.max_treedepth) if args.kind == "nuts" else "HMC path_length=2"
         out = {
             "metric": "leapfrog-steps/sec (all chains)", "value": value, "unit": "leapfrog-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall_max * 1e3 / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "C3: %d chains/GPU x dim %d %s, NUTS max_treedepth=%d, diag mass adapt, "
-                            "tune %d + draws %d in %d launches of %d iterations"
-                            % (chains, args.dim, target_desc, args.max_treedepth, n_tune, n_total - n_tune, K, ips),
+                "workload": "C3: %d chains/GPU x dim %d %s, %s, diag mass adapt, tune %d + draws %d in %d launches of "
+                            "%d iterations" % (chains, args.dim, target_desc, method, n_tune, n_total - n_tune, K, ips),
                 "chains_per_gpu": chains, "dim": args.dim, "target": args.target, "tune": n_tune,
                 "draws": n_total - n_tune, "rng": "MT19937 (numpy legacy stream, same-seed parity mode)",
                 "trace_in_hbm": not args.no_trace, "parallelism": "chain-block x%d" % world,

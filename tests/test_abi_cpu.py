@@ -137,3 +137,12 @@ def test_blas_probe_emulation_matches_numpy_here():
     if mode == _abi.SDOT_OPENBLAS_SKYLAKEX and hits < total:
         pytest.skip("host BLAS is not one of the two restated OpenBLAS kernels")
     assert hits == total
+
+
+def test_bench_and_entry_modules_import_without_gpu():
+    import importlib
+
+    bench = importlib.import_module("bench")
+    assert bench.usable_cores() >= 1 and bench.HBM_PEAK == 8.0e12
+    entry = importlib.import_module("__graft_entry__")
+    assert callable(entry.build) and callable(entry.smoke)
