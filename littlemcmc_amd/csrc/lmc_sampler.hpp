@@ -123,14 +123,24 @@ __device__ __forceinline__ double pdot_v(const double (&a)[NS], const double (&v
     for (int s = 0; s < NS; ++s) acc = __builtin_fma(a[s], var[s] * b[s], acc);
     return acc;
 }
-// same with the float32 velocity of a float32 momentum (the start state): v = f32(var * f32(b))
+// per-lane partial of a . v for an already formed velocity v
 template <int NS>
-__device__ __forceinline__ double pdot_v32(const double (&a)[NS], const double (&var)[NS], const double (&b)[NS]) {
+__device__ __forceinline__ double pdot(const double (&a)[NS], const double (&v)[NS]) {
     double acc = 0.0;
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
-        acc = __builtin_fma(a[s], static_cast<double>(static_cast<float>(var[s]) * static_cast<float>(b[s])), acc);
+    for (int s = 0; s < NS; ++s) acc = __builtin_fma(a[s], v[s], acc);
     return acc;
+}
+// velocity of a trajectory end: var (.) p, or its float32 product while the end still is the float32 start state
+template <int NS>
+__device__ __forceinline__ void end_velocity(double (&v)[NS], const double (&var)[NS], const double (&p)[NS], bool f32_start) {
+    if (f32_start) {   // wave-uniform branch
+#pragma unroll
+        for (int s = 0; s < NS; ++s) v[s] = static_cast<double>(static_cast<float>(var[s]) * static_cast<float>(p[s]));
+    } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) v[s] = var[s] * p[s];
+    }
 }
 
 // ---- float32 start-state kinetic energy: 0.5f * sdot(p, v) --------------------------------------------
@@ -495,29 +505,31 @@ __device__ inline void nuts_transition(TeamT& tm, const Target& tgt, const doubl
             const double t = psum[s] + tps[s];
             psum[s] = momentum_f32 ? static_cast<double>(static_cast<float>(t)) : t;
         }
+        // velocities of the four momenta involved, each computed once: the two trajectory ends as they were BEFORE
+        // this doubling (float32 product while an end still is the float32 start state) and the subtree's two ends
+        double oLv[NS], oRv[NS], vtl[NS], vtr[NS];
+        end_velocity<NS>(oLv, var, Lp, l_start);
+        end_velocity<NS>(oRv, var, Rp, r_start);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { vtl[s] = var[s] * tlp[s]; vtr[s] = var[s] * trp[s]; }
         double dots[6];
-        if (right) {
-            // old right end (p, v) is needed for the second extra check
+        if (right) {   // new right end = far end of the subtree (trp == cp); left end unchanged
             double p1[NS], p2[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) { p1[s] = psum[s] + tlp[s]; p2[s] = Rp[s] + tps[s]; }
-            dots[2] = l_start ? pdot_v32<NS>(p1, var, Lp) : pdot_v<NS>(p1, var, Lp);
-            dots[3] = pdot_v<NS>(p1, var, tlp);
-            dots[4] = r_start ? pdot_v32<NS>(p2, var, Rp) : pdot_v<NS>(p2, var, Rp);
-            dots[5] = pdot_v<NS>(p2, var, trp);
+            dots[0] = pdot<NS>(psum, oLv); dots[1] = pdot<NS>(psum, vtr);
+            dots[2] = pdot<NS>(p1, oLv);   dots[3] = pdot<NS>(p1, vtl);
+            dots[4] = pdot<NS>(p2, oRv);   dots[5] = pdot<NS>(p2, vtr);
             vcopy(Rq, cq); vcopy(Rp, cp); vcopy(Rg, cg); r_start = false;
-        } else {
+        } else {       // new left end = far end of the subtree; right end unchanged
             double p1[NS], p2[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) { p1[s] = tps[s] + Lp[s]; p2[s] = tlp[s] + psum[s]; }
-            dots[2] = pdot_v<NS>(p1, var, trp);
-            dots[3] = l_start ? pdot_v32<NS>(p1, var, Lp) : pdot_v<NS>(p1, var, Lp);
-            dots[4] = pdot_v<NS>(p2, var, tlp);
-            dots[5] = r_start ? pdot_v32<NS>(p2, var, Rp) : pdot_v<NS>(p2, var, Rp);
+            dots[0] = pdot<NS>(psum, vtr); dots[1] = pdot<NS>(psum, oRv);
+            dots[2] = pdot<NS>(p1, vtr);   dots[3] = pdot<NS>(p1, oLv);
+            dots[4] = pdot<NS>(p2, vtl);   dots[5] = pdot<NS>(p2, oRv);
             vcopy(Lq, cq); vcopy(Lp, cp); vcopy(Lg, cg); l_start = false;
         }
-        dots[0] = l_start ? pdot_v32<NS>(psum, var, Lp) : pdot_v<NS>(psum, var, Lp);
-        dots[1] = r_start ? pdot_v32<NS>(psum, var, Rp) : pdot_v<NS>(psum, var, Rp);
         if (tm.any_nonpositive6(dots)) { turning = true; exhausted = false; break; }
     }
 
