@@ -210,6 +210,11 @@ typedef struct lmc_chain_state {
 } lmc_chain_state;
 int lmc_engine_get_chain_state(lmc_engine* e, const lmc_chain_state* dst);
 int lmc_engine_set_chain_state(lmc_engine* e, const lmc_chain_state* src);
+/* Running per-chain moments of the post-warm-up draws, kept on the device so that cross-chain R-hat needs no
+ * trace (the only quantities the multi-GPU gather moves): mean [chains][dim], m2 = sum of squared
+ * deviations [chains][dim], n [chains]. Enable before reset_tuning(); reset with it. */
+int lmc_engine_keep_moments(lmc_engine* e, int32_t enable);
+int lmc_engine_get_moments(lmc_engine* e, double* mean, double* m2, int32_t* n);
 int lmc_engine_get_status(lmc_engine* e, int32_t* status);
 int lmc_engine_get_counters(lmc_engine* e, int64_t* counters);
 

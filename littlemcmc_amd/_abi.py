@@ -90,6 +90,8 @@ _SIGNATURES = {
     "lmc_engine_get_adapt_state": (C.c_int, [_P, _P, _P, _P, _P]),
     "lmc_engine_get_chain_state": (C.c_int, [_P, C.POINTER(ChainState)]),
     "lmc_engine_set_chain_state": (C.c_int, [_P, C.POINTER(ChainState)]),
+    "lmc_engine_keep_moments": (C.c_int, [_P, C.c_int32]),
+    "lmc_engine_get_moments": (C.c_int, [_P, _P, _P, _P]),
     "lmc_engine_get_status": (C.c_int, [_P, _P]),
     "lmc_engine_get_counters": (C.c_int, [_P, _P]),
     "lmc_engine_trajectory": (C.c_int, [_P, _P, _P, C.c_int32, C.c_double, C.c_int32, C.c_int32,

@@ -224,6 +224,11 @@ __global__ void reset_kernel(ChainArrays A, const double* init_mean, const float
             A.n_samples[c] = 0;
         }
     }
+    if (reset_step && A.mom_mean != nullptr) {
+        A.mom_mean[idx] = 0.0;
+        A.mom_m2[idx] = 0.0;
+        if (e == 0) A.mom_n[c] = 0;
+    }
     if (reset_step && e == 0) {
         A.da[c * 4 + 0] = log_step0;
         A.da[c * 4 + 1] = log_step0;
@@ -873,6 +878,37 @@ int lmc_engine_get_adapt_state(lmc_engine* e, float* var, double* dual_avg, int3
     if (dual_avg) HIP_TRY(e, hipMemcpy(dual_avg, e->A.da, C * 4 * sizeof(double), hipMemcpyDefault));
     if (da_count) HIP_TRY(e, hipMemcpy(da_count, e->A.da_count, C * sizeof(int), hipMemcpyDefault));
     if (n_samples) HIP_TRY(e, hipMemcpy(n_samples, e->A.n_samples, C * sizeof(int), hipMemcpyDefault));
+    return LMC_OK;
+}
+
+int lmc_engine_keep_moments(lmc_engine* e, int32_t enable) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    ChainArrays& A = e->A;
+    const size_t C = e->cfg.chains, dp = e->dpad;
+    if (enable && !A.mom_mean) {
+        int rc;
+        if ((rc = dev_alloc(e, &A.mom_mean, C * dp)) != LMC_OK) return rc;
+        if ((rc = dev_alloc(e, &A.mom_m2, C * dp)) != LMC_OK) return rc;
+        if ((rc = dev_alloc(e, &A.mom_n, C)) != LMC_OK) return rc;
+    } else if (!enable && A.mom_mean) {
+        dev_free(e, A.mom_mean); dev_free(e, A.mom_m2); dev_free(e, A.mom_n);
+        A.mom_mean = nullptr; A.mom_m2 = nullptr; A.mom_n = nullptr;
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return LMC_OK;
+}
+
+int lmc_engine_get_moments(lmc_engine* e, double* mean, double* m2, int32_t* n) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    if (!e->A.mom_mean) return fail(e, LMC_ERR_STATE, "moments are not kept (call lmc_engine_keep_moments first)");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const size_t C = e->cfg.chains, d = e->cfg.dim, dp = e->dpad;
+    if (mean) HIP_TRY(e, hipMemcpy2D(mean, d * sizeof(double), e->A.mom_mean, dp * sizeof(double), d * sizeof(double), C, hipMemcpyDefault));
+    if (m2) HIP_TRY(e, hipMemcpy2D(m2, d * sizeof(double), e->A.mom_m2, dp * sizeof(double), d * sizeof(double), C, hipMemcpyDefault));
+    if (n) HIP_TRY(e, hipMemcpy(n, e->A.mom_n, C * sizeof(int), hipMemcpyDefault));
     return LMC_OK;
 }
 

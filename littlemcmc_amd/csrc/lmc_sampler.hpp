@@ -67,6 +67,9 @@ struct ChainArrays {
     double* rng_gauss;    // [C]
     int* status;          // [C]
     long long* counters;  // [C][kNumCounters]
+    double* mom_mean;     // [C][dpad] running mean of the post-warm-up draws (nullptr = not kept)
+    double* mom_m2;       // [C][dpad] running sum of squared deviations (Welford)
+    int* mom_n;           // [C] number of draws accumulated
     double* scratch;      // [C][scratch_stride]
     long long scratch_stride;
     // outputs (row = iteration index relative to the engine's reserved capacity)
@@ -789,6 +792,23 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         if (out.diverging && !tune) ++ct_divs;
         ++iter_count;
         if (!tune) ++ct_after;
+
+        // ---- running per-chain moments of the post-warm-up draws (optional): enough for R-hat without a trace
+        if (A.mom_mean != nullptr && !tune) {
+            const int n_new = first_i32(A.mom_n[c]) + 1;
+            const double inv_n = 1.0 / static_cast<double>(n_new);
+            double mm[NS], m2[NS];
+            vload<NS>(A.mom_mean + row, mm); vload<NS>(A.mom_m2 + row, m2);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double dlt = q[s] - mm[s];
+                mm[s] = mm[s] + dlt * inv_n;
+                m2[s] = m2[s] + dlt * (q[s] - mm[s]);
+            }
+            vstore<NS>(A.mom_mean + row, mm); vstore<NS>(A.mom_m2 + row, m2);
+            tm.sync();
+            if (tid == 0) A.mom_n[c] = n_new;
+        }
 
         // ---- outputs: draw row + stats
         const long long orow = static_cast<long long>(c) * A.cap + git;

@@ -112,6 +112,26 @@ def summarize(x, split=True, max_lag=None, group=None, chunk=2048, reduce_device
     return finalize(all_reduce_stats(stats, group=group, reduce_device=reduce_device))
 
 
+def rhat_from_moments(mean, m2, n, group=None, reduce_device=None):
+    """(Non-split) R-hat[d] from per-chain running moments -- mean[chains, d], m2[chains, d] (sum of squared
+    deviations), n[chains] equal draws per chain -- reduced over ranks with one all-reduce of
+    {chains, sum mean, sum mean^2, sum var}. This is the trace-free diagnostic of SURVEY.md section 8e."""
+    mean = torch.as_tensor(mean, dtype=torch.float64)
+    m2 = torch.as_tensor(m2, dtype=torch.float64)
+    nd = float(torch.as_tensor(n).to(torch.float64).mean())
+    stats = {"n_chains": torch.tensor(float(mean.shape[0]), dtype=torch.float64, device=mean.device),
+             "n_draws": torch.tensor(nd, dtype=torch.float64, device=mean.device),
+             "sum_mean": mean.sum(dim=0), "sum_mean_sq": (mean ** 2).sum(dim=0),
+             "sum_var": (m2 / (nd - 1.0)).sum(dim=0),
+             "sum_acov": torch.zeros(2, mean.shape[1], dtype=torch.float64, device=mean.device)}
+    stats = all_reduce_stats(stats, group=group, reduce_device=reduce_device)
+    m = float(stats["n_chains"])
+    w = stats["sum_var"] / m
+    gmean = stats["sum_mean"] / m
+    b_over_n = (stats["sum_mean_sq"] - m * gmean ** 2) / (m - 1.0) if m > 1 else torch.zeros_like(w)
+    return torch.sqrt((w * (nd - 1.0) / nd + b_over_n) / w)
+
+
 class _DevicePtr:
     """__cuda_array_interface__ shim: view engine-owned HBM as a torch tensor without copying."""
 

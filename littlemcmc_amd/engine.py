@@ -210,6 +210,17 @@ class Engine:
                 setattr(st, name, a.ctypes.data)
         self._check(self._lib.lmc_engine_set_chain_state(self._h, C.byref(st)))
 
+    def keep_moments(self, enable=True):
+        """Accumulate per-chain mean / M2 of the post-warm-up draws on the device (no trace needed for R-hat)."""
+        self._check(self._lib.lmc_engine_keep_moments(self._h, int(bool(enable))))
+
+    def moments(self):
+        mean = np.empty((self.chains, self.dim))
+        m2 = np.empty((self.chains, self.dim))
+        n = np.empty(self.chains, dtype=np.int32)
+        self._check(self._lib.lmc_engine_get_moments(self._h, _abi.ptr(mean), _abi.ptr(m2), _abi.ptr(n)))
+        return mean, m2, n
+
     def status(self):
         st = np.empty(self.chains, dtype=np.int32)
         self._check(self._lib.lmc_engine_get_status(self._h, _abi.ptr(st)))

@@ -35,3 +35,49 @@ def test_sample_distributed_single_rank_equals_sample():
     np.testing.assert_array_equal(tr, tr2)
     np.testing.assert_array_equal(st["tree_size"], st2["tree_size"])
     assert diag["rhat"].shape == (d,) and diag["n_chains"] == 12.0
+
+
+def test_running_moments_match_the_trace_and_give_rhat_without_one():
+    """lmc_engine_keep_moments: per-chain Welford mean / M2 of the post-warm-up draws, accumulated inside the
+    transition kernel, equal the same statistics of the trace; R-hat follows from them with no trace in HBM."""
+    d, chains, tune, draws = 70, 48, 120, 150          # d = 70: padded lanes, 2 elements per thread
+    seeds = np.arange(chains, dtype=np.uint32) + 11
+    start = np.zeros((chains, d))
+
+    def run(keep_trace):
+        eng = lmc.Engine(lmc.targets.AR1(d, 0.5), chains=chains)
+        eng.keep_moments(True)
+        eng.seed(seeds)
+        eng.set_position(start)
+        eng.reset_tuning()
+        eng.reserve(tune + draws, keep_trace=keep_trace, trace_begin=tune)
+        eng.run(tune, 0, 100)                          # launch boundaries inside warm-up and inside the draws
+        eng.run(tune, 100, 100)
+        eng.run(tune, 200, tune + draws - 200)
+        eng.synchronize()
+        return eng
+
+    with run(True) as eng:
+        trace = eng.trace(tune, draws)
+        mean, m2, n = eng.moments()
+    assert np.all(n == draws)
+    np.testing.assert_allclose(mean, trace.mean(axis=1), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(m2, ((trace - trace.mean(axis=1, keepdims=True)) ** 2).sum(axis=1), rtol=1e-10)
+
+    with run(False) as eng:                            # no trace at all: same moments (same seeds, same chains)
+        mean2, m22, n2 = eng.moments()
+        eng.reset_tuning()
+        assert np.all(eng.moments()[2] == 0)           # reset with the tuning state
+    np.testing.assert_array_equal(mean2, mean)
+    np.testing.assert_array_equal(m22, m2)
+
+    rhat = dg.rhat_from_moments(mean, m2, n).numpy()
+    want, _ = odg.rhat_ess(trace, do_split=False)
+    np.testing.assert_allclose(rhat, want, rtol=1e-9)
+    assert np.all(rhat < 1.1)
+
+
+def test_moments_require_opt_in():
+    with lmc.Engine(lmc.targets.StdNormal(4), chains=2) as eng:
+        with pytest.raises(lmc._abi.HipLibraryError, match="keep_moments"):
+            eng.moments()
