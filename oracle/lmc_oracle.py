@@ -19,6 +19,7 @@ container (same numpy/OpenBLAS) on the fixtures in tests/golden/.
 from collections import namedtuple
 
 import numpy as np
+import scipy.linalg
 
 # integration.py:25
 State = namedtuple("State", "q p v g energy logp")
@@ -75,6 +76,9 @@ class DiagAdaptPotential:
     def velocity(self, x):  # :206-208
         return np.multiply(self.var, x)
 
+    def velocity_into(self, x, out):  # :216-219
+        np.multiply(self.var, x, out=out)
+
     def random(self, rng):  # :221-224
         vals = rng.normal(size=self.n).astype("float32")
         return self.inv_stds * vals
@@ -112,11 +116,155 @@ class DiagPotential:
     def velocity(self, x):
         return self.var * x
 
+    def velocity_into(self, x, out):  # :378-387
+        np.multiply(self.var, x, out=out)
+
     def random(self, rng):  # :374-376
         return rng.normal(size=self.var.shape) * self.inv_stds
 
     def update(self, sample, tune):
         pass
+
+
+class _WelfordCov:
+    """quadpotential.py:560-615 (_WeightedCovariance): float64 mean and raw second moment, full d x d."""
+
+    def __init__(self, n, mean=None, cov=None, weight=0):
+        self.n_samples = float(weight)
+        self.mean = np.zeros(n) if mean is None else np.array(mean, dtype="d", copy=True)
+        self.raw = np.eye(n) if cov is None else np.array(cov, dtype="d", copy=True)
+        self.raw[:] *= self.n_samples
+
+    def add(self, x):  # :594-600 with weight == 1 (rows scale with the NEW residual, columns with the OLD one)
+        self.n_samples += 1
+        old = x - self.mean
+        self.mean[:] += old / self.n_samples
+        new = x - self.mean
+        self.raw[:] += 1 * new[:, None] * old[None, :]
+
+
+class FullPotential:
+    """quadpotential.py:428-468 (QuadPotentialFull): float32 covariance, float32 momentum through a
+    triangular solve with the transposed Cholesky factor."""
+
+    momentum_f32 = True
+    dense = True
+
+    def __init__(self, cov, dtype="float32"):
+        self.cov = np.array(cov, dtype=dtype, copy=True)
+        self.chol = scipy.linalg.cholesky(self.cov, lower=True)
+        self.n = len(self.cov)
+        self.n_samples = 0
+
+    def reset(self):
+        pass
+
+    def velocity(self, x):  # :446-448 (float32 x -> float32 sgemv, float64 x -> promoted dgemv)
+        return np.dot(self.cov, x)
+
+    def velocity_into(self, x, out):  # :461-464
+        np.dot(self.cov, x, out=out)
+
+    def random(self, rng):  # :450-453
+        vals = rng.normal(size=self.n).astype(self.cov.dtype)
+        return scipy.linalg.solve_triangular(self.chol.T, vals, overwrite_b=True)
+
+    def update(self, sample, tune):
+        pass
+
+
+class FullInvPotential:
+    """quadpotential.py:388-425 (QuadPotentialFullInv): mass matrix A given, velocity by two triangular solves,
+    float64 momentum L n."""
+
+    momentum_f32 = False
+    dense = True
+
+    def __init__(self, A):
+        self.L = scipy.linalg.cholesky(A, lower=True)
+        self.n = self.L.shape[0]
+        self.n_samples = 0
+
+    def reset(self):
+        pass
+
+    def velocity(self, x):  # :404-409
+        return scipy.linalg.cho_solve((self.L, True), x)
+
+    def velocity_into(self, x, out):
+        out[:] = scipy.linalg.cho_solve((self.L, True), x)
+
+    def random(self, rng):  # :411-414
+        return np.dot(self.L, rng.normal(size=self.n))
+
+    def update(self, sample, tune):
+        pass
+
+
+class FullAdaptPotential(FullPotential):
+    """quadpotential.py:471-557 (QuadPotentialFullAdapt): foreground/background covariance estimators, the
+    float32 covariance and its Cholesky factor refreshed every ``update_window`` tuning samples, the
+    adaptation window growing by ``multiplier`` each time the background estimator takes over.
+
+    The reference's ``reset()`` is the base-class no-op (quadpotential.py:136-138), so its SEQUENTIAL driver hands
+    chain k the matrix chain k-1 ended with; its multi-process driver gives every chain a fresh copy. ``reset``
+    here restores the constructor state, i.e. every chain is what the reference computes for a one-chain run with
+    that chain's seed (the goldens are captured that way)."""
+
+    def __init__(self, n, initial_mean, initial_cov=None, initial_weight=0, adaptation_window=101,
+                 adaptation_window_multiplier=2, update_window=1, dtype="float32"):
+        if initial_cov is None:  # :501-503
+            initial_cov = np.eye(n, dtype=dtype)
+            initial_weight = 1
+        self._init = (n, np.array(initial_mean, dtype="d"), np.array(initial_cov), initial_weight,
+                      int(adaptation_window), float(adaptation_window_multiplier), int(update_window), dtype)
+        self.reset()
+
+    def reset(self):
+        n, mean, cov, weight, window, mult, upd, dtype = self._init
+        self.n = n
+        self.cov = np.array(cov, dtype=dtype, copy=True)
+        self.chol = scipy.linalg.cholesky(self.cov, lower=True)
+        self.chol_error = None
+        self.fore = _WelfordCov(n, mean, cov, weight)
+        self.back = _WelfordCov(n)
+        self.n_samples = 0
+        self.window, self.multiplier, self.update_window = window, mult, upd
+        self.previous_update = 0
+
+    def _refresh(self, est):  # :521-526
+        np.divide(est.raw, est.n_samples - 1, out=self.cov)  # float64 quotient stored as float32
+        try:
+            self.chol = scipy.linalg.cholesky(self.cov, lower=True)
+        except (scipy.linalg.LinAlgError, ValueError) as error:
+            self.chol_error = error  # the old factor stays in use
+
+    def update(self, sample, tune):  # :528-552
+        if not tune:
+            return
+        delta = self.n_samples - self.previous_update
+        self.fore.add(sample)
+        self.back.add(sample)
+        if (delta + 1) % self.update_window == 0:
+            self._refresh(self.fore)
+        if delta >= self.window:
+            self.fore = self.back
+            self.back = _WelfordCov(self.n)
+            self.previous_update = self.n_samples
+            self.window = int(self.window * self.multiplier)
+        self.n_samples += 1
+
+
+def quad_potential(scaling, is_cov):
+    """quadpotential.py:33-65 for dense arrays: covariance -> Full, precision/Hessian -> FullInv."""
+    c = np.asarray(scaling)
+    if c.ndim == 1:
+        return quad_potential_diag(c, is_cov)
+    dg = np.diag(c)
+    bad = np.nonzero(np.logical_or(np.isnan(dg), dg <= 0))[0]
+    if len(bad):
+        raise ValueError("Scaling is not positive definite. Check indexes %s." % (bad,))
+    return FullPotential(c) if is_cov else FullInvPotential(c)
 
 
 def quad_potential_diag(scaling, is_cov):
@@ -147,7 +295,7 @@ def leapfrog(pot, f, eps, s):
     q = (s.q + eps * v).astype(s.q.dtype)
     logp, g = f(q)
     p = p + dt * g
-    np.multiply(pot.var, p, out=v)
+    pot.velocity_into(p, v)   # in place, integration.py:118
     kinetic = 0.5 * np.dot(p, v)
     return State(q, p, v, g, kinetic - logp, logp)
 
@@ -427,7 +575,7 @@ class Step:
             potential = DiagAdaptPotential(d, np.zeros(d), np.ones(d), 10)
         if scaling is not None and potential is not None:
             raise ValueError("Cannot specify both `potential` and `scaling`.")
-        self.pot = potential if potential is not None else quad_potential_diag(scaling, is_cov)
+        self.pot = potential if potential is not None else quad_potential(scaling, is_cov)
         self.path_length = path_length
         self.max_treedepth = max_treedepth
         self.early_max_treedepth = early_max_treedepth
@@ -493,7 +641,7 @@ def jitter_start(seed0, d):
 
 
 def init_nuts(f, d, init="auto", seeds=None, **kwargs):
-    """sampling.py:524-605, diagonal modes."""
+    """sampling.py:524-605."""
     if not isinstance(init, str):
         raise TypeError("init must be a string.")
     init = init.lower()
@@ -503,9 +651,16 @@ def init_nuts(f, d, init="auto", seeds=None, **kwargs):
         start = np.zeros(d)
     elif init == "jitter+adapt_diag":
         start = jitter_start(seeds[0], d) if seeds is not None else 2 * np.random.rand(d) - 1
+    elif init == "adapt_full":
+        start = np.zeros(d)
+    elif init == "jitter+adapt_full":
+        start = jitter_start(seeds[0], d) if seeds is not None else 2 * np.random.rand(d) - 1
     else:
         raise ValueError("Unknown initializer: {}.".format(init))
-    pot = DiagAdaptPotential(d, start, np.ones(d), 10)
+    if init.endswith("adapt_full"):  # sampling.py:588-597
+        pot = FullAdaptPotential(d, start, np.eye(d), 10)
+    else:
+        pot = DiagAdaptPotential(d, start, np.ones(d), 10)
     return start, Step(f, d, kind="nuts", potential=pot, **kwargs)
 
 

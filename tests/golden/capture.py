@@ -282,10 +282,173 @@ def capture_seeds():
     out["stream_state_pos"] = np.array(rs.get_state()[2])
     save("seeds", **out)
 
+# ---------------------------------------------------------------------------------------
+# 7. dense mass matrices: unit values, estimator sequences, end-to-end runs
+# ---------------------------------------------------------------------------------------
+def _spd(rs, d):
+    a = rs.randn(d, d) / np.sqrt(d)
+    return a @ a.T + 0.5 * np.eye(d)
+
+
+def ar1_cov(d, rho):
+    idx = np.arange(d)
+    return rho ** np.abs(idx[:, None] - idx[None, :])
+
+
+def capture_dense_units():
+    from littlemcmc import quadpotential as rq
+
+    out = {}
+    cases = [("full", 5, "std_normal"), ("full", 12, "ar1"), ("full", 70, "ar1"), ("full", 128, "std_normal"),
+             ("inv", 5, "std_normal"), ("inv", 12, "ar1"), ("inv", 70, "ar1")]
+    for ci, (kind, d, fam) in enumerate(cases):
+        rs = np.random.RandomState(300 + ci)
+        mat = _spd(rs, d)                      # covariance for "full", mass (inverse covariance) for "inv"
+        pot = rq.quad_potential(mat, kind == "full")
+        f = targets.make(fam, d)
+        step = ref.HamiltonianMC(f, d, potential=pot)
+        np.random.seed(4000 + ci)
+        draws = np.array([pot.random() for _ in range(3)])
+        q0 = 0.3 * np.random.randn(d)
+        p0 = pot.random()
+        x = np.random.randn(d)
+        eps, n = 0.05, (12 if d <= 16 else 4)
+        st = step.integrator.compute_state(q0, p0)
+        states = [st]
+        for _ in range(n):
+            st = step.integrator.step(eps, st)
+            states.append(st)
+        for _ in range(n):
+            st = step.integrator.step(-eps, st)
+            states.append(st)
+        key = "c%d_" % ci
+        out[key + "kind"] = np.array(kind)
+        out[key + "family"] = np.array(fam)
+        out[key + "d"] = np.array(d)
+        out[key + "matrix"] = mat
+        out[key + "seed"] = np.array(4000 + ci)
+        out[key + "random"] = draws.astype("d")
+        out[key + "random_dtype"] = np.array(str(draws.dtype))
+        out[key + "x"] = x
+        out[key + "velocity"] = np.asarray(pot.velocity(x), dtype="d")
+        out[key + "energy_x"] = np.array(float(pot.energy(x)))
+        out[key + "eps"] = np.array(eps)
+        out[key + "n"] = np.array(n)
+        out[key + "params"] = f.params()
+        for k, v in state_rows(states).items():
+            out[key + k] = v
+    out["n_cases"] = np.array(len(cases))
+    save("dense_units", **out)
+
+
+def capture_dense_adapt():
+    from littlemcmc.quadpotential import QuadPotentialFullAdapt
+
+    out = {}
+    rs = np.random.RandomState(77)
+    d = 6
+    true_cov = _spd(rs, d) * 3.0
+    samples = rs.multivariate_normal(np.linspace(-1, 1, d), true_cov, size=140)
+    for name, kw in [("w20", dict(adaptation_window=20)), ("w15u4", dict(adaptation_window=15, update_window=4))]:
+        pot = QuadPotentialFullAdapt(d, samples[0] * 0.0 + 0.25, np.eye(d), 10, **kw)
+        rows = {k: [] for k in ("cov", "chol", "fmean", "fraw", "fn", "bmean", "braw", "bn", "window", "prev", "ns")}
+        for x in samples:
+            pot.update(x, None, True)
+            rows["cov"].append(np.array(pot._cov, dtype="d"))
+            rows["chol"].append(np.array(pot._chol, dtype="d"))
+            rows["fmean"].append(pot._foreground_cov.mean.copy())
+            rows["fraw"].append(pot._foreground_cov.raw_cov.copy())
+            rows["fn"].append(pot._foreground_cov.n_samples)
+            rows["bmean"].append(pot._background_cov.mean.copy())
+            rows["braw"].append(pot._background_cov.raw_cov.copy())
+            rows["bn"].append(pot._background_cov.n_samples)
+            rows["window"].append(pot._adaptation_window)
+            rows["prev"].append(pot._previous_update)
+            rows["ns"].append(pot._n_samples)
+        for k, v in rows.items():
+            out[name + "_" + k] = np.array(v)
+        out[name + "_kw_names"] = np.array(list(kw.keys()), dtype="U32")
+        out[name + "_kw_vals"] = np.array(list(kw.values()), dtype="d")
+    out["samples"] = samples
+    out["initial_mean"] = samples[0] * 0.0 + 0.25
+    # singular estimate (tests/test_quadpotential.py:215-224): the factor must survive, the error must be recorded
+    pot = QuadPotentialFullAdapt(2, np.zeros(2), np.eye(2), 0, adaptation_window=10)
+    for _ in range(11):
+        pot.update(np.ones(2), None, True)
+    out["singular_cov"] = np.array(pot._cov, dtype="d")
+    out["singular_chol"] = np.array(pot._chol, dtype="d")
+    out["singular_failed"] = np.array(pot._chol_error is not None)
+    save("dense_adapt", **out)
+
+
+def capture_dense_e2e():
+    from littlemcmc import quadpotential as rq
+
+    runs = [
+        # name, family, d, kind, potential, chains, tune, draws
+        ("e2e_nuts_full_ar1_12", "ar1", 12, "nuts", "full", 2, 200, 100),
+        ("e2e_nuts_fullinv_ar1_12", "ar1", 12, "nuts", "inv", 2, 200, 100),
+        ("e2e_hmc_full_std10", "std_normal", 10, "hmc", "full", 2, 200, 100),
+        ("e2e_nuts_adaptfull_ar1_10_a", "ar1", 10, "nuts", "adapt_full", 1, 260, 100),
+        ("e2e_nuts_adaptfull_ar1_10_b", "ar1", 10, "nuts", "jitter+adapt_full", 1, 260, 100),
+        ("e2e_nuts_adaptfull_std70", "std_normal", 70, "nuts", "jitter+adapt_full", 1, 120, 30),
+    ]
+    for ri, (name, fam, d, kind, potk, chains, tune, draws) in enumerate(runs):
+        f = targets.make(fam, d)
+        rho = 0.9
+        extra = {}
+        if potk in ("full", "inv"):
+            cov = ar1_cov(d, rho) if fam == "ar1" else _spd(np.random.RandomState(9), d)
+            mat = cov if potk == "full" else np.linalg.inv(cov)
+            pot = rq.quad_potential(mat, potk == "full")
+            cls = ref.HamiltonianMC if kind == "hmc" else ref.NUTS
+            step = cls(f, d, potential=pot)
+            extra["matrix"] = mat
+            trace, stats = ref.sample(f, d, draws=draws, tune=tune, step=step, chains=chains, cores=1,
+                                      progressbar=False, random_seed=SEED + ri, discard_tuned_samples=False)
+            np.random.seed(SEED + ri)
+            seeds = np.array([np.random.randint(2 ** 30) for _ in range(chains)])
+        else:
+            import littlemcmc.sampling as ref_sampling
+            made = {}
+            orig = ref_sampling.init_nuts
+
+            def spy(*a, **k):
+                st, sp = orig(*a, **k)
+                made["step"] = sp
+                return st, sp
+
+            ref_sampling.init_nuts = spy
+            seeds = np.array([SEED % 100000 + 31 * ri])
+            try:
+                trace, stats = ref.sample(f, d, draws=draws, tune=tune, chains=1, cores=1, init=potk,
+                                          progressbar=False, random_seed=[int(seeds[0])],
+                                          discard_tuned_samples=False)
+            finally:
+                ref_sampling.init_nuts = orig
+            step = made["step"]
+            extra["final_cov"] = np.array(step.potential._cov, dtype="d")
+            extra["final_chol"] = np.array(step.potential._chol, dtype="d")
+            extra["final_window"] = np.array(step.potential._adaptation_window)
+            extra["final_prev"] = np.array(step.potential._previous_update)
+        arrays = dict(
+            family=np.array(fam), kind=np.array(kind), potential=np.array(potk), d=np.array(d),
+            chains=np.array(chains), tune=np.array(tune), draws=np.array(draws), seeds=seeds,
+            random_seed=np.array(SEED + ri), params=f.params(), trace=trace,
+            final_da=np.array([float(np.ravel(x)[0]) for x in (
+                step.step_adapt._log_step, step.step_adapt._log_bar, step.step_adapt._hbar,
+                step.step_adapt._count)]),
+        )
+        arrays.update(extra)
+        for k, v in stats.items():
+            arrays["stat_" + k] = v
+        save(name, **arrays)
+
+
+CAPTURES = {"leapfrog": capture_leapfrog, "transitions": capture_transitions, "adapt": capture_adapt,
+            "e2e": capture_e2e, "seeds": capture_seeds, "dense_units": capture_dense_units,
+            "dense_adapt": capture_dense_adapt, "dense_e2e": capture_dense_e2e}
 
 if __name__ == "__main__":
-    capture_leapfrog()
-    capture_transitions()
-    capture_adapt()
-    capture_e2e()
-    capture_seeds()
+    for which in (sys.argv[1:] or list(CAPTURES)):
+        CAPTURES[which]()
