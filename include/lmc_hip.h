@@ -41,6 +41,12 @@ extern "C" {
  * tuning) / quadpotential.py:346 (QuadPotentialDiag, fixed diagonal, float64 momentum draw) */
 #define LMC_POT_DIAG_ADAPT 0
 #define LMC_POT_DIAG 1
+/* dense mass matrices (dim <= 256): quadpotential.py:428 (QuadPotentialFull: float32 covariance, float32
+ * momentum by a triangular solve), :388 (QuadPotentialFullInv: mass matrix A given, float64 momentum L n),
+ * :471 (QuadPotentialFullAdapt: covariance + Cholesky factor re-estimated while tuning, one matrix per chain) */
+#define LMC_POT_FULL 2
+#define LMC_POT_FULL_INV 3
+#define LMC_POT_FULL_ADAPT 4
 
 /* built-in device log-densities (littlemcmc_amd/csrc/lmc_targets.hpp); LMC_TARGET_USER exists only in
  * libraries built with a user target header (littlemcmc_amd/targets.py: UserTarget) */
@@ -143,6 +149,18 @@ int lmc_engine_set_target_params(lmc_engine* e, const double* params, int64_t n)
 int lmc_engine_set_potential(lmc_engine* e, const double* initial_mean, const double* initial_diag,
                              double initial_weight, int32_t per_chain);
 
+/* ---- dense potentials (cfg.potential = LMC_POT_FULL / FULL_INV / FULL_ADAPT). matrix: [dim][dim] row-major,
+ *      the same for every chain.
+ *      FULL:       QuadPotentialFull(cov) (quadpotential.py:431-444): matrix = covariance, cast to float32 and
+ *                  factorised (failure -> LMC_ERR_INVALID, as scipy.linalg.cholesky raises).
+ *      FULL_INV:   QuadPotentialFullInv(A) (quadpotential.py:391-402): matrix = A (inverse covariance).
+ *      FULL_ADAPT: QuadPotentialFullAdapt(n, initial_mean, initial_cov, initial_weight, adaptation_window,
+ *                  adaptation_window_multiplier, update_window) (quadpotential.py:474-519); matrix = initial_cov.
+ *      initial_mean .. update_window are read for FULL_ADAPT only. Also the state reset_tuning() restores. */
+int lmc_engine_set_dense_potential(lmc_engine* e, const double* matrix, const double* initial_mean,
+                                   double initial_weight, int32_t adaptation_window,
+                                   double adaptation_window_multiplier, int32_t update_window);
+
 /* ---- RNG: np.random.seed(seeds[c]) for every chain (sampling.py:496-497) ------------------------- */
 int lmc_engine_seed(lmc_engine* e, const uint32_t* seeds);
 /* np.random.get_state()/set_state() of one chain: key[624], pos, has_gauss, cached_gaussian */
@@ -210,6 +228,30 @@ typedef struct lmc_chain_state {
 } lmc_chain_state;
 int lmc_engine_get_chain_state(lmc_engine* e, const lmc_chain_state* dst);
 int lmc_engine_set_chain_state(lmc_engine* e, const lmc_chain_state* src);
+/* Dense-potential state of every chain (FULL_ADAPT: per chain; FULL / FULL_INV: get() replicates the shared
+ * matrices). Matrices [chains][dim][dim] row-major in the reference's orientation, vectors [chains][dim],
+ * scalars [chains]; NULL = skipped. set() is for checkpoint / resume and per-iteration parity tests. */
+typedef struct lmc_dense_state {
+    float* cov;              /* potential._cov (FULL_INV: float32 of A^-1, get only) */
+    float* chol;             /* potential._chol, lower (FULL_INV: float32 of L, get only) */
+    double* fore_mean;       /* potential._foreground_cov.mean */
+    double* fore_raw_cov;    /* potential._foreground_cov.raw_cov */
+    double* fore_n;          /* potential._foreground_cov.n_samples */
+    double* back_mean;
+    double* back_raw_cov;
+    double* back_n;
+    int32_t* window;         /* potential._adaptation_window */
+    int32_t* previous_update;/* potential._previous_update */
+    int32_t* chol_failures;  /* refreshes whose factorisation failed: potential._chol_error is not None */
+} lmc_dense_state;
+int lmc_engine_get_dense_state(lmc_engine* e, const lmc_dense_state* dst);
+int lmc_engine_set_dense_state(lmc_engine* e, const lmc_dense_state* src);
+/* cov / chol [dim][dim] of ONE chain (the host mirror of step.potential after sample()). */
+int lmc_engine_get_dense_chain(lmc_engine* e, int32_t chain, float* cov, float* chol);
+/* Test entry: potential.update(sample = current position, grad, tune) for every chain (quadpotential.py:528-552).
+ * During lmc_engine_run() the same kernel runs after every tuning iteration. */
+int lmc_engine_dense_update(lmc_engine* e, int32_t tune);
+
 /* Running per-chain moments of the post-warm-up draws, kept on the device so that cross-chain R-hat needs no
  * trace (the only quantities the multi-GPU gather moves): mean [chains][dim], m2 = sum of squared
  * deviations [chains][dim], n [chains]. Enable before reset_tuning(); reset with it. */

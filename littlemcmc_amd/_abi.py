@@ -15,7 +15,7 @@ ABI_VERSION = 1
 OK = 0
 
 KIND_NUTS, KIND_HMC = 0, 1
-POT_DIAG_ADAPT, POT_DIAG = 0, 1
+POT_DIAG_ADAPT, POT_DIAG, POT_FULL, POT_FULL_INV, POT_FULL_ADAPT = range(5)
 TARGET_STD_NORMAL, TARGET_DIAG_GAUSSIAN, TARGET_AR1, TARGET_FUNNEL, TARGET_NORMAL1D, TARGET_USER = range(6)
 STATUS_BAD_INITIAL_ENERGY, STATUS_NAN_LOGBERN = 1, 2
 SDOT_NATIVE, SDOT_OPENBLAS_SKYLAKEX, SDOT_OPENBLAS_HASWELL = 0, 1, 2
@@ -56,6 +56,17 @@ class ChainState(C.Structure):
     _fields_ = [(name, C.c_void_p) for name, _dt, _vec in FIELDS]
 
 
+class DenseState(C.Structure):
+    """struct lmc_dense_state (include/lmc_hip.h): (name, dtype, shape kind) with shape kind "m" = [chains, d, d],
+    "v" = [chains, d], "s" = [chains]; pointers, NULL = skip."""
+
+    FIELDS = (("cov", np.float32, "m"), ("chol", np.float32, "m"), ("fore_mean", np.float64, "v"),
+              ("fore_raw_cov", np.float64, "m"), ("fore_n", np.float64, "s"), ("back_mean", np.float64, "v"),
+              ("back_raw_cov", np.float64, "m"), ("back_n", np.float64, "s"), ("window", np.int32, "s"),
+              ("previous_update", np.int32, "s"), ("chol_failures", np.int32, "s"))
+    _fields_ = [(name, C.c_void_p) for name, _dt, _k in FIELDS]
+
+
 _SIGNATURES = {
     # name: (restype, [argtypes])
     "lmc_config_defaults": (None, [C.POINTER(Config), C.c_int32, C.c_int32]),
@@ -68,6 +79,11 @@ _SIGNATURES = {
     "lmc_engine_synchronize": (C.c_int, [_P]),
     "lmc_engine_set_target_params": (C.c_int, [_P, _P, C.c_int64]),
     "lmc_engine_set_potential": (C.c_int, [_P, _P, _P, C.c_double, C.c_int32]),
+    "lmc_engine_set_dense_potential": (C.c_int, [_P, _P, _P, C.c_double, C.c_int32, C.c_double, C.c_int32]),
+    "lmc_engine_get_dense_state": (C.c_int, [_P, C.POINTER(DenseState)]),
+    "lmc_engine_set_dense_state": (C.c_int, [_P, C.POINTER(DenseState)]),
+    "lmc_engine_dense_update": (C.c_int, [_P, C.c_int32]),
+    "lmc_engine_get_dense_chain": (C.c_int, [_P, C.c_int32, _P, _P]),
     "lmc_engine_seed": (C.c_int, [_P, _P]),
     "lmc_engine_set_rng_state": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_double]),
     "lmc_engine_get_rng_state": (C.c_int, [_P, C.c_int32, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32),

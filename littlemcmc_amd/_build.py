@@ -2,7 +2,9 @@
 littlemcmc_amd.targets.UserTarget (which rebuilds the library around a user-supplied device
 log-density header)."""
 import os
+import shutil
 import subprocess
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -36,21 +38,43 @@ def needs_build(out=None):
 
 
 def build(out=None, extra_flags=(), force=False, verbose=False):
-    """Compile csrc/lmc_engine.hip -> liblmc_hip.so. Raises on failure (no fallback)."""
+    """Compile csrc/*.hip -> liblmc_hip.so (one hipcc process per translation unit, then a link). Raises on
+    failure (no fallback)."""
     out = out or lib_path()
     if not force and not needs_build(out):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", CSRC] + list(extra_flags) + ["-o", out, os.path.join(CSRC, "lmc_engine.hip")]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed (%d):\n%s\n%s" % (res.returncode, res.stdout, res.stderr))
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    units = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    objdir = tempfile.mkdtemp(prefix="lmc_build_")
+    try:
+        procs = []
+        for src in units:
+            obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+            cmd = [hipcc] + compile_flags + ["-I", CSRC] + list(extra_flags) + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        objs = []
+        for cmd, obj, proc in procs:
+            so, se = proc.communicate()
+            if proc.returncode != 0:
+                raise RuntimeError("hipcc failed (%d): %s\n%s\n%s" % (proc.returncode, " ".join(cmd), so, se))
+            objs.append(obj)
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+        if verbose:
+            print(" ".join(link))
+        res = subprocess.run(link, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("link failed (%d):\n%s\n%s" % (res.returncode, res.stdout, res.stderr))
+    finally:
+        shutil.rmtree(objdir, ignore_errors=True)
     return out
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+
+    print(build(force="--force" in sys.argv or True, verbose=True))

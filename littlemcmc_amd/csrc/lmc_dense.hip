@@ -1,0 +1,121 @@
+// Second translation unit of liblmc_hip.so: the dense-mass-matrix kernels (lmc_dense.hpp) and their launchers.
+// Kept apart from lmc_engine.hip so that the two sets of kernel instantiations compile in parallel.
+#include <hip/hip_runtime.h>
+
+#include "../../include/lmc_hip.h"
+#include "lmc_dense.hpp"
+#include "lmc_dense_launch.hpp"
+#ifdef LMC_USER_TARGET_HEADER
+#include LMC_USER_TARGET_HEADER
+#endif
+
+namespace lmc {
+
+#ifdef LMC_USER_TARGET_HEADER
+#define DENSE_USER_CASE(CALL) case LMC_TARGET_USER: { CALL(UserTarget); } break;
+#else
+#define DENSE_USER_CASE(CALL)
+#endif
+
+#if defined(LMC_USER_TARGET_HEADER) && defined(LMC_ONLY_USER)
+#define DENSE_FAMILY_SWITCH(family, CALL) \
+    switch (family) {                     \
+        DENSE_USER_CASE(CALL)             \
+        default: return kDenseUnsupported; \
+    }
+#else
+#define DENSE_FAMILY_SWITCH(family, CALL)                                   \
+    switch (family) {                                                       \
+        case LMC_TARGET_STD_NORMAL: { CALL(StdNormalTarget); } break;       \
+        case LMC_TARGET_DIAG_GAUSSIAN: { CALL(DiagGaussianTarget); } break; \
+        case LMC_TARGET_AR1: { CALL(AR1Target); } break;                    \
+        case LMC_TARGET_FUNNEL: { CALL(FunnelTarget); } break;              \
+        case LMC_TARGET_NORMAL1D: { CALL(Normal1DTarget); } break;          \
+        DENSE_USER_CASE(CALL)                                               \
+        default: return kDenseUnsupported;                                  \
+    }
+#endif
+
+#define DENSE_SHAPE_SWITCH(ns, mat_f64, BODY)                                              \
+    if (mat_f64) {                                                                         \
+        typedef double MatT;                                                               \
+        switch (ns) {                                                                      \
+            case 1: { constexpr int NS = 1; BODY; } break;                                 \
+            case 2: { constexpr int NS = 2; BODY; } break;                                 \
+            case 4: { constexpr int NS = 4; BODY; } break;                                 \
+            default: return kDenseUnsupported;                                             \
+        }                                                                                  \
+    } else {                                                                               \
+        typedef float MatT;                                                                \
+        switch (ns) {                                                                      \
+            case 1: { constexpr int NS = 1; BODY; } break;                                 \
+            case 2: { constexpr int NS = 2; BODY; } break;                                 \
+            case 4: { constexpr int NS = 4; BODY; } break;                                 \
+            default: return kDenseUnsupported;                                             \
+        }                                                                                  \
+    }
+
+int dense_launch_run(int family, int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
+                     const SamplerParams& P, const double* tparams) {
+    const dim3 grid(A.chains), block(64);
+    const int lds = dense_lds_doubles(A.dpad) * 8;
+    (void)hipGetLastError();
+#define RUN_CALL(T) \
+    DENSE_SHAPE_SWITCH(ns, mat_f64, hipLaunchKernelGGL((run_dense_kernel<NS, MatT, T>), grid, block, lds, stream, A, D, P, tparams))
+    DENSE_FAMILY_SWITCH(family, RUN_CALL)
+#undef RUN_CALL
+    return static_cast<int>(hipGetLastError());
+}
+
+int dense_launch_trajectory(int family, int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A,
+                            const DenseArrays& D, const double* tparams, const double* q0, const double* p0,
+                            int p0_is_f32, int sdot_mode, double eps, int n_fwd, int n_back, double* oq, double* op,
+                            double* ov, double* og, double* oe, double* ol) {
+    const dim3 grid(A.chains), block(64);
+    const int lds = 2 * A.dpad * 8;
+    (void)hipGetLastError();
+#define TRAJ_CALL(T)                                                                                                   \
+    DENSE_SHAPE_SWITCH(ns, mat_f64, hipLaunchKernelGGL((dense_trajectory_kernel<NS, MatT, T>), grid, block, lds, stream, A, D, \
+                                                       tparams, q0, p0, p0_is_f32, sdot_mode, eps, n_fwd, n_back, oq, op, ov,  \
+                                                       og, oe, ol))
+    DENSE_FAMILY_SWITCH(family, TRAJ_CALL)
+#undef TRAJ_CALL
+    return static_cast<int>(hipGetLastError());
+}
+
+int dense_launch_momentum(int ns, hipStream_t stream, const ChainArrays& A, const DenseArrays& D, double* out) {
+    const dim3 grid(A.chains), block(64);
+    const int lds = 2 * A.dpad * 8;
+    (void)hipGetLastError();
+    switch (ns) {
+        case 1: hipLaunchKernelGGL((dense_momentum_kernel<1>), grid, block, lds, stream, A, D, out); break;
+        case 2: hipLaunchKernelGGL((dense_momentum_kernel<2>), grid, block, lds, stream, A, D, out); break;
+        case 4: hipLaunchKernelGGL((dense_momentum_kernel<4>), grid, block, lds, stream, A, D, out); break;
+        default: return kDenseUnsupported;
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
+int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, double multiplier,
+                       int update_window) {
+    const int lds = dense_adapt_lds_bytes(A.d);
+    if (lds > 64 * 1024) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_adapt_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (err != hipSuccess) return static_cast<int>(err);
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(dense_adapt_kernel, dim3(A.chains), dim3(kAdaptThreads), lds, stream, A, D, multiplier, update_window);
+    return static_cast<int>(hipGetLastError());
+}
+
+int dense_launch_reset(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, const float* cov1T,
+                       const float* fac1, const double* raw1T, const double* mean1, double weight, int window, int d8) {
+    const int per_chain = (d8 * A.dpad + 255) / 256;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(dense_reset_kernel, dim3(A.chains, per_chain < 64 ? per_chain : 64), dim3(256), 0, stream, A, D,
+                       cov1T, fac1, raw1T, mean1, weight, window, d8);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace lmc

@@ -1,0 +1,757 @@
+// Dense mass matrices on the device: QuadPotentialFull / FullInv / FullAdapt.
+//
+//   velocity / energy   <- /root/reference/littlemcmc/quadpotential.py:446-464 (Full), :404-425 (FullInv)
+//   momentum draw       <- quadpotential.py:450-453 (float32 triangular solve), :411-414 (float64 L n)
+//   covariance estimate <- quadpotential.py:521-552 (FullAdapt.update), :560-615 (_WeightedCovariance)
+//   leapfrog            <- integration.py:52-66, :100-121
+//   NUTS / HMC          <- nuts.py:204-435, hmc.py:140-182 (same iterative tree as lmc_sampler.hpp)
+//
+// What changes against the diagonal kernel (lmc_sampler.hpp):
+//  * A velocity is a d x d matrix-vector product, so velocities are STORED with every tree node instead of being
+//    recomputed, and the kernel is bound by streaming the matrix, not by VALU issue. One chain = one wavefront;
+//    thread t owns elements t*NS .. t*NS+NS-1 of every vector.
+//  * Matrix layout: M^-1 is kept TRANSPOSED, covT[j][i] = cov[i][j], rows padded to dpad. Row j is contiguous
+//    over i, so   v_i = sum_j cov[i][j] p_j   is a sweep over rows with lane-contiguous (coalesced) loads and the
+//    operand p_j broadcast from LDS; no cross-lane reduction. float32 storage (as the reference), float64 products.
+//  * ONE sweep per leapfrog instead of the reference's two: the sweep at the end of a step forms both
+//    v' = C p' and w' = C g'; the next half step uses C (p' + dt g') = v' + dt w'. Same value up to the rounding
+//    of one float64 addition; halves the bytes that bound the kernel.
+//  * Tree nodes and both trajectory ends live in the chain's HBM scratch row (L2 resident while the chain is hot):
+//    next to a 64 KiB matrix sweep per leapfrog their traffic is noise, and the register file stays free for
+//    the sweep's loads in flight.
+//  * FullAdapt's per-iteration covariance refresh + Cholesky is a separate kernel (one workgroup per chain, matrix
+//    in LDS) launched between iterations while tuning; see dense_adapt_kernel.
+#pragma once
+#include "lmc_dense_types.hpp"
+
+namespace lmc {
+
+// N matrix entries of one thread as one vector register group: loads from HBM become global_load_dwordx{N}
+template <class T, int N> struct PackOf { typedef T type __attribute__((ext_vector_type(N))); };
+template <class T> struct PackOf<T, 1> { typedef T type; };
+template <class T, int N> using Pack = typename PackOf<T, N>::type;
+template <int N, class P> __device__ __forceinline__ auto pack_get(const P& p, int s) {
+    if constexpr (N == 1) return p; else return p[s];
+}
+
+// ---- one sweep over the transposed matrix: acc[v][s] = sum_j M[j][lane*NS+s] * x[j][v] --------------------------
+// x: LDS, NV operands interleaved per row index. float64 fused multiply-adds on the promoted matrix entries
+// (numpy promotes the float32 matrix and calls dgemv; only the summation order differs).
+template <int NS, int NV, class MatT>
+__device__ __forceinline__ void dense_sweep(const MatT* __restrict__ M, int d, int dpad, const lds_double* x,
+                                            double (&acc)[NV][NS]) {
+    typedef __attribute__((address_space(1))) const Pack<MatT, NS> glb_pack;
+    glb_pack* col = (glb_pack*)(M + lane_id() * NS);
+    const int stride = dpad / NS;   // in packs
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[v][s] = 0.0;
+#pragma unroll 8
+    for (int j = 0; j < d; ++j) {
+        const Pack<MatT, NS> m = col[static_cast<long long>(j) * stride];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const double xj = x[j * NV + v];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[v][s] = __builtin_fma(static_cast<double>(pack_get<NS>(m, s)), xj, acc[v][s]);
+        }
+    }
+}
+
+// stage one or two operand vectors for dense_sweep (thread t writes its own elements, every lane reads all)
+template <int NS>
+__device__ __forceinline__ void stage2(lds_double* x, const double (&a)[NS], const double (&b)[NS]) {
+    wave_sync();   // earlier readers of the area are done
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = lane_id() * NS + s;
+        x[2 * e] = a[s];
+        x[2 * e + 1] = b[s];
+    }
+    wave_sync();
+}
+
+// v = C p and w = C g in one sweep
+template <int NS, class MatT>
+__device__ __forceinline__ void velocity2(const MatT* M, int d, int dpad, lds_double* xop, const double (&p)[NS],
+                                          const double (&g)[NS], double (&v)[NS], double (&w)[NS]) {
+    stage2<NS>(xop, p, g);
+    double acc[2][NS];
+    dense_sweep<NS, 2, MatT>(M, d, dpad, xop, acc);
+    vcopy(v, acc[0]);
+    vcopy(w, acc[1]);
+}
+
+// ---- momentum draws ----------------------------------------------------------------------------------------
+__device__ __forceinline__ float readlane_f32(float x, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+
+// quadpotential.py:450-453: solve_triangular(chol.T, float32(normals)) -- the column sweep of the reference
+// BLAS strsv (upper, no-trans): x_j /= U_jj, then x_i -= x_j U_ij for i < j, j descending. U_ij = L[j][i] is
+// row j of the row-major factor: contiguous over i. Rows are fetched 8 at a time one block ahead of use.
+template <int NS>
+__device__ inline void dense_momentum_full(const float* __restrict__ L, int d, int dpad, const lds_double* z,
+                                           double (&p0)[NS]) {
+    typedef __attribute__((address_space(1))) const Pack<float, NS> glb_pack;
+    constexpr int B = 8;
+    const int lane = lane_id();
+    float x[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = lane * NS + s;
+        x[s] = (e < d) ? static_cast<float>(z[e]) : 0.0f;
+    }
+    glb_pack* col = (glb_pack*)(L + lane * NS);
+    const int stride = dpad / NS;
+    const int d8 = (d + B - 1) / B * B;
+    Pack<float, NS> cur[B], nxt[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) nxt[b] = col[static_cast<long long>(d8 - B + b) * stride];
+    for (int jb = d8 - B; jb >= 0; jb -= B) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) cur[b] = nxt[b];
+        if (jb >= B) {
+#pragma unroll
+            for (int b = 0; b < B; ++b) nxt[b] = col[static_cast<long long>(jb - B + b) * stride];
+        }
+#pragma unroll
+        for (int b = B - 1; b >= 0; --b) {
+            const int j = jb + b;          // wave-uniform
+            constexpr int kNsMask = NS - 1;
+            const int sj = b & kNsMask;    // == j % NS (jb is a multiple of 8, NS divides 8)
+            const int t = j / NS;          // owner lane
+            float xs = 0.0f, ls = 1.0f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if (s == sj) { xs = x[s]; ls = pack_get<NS>(cur[b], s); }
+            const float xj = readlane_f32(xs, t) / readlane_f32(ls, t);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = lane * NS + s;
+                if (i < j) x[s] = x[s] - pack_get<NS>(cur[b], s) * xj;
+                if (s == sj && lane == t) x[s] = xj;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) p0[s] = static_cast<double>(x[s]);
+}
+
+// quadpotential.py:411-414: p = L n in float64 (LT rows = columns of L)
+template <int NS>
+__device__ inline void dense_momentum_inv(const double* __restrict__ LT, int d, int dpad, const lds_double* z,
+                                          double (&p0)[NS]) {
+    double acc[1][NS];
+    dense_sweep<NS, 1, double>(LT, d, dpad, z, acc);
+    vcopy(p0, acc[0]);
+}
+
+// ---- start state (integration.py:52-66) -----------------------------------------------------------------------
+// Out: v0/w0 = C p0, C g0 in float64 (feed the first half step), v0s = the velocity the reference STORES in the
+// start State (float32 for the float32-momentum potentials: numpy's sgemv; we round the float64 sweep once, which
+// differs from sgemv's float32 accumulation by a few float32 ulps), e0.
+template <int NS, class MatT>
+__device__ inline double dense_start_state(Team<1>& tm, const MatT* M, int d, int dpad, double* lds, bool momentum_f32,
+                                           int sdot_mode, const double (&p0)[NS], const double (&g0)[NS], double logp0,
+                                           double (&v0)[NS], double (&w0)[NS], double (&v0s)[NS]) {
+    velocity2<NS, MatT>(M, d, dpad, (lds_double*)lds, p0, g0, v0, w0);
+    if (!momentum_f32) {
+        vcopy(v0s, v0);
+        return first_f64(0.5 * tm.sum(pdot<NS>(p0, v0)) - logp0);
+    }
+    float vf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        vf[s] = static_cast<float>(v0[s]);
+        v0s[s] = static_cast<double>(vf[s]);
+    }
+    float kin;
+    if (sdot_mode == kSdotNative) {
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            part = __builtin_fma(p0[s], static_cast<double>(vf[s]), part);   // exact float32 products, float64 sum
+        kin = 0.5f * static_cast<float>(tm.sum(part));
+    } else {   // 0.5f * cblas_sdot(p, v) in OpenBLAS' summation order (quadpotential.py:455-459)
+        wave_sync();
+        float* x = reinterpret_cast<float*>(lds);
+        float* y = x + dpad;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            x[lane_id() * NS + s] = static_cast<float>(p0[s]);
+            y[lane_id() * NS + s] = vf[s];
+        }
+        wave_sync();
+        kin = 0.5f * sdot_openblas(x, y, d, sdot_mode);
+        wave_sync();
+    }
+    return first_f64(static_cast<double>(kin) - logp0);
+}
+
+// ---- leapfrog (integration.py:100-121) with a dense mass matrix -----------------------------------------------
+// State in/out: q, p, g, v = C p, w = C g.
+template <int NS, class MatT, class Target>
+__device__ __forceinline__ void dense_leapfrog(Team<1>& tm, const Target& tgt, const MatT* M, int d, int dpad,
+                                               lds_double* xop, double eps, double (&q)[NS], double (&p)[NS],
+                                               double (&g)[NS], double (&v)[NS], double (&w)[NS], double& energy,
+                                               double& logp) {
+    const double dt = 0.5 * eps;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        p[s] = p[s] + dt * g[s];
+        const double vh = v[s] + dt * w[s];   // C (p + dt g)
+        q[s] = q[s] + eps * vh;
+    }
+    logp = first_f64(tgt.logp_grad(tm, q, g));
+#pragma unroll
+    for (int s = 0; s < NS; ++s) p[s] = p[s] + dt * g[s];
+    velocity2<NS, MatT>(M, d, dpad, xop, p, g, v, w);
+    energy = first_f64(0.5 * tm.sum(pdot<NS>(p, v)) - logp);
+}
+
+// ---- per-chain HBM rows: trajectory ends and subtree stack -------------------------------------------------------
+struct DenseScratch {
+    glb_double* base;
+    int dpad;
+    // k: 0 q, 1 p, 2 g, 3 v, 4 w
+    __device__ __forceinline__ glb_double* end(int right, int k) const { return base + (right * 5 + k) * dpad; }
+    // k: 0 lp, 1 lv, 2 rp, 3 rv, 4 psum, 5 proposal q
+    __device__ __forceinline__ glb_double* level(int j, int k) const { return base + (10 + 6 * j + k) * dpad; }
+};
+
+// ---- NUTS transition: the tree of lmc_sampler.hpp with stored velocities -------------------------------------------
+template <int NS, class MatT, class Target>
+__device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, const MatT* M, int d, int dpad,
+                                             lds_double* xop, RngState& rng, const DenseScratch& scr, double (&q)[NS],
+                                             const double (&p0)[NS], const double (&g0)[NS], const double (&v0)[NS],
+                                             const double (&w0)[NS], const double (&v0s)[NS], double e0, double logp0,
+                                             double step_size, double emax, int max_depth, bool momentum_f32,
+                                             TransitionOut& out) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        vstore_as<NS>(scr.end(r, 0), q); vstore_as<NS>(scr.end(r, 1), p0); vstore_as<NS>(scr.end(r, 2), g0);
+        vstore_as<NS>(scr.end(r, 3), v0); vstore_as<NS>(scr.end(r, 4), w0);
+    }
+    double psum[NS], propq[NS];
+    vcopy(psum, p0); vcopy(propq, q);
+    bool l_start = true, r_start = true;   // the end still is the start state: its stored velocity is v0s
+    double prop_e = e0, prop_logp = logp0;
+    double coff = 0.0, w_start = 1.0, wn = 0.0, an = 0.0, max_de = 0.0;   // linear-domain weights, see lmc_sampler.hpp
+    int depth = 0, n_leap = 0;
+    bool diverging = false, turning = false, exhausted = true;
+    LevelScalars lsc = {0.0, 0.0, 0.0, 0.0};
+    UniformWindow win;
+    window_reset(win);
+
+    for (int dd = 0; dd < max_depth; ++dd) {
+        const bool right = window_next(rng, win) < 0.5;   // nuts.py:213
+        const double eps = right ? step_size : -step_size;
+        const int side = right ? 1 : 0;
+        double cq[NS], cp[NS], cg[NS], cv[NS], cw[NS];
+        vload_as<NS>(scr.end(side, 0), cq); vload_as<NS>(scr.end(side, 1), cp); vload_as<NS>(scr.end(side, 2), cg);
+        vload_as<NS>(scr.end(side, 3), cv); vload_as<NS>(scr.end(side, 4), cw);
+
+        double tlp[NS], tlv[NS], trp[NS], trv[NS], tps[NS], tq[NS];   // in-flight node
+        double tw = 0.0, ta = 0.0, tpe = 0.0, tplogp = 0.0;
+        const int n_leaves = 1 << depth;
+        for (int i = 0; i < n_leaves; ++i) {
+            double energy, logp;
+            dense_leapfrog<NS, MatT>(tm, tgt, M, d, dpad, xop, eps, cq, cp, cg, cv, cw, energy, logp);
+            ++n_leap;
+            double de = first_f64(energy - e0);
+            if (isnan(de)) de = INFINITY;
+            if (fabs(de) > fabs(max_de)) max_de = de;
+            if (!(fabs(de) < emax)) { diverging = true; break; }   // nuts.py:358,370-375
+            const double x = -de;
+            if (x - coff > 600.0) {
+                const double f = exp_uniform(coff - x);
+                lsc.w *= f; lsc.a *= f;
+                wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
+                coff = x;
+            }
+            tw = exp_uniform_fast(x - coff);
+            const double sat = (coff == 0.0) ? fmin(1.0, tw) : ((x >= 0.0) ? 1.0 : exp_uniform(x));
+            ta = tw * sat;
+            vcopy(tlp, cp); vcopy(trp, cp); vcopy(tps, cp); vcopy(tlv, cv); vcopy(trv, cv); vcopy(tq, cq);
+            tpe = energy; tplogp = logp;
+            int j = 0;
+            while ((i >> j) & 1) {   // merge stack[j] (a, earlier) with t (b); nuts.py:377-417
+                double alp[NS], alv[NS], arp[NS], arv[NS], aps[NS], aq[NS];
+                double aw, aa, ape, aplogp;
+                vload_as<NS>(scr.level(j, 0), alp); vload_as<NS>(scr.level(j, 1), alv);
+                vload_as<NS>(scr.level(j, 2), arp); vload_as<NS>(scr.level(j, 3), arv);
+                vload_as<NS>(scr.level(j, 4), aps); vload_as<NS>(scr.level(j, 5), aq);
+                lsc.get(j, aw, aa, ape, aplogp);
+                double ps[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) ps[s] = aps[s] + tps[s];
+                bool turn;
+                if (j > 0) {   // nuts.py:389-396
+                    double p1[NS], p2[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) { p1[s] = aps[s] + tlp[s]; p2[s] = arp[s] + tps[s]; }
+                    double dots[6] = {pdot<NS>(ps, alv), pdot<NS>(ps, trv), pdot<NS>(p1, alv),
+                                      pdot<NS>(p1, tlv), pdot<NS>(p2, arv), pdot<NS>(p2, trv)};
+                    turn = tm.any_nonpositive6(dots);
+                } else {
+                    turn = tm.any_nonpositive2(pdot<NS>(ps, alv), pdot<NS>(ps, trv));
+                }
+                const double wsum = aw + tw;
+                const double asum = aa + ta;
+                const bool take_b = uniform_true(window_next(rng, win) * wsum < tw);   // nuts.py:404
+                vcopy(tlp, alp); vcopy(tlv, alv); vcopy(tps, ps);
+                if (!take_b) { vcopy(tq, aq); tpe = ape; tplogp = aplogp; }
+                tw = wsum; ta = asum;
+                ++j;
+                if (turn) { turning = true; break; }
+            }
+            if (turning) break;
+            if (i + 1 < n_leaves) {
+                vstore_as<NS>(scr.level(j, 0), tlp); vstore_as<NS>(scr.level(j, 1), tlv);
+                vstore_as<NS>(scr.level(j, 2), trp); vstore_as<NS>(scr.level(j, 3), trv);
+                vstore_as<NS>(scr.level(j, 4), tps); vstore_as<NS>(scr.level(j, 5), tq);
+                lsc.put(j, tw, ta, tpe, tplogp);
+            }
+        }
+        ++depth;   // nuts.py:315
+        if (diverging || turning) { exhausted = false; break; }
+
+        // ---- accepted subtree: merge into the trajectory (nuts.py:321-340)
+        if (uniform_true(window_next(rng, win) * (w_start + wn) < tw)) {
+            vcopy(propq, tq); prop_e = tpe; prop_logp = tplogp;
+        }
+        wn = first_f64(wn + tw);
+        an = first_f64(an + ta);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {   // in place; float32 storage when the start momentum is float32
+            const double t = psum[s] + tps[s];
+            psum[s] = momentum_f32 ? static_cast<double>(static_cast<float>(t)) : t;
+        }
+        double oLv[NS], oRv[NS], oP[NS];
+        if (l_start) vcopy(oLv, v0s); else vload_as<NS>(scr.end(0, 3), oLv);
+        if (r_start) vcopy(oRv, v0s); else vload_as<NS>(scr.end(1, 3), oRv);
+        vload_as<NS>(scr.end(side, 1), oP);   // momentum of the end that is being replaced
+        double dots[6];
+        double p1[NS], p2[NS];
+        if (right) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { p1[s] = psum[s] + tlp[s]; p2[s] = oP[s] + tps[s]; }
+            dots[0] = pdot<NS>(psum, oLv); dots[1] = pdot<NS>(psum, trv);
+            dots[2] = pdot<NS>(p1, oLv);   dots[3] = pdot<NS>(p1, tlv);
+            dots[4] = pdot<NS>(p2, oRv);   dots[5] = pdot<NS>(p2, trv);
+            r_start = false;
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { p1[s] = tps[s] + oP[s]; p2[s] = tlp[s] + psum[s]; }
+            dots[0] = pdot<NS>(psum, trv); dots[1] = pdot<NS>(psum, oRv);
+            dots[2] = pdot<NS>(p1, trv);   dots[3] = pdot<NS>(p1, oLv);
+            dots[4] = pdot<NS>(p2, tlv);   dots[5] = pdot<NS>(p2, oRv);
+            l_start = false;
+        }
+        vstore_as<NS>(scr.end(side, 0), cq); vstore_as<NS>(scr.end(side, 1), cp); vstore_as<NS>(scr.end(side, 2), cg);
+        vstore_as<NS>(scr.end(side, 3), cv); vstore_as<NS>(scr.end(side, 4), cw);
+        if (tm.any_nonpositive6(dots)) { turning = true; exhausted = false; break; }
+    }
+
+    const double mean_accept = (wn > 0.0) ? first_f64(an / wn) : 0.0;   // nuts.py:421-425
+    vcopy(q, propq);
+    out.accept = mean_accept;
+    out.energy = prop_e;
+    out.energy_error = first_f64(prop_e - e0);
+    out.max_energy_error = max_de;
+    out.model_logp = prop_logp;
+    out.depth = depth;
+    out.n_leapfrog = n_leap;
+    out.diverging = diverging;
+    out.exhausted = exhausted;
+    out.accepted = 0;
+    out.nan_logbern = 0;
+}
+
+// ---- HMC transition (hmc.py:140-182) ---------------------------------------------------------------------------
+template <int NS, class MatT, class Target>
+__device__ inline void dense_hmc_transition(Team<1>& tm, const Target& tgt, const MatT* M, int d, int dpad,
+                                            lds_double* xop, RngState& rng, double (&q)[NS], const double (&p0)[NS],
+                                            const double (&g0)[NS], const double (&v0)[NS], const double (&w0)[NS],
+                                            double e0, double logp0, double step_size, double emax, double path_length,
+                                            int max_steps, TransitionOut& out) {
+    UniformWindow win;
+    window_reset(win);
+    const double plen = first_f64(window_next(rng, win) * path_length);
+    int n_steps = static_cast<int>(plen / step_size);
+    n_steps = n_steps < 1 ? 1 : n_steps;
+    n_steps = n_steps > max_steps ? max_steps : n_steps;
+    double cq[NS], cp[NS], cg[NS], cv[NS], cw[NS];
+    vcopy(cq, q); vcopy(cp, p0); vcopy(cg, g0); vcopy(cv, v0); vcopy(cw, w0);
+    double energy = e0, logp = logp0;
+    for (int i = 0; i < n_steps; ++i)
+        dense_leapfrog<NS, MatT>(tm, tgt, M, d, dpad, xop, step_size, cq, cp, cg, cv, cw, energy, logp);
+    bool diverging = !isfinite(energy);
+    double de = first_f64(e0 - energy);
+    if (isnan(de)) de = -INFINITY;
+    if (fabs(de) > emax) diverging = true;
+    const double accept = first_f64(fmin(1.0, exp_uniform(de)));
+    bool accepted = false;
+    if (!diverging) {
+        const double u = window_next(rng, win);
+        if (!(u >= accept)) { accepted = true; vcopy(q, cq); }
+    }
+    out.accept = accept;
+    out.energy = energy;
+    out.energy_error = de;
+    out.max_energy_error = plen;
+    out.model_logp = logp;
+    out.depth = n_steps;
+    out.n_leapfrog = n_steps;
+    out.diverging = diverging;
+    out.exhausted = 0;
+    out.accepted = accepted;
+    out.nan_logbern = 0;
+}
+
+// ---- the iteration kernel ----------------------------------------------------------------------------------------
+// LDS: [0, 2*dpad) doubles = sweep operands / normal(size=d) + its staging / float32 sdot staging; then the chain's
+// MT19937 state for the duration of the launch.
+constexpr int dense_lds_doubles(int dpad) { return 2 * dpad + kLdsMtDoubles; }
+
+template <int NS, class MatT, template <int> class TargetT>
+__global__ __launch_bounds__(64) void run_dense_kernel(ChainArrays A, DenseArrays D, SamplerParams P, const double* tparams) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int c = blockIdx.x;
+    const int d = A.d, dpad = A.dpad;
+    const long long row = static_cast<long long>(c) * dpad;
+    Team<1> tm{nullptr, 0};
+    const int tid = tm.tid();
+    if (A.status[c] & kStatusBadInitialEnergy) return;
+
+    TargetT<NS> tgt;
+    tgt.init(tm, tparams, d);
+    const MatT* M = static_cast<const MatT*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
+    lds_double* xop = (lds_double*)lds;
+
+    double q[NS];
+    vload<NS>(A.q + row, q);
+    RngState rng;
+    uint32_t* mt_glb = A.mt + static_cast<long long>(c) * kMtN;
+    uint32_t* mt_lds = reinterpret_cast<uint32_t*>(lds + 2 * dpad);
+    for (int i = tid; i < kMtN; i += 64) mt_lds[i] = mt_glb[i];
+    tm.sync();
+    rng.mt = mt_lds;
+    rng.pos = first_i32(A.rng_pos[c]);
+    rng.has_gauss = first_i32(A.rng_has_gauss[c]);
+    rng.gauss = first_f64(A.rng_gauss[c]);
+    DualAverage da;
+    dual_average_load(A, c, da);
+    int iter_count = first_i32(A.iter_count[c]);
+    long long ct_maxdepth = 0, ct_divs = 0, ct_after = 0, ct_leap = 0;
+    int status = 0;
+    DenseScratch scr;
+    scr.base = (glb_double*)(A.scratch + static_cast<long long>(c) * A.scratch_stride);
+    scr.dpad = dpad;
+    const bool momentum_f32 = P.momentum_f32 != 0;
+
+    for (int it = 0; it < P.n_iters; ++it) {
+        const long long git = P.iter_begin + it;
+        const bool tune = git < P.n_tune;
+
+        // ---- momentum draw
+        rng_normals(rng, d, lds, lds + dpad);
+        double p0[NS];
+        if (D.kind == kDenseFullInv)
+            dense_momentum_inv<NS>(static_cast<const double*>(D.fac), d, dpad, xop, p0);
+        else
+            dense_momentum_full<NS>(static_cast<const float*>(D.fac) + static_cast<long long>(c) * D.fac_stride, d, dpad, xop, p0);
+
+        // ---- start state
+        double g0[NS], v0[NS], w0[NS], v0s[NS];
+        const double logp0 = first_f64(tgt.logp_grad(tm, q, g0));
+        const double e0 = dense_start_state<NS, MatT>(tm, M, d, dpad, lds, momentum_f32, P.sdot_mode, p0, g0, logp0, v0, w0, v0s);
+        if (!isfinite(e0)) {   // base_hmc.py:145-148
+            status |= kStatusBadInitialEnergy;
+            break;
+        }
+        const bool adapt_step = tune && P.adapt_step_size;
+        const double step_size = adapt_step ? da.step_now : da.step_bar_now;
+
+        TransitionOut out;
+        if (P.kind == 0) {
+            const int md = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
+            dense_nuts_transition<NS, MatT>(tm, tgt, M, d, dpad, xop, rng, scr, q, p0, g0, v0, w0, v0s, e0, logp0,
+                                            step_size, P.emax, md, momentum_f32, out);
+            if (out.exhausted && !tune) ++ct_maxdepth;
+        } else {
+            dense_hmc_transition<NS, MatT>(tm, tgt, M, d, dpad, xop, rng, q, p0, g0, v0, w0, e0, logp0, step_size,
+                                           P.emax, P.path_length, P.max_steps, out);
+        }
+        ct_leap += out.n_leapfrog;
+        if (adapt_step) dual_average_update(A, P, out.accept, da);
+
+        if (out.diverging && !tune) ++ct_divs;
+        ++iter_count;
+        if (!tune) ++ct_after;
+        if (A.mom_mean != nullptr && !tune) moments_update<NS>(A, tm, c, row, q);
+        write_outputs<NS>(A, c, tid, git, q, out, da.step_now, da.step_bar_now, tune);
+    }
+
+    tm.sync();
+    for (int i = tid; i < kMtN; i += 64) mt_glb[i] = mt_lds[i];
+    vstore<NS>(A.q + row, q);
+    if (tid == 0) {
+        A.rng_pos[c] = rng.pos;
+        A.rng_has_gauss[c] = rng.has_gauss;
+        A.rng_gauss[c] = rng.gauss;
+        A.da[c * 4 + 0] = da.log_step;
+        A.da[c * 4 + 1] = da.log_bar;
+        A.da[c * 4 + 2] = da.hbar;
+        A.da_count[c] = da.count;
+        A.iter_count[c] = iter_count;
+        A.status[c] |= status;
+        A.counters[c * kNumCounters + kCtMaxTreedepth] += ct_maxdepth;
+        A.counters[c * kNumCounters + kCtDivsSample] += ct_divs;
+        A.counters[c * kNumCounters + kCtSamplesAfterTune] += ct_after;
+        A.counters[c * kNumCounters + kCtLeapfrogs] += ct_leap;
+    }
+}
+
+// ---- unit kernels (test entries behind lmc_engine_trajectory / lmc_engine_draw_momentum) -----------------------
+template <int NS, class MatT, template <int> class TargetT>
+__global__ __launch_bounds__(64) void dense_trajectory_kernel(ChainArrays A, DenseArrays D, const double* tparams,
+                                                              const double* q0, const double* p0in, int p0_is_f32,
+                                                              int sdot_mode, double eps, int n_fwd, int n_back,
+                                                              double* oq, double* op, double* ov, double* og, double* oe,
+                                                              double* ol) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int c = blockIdx.x;
+    const int lane = lane_id();
+    const int d = A.d, dpad = A.dpad;
+    Team<1> tm{nullptr, 0};
+    TargetT<NS> tgt;
+    tgt.init(tm, tparams, d);
+    const MatT* M = static_cast<const MatT*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
+    double q[NS], p[NS], g[NS], v[NS], w[NS], vs[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = lane * NS + s;
+        q[s] = (e < d) ? q0[static_cast<long long>(c) * d + e] : 0.0;
+        p[s] = (e < d) ? p0in[static_cast<long long>(c) * d + e] : 0.0;
+        if (p0_is_f32) p[s] = static_cast<double>(static_cast<float>(p[s]));
+    }
+    const int n_states = n_fwd + n_back + 1;
+    double logp = first_f64(tgt.logp_grad(tm, q, g));
+    double energy = dense_start_state<NS, MatT>(tm, M, d, dpad, lds, p0_is_f32 != 0, sdot_mode, p, g, logp, v, w, vs);
+    for (int k = 0; k < n_states; ++k) {
+        if (k > 0) {
+            dense_leapfrog<NS, MatT>(tm, tgt, M, d, dpad, (lds_double*)lds, (k <= n_fwd) ? eps : -eps, q, p, g, v, w, energy, logp);
+            vcopy(vs, v);
+        }
+        const long long base = (static_cast<long long>(c) * n_states + k) * d;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int e = lane * NS + s;
+            if (e < d) {
+                oq[base + e] = q[s];
+                op[base + e] = p[s];
+                ov[base + e] = vs[s];
+                og[base + e] = g[s];
+            }
+        }
+        if (lane == 0) {
+            oe[static_cast<long long>(c) * n_states + k] = energy;
+            ol[static_cast<long long>(c) * n_states + k] = logp;
+        }
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(64) void dense_momentum_kernel(ChainArrays A, DenseArrays D, double* out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int c = blockIdx.x;
+    const int lane = lane_id();
+    const int d = A.d, dpad = A.dpad;
+    RngState r;
+    r.mt = A.mt + static_cast<long long>(c) * kMtN;
+    r.pos = first_i32(A.rng_pos[c]);
+    r.has_gauss = first_i32(A.rng_has_gauss[c]);
+    r.gauss = first_f64(A.rng_gauss[c]);
+    rng_normals(r, d, lds, lds + dpad);
+    double p0[NS];
+    if (D.kind == kDenseFullInv)
+        dense_momentum_inv<NS>(static_cast<const double*>(D.fac), d, dpad, (lds_double*)lds, p0);
+    else
+        dense_momentum_full<NS>(static_cast<const float*>(D.fac) + static_cast<long long>(c) * D.fac_stride, d, dpad,
+                                (lds_double*)lds, p0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = lane * NS + s;
+        if (e < d) out[static_cast<long long>(c) * d + e] = p0[s];
+    }
+    if (lane == 0) {
+        A.rng_pos[c] = r.pos;
+        A.rng_has_gauss[c] = r.has_gauss;
+        A.rng_gauss[c] = r.gauss;
+    }
+}
+
+// ---- FullAdapt.update (quadpotential.py:528-552): one workgroup per chain -----------------------------------------
+// Both estimators take the new sample (Welford rank-1 updates of the d x d second moments, float64, in HBM); when
+// a refresh is due the foreground estimate becomes the float32 covariance, its lower triangle is staged in LDS
+// (packed by columns) and factorised there; the factor is written back row-major. A failed factorisation (pivot
+// <= 0 or a non-finite entry: scipy.linalg.cholesky raises) keeps the previous factor and is counted.
+constexpr int kAdaptThreads = 256;
+__device__ __forceinline__ int packed_col_start(int j, int d) { return j * d - (j * (j - 1)) / 2; }
+constexpr int dense_adapt_lds_bytes(int d) { return (d * (d + 1) / 2) * 4 + 4 * d * 8 + 16; }
+
+__device__ inline bool cholesky_lds(float* a, int d, int tid) {   // packed-by-columns lower triangle, in place
+    const int tx = tid & 63, ty = tid >> 6;
+    for (int k = 0; k < d; ++k) {
+        __syncthreads();
+        float* ck = a + packed_col_start(k, d);   // column k: entries (k..d-1, k)
+        const float akk = ck[0];
+        if (!(akk > 0.0f) || !(akk < INFINITY)) return false;   // uniform: every thread reads the same word
+        const float lkk = sqrtf(akk);
+        __syncthreads();
+        for (int i = k + 1 + tid; i < d; i += kAdaptThreads) ck[i - k] = ck[i - k] / lkk;
+        if (tid == 0) ck[0] = lkk;
+        __syncthreads();
+        for (int j = k + 1 + ty; j < d; j += kAdaptThreads / 64) {
+            const float ljk = ck[j - k];
+            float* cj = a + packed_col_start(j, d);
+            for (int i = j + tx; i < d; i += 64) cj[i - j] = __builtin_fmaf(-ck[i - k], ljk, cj[i - j]);
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
+__global__ __launch_bounds__(kAdaptThreads) void dense_adapt_kernel(ChainArrays A, DenseArrays D, double multiplier,
+                                                                    int update_window) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int d = A.d, dpad = A.dpad;
+    double* oldf = lds;            // [d] x - mean_before (foreground)
+    double* newf = lds + d;        // [d] x - mean_after
+    double* oldb = lds + 2 * d;
+    double* newb = lds + 3 * d;
+    int* flag = reinterpret_cast<int*>(lds + 4 * d);
+    float* tri = reinterpret_cast<float*>(lds + 4 * d + 2);
+    const long long plane = static_cast<long long>(A.chains) * dpad;
+    const long long mplane = static_cast<long long>(A.chains) * d * dpad;
+    const int sel = D.esel[c];
+    const int n_samples = A.n_samples[c];
+    const int prev = D.prev_update[c];
+    const int window = D.window[c];
+    const int delta = n_samples - prev;
+    const double nf = D.en[c * 2 + sel] + 1.0, nb = D.en[c * 2 + 1 - sel] + 1.0;
+    double* meanf = D.emean + sel * plane + static_cast<long long>(c) * dpad;
+    double* meanb = D.emean + (1 - sel) * plane + static_cast<long long>(c) * dpad;
+    double* rawf = D.rawT + sel * mplane + static_cast<long long>(c) * d * dpad;
+    double* rawb = D.rawT + (1 - sel) * mplane + static_cast<long long>(c) * d * dpad;
+    float* covT = static_cast<float*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
+    float* fac = static_cast<float*>(D.fac) + static_cast<long long>(c) * D.fac_stride;
+    if (tid == 0) *flag = 0;
+    for (int i = tid; i < d; i += kAdaptThreads) {   // quadpotential.py:594-599
+        const double x = A.q[static_cast<long long>(c) * dpad + i];
+        double m = meanf[i];
+        double od = x - m;
+        m = m + od / nf;
+        meanf[i] = m;
+        oldf[i] = od; newf[i] = x - m;
+        m = meanb[i];
+        od = x - m;
+        m = m + od / nb;
+        meanb[i] = m;
+        oldb[i] = od; newb[i] = x - m;
+    }
+    __syncthreads();
+    const bool refresh = ((delta + 1) % update_window) == 0;   // quadpotential.py:542-543
+    const double denom = nf - 1.0;
+    bool bad = false;
+    const int total = d * dpad;
+    for (int idx = tid; idx < total; idx += kAdaptThreads) {
+        const int j = idx / dpad, i = idx - j * dpad;
+        if (i >= d) continue;
+        const double rf = rawf[idx] + 1.0 * newf[i] * oldf[j];   // raw_cov[i][j] += weight * new_i * old_j
+        rawf[idx] = rf;
+        rawb[idx] = rawb[idx] + 1.0 * newb[i] * oldb[j];
+        if (refresh) {
+            const float cv = static_cast<float>(rf / denom);   // np.divide(raw, n - 1, out=float32)
+            covT[idx] = cv;
+            bad |= !isfinite(cv);
+            if (i >= j) tri[packed_col_start(j, d) + i - j] = cv;   // cov[i][j], i >= j
+        }
+    }
+    if (bad) *flag = 1;   // benign race: every writer stores 1
+    __syncthreads();
+    if (refresh) {
+        bool ok = (*flag == 0);
+        if (ok) ok = cholesky_lds(tri, d, tid);
+        if (ok) {
+            for (int idx = tid; idx < total; idx += kAdaptThreads) {
+                const int i = idx / dpad, j = idx - i * dpad;   // row i of L
+                if (j < d) fac[idx] = (j <= i) ? tri[packed_col_start(j, d) + i - j] : 0.0f;
+            }
+        } else if (tid == 0) {
+            D.chol_failed[c] += 1;
+        }
+    }
+    __syncthreads();
+    const bool switch_window = delta >= window;   // quadpotential.py:547-552
+    if (switch_window) {
+        for (int idx = tid; idx < total; idx += kAdaptThreads) rawf[idx] = 0.0;   // fresh background: eye * 0
+        for (int i = tid; i < d; i += kAdaptThreads) meanf[i] = 0.0;
+    }
+    if (tid == 0) {
+        if (switch_window) {
+            D.en[c * 2 + sel] = 0.0;
+            D.en[c * 2 + 1 - sel] = nb;
+            D.esel[c] = 1 - sel;
+            D.prev_update[c] = n_samples;
+            D.window[c] = static_cast<int>(static_cast<double>(window) * multiplier);
+        } else {
+            D.en[c * 2 + sel] = nf;
+            D.en[c * 2 + 1 - sel] = nb;
+        }
+        A.n_samples[c] = n_samples + 1;
+    }
+}
+
+// QuadPotentialFullAdapt.__init__ for every chain (quadpotential.py:474-519): replicate the initial covariance,
+// its factor and the foreground estimator (mean, raw = weight * cov, n = weight); empty background.
+__global__ __launch_bounds__(256) void dense_reset_kernel(ChainArrays A, DenseArrays D, const float* cov1T,
+                                                          const float* fac1, const double* raw1T, const double* mean1,
+                                                          double weight, int window, int d8) {
+    const int c = blockIdx.x;
+    const int d = A.d, dpad = A.dpad;
+    const long long plane = static_cast<long long>(A.chains) * dpad;
+    const long long mplane = static_cast<long long>(A.chains) * d * dpad;
+    float* covT = static_cast<float*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
+    float* fac = static_cast<float*>(D.fac) + static_cast<long long>(c) * D.fac_stride;
+    double* raw0 = D.rawT + static_cast<long long>(c) * d * dpad;
+    double* mean0 = D.emean + static_cast<long long>(c) * dpad;
+    const int total = d8 * dpad;
+    for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < total; idx += gridDim.y * blockDim.x) {
+        fac[idx] = fac1[idx];
+        if (idx < d * dpad) {
+            covT[idx] = cov1T[idx];
+            raw0[idx] = raw1T[idx] * weight;
+            raw0[mplane + idx] = 0.0;
+        }
+        if (idx < dpad) {
+            mean0[idx] = mean1[idx];
+            mean0[plane + idx] = 0.0;
+        }
+    }
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+        D.en[c * 2 + 0] = weight;
+        D.en[c * 2 + 1] = 0.0;
+        D.esel[c] = 0;
+        D.prev_update[c] = 0;
+        D.window[c] = window;
+        D.chol_failed[c] = 0;
+        A.n_samples[c] = 0;
+    }
+}
+
+}  // namespace lmc

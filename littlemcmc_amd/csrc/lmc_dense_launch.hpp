@@ -1,0 +1,24 @@
+// Host-callable launchers of the dense-mass kernels (lmc_dense.hip); called by the C ABI in lmc_engine.hip.
+// Return value: 0 = launched, kDenseUnsupported = no such instantiation in this build, otherwise a hipError_t.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lmc_dense_types.hpp"
+
+namespace lmc {
+
+constexpr int kDenseUnsupported = -1;
+
+int dense_launch_run(int family, int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
+                     const SamplerParams& P, const double* tparams);
+int dense_launch_trajectory(int family, int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A,
+                            const DenseArrays& D, const double* tparams, const double* q0, const double* p0,
+                            int p0_is_f32, int sdot_mode, double eps, int n_fwd, int n_back, double* oq, double* op,
+                            double* ov, double* og, double* oe, double* ol);
+int dense_launch_momentum(int ns, hipStream_t stream, const ChainArrays& A, const DenseArrays& D, double* out);
+int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, double multiplier,
+                       int update_window);
+int dense_launch_reset(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, const float* cov1T,
+                       const float* fac1, const double* raw1T, const double* mean1, double weight, int window, int d8);
+
+}  // namespace lmc

@@ -1,0 +1,30 @@
+// Types shared by the dense-mass kernels (lmc_dense.hpp, compiled in lmc_dense.hip) and the host side of the
+// C ABI (lmc_engine.hip). No kernels here: both translation units include this file.
+#pragma once
+#include "lmc_sampler.hpp"
+
+namespace lmc {
+
+enum DenseKind : int { kDenseFull = 2, kDenseFullInv = 3, kDenseFullAdapt = 4 };   // == LMC_POT_FULL*
+
+struct DenseArrays {
+    int kind;
+    void* covT;             // MatT [P][d][dpad]: transposed inverse mass matrix (P = chains for FullAdapt, else 1)
+    void* fac;              // Full*: float Cholesky factor L of cov, row-major lower [P][d8][dpad] (rows >= d identity);
+                            // FullInv: double LT[j][i] = L[i][j] of the mass matrix A = L L^T, [d][dpad]
+    long long mat_stride;   // elements between two chains' matrices (0 = shared)
+    long long fac_stride;
+    // FullAdapt estimators (slot esel[c] = foreground)
+    double* rawT;           // [2][C][d][dpad]   rawT[j][i] = raw_cov[i][j]
+    double* emean;          // [2][C][dpad]
+    double* en;             // [C][2]            n_samples of the two estimators
+    int* esel;              // [C]
+    int* prev_update;       // [C]
+    int* window;            // [C]
+    int* chol_failed;       // [C]  number of refreshes whose factorisation failed (old factor kept)
+};
+
+// per-chain HBM scratch row of the dense kernels: 2 trajectory ends x {q, p, g, v, w} + 6 vectors per subtree level
+constexpr int dense_scratch_vectors(int max_levels) { return 10 + 6 * max_levels; }
+
+}  // namespace lmc

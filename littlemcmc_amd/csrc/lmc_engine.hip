@@ -15,6 +15,7 @@
 
 #include "../../include/lmc_hip.h"
 #include "lmc_sampler.hpp"
+#include "lmc_dense_launch.hpp"
 #ifdef LMC_USER_TARGET_HEADER
 #include LMC_USER_TARGET_HEADER
 #endif
@@ -278,6 +279,15 @@ struct lmc_engine {
     bool potential_set = false;
     double* da_tables = nullptr;   // [2][da_table_len]: sqrt(count), count ** -k
     double initial_step = 0.0;
+    // dense mass matrices (cfg.potential >= LMC_POT_FULL)
+    DenseArrays D;
+    int d8 = 0;                    // rows of the stored Cholesky factor (dim rounded up to 8)
+    float* cov1T = nullptr;        // FULL_ADAPT: initial matrices of ONE chain, replicated by reset
+    float* fac1 = nullptr;
+    double* raw1T = nullptr;
+    double* mean1 = nullptr;
+    double dense_weight = 1.0, dense_multiplier = 2.0;
+    int dense_window = 101, dense_update_window = 1;
     std::vector<void*> allocs;
     std::string err;
 };
@@ -364,6 +374,67 @@ struct DevBuf {   // RAII staging buffer: device copy of a host-or-device array
     hipError_t alloc(size_t n) { return hipMalloc(reinterpret_cast<void**>(&p), (n ? n : 1) * sizeof(T)); }
 };
 
+// ---- dense mass matrices: host side -----------------------------------------------------------------------
+static int dense_fail(lmc_engine* e, int rc, const char* what) {
+    if (rc == kDenseUnsupported)
+        return fail(e, LMC_ERR_INVALID, "%s: no dense-mass kernel for target family %d / dim %d in this build", what,
+                    e->cfg.target_family, e->cfg.dim);
+    return fail(e, LMC_ERR_HIP, "%s: %s", what, hipGetErrorString(static_cast<hipError_t>(rc)));
+}
+
+// In-place lower Cholesky, column by column with the operation order of the device kernel (cholesky_lds):
+// pivot sqrt, column divided by the pivot, trailing update with one fused multiply-add per entry.
+template <class T>
+static bool host_cholesky(std::vector<T>& a, int d) {   // a: [d][d] row-major, lower triangle in/out
+    for (int k = 0; k < d; ++k) {
+        const T akk = a[static_cast<size_t>(k) * d + k];
+        if (!(akk > T(0)) || !std::isfinite(akk)) return false;
+        const T lkk = std::sqrt(akk);
+        a[static_cast<size_t>(k) * d + k] = lkk;
+        for (int i = k + 1; i < d; ++i) a[static_cast<size_t>(i) * d + k] = a[static_cast<size_t>(i) * d + k] / lkk;
+        for (int j = k + 1; j < d; ++j) {
+            const T ljk = a[static_cast<size_t>(j) * d + k];
+            for (int i = j; i < d; ++i)
+                a[static_cast<size_t>(i) * d + j] = std::fma(-a[static_cast<size_t>(i) * d + k], ljk, a[static_cast<size_t>(i) * d + j]);
+        }
+    }
+    for (int i = 0; i < d; ++i)
+        for (int j = i + 1; j < d; ++j) a[static_cast<size_t>(i) * d + j] = T(0);
+    return true;
+}
+
+static int dense_reset(lmc_engine* e) {   // FULL_ADAPT: constructor state for every chain
+    const int rc = dense_launch_reset(e->stream, e->A, e->D, e->cov1T, e->fac1, e->raw1T, e->mean1, e->dense_weight,
+                                      e->dense_window, e->d8);
+    if (rc != 0) return dense_fail(e, rc, "dense reset");
+    return LMC_OK;
+}
+
+static int dense_run(lmc_engine* e, SamplerParams P) {
+    P.momentum_f32 = e->cfg.potential != LMC_POT_FULL_INV;   // quadpotential.py:452 (float32) vs :413 (float64)
+    P.adapt_mass = 0;
+    const bool mat_f64 = e->cfg.potential == LMC_POT_FULL_INV;
+    const long long end = P.iter_begin + P.n_iters;
+    long long it = P.iter_begin;
+    while (it < end) {
+        // while tuning, FullAdapt refreshes covariance and factor after EVERY iteration (quadpotential.py:528-552):
+        // one iteration per launch, the update kernel in between; everything else runs whole blocks of iterations
+        const bool adapt = e->cfg.potential == LMC_POT_FULL_ADAPT && it < P.n_tune;
+        const long long n = adapt ? 1 : end - it;
+        SamplerParams Q = P;
+        Q.iter_begin = it;
+        Q.n_iters = static_cast<int>(n);
+        int rc = dense_launch_run(e->cfg.target_family, e->ns, mat_f64, e->stream, e->A, e->D, Q, e->tparams);
+        if (rc != 0) return dense_fail(e, rc, "run");
+        if (adapt) {
+            rc = dense_launch_adapt(e->stream, e->A, e->D, e->dense_multiplier, e->dense_update_window);
+            if (rc != 0) return dense_fail(e, rc, "dense update");
+        }
+        it += n;
+    }
+    return LMC_OK;
+}
+
 static int ns_for_dim(int d) {
     const int need = (d + 63) / 64;
     int ns = 1;
@@ -436,6 +507,10 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
                     LMC_ABI_VERSION);
     if (cfg->chains < 1 || cfg->dim < 1) return fail(nullptr, LMC_ERR_INVALID, "chains and dim must be >= 1");
     if (cfg->dim > 1024) return fail(nullptr, LMC_ERR_INVALID, "dim > 1024 is not supported (one wavefront per chain)");
+    if (cfg->potential < LMC_POT_DIAG_ADAPT || cfg->potential > LMC_POT_FULL_ADAPT)
+        return fail(nullptr, LMC_ERR_INVALID, "unknown potential %d", cfg->potential);
+    if (cfg->potential >= LMC_POT_FULL && cfg->dim > 256)
+        return fail(nullptr, LMC_ERR_INVALID, "dense mass matrices are supported up to dim 256 (got %d)", cfg->dim);
     if (!lmc_has_target(cfg->target_family))
         return fail(nullptr, LMC_ERR_INVALID, "target family %d is not built into this library", cfg->target_family);
     if (cfg->target_family == LMC_TARGET_NORMAL1D && cfg->dim != 1)
@@ -526,6 +601,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     TRY_ALLOC(dev_alloc(e, &A.status, C));
     TRY_ALLOC(dev_alloc(e, &A.counters, C * kNumCounters));
     A.scratch_stride = static_cast<long long>(max_levels - nlds + 1) * 4 * dp;
+    const bool dense = cfg->potential >= LMC_POT_FULL;
+    if (dense) A.scratch_stride = static_cast<long long>(dense_scratch_vectors(max_levels)) * dp;
     TRY_ALLOC(dev_alloc(e, &A.scratch, C * static_cast<size_t>(A.scratch_stride), false));
     TRY_ALLOC(dev_alloc(e, &e->init_mean, C * dp));
     TRY_ALLOC(dev_alloc(e, &e->init_diag, C * dp));
@@ -545,11 +622,53 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         A.da_table_len = len;
     }
 #undef TRY_ALLOC
-    // default potential of BaseHMC (base_hmc.py:109-113): QuadPotentialDiagAdapt(d, zeros, ones, 10)
+    std::memset(&e->D, 0, sizeof(e->D));
+    if (dense) {
+        DenseArrays& D = e->D;
+        const size_t d = cfg->dim;
+        e->d8 = (cfg->dim + 7) / 8 * 8;
+        D.kind = cfg->potential;
+        const bool per_chain = cfg->potential == LMC_POT_FULL_ADAPT;
+        const size_t P = per_chain ? C : 1;
+        D.mat_stride = per_chain ? static_cast<long long>(d * dp) : 0;
+        D.fac_stride = per_chain ? static_cast<long long>(e->d8) * static_cast<long long>(dp) : 0;
+        if (cfg->potential == LMC_POT_FULL_INV) {
+            double *m = nullptr, *f = nullptr;
+            if ((rc = dev_alloc(e, &m, d * dp)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &f, d * dp)) != LMC_OK) return bail(rc);
+            D.covT = m; D.fac = f;
+        } else {
+            float *m = nullptr, *f = nullptr;
+            if ((rc = dev_alloc(e, &m, P * d * dp)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &f, P * e->d8 * dp)) != LMC_OK) return bail(rc);
+            D.covT = m; D.fac = f;
+        }
+        if (per_chain) {
+            if ((rc = dev_alloc(e, &D.rawT, 2 * C * d * dp)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &D.emean, 2 * C * dp)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &D.en, 2 * C)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &D.esel, C)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &D.prev_update, C)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &D.window, C)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &D.chol_failed, C)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &e->cov1T, d * dp)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &e->fac1, static_cast<size_t>(e->d8) * dp)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &e->raw1T, d * dp)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &e->mean1, dp)) != LMC_OK) return bail(rc);
+        }
+    }
+    // default potential of BaseHMC (base_hmc.py:109-113): QuadPotentialDiagAdapt(d, zeros, ones, 10); a dense
+    // engine starts from the identity (QuadPotentialFullAdapt's own default, quadpotential.py:501-503)
     {
         std::vector<double> ones(cfg->dim, 1.0), zeros(cfg->dim, 0.0);
         rc = lmc_engine_set_potential(e, zeros.data(), ones.data(), 10.0, 0);
         if (rc != LMC_OK) return bail(rc);
+        if (dense) {
+            std::vector<double> eye(static_cast<size_t>(cfg->dim) * cfg->dim, 0.0);
+            for (int i = 0; i < cfg->dim; ++i) eye[static_cast<size_t>(i) * cfg->dim + i] = 1.0;
+            rc = lmc_engine_set_dense_potential(e, eye.data(), zeros.data(), 1.0, 101, 2.0, 1);
+            if (rc != LMC_OK) return bail(rc);
+        }
         // seed 0 so that an engine used without lmc_engine_seed() is still deterministic
         std::vector<uint32_t> seeds(C, 0u);
         rc = lmc_engine_seed(e, seeds.data());
@@ -636,6 +755,258 @@ int lmc_engine_set_potential(lmc_engine* e, const double* initial_mean, const do
     return LMC_OK;
 }
 
+int lmc_engine_set_dense_potential(lmc_engine* e, const double* matrix, const double* initial_mean,
+                                   double initial_weight, int32_t adaptation_window,
+                                   double adaptation_window_multiplier, int32_t update_window) {
+    if (!e || !matrix) return fail(e, LMC_ERR_INVALID, "matrix is required");
+    if (e->cfg.potential < LMC_POT_FULL)
+        return fail(e, LMC_ERR_STATE, "the engine was created with a diagonal potential (cfg.potential = %d)", e->cfg.potential);
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const int d = e->cfg.dim, dp = e->dpad, d8 = e->d8;
+    const size_t dd = static_cast<size_t>(d) * d;
+    std::vector<double> m(dd), mean(d, 0.0);
+    HIP_TRY(e, hipMemcpy(m.data(), matrix, dd * sizeof(double), hipMemcpyDefault));
+    if (initial_mean) HIP_TRY(e, hipMemcpy(mean.data(), initial_mean, d * sizeof(double), hipMemcpyDefault));
+    for (size_t i = 0; i < dd; ++i)
+        if (!std::isfinite(m[i])) return fail(e, LMC_ERR_INVALID, "array must not contain infs or NaNs");
+    if (e->cfg.potential == LMC_POT_FULL_INV) {
+        // L = cholesky(A) (quadpotential.py:402); velocity = cho_solve((L, True), x) (:406) is served by the
+        // explicit inverse  Sigma = L^-T L^-1  (formed once, extended precision), random = L n (:413)
+        std::vector<double> L(m);
+        if (!host_cholesky(L, d)) return fail(e, LMC_ERR_INVALID, "matrix is not positive definite");
+        std::vector<long double> Li(dd, 0.0L);   // L^-1, lower
+        for (int c = 0; c < d; ++c)
+            for (int i = c; i < d; ++i) {
+                long double acc = (i == c) ? 1.0L : 0.0L;
+                for (int k = c; k < i; ++k) acc -= static_cast<long double>(L[static_cast<size_t>(i) * d + k]) * Li[static_cast<size_t>(k) * d + c];
+                Li[static_cast<size_t>(i) * d + c] = acc / L[static_cast<size_t>(i) * d + i];
+            }
+        std::vector<double> covT(static_cast<size_t>(d) * dp, 0.0), LT(static_cast<size_t>(d) * dp, 0.0);
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                long double acc = 0.0L;
+                for (int k = (i > j ? i : j); k < d; ++k) acc += Li[static_cast<size_t>(k) * d + i] * Li[static_cast<size_t>(k) * d + j];
+                covT[static_cast<size_t>(j) * dp + i] = static_cast<double>(acc);           // Sigma[i][j]
+                LT[static_cast<size_t>(j) * dp + i] = L[static_cast<size_t>(i) * d + j];    // L[i][j]
+            }
+        HIP_TRY(e, hipMemcpy(e->D.covT, covT.data(), covT.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(e->D.fac, LT.data(), LT.size() * sizeof(double), hipMemcpyHostToDevice));
+        return LMC_OK;
+    }
+    // QuadPotentialFull / FullAdapt: float32 covariance and its lower Cholesky factor (quadpotential.py:441-443)
+    std::vector<float> cov(dd);
+    for (size_t i = 0; i < dd; ++i) cov[i] = static_cast<float>(m[i]);
+    std::vector<float> L(cov);
+    if (!host_cholesky(L, d)) return fail(e, LMC_ERR_INVALID, "matrix is not positive definite");
+    std::vector<float> covT(static_cast<size_t>(d) * dp, 0.0f), fac(static_cast<size_t>(d8) * dp, 0.0f);
+    std::vector<double> rawT(static_cast<size_t>(d) * dp, 0.0), mean_p(dp, 0.0);
+    for (int i = 0; i < d; ++i) {
+        mean_p[i] = mean[i];
+        for (int j = 0; j < d; ++j) {
+            covT[static_cast<size_t>(j) * dp + i] = cov[static_cast<size_t>(i) * d + j];
+            rawT[static_cast<size_t>(j) * dp + i] = m[static_cast<size_t>(i) * d + j];      // float64 initial_cov (:506-508)
+            fac[static_cast<size_t>(i) * dp + j] = L[static_cast<size_t>(i) * d + j];
+        }
+    }
+    for (int i = d; i < d8; ++i) fac[static_cast<size_t>(i) * dp + i] = 1.0f;   // padding rows: identity
+    if (e->cfg.potential == LMC_POT_FULL) {
+        HIP_TRY(e, hipMemcpy(e->D.covT, covT.data(), covT.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(e->D.fac, fac.data(), fac.size() * sizeof(float), hipMemcpyHostToDevice));
+        return LMC_OK;
+    }
+    if (adaptation_window < 1 || update_window < 1 || !(adaptation_window_multiplier > 0.0) || initial_weight < 0.0)
+        return fail(e, LMC_ERR_INVALID, "bad FullAdapt parameters");
+    HIP_TRY(e, hipMemcpy(e->cov1T, covT.data(), covT.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->fac1, fac.data(), fac.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->raw1T, rawT.data(), rawT.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->mean1, mean_p.data(), mean_p.size() * sizeof(double), hipMemcpyHostToDevice));
+    e->dense_weight = initial_weight;
+    e->dense_window = adaptation_window;
+    e->dense_multiplier = adaptation_window_multiplier;
+    e->dense_update_window = update_window;
+    int rc = dense_reset(e);
+    if (rc != LMC_OK) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return LMC_OK;
+}
+
+int lmc_engine_dense_update(lmc_engine* e, int32_t tune) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    if (e->cfg.potential < LMC_POT_FULL) return fail(e, LMC_ERR_STATE, "not a dense potential");
+    if (!tune || e->cfg.potential != LMC_POT_FULL_ADAPT) return LMC_OK;   // update() returns at once (quadpotential.py:530-531)
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const int rc = dense_launch_adapt(e->stream, e->A, e->D, e->dense_multiplier, e->dense_update_window);
+    if (rc != 0) return dense_fail(e, rc, "dense update");
+    return LMC_OK;
+}
+
+static int dense_state_xfer(lmc_engine* e, const lmc_dense_state* st, bool to_user) {
+    if (!e || !st) return fail(e, LMC_ERR_INVALID, "null argument");
+    if (e->cfg.potential < LMC_POT_FULL) return fail(e, LMC_ERR_STATE, "not a dense potential");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const size_t C = e->cfg.chains, d = e->cfg.dim, dp = e->dpad, d8 = e->d8;
+    const bool adapt = e->cfg.potential == LMC_POT_FULL_ADAPT;
+    const bool inv = e->cfg.potential == LMC_POT_FULL_INV;
+    const DenseArrays& D = e->D;
+    if (!to_user && !adapt) return fail(e, LMC_ERR_STATE, "only FULL_ADAPT has settable dense state");
+    if (!adapt && (st->fore_mean || st->fore_raw_cov || st->fore_n || st->back_mean || st->back_raw_cov || st->back_n ||
+                   st->window || st->previous_update || st->chol_failures))
+        return fail(e, LMC_ERR_STATE, "estimator fields exist for FULL_ADAPT only");
+    const size_t P = adapt ? C : 1;
+    // matrices: device [P][rows][dp] (transposed for cov) <-> user [C][d][d]
+    auto mat_to_user = [&](float* user, const void* dev, size_t rows, bool dev_f64, bool transpose) -> int {
+        std::vector<float> host_f(dev_f64 ? 0 : P * rows * dp);
+        std::vector<double> host_d(dev_f64 ? P * rows * dp : 0);
+        if (dev_f64) HIP_TRY(e, hipMemcpy(host_d.data(), dev, host_d.size() * sizeof(double), hipMemcpyDeviceToHost));
+        else HIP_TRY(e, hipMemcpy(host_f.data(), dev, host_f.size() * sizeof(float), hipMemcpyDeviceToHost));
+        std::vector<float> out(C * d * d);
+        for (size_t c = 0; c < C; ++c) {
+            const size_t pc = adapt ? c : 0;
+            for (size_t i = 0; i < d; ++i)
+                for (size_t j = 0; j < d; ++j) {
+                    const size_t src = pc * rows * dp + (transpose ? j * dp + i : i * dp + j);
+                    out[(c * d + i) * d + j] = dev_f64 ? static_cast<float>(host_d[src]) : host_f[src];
+                }
+        }
+        HIP_TRY(e, hipMemcpy(user, out.data(), out.size() * sizeof(float), hipMemcpyDefault));
+        return LMC_OK;
+    };
+    int rc;
+    std::vector<int> sel(C, 0);
+    if (adapt) HIP_TRY(e, hipMemcpy(sel.data(), D.esel, C * sizeof(int), hipMemcpyDeviceToHost));
+    if (to_user) {
+        if (st->cov && (rc = mat_to_user(st->cov, D.covT, d, inv, true)) != LMC_OK) return rc;
+        if (st->chol && (rc = mat_to_user(st->chol, D.fac, inv ? d : d8, inv, inv)) != LMC_OK) return rc;
+    } else {
+        auto mat_from_user = [&](const float* user, float* dev, size_t rows, bool transpose) -> int {
+            std::vector<float> in(C * d * d), host(C * rows * dp, 0.0f);
+            HIP_TRY(e, hipMemcpy(in.data(), user, in.size() * sizeof(float), hipMemcpyDefault));
+            for (size_t c = 0; c < C; ++c) {
+                for (size_t i = 0; i < d; ++i)
+                    for (size_t j = 0; j < d; ++j)
+                        host[c * rows * dp + (transpose ? j * dp + i : i * dp + j)] = in[(c * d + i) * d + j];
+                for (size_t i = d; i < rows; ++i) host[c * rows * dp + i * dp + i] = 1.0f;
+            }
+            HIP_TRY(e, hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+            return LMC_OK;
+        };
+        if (st->cov && (rc = mat_from_user(st->cov, static_cast<float*>(D.covT), d, true)) != LMC_OK) return rc;
+        if (st->chol && (rc = mat_from_user(st->chol, static_cast<float*>(D.fac), d8, false)) != LMC_OK) return rc;
+    }
+    if (!adapt) return LMC_OK;
+    const size_t mplane = C * d * dp, plane = C * dp;
+    // estimators: slot sel[c] is the foreground; set() writes the canonical layout (slot 0 = foreground)
+    if (!to_user && (st->fore_mean || st->fore_raw_cov || st->fore_n || st->back_mean || st->back_raw_cov || st->back_n)) {
+        if (!(st->fore_mean && st->fore_raw_cov && st->fore_n && st->back_mean && st->back_raw_cov && st->back_n))
+            return fail(e, LMC_ERR_INVALID, "the estimator fields must be set together");
+        std::fill(sel.begin(), sel.end(), 0);
+        HIP_TRY(e, hipMemcpy(D.esel, sel.data(), C * sizeof(int), hipMemcpyHostToDevice));
+    }
+    auto raw_xfer = [&](double* user, int which) -> int {   // which: 0 foreground, 1 background
+        if (!user) return LMC_OK;
+        std::vector<double> host(2 * mplane), buf(C * d * d);
+        if (to_user) {
+            HIP_TRY(e, hipMemcpy(host.data(), D.rawT, host.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t c = 0; c < C; ++c) {
+                const size_t slot = which == 0 ? sel[c] : 1 - sel[c];
+                for (size_t i = 0; i < d; ++i)
+                    for (size_t j = 0; j < d; ++j) buf[(c * d + i) * d + j] = host[slot * mplane + c * d * dp + j * dp + i];
+            }
+            HIP_TRY(e, hipMemcpy(user, buf.data(), buf.size() * sizeof(double), hipMemcpyDefault));
+        } else {
+            HIP_TRY(e, hipMemcpy(buf.data(), user, buf.size() * sizeof(double), hipMemcpyDefault));
+            std::vector<double> one(mplane, 0.0);
+            for (size_t c = 0; c < C; ++c)
+                for (size_t i = 0; i < d; ++i)
+                    for (size_t j = 0; j < d; ++j) one[c * d * dp + j * dp + i] = buf[(c * d + i) * d + j];
+            HIP_TRY(e, hipMemcpy(D.rawT + which * mplane, one.data(), mplane * sizeof(double), hipMemcpyHostToDevice));
+        }
+        return LMC_OK;
+    };
+    auto mean_xfer = [&](double* user, int which) -> int {
+        if (!user) return LMC_OK;
+        std::vector<double> host(2 * plane), buf(C * d);
+        if (to_user) {
+            HIP_TRY(e, hipMemcpy(host.data(), D.emean, host.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t c = 0; c < C; ++c) {
+                const size_t slot = which == 0 ? sel[c] : 1 - sel[c];
+                for (size_t i = 0; i < d; ++i) buf[c * d + i] = host[slot * plane + c * dp + i];
+            }
+            HIP_TRY(e, hipMemcpy(user, buf.data(), buf.size() * sizeof(double), hipMemcpyDefault));
+        } else {
+            HIP_TRY(e, hipMemcpy(buf.data(), user, buf.size() * sizeof(double), hipMemcpyDefault));
+            std::vector<double> one(plane, 0.0);
+            for (size_t c = 0; c < C; ++c)
+                for (size_t i = 0; i < d; ++i) one[c * dp + i] = buf[c * d + i];
+            HIP_TRY(e, hipMemcpy(D.emean + which * plane, one.data(), plane * sizeof(double), hipMemcpyHostToDevice));
+        }
+        return LMC_OK;
+    };
+    auto n_xfer = [&](double* user, int which) -> int {
+        if (!user) return LMC_OK;
+        std::vector<double> host(2 * C), buf(C);
+        HIP_TRY(e, hipMemcpy(host.data(), D.en, host.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (to_user) {
+            for (size_t c = 0; c < C; ++c) buf[c] = host[2 * c + (which == 0 ? sel[c] : 1 - sel[c])];
+            HIP_TRY(e, hipMemcpy(user, buf.data(), C * sizeof(double), hipMemcpyDefault));
+        } else {
+            HIP_TRY(e, hipMemcpy(buf.data(), user, C * sizeof(double), hipMemcpyDefault));
+            for (size_t c = 0; c < C; ++c) host[2 * c + which] = buf[c];
+            HIP_TRY(e, hipMemcpy(D.en, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        return LMC_OK;
+    };
+    if ((rc = raw_xfer(st->fore_raw_cov, 0)) != LMC_OK) return rc;
+    if ((rc = raw_xfer(st->back_raw_cov, 1)) != LMC_OK) return rc;
+    if ((rc = mean_xfer(st->fore_mean, 0)) != LMC_OK) return rc;
+    if ((rc = mean_xfer(st->back_mean, 1)) != LMC_OK) return rc;
+    if ((rc = n_xfer(st->fore_n, 0)) != LMC_OK) return rc;
+    if ((rc = n_xfer(st->back_n, 1)) != LMC_OK) return rc;
+    auto ints = [&](int32_t* user, int* dev) -> int {
+        if (!user) return LMC_OK;
+        if (to_user) HIP_TRY(e, hipMemcpy(user, dev, C * sizeof(int), hipMemcpyDefault));
+        else HIP_TRY(e, hipMemcpy(dev, user, C * sizeof(int), hipMemcpyDefault));
+        return LMC_OK;
+    };
+    if ((rc = ints(st->window, D.window)) != LMC_OK) return rc;
+    if ((rc = ints(st->previous_update, D.prev_update)) != LMC_OK) return rc;
+    if ((rc = ints(st->chol_failures, D.chol_failed)) != LMC_OK) return rc;
+    return LMC_OK;
+}
+
+int lmc_engine_get_dense_chain(lmc_engine* e, int32_t chain, float* cov, float* chol) {
+    if (!e || chain < 0 || chain >= e->cfg.chains) return fail(e, LMC_ERR_INVALID, "bad chain index");
+    if (e->cfg.potential < LMC_POT_FULL) return fail(e, LMC_ERR_STATE, "not a dense potential");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const size_t d = e->cfg.dim, dp = e->dpad;
+    const bool inv = e->cfg.potential == LMC_POT_FULL_INV;
+    const size_t esz = inv ? sizeof(double) : sizeof(float);
+    auto fetch = [&](float* user, const void* dev, long long stride, bool transpose) -> int {
+        std::vector<char> raw(d * dp * esz);
+        const char* src = static_cast<const char*>(dev) + static_cast<size_t>(chain) * static_cast<size_t>(stride) * esz;
+        HIP_TRY(e, hipMemcpy(raw.data(), src, raw.size(), hipMemcpyDeviceToHost));
+        std::vector<float> out(d * d);
+        for (size_t i = 0; i < d; ++i)
+            for (size_t j = 0; j < d; ++j) {
+                const size_t k = transpose ? j * dp + i : i * dp + j;
+                out[i * d + j] = inv ? static_cast<float>(reinterpret_cast<const double*>(raw.data())[k])
+                                     : reinterpret_cast<const float*>(raw.data())[k];
+            }
+        HIP_TRY(e, hipMemcpy(user, out.data(), out.size() * sizeof(float), hipMemcpyDefault));
+        return LMC_OK;
+    };
+    int rc;
+    if (cov && (rc = fetch(cov, e->D.covT, e->D.mat_stride, true)) != LMC_OK) return rc;
+    if (chol && (rc = fetch(chol, e->D.fac, e->D.fac_stride, inv)) != LMC_OK) return rc;
+    return LMC_OK;
+}
+
+int lmc_engine_get_dense_state(lmc_engine* e, const lmc_dense_state* dst) { return dense_state_xfer(e, dst, true); }
+int lmc_engine_set_dense_state(lmc_engine* e, const lmc_dense_state* src) { return dense_state_xfer(e, src, false); }
+
 int lmc_engine_seed(lmc_engine* e, const uint32_t* seeds) {
     if (!e || !seeds) return fail(e, LMC_ERR_INVALID, "null argument");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
@@ -712,7 +1083,13 @@ int lmc_engine_reset_tuning(lmc_engine* e) {
     if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     // QuadPotentialDiag.reset() is a no-op (quadpotential.py:138-140): only the adaptive potential resets
-    return launch_reset(e, 1, e->cfg.potential == LMC_POT_DIAG_ADAPT ? 1 : 0);
+    int rc = launch_reset(e, 1, e->cfg.potential == LMC_POT_DIAG_ADAPT ? 1 : 0);
+    if (rc != LMC_OK) return rc;
+    // FullAdapt: the reference's reset() is the inherited no-op, so its sequential driver hands chain k the matrix
+    // of chain k-1; chains here are independent, each one a fresh one-chain run (what the reference's
+    // multi-process driver computes): restore the constructor state
+    if (e->cfg.potential == LMC_POT_FULL_ADAPT) return dense_reset(e);
+    return LMC_OK;
 }
 
 int lmc_engine_set_dual_average(lmc_engine* e, double log_step, double log_bar, double hbar, int32_t count) {
@@ -776,6 +1153,7 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
     P.nlds = e->nlds;
     P.lds_doubles = e->lds_bytes / 8;
     P.sdot_mode = e->cfg.start_energy_sdot;
+    if (e->cfg.potential >= LMC_POT_FULL) return dense_run(e, P);
     const int run_lds = e->lds_bytes + lds_tail_doubles(e->run_w) * 8;   // subtree stack + MT19937 + team exchange
     const dim3 grid(e->cfg.chains), block(64 * e->run_w);
 #define RUN_ONE(NSV, WV, T)                                                                                    \
@@ -1039,6 +1417,13 @@ int lmc_engine_trajectory(lmc_engine* e, const double* q0, const double* p0, int
     HIP_TRY(e, oe.alloc(C * ns)); HIP_TRY(e, ol.alloc(C * ns));
     HIP_TRY(e, hipMemcpyAsync(dq0.p, q0, C * d * sizeof(double), hipMemcpyDefault, e->stream));
     HIP_TRY(e, hipMemcpyAsync(dp0.p, p0, C * d * sizeof(double), hipMemcpyDefault, e->stream));
+    if (e->cfg.potential >= LMC_POT_FULL) {
+        const int rc = dense_launch_trajectory(e->cfg.target_family, e->ns, e->cfg.potential == LMC_POT_FULL_INV, e->stream,
+                                               e->A, e->D, e->tparams, dq0.p, dp0.p, p0_is_f32,
+                                               e->cfg.start_energy_sdot, eps, n_fwd, n_back, oq.p, op.p, ov.p, og.p,
+                                               oe.p, ol.p);
+        if (rc != 0) return dense_fail(e, rc, "trajectory");
+    } else {
     const dim3 grid(e->cfg.chains), block(64);
 #define TRAJ_CALL(T)                                                                                          \
     LMC_NS_SWITCH(e, e->ns, LMC_LAUNCH((trajectory_kernel<NS, T>), grid, block, e->dpad * 8, e->stream, e->A,   \
@@ -1047,6 +1432,7 @@ int lmc_engine_trajectory(lmc_engine* e, const double* q0, const double* p0, int
     LMC_FAMILY_SWITCH(e, e->cfg.target_family, TRAJ_CALL)
 #undef TRAJ_CALL
     HIP_TRY(e, hipGetLastError());
+    }
     HIP_TRY(e, hipMemcpyAsync(out_q, oq.p, C * ns * d * sizeof(double), hipMemcpyDefault, e->stream));
     HIP_TRY(e, hipMemcpyAsync(out_p, op.p, C * ns * d * sizeof(double), hipMemcpyDefault, e->stream));
     HIP_TRY(e, hipMemcpyAsync(out_v, ov.p, C * ns * d * sizeof(double), hipMemcpyDefault, e->stream));
@@ -1105,11 +1491,16 @@ int lmc_engine_draw_momentum(lmc_engine* e, double* out) {
     const size_t C = e->cfg.chains, d = e->cfg.dim;
     DevBuf<double> dout;
     HIP_TRY(e, dout.alloc(C * d));
-    const int f32 = e->cfg.potential == LMC_POT_DIAG_ADAPT;
-    const dim3 grid(e->cfg.chains), block(64);
-    const int lds = 2 * e->dpad * 8;
-    LMC_NS_SWITCH(e, e->ns, LMC_LAUNCH((momentum_kernel<NS>), grid, block, lds, e->stream, e->A, f32, dout.p))
-    HIP_TRY(e, hipGetLastError());
+    if (e->cfg.potential >= LMC_POT_FULL) {
+        const int rc = dense_launch_momentum(e->ns, e->stream, e->A, e->D, dout.p);
+        if (rc != 0) return dense_fail(e, rc, "draw_momentum");
+    } else {
+        const int f32 = e->cfg.potential == LMC_POT_DIAG_ADAPT;
+        const dim3 grid(e->cfg.chains), block(64);
+        const int lds = 2 * e->dpad * 8;
+        LMC_NS_SWITCH(e, e->ns, LMC_LAUNCH((momentum_kernel<NS>), grid, block, lds, e->stream, e->A, f32, dout.p))
+        HIP_TRY(e, hipGetLastError());
+    }
     HIP_TRY(e, hipMemcpyAsync(out, dout.p, C * d * sizeof(double), hipMemcpyDefault, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return LMC_OK;

@@ -611,6 +611,90 @@ constexpr int run_waves_per_simd(int ns) {
 constexpr int kLdsMtDoubles = 320;
 constexpr int lds_tail_doubles(int w) { return w == 1 ? kLdsMtDoubles : kLdsMtDoubles + 2 * w * kTeamSlots + 4; }
 
+// ---- pieces of the iteration body shared by the diagonal and the dense-mass kernels ---------------------------
+struct DualAverage {   // step_sizes.py:49-99, wave-uniform
+    double log_step, log_bar, hbar, mu;
+    int count;
+    double step_now, step_bar_now;   // exp(log_step), exp(log_bar)
+};
+__device__ __forceinline__ void dual_average_load(const ChainArrays& A, int c, DualAverage& da) {
+    da.log_step = first_f64(A.da[c * 4 + 0]);
+    da.log_bar = first_f64(A.da[c * 4 + 1]);
+    da.hbar = first_f64(A.da[c * 4 + 2]);
+    da.mu = first_f64(A.da[c * 4 + 3]);
+    da.count = first_i32(A.da_count[c]);
+    da.step_now = exp_uniform(da.log_step);
+    da.step_bar_now = exp_uniform(da.log_bar);
+}
+__device__ __forceinline__ void dual_average_update(const ChainArrays& A, const SamplerParams& P, double accept, DualAverage& da) {
+    const double w = 1.0 / (static_cast<double>(da.count) + P.t0);
+    da.hbar = first_f64((1.0 - w) * da.hbar + w * (P.target_accept - accept));
+    // sqrt(count) and count ** -k come from host-built tables (glibc sqrt/pow: the very values the
+    // reference's Python floats get); the device pow is only the fallback beyond the table
+    double sq, mk;
+    if (da.count < A.da_table_len) {
+        sq = first_f64(A.da_sqrt[da.count]);
+        mk = first_f64(A.da_mk[da.count]);
+    } else {
+        sq = sqrt(static_cast<double>(da.count));
+        mk = pow(static_cast<double>(da.count), -P.k);
+    }
+    da.log_step = first_f64(da.mu - da.hbar * sq / P.gamma);
+    da.log_bar = first_f64(mk * da.log_step + (1.0 - mk) * da.log_bar);
+    ++da.count;
+    da.step_now = exp_uniform(da.log_step);
+    da.step_bar_now = exp_uniform(da.log_bar);
+}
+
+// running per-chain moments of the post-warm-up draws (optional): enough for R-hat without a trace
+template <int NS, class TeamT>
+__device__ __forceinline__ void moments_update(const ChainArrays& A, TeamT& tm, int c, long long row, const double (&q)[NS]) {
+    const int n_new = first_i32(A.mom_n[c]) + 1;
+    const double inv_n = 1.0 / static_cast<double>(n_new);
+    double mm[NS], m2[NS];
+    vload<NS>(A.mom_mean + row, mm); vload<NS>(A.mom_m2 + row, m2);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const double dlt = q[s] - mm[s];
+        mm[s] = mm[s] + dlt * inv_n;
+        m2[s] = m2[s] + dlt * (q[s] - mm[s]);
+    }
+    vstore<NS>(A.mom_mean + row, mm); vstore<NS>(A.mom_m2 + row, m2);
+    tm.sync();
+    if (tm.tid() == 0) A.mom_n[c] = n_new;
+}
+
+// draw row + per-draw statistics of iteration `git`
+template <int NS>
+__device__ __forceinline__ void write_outputs(const ChainArrays& A, int c, int tid, long long git, const double (&q)[NS],
+                                              const TransitionOut& out, double step_now, double step_bar_now, bool tune) {
+    const int d = A.d;
+    const long long orow = static_cast<long long>(c) * A.cap + git;
+    if (A.trace != nullptr && git >= A.trace_begin) {
+        double* tr = A.trace + (static_cast<long long>(c) * (A.cap - A.trace_begin) + (git - A.trace_begin)) * d;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int e = tid * NS + s;
+            if (e < d) tr[e] = q[s];
+        }
+    }
+    if (tid == 0) {
+        const long long fs = static_cast<long long>(A.chains) * A.cap;
+        A.stat_f64[kSfStepSize * fs + orow] = step_now;
+        A.stat_f64[kSfStepSizeBar * fs + orow] = step_bar_now;
+        A.stat_f64[kSfAccept * fs + orow] = out.accept;
+        A.stat_f64[kSfEnergyError * fs + orow] = out.energy_error;
+        A.stat_f64[kSfEnergy * fs + orow] = out.energy;
+        A.stat_f64[kSfMaxEnergyError * fs + orow] = out.max_energy_error;
+        A.stat_f64[kSfModelLogp * fs + orow] = out.model_logp;
+        A.stat_i32[kSiDepth * fs + orow] = out.depth;
+        A.stat_i32[kSiTreeSize * fs + orow] = out.n_leapfrog;
+        A.stat_u8[kSbDiverging * fs + orow] = static_cast<unsigned char>(out.diverging);
+        A.stat_u8[kSbTune * fs + orow] = static_cast<unsigned char>(tune);
+        A.stat_u8[kSbAccepted * fs + orow] = static_cast<unsigned char>(out.accepted);
+    }
+}
+
 template <int NS, int W, template <int> class TargetT>
 __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(ChainArrays A, SamplerParams P, const double* tparams) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -650,12 +734,8 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     rng.pos = first_i32(A.rng_pos[c]);
     rng.has_gauss = first_i32(A.rng_has_gauss[c]);
     rng.gauss = first_f64(A.rng_gauss[c]);
-    double log_step = first_f64(A.da[c * 4 + 0]);
-    double log_bar = first_f64(A.da[c * 4 + 1]);
-    double hbar = first_f64(A.da[c * 4 + 2]);
-    const double mu = first_f64(A.da[c * 4 + 3]);
-    int da_count = first_i32(A.da_count[c]);
-    double step_now = exp_uniform(log_step), step_bar_now = exp_uniform(log_bar);
+    DualAverage da;
+    dual_average_load(A, c, da);
     int iter_count = first_i32(A.iter_count[c]);
     int n_samples = first_i32(A.n_samples[c]);
     int wsel = first_i32(A.wsel[c]);
@@ -704,7 +784,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
 
         // ---- step size for this iteration (base_hmc.py:151-153)
         const bool adapt_step = tune && P.adapt_step_size;
-        const double step_size = adapt_step ? step_now : step_bar_now;   // exp(log_step) / exp(log_bar)
+        const double step_size = adapt_step ? da.step_now : da.step_bar_now;   // exp(log_step) / exp(log_bar)
 
         TransitionOut out;
         if (P.kind == 0) {
@@ -720,25 +800,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         ct_leap += out.n_leapfrog;
 
         // ---- dual averaging (step_sizes.py:71-92)
-        if (adapt_step) {
-            const double w = 1.0 / (static_cast<double>(da_count) + P.t0);
-            hbar = first_f64((1.0 - w) * hbar + w * (P.target_accept - out.accept));
-            // sqrt(count) and count ** -k come from host-built tables (glibc sqrt/pow: the very values the
-            // reference's Python floats get); the device pow is only the fallback beyond the table
-            double sq, mk;
-            if (da_count < A.da_table_len) {
-                sq = first_f64(A.da_sqrt[da_count]);
-                mk = first_f64(A.da_mk[da_count]);
-            } else {
-                sq = sqrt(static_cast<double>(da_count));
-                mk = pow(static_cast<double>(da_count), -P.k);
-            }
-            log_step = first_f64(mu - hbar * sq / P.gamma);
-            log_bar = first_f64(mk * log_step + (1.0 - mk) * log_bar);
-            ++da_count;
-            step_now = exp_uniform(log_step);
-            step_bar_now = exp_uniform(log_bar);
-        }
+        if (adapt_step) dual_average_update(A, P, out.accept, da);
 
         // ---- diagonal mass adaptation (quadpotential.py:231-245, :324-340)
         if (tune && P.adapt_mass) {
@@ -793,48 +855,8 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         ++iter_count;
         if (!tune) ++ct_after;
 
-        // ---- running per-chain moments of the post-warm-up draws (optional): enough for R-hat without a trace
-        if (A.mom_mean != nullptr && !tune) {
-            const int n_new = first_i32(A.mom_n[c]) + 1;
-            const double inv_n = 1.0 / static_cast<double>(n_new);
-            double mm[NS], m2[NS];
-            vload<NS>(A.mom_mean + row, mm); vload<NS>(A.mom_m2 + row, m2);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const double dlt = q[s] - mm[s];
-                mm[s] = mm[s] + dlt * inv_n;
-                m2[s] = m2[s] + dlt * (q[s] - mm[s]);
-            }
-            vstore<NS>(A.mom_mean + row, mm); vstore<NS>(A.mom_m2 + row, m2);
-            tm.sync();
-            if (tid == 0) A.mom_n[c] = n_new;
-        }
-
-        // ---- outputs: draw row + stats
-        const long long orow = static_cast<long long>(c) * A.cap + git;
-        if (A.trace != nullptr && git >= A.trace_begin) {
-            double* tr = A.trace + (static_cast<long long>(c) * (A.cap - A.trace_begin) + (git - A.trace_begin)) * d;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int e = tid * NS + s;
-                if (e < d) tr[e] = q[s];
-            }
-        }
-        if (tid == 0) {
-            const long long fs = static_cast<long long>(A.chains) * A.cap;
-            A.stat_f64[kSfStepSize * fs + orow] = step_now;
-            A.stat_f64[kSfStepSizeBar * fs + orow] = step_bar_now;
-            A.stat_f64[kSfAccept * fs + orow] = out.accept;
-            A.stat_f64[kSfEnergyError * fs + orow] = out.energy_error;
-            A.stat_f64[kSfEnergy * fs + orow] = out.energy;
-            A.stat_f64[kSfMaxEnergyError * fs + orow] = out.max_energy_error;
-            A.stat_f64[kSfModelLogp * fs + orow] = out.model_logp;
-            A.stat_i32[kSiDepth * fs + orow] = out.depth;
-            A.stat_i32[kSiTreeSize * fs + orow] = out.n_leapfrog;
-            A.stat_u8[kSbDiverging * fs + orow] = static_cast<unsigned char>(out.diverging);
-            A.stat_u8[kSbTune * fs + orow] = static_cast<unsigned char>(tune);
-            A.stat_u8[kSbAccepted * fs + orow] = static_cast<unsigned char>(out.accepted);
-        }
+        if (A.mom_mean != nullptr && !tune) moments_update<NS>(A, tm, c, row, q);
+        write_outputs<NS>(A, c, tid, git, q, out, da.step_now, da.step_bar_now, tune);
     }
 
     // ---- store persistent chain state
@@ -850,10 +872,10 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         A.rng_pos[c] = rng.pos;
         A.rng_has_gauss[c] = rng.has_gauss;
         A.rng_gauss[c] = rng.gauss;
-        A.da[c * 4 + 0] = log_step;
-        A.da[c * 4 + 1] = log_bar;
-        A.da[c * 4 + 2] = hbar;
-        A.da_count[c] = da_count;
+        A.da[c * 4 + 0] = da.log_step;
+        A.da[c * 4 + 1] = da.log_bar;
+        A.da[c * 4 + 2] = da.hbar;
+        A.da_count[c] = da.count;
         A.iter_count[c] = iter_count;
         A.n_samples[c] = n_samples;
         A.wsel[c] = wsel;

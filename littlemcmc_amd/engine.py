@@ -28,7 +28,9 @@ class Engine:
         cfg.device = int(device)
         cfg.kind = {"nuts": _abi.KIND_NUTS, "hmc": _abi.KIND_HMC}[kind]
         cfg.target_family = int(target.family)
-        cfg.potential = {"diag_adapt": _abi.POT_DIAG_ADAPT, "diag": _abi.POT_DIAG}[potential]
+        cfg.potential = {"diag_adapt": _abi.POT_DIAG_ADAPT, "diag": _abi.POT_DIAG, "full": _abi.POT_FULL,
+                         "full_inv": _abi.POT_FULL_INV, "full_adapt": _abi.POT_FULL_ADAPT}[potential]
+        self.potential = potential
         cfg.adapt_step_size = int(bool(adapt_step_size))
         cfg.target_accept = float(target_accept)
         cfg.emax = float(Emax)
@@ -209,6 +211,56 @@ class Engine:
                 keep.append(a)
                 setattr(st, name, a.ctypes.data)
         self._check(self._lib.lmc_engine_set_chain_state(self._h, C.byref(st)))
+
+    # ---- dense mass matrices (QuadPotentialFull / FullInv / FullAdapt) ---------------------------------
+    def set_dense_potential(self, matrix, initial_mean=None, initial_weight=0.0, adaptation_window=101,
+                            adaptation_window_multiplier=2.0, update_window=1):
+        m = np.ascontiguousarray(matrix, dtype=np.float64)
+        if m.shape != (self.dim, self.dim):
+            raise ValueError("matrix must have shape (%d, %d)" % (self.dim, self.dim))
+        mean = None if initial_mean is None else np.ascontiguousarray(initial_mean, dtype=np.float64)
+        self._check(self._lib.lmc_engine_set_dense_potential(
+            self._h, _abi.ptr(m), None if mean is None else _abi.ptr(mean), float(initial_weight),
+            int(adaptation_window), float(adaptation_window_multiplier), int(update_window)))
+
+    def _dense_shape(self, kind):
+        return {"m": (self.chains, self.dim, self.dim), "v": (self.chains, self.dim), "s": (self.chains,)}[kind]
+
+    def dense_chain(self, chain=0):
+        """(cov, chol) of one chain, float32 [dim, dim]."""
+        cov = np.empty((self.dim, self.dim), dtype=np.float32)
+        chol = np.empty((self.dim, self.dim), dtype=np.float32)
+        self._check(self._lib.lmc_engine_get_dense_chain(self._h, int(chain), _abi.ptr(cov), _abi.ptr(chol)))
+        return cov, chol
+
+    def get_dense_state(self, fields=None):
+        """cov / chol of every chain; for "full_adapt" also the two covariance estimators and the window state.
+        ``fields`` restricts the copy (the matrices are chains x dim x dim)."""
+        st = _abi.DenseState()
+        out = {}
+        for name, dt, kind in _abi.DenseState.FIELDS:
+            if self.potential != "full_adapt" and name not in ("cov", "chol"):
+                continue
+            if fields is not None and name not in fields:
+                continue
+            out[name] = np.empty(self._dense_shape(kind), dtype=dt)
+            setattr(st, name, out[name].ctypes.data)
+        self._check(self._lib.lmc_engine_get_dense_state(self._h, C.byref(st)))
+        return out
+
+    def set_dense_state(self, state):
+        st = _abi.DenseState()
+        keep = []
+        for name, dt, kind in _abi.DenseState.FIELDS:
+            if name in state and state[name] is not None:
+                a = np.ascontiguousarray(np.broadcast_to(np.asarray(state[name], dtype=dt), self._dense_shape(kind)))
+                keep.append(a)
+                setattr(st, name, a.ctypes.data)
+        self._check(self._lib.lmc_engine_set_dense_state(self._h, C.byref(st)))
+
+    def dense_update(self, tune=True):
+        """potential.update(current position, grad, tune) for every chain (quadpotential.py:528-552)."""
+        self._check(self._lib.lmc_engine_dense_update(self._h, int(bool(tune))))
 
     def keep_moments(self, enable=True):
         """Accumulate per-chain mean / M2 of the post-warm-up draws on the device (no trace needed for R-hat)."""

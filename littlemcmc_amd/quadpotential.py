@@ -1,5 +1,5 @@
-"""Mass matrices (potentials) -- host-side mirror of /root/reference/littlemcmc/quadpotential.py
-for the diagonal family, which is the one on the GPU hot path.
+"""Mass matrices (potentials) -- host-side mirror of /root/reference/littlemcmc/quadpotential.py:
+the diagonal family of the hot path and the dense family (section 8f-3).
 
 The objects keep the reference's constructor signatures and protocol (``velocity``, ``energy``,
 ``velocity_energy``, ``random``, ``update``, ``reset``; quadpotential.py:93-140) but hold no
@@ -7,8 +7,10 @@ numerics of their own: every method is a call into liblmc_hip.so (a one-chain en
 consumes the *global* legacy numpy stream exactly like the reference does -- the MT19937 state
 is handed to the device and back -- so ``np.random.seed(...)`` keeps its meaning.
 
-Dense potentials (QuadPotentialFull / FullInv / FullAdapt, quadpotential.py:390-615) are
-outside the hot-path scope and raise NotImplementedError.
+Dense potentials (QuadPotentialFull / FullInv / FullAdapt, quadpotential.py:390-615) run on the device for
+model_ndim <= 256: matrix sweeps inside the leapfrog, triangular-solve momentum draws, and for FullAdapt a
+batched covariance refresh + Cholesky kernel after every tuning iteration (littlemcmc_amd/csrc/lmc_dense.hpp).
+Sparse scalings (QuadPotentialSparse needs scikit-sparse in the reference) are not implemented.
 """
 import numpy as np
 
@@ -59,7 +61,8 @@ def quad_potential(C, is_cov):
 class QuadPotential:
     """Protocol base (quadpotential.py:93-140). Numerics live on the device."""
 
-    _engine_kind = None  # "diag_adapt" | "diag"
+    _engine_kind = None  # "diag_adapt" | "diag" | "full" | "full_inv" | "full_adapt"
+    _momentum_f32 = False
 
     def __init__(self, n):
         self._n = int(n)
@@ -126,7 +129,7 @@ class QuadPotential:
         eng.set_rng_state(0, np.random.get_state())
         p = eng.draw_momentum()[0]
         np.random.set_state(eng.get_rng_state(0))
-        return p.astype(np.float32) if self._engine_kind == "diag_adapt" else p
+        return p.astype(np.float32) if self._momentum_f32 else p
 
     def update(self, sample, grad, tune):
         raise NotImplementedError(
@@ -145,6 +148,7 @@ class QuadPotentialDiagAdapt(QuadPotential):
     """quadpotential.py:148-291: float32 diagonal adapted from the tuning draws' variance."""
 
     _engine_kind = "diag_adapt"
+    _momentum_f32 = True
 
     def __init__(self, n, initial_mean, initial_diag=None, initial_weight=0, adaptation_window=101,
                  adaptation_window_multiplier=1, dtype=None):
@@ -209,15 +213,155 @@ class QuadPotentialDiag(QuadPotential):
         pass
 
 
-def _dense_out_of_scope(name):
-    def __init__(self, *a, **k):
-        raise NotImplementedError(
-            "%s (dense mass matrix) is outside the GPU hot path of this build; use the diagonal "
-            "potentials (SURVEY.md section 8f-3)" % name)
-
-    return type(name, (QuadPotential,), {"__init__": __init__})
+MAX_DENSE_NDIM = 256
 
 
-QuadPotentialFull = _dense_out_of_scope("QuadPotentialFull")
-QuadPotentialFullInv = _dense_out_of_scope("QuadPotentialFullInv")
-QuadPotentialFullAdapt = _dense_out_of_scope("QuadPotentialFullAdapt")
+def _square(a, what):
+    a = np.asarray(a)
+    if a.ndim != 2 or a.shape[0] != a.shape[1]:
+        raise ValueError("%s must be a square two-dimensional array" % what)
+    if a.shape[0] > MAX_DENSE_NDIM:
+        raise NotImplementedError("dense mass matrices run on the device up to model_ndim = %d" % MAX_DENSE_NDIM)
+    return a
+
+
+class _DensePotential(QuadPotential):
+    """Shared plumbing of the dense potentials: the matrix is factorised by liblmc_hip when it is pushed to an
+    engine; a matrix that is not positive definite surfaces as numpy.linalg.LinAlgError, the exception
+    scipy.linalg.cholesky raises in the reference's constructors."""
+
+    def _matrix_args(self):
+        raise NotImplementedError
+
+    def _push_initial(self, engine):
+        from ._abi import HipLibraryError
+
+        try:
+            engine.set_dense_potential(*self._matrix_args())
+        except HipLibraryError as err:
+            if "positive definite" in str(err) or "infs or NaNs" in str(err):
+                raise np.linalg.LinAlgError(str(err)) from None
+            raise
+        self._pull(engine)
+
+    def _pull(self, engine, chain=0):
+        self._cov, self._chol = engine.dense_chain(chain)
+
+    def _validate(self):
+        """Factorise now (one-chain engine), like the reference's constructors do."""
+        self._eng()
+
+
+class QuadPotentialFull(_DensePotential):
+    """quadpotential.py:428-468: float32 covariance ``cov``; velocity = cov @ x, momentum = solve(chol.T, z)."""
+
+    _engine_kind = "full"
+    _momentum_f32 = True
+
+    def __init__(self, cov, dtype=None):
+        if dtype not in (None, "float32", np.float32):
+            raise NotImplementedError("the device mass matrix is float32, like the reference's default")
+        cov = _square(cov, "cov")
+        super().__init__(cov.shape[0])
+        self.dtype = "float32"
+        self._matrix = np.array(cov, dtype="d")
+        self._cov = np.array(cov, dtype="float32", copy=True)
+        self._chol = None
+        self._n_samples = 0
+
+    def _matrix_args(self):
+        return (self._matrix,)
+
+    __call__ = QuadPotential.random
+
+
+class QuadPotentialFullInv(_DensePotential):
+    """quadpotential.py:388-425: mass matrix ``A`` (inverse covariance); velocity = A^-1 x, momentum = L z."""
+
+    _engine_kind = "full_inv"
+    _momentum_f32 = False
+
+    def __init__(self, A, dtype=None):
+        A = _square(A, "A")
+        super().__init__(A.shape[0])
+        self.dtype = "float32" if dtype is None else dtype
+        self._matrix = np.array(A, dtype="d")
+        self._n_samples = 0
+
+    def _matrix_args(self):
+        return (self._matrix,)
+
+    def _pull(self, engine, chain=0):
+        self._cov, chol = engine.dense_chain(chain)
+        self.L = chol.astype("d")
+
+
+class QuadPotentialFullAdapt(_DensePotential):
+    """quadpotential.py:471-557: dense covariance re-estimated from the tuning draws (two running estimators,
+    growing adaptation windows), refreshed together with its Cholesky factor every ``update_window`` samples.
+
+    Every chain adapts its own matrix. ``reset()`` restores the constructor state (the reference's reset is the
+    inherited no-op, so its sequential driver carries chain k-1's matrix into chain k; its multi-process driver
+    -- and this engine -- start every chain fresh)."""
+
+    _engine_kind = "full_adapt"
+    _momentum_f32 = True
+
+    def __init__(self, n, initial_mean, initial_cov=None, initial_weight=0, adaptation_window=101,
+                 adaptation_window_multiplier=2, update_window=1, dtype=None):
+        initial_mean = np.asarray(initial_mean)
+        if initial_cov is not None:
+            initial_cov = np.asarray(initial_cov)
+            if initial_cov.ndim != 2:
+                raise ValueError("Initial covariance must be two-dimensional.")
+        if initial_mean.ndim != 1:
+            raise ValueError("Initial mean must be one-dimensional.")
+        if initial_cov is not None and initial_cov.shape != (n, n):
+            raise ValueError("Wrong shape for initial_cov: expected %s got %s" % (n, initial_cov.shape))
+        if len(initial_mean) != n:
+            raise ValueError("Wrong shape for initial_mean: expected %s got %s" % (n, len(initial_mean)))
+        if dtype not in (None, "float32", np.float32):
+            raise NotImplementedError("the device mass matrix is float32, like the reference's default")
+        if n > MAX_DENSE_NDIM:
+            raise NotImplementedError("dense mass matrices run on the device up to model_ndim = %d" % MAX_DENSE_NDIM)
+        super().__init__(n)
+        self.dtype = "float32"
+        if initial_cov is None:  # quadpotential.py:501-503
+            initial_cov = np.eye(n, dtype="float32")
+            initial_weight = 1
+        self._initial_mean = np.array(initial_mean, dtype="d")
+        self._matrix = np.array(initial_cov, dtype="d")
+        self._initial_weight = float(initial_weight)
+        self._adaptation_window = int(adaptation_window)
+        self._adaptation_window_multiplier = float(adaptation_window_multiplier)
+        self._update_window = int(update_window)
+        self._cov = np.array(initial_cov, dtype="float32", copy=True)
+        self._chol = None
+        self._chol_error = None
+        self._previous_update = 0
+        self._n_samples = 0
+        self._initial_window = int(adaptation_window)
+
+    def _matrix_args(self):
+        return (self._matrix, self._initial_mean, self._initial_weight, self._initial_window,
+                self._adaptation_window_multiplier, self._update_window)
+
+    def _pull(self, engine, chain=0):
+        self._cov, self._chol = engine.dense_chain(chain)
+        st = engine.get_dense_state(fields=("window", "previous_update", "chol_failures"))
+        self._adaptation_window = int(st["window"][chain])
+        self._previous_update = int(st["previous_update"][chain])
+        self._n_samples = int(engine.adapt_state()["n_samples"][chain])
+        if int(st["chol_failures"][chain]):
+            self._chol_error = np.linalg.LinAlgError("the covariance estimate was not positive definite")
+
+    def update(self, sample, grad, tune):
+        """quadpotential.py:528-552 as one device call (covariance refresh + Cholesky kernel)."""
+        eng = self._eng()
+        eng.set_position(np.asarray(sample, dtype="d").reshape(1, self._n))
+        eng.dense_update(tune)
+        self._pull(eng)
+
+    def raise_ok(self, vmap=None):   # quadpotential.py:554-557
+        if self._chol_error is not None:
+            raise ValueError("{0}".format(self._chol_error))

@@ -16,7 +16,7 @@ import numpy as np
 from . import _abi
 from .base_hmc import raise_for_status
 from .nuts import NUTS
-from .quadpotential import QuadPotentialDiagAdapt
+from .quadpotential import QuadPotentialDiagAdapt, QuadPotentialFullAdapt
 from .targets import require_device_target
 
 _log = logging.getLogger("littlemcmc_amd")
@@ -37,7 +37,8 @@ def _derive_seeds(random_seed, chains):
 
 
 def init_nuts(logp_dlogp_func, model_ndim=None, init="auto", random_seed=None, size=None, **kwargs):
-    """Set up start point and NUTS sampler (sampling.py:524-605). Diagonal modes only."""
+    """Set up start point and NUTS sampler (sampling.py:524-605): "adapt_diag", "jitter+adapt_diag",
+    "adapt_full", "jitter+adapt_full" (dense modes: model_ndim <= 256)."""
     if model_ndim is None:
         model_ndim = size if size is not None else getattr(logp_dlogp_func, "d", None)
     require_device_target(logp_dlogp_func, model_ndim)
@@ -54,13 +55,16 @@ def init_nuts(logp_dlogp_func, model_ndim=None, init="auto", random_seed=None, s
         start = np.zeros(model_ndim)
     elif init == "jitter+adapt_diag":
         start = 2 * np.random.rand(model_ndim) - 1
-    elif init in ("adapt_full", "jitter+adapt_full"):
-        raise NotImplementedError(
-            "init=%r needs a dense mass matrix, which is outside the GPU hot path of this build "
-            "(SURVEY.md section 8f-3); use 'adapt_diag' or 'jitter+adapt_diag'" % init)
+    elif init == "adapt_full":
+        start = np.zeros(model_ndim)
+    elif init == "jitter+adapt_full":
+        start = 2 * np.random.rand(model_ndim) - 1
     else:
         raise ValueError("Unknown initializer: {}.".format(init))
-    potential = QuadPotentialDiagAdapt(model_ndim, start, np.ones(model_ndim), 10)
+    if init.endswith("adapt_full"):   # sampling.py:588-597
+        potential = QuadPotentialFullAdapt(model_ndim, start, np.eye(model_ndim), 10)
+    else:
+        potential = QuadPotentialDiagAdapt(model_ndim, start, np.ones(model_ndim), 10)
     step = NUTS(logp_dlogp_func=logp_dlogp_func, model_ndim=model_ndim, potential=potential, **kwargs)
     return start, step
 

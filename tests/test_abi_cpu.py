@@ -88,8 +88,12 @@ def test_reference_argument_errors():
         lmc.init_nuts(tgt, 3, init=3)
     with pytest.raises(ValueError, match="Unknown initializer"):   # sampling.py:599
         lmc.init_nuts(tgt, 3, init="nope")
-    with pytest.raises(NotImplementedError):          # dense mass matrices: out of scope
-        lmc.init_nuts(tgt, 3, init="adapt_full")
+    start, step = lmc.init_nuts(tgt, 3, init="adapt_full")   # sampling.py:588-592 (host objects only: no GPU needed)
+    assert isinstance(step.potential, lmc.QuadPotentialFullAdapt) and not start.any()
+    with pytest.raises(NotImplementedError):          # dense mass matrices live on the device up to 256 dimensions
+        lmc.QuadPotentialFull(np.eye(257))
+    with pytest.raises(ValueError, match="two-dimensional"):   # quadpotential.py:485-486
+        lmc.QuadPotentialFullAdapt(3, np.zeros(3), np.ones(3), 1)
     from littlemcmc_amd.quadpotential import PositiveDefiniteError
 
     with pytest.raises(PositiveDefiniteError):        # tests/test_quadpotential.py:21-24

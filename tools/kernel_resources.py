@@ -5,8 +5,12 @@ import subprocess
 import sys
 
 args = sys.argv[1:]
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-mllvm", "-disable-machine-licm",
-       "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/lmc_kres.so", "littlemcmc_amd/csrc/lmc_engine.hip"] + args
+unit = "lmc_engine"
+if args and args[0] in ("lmc_engine", "lmc_dense"):   # translation unit to analyse (default: the diagonal kernels)
+    unit = args.pop(0)
+cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c", "-mllvm", "-disable-machine-licm",
+       "-I", "littlemcmc_amd/csrc", "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/lmc_kres.o",
+       "littlemcmc_amd/csrc/%s.hip" % unit] + args
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
 rows = []
