@@ -107,6 +107,13 @@ def cpu_baseline(name, dim, seeds, start, budget_iters):
     }
 
 
+DIAG_LIMITER = ("measured: VALU issue (f64 at 16 lanes/clk), ~220 VALU instr per leapfrog at ~90% issue "
+                "utilisation with 3 waves/SIMD; the trajectory lives in registers/LDS, so HBM traffic is "
+                "a few % of the algorithmic bytes and frac can exceed 1 (profiles/, DESIGN.md section 6)")
+DENSE_LIMITER = ("one float32 d x d matrix sweep per leapfrog (4 d^2 B; the reference does two): per-chain matrices "
+                 "(full_adapt) stream from HBM / Infinity Cache, a shared matrix (full) from L2; DESIGN.md section 9")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +125,9 @@ def main():
     ap.add_argument("--iters-per-step", type=int, default=100, help="NUTS iterations per chain per launch")
     ap.add_argument("--max-treedepth", type=int, default=10)
     ap.add_argument("--kind", default="nuts", choices=["nuts", "hmc"], help="step method (hmc: path_length 2.0)")
+    ap.add_argument("--mass", default="diag", choices=["diag", "full", "full_adapt"],
+                    help="mass matrix: diag = QuadPotentialDiagAdapt (headline), full = QuadPotentialFull with the "
+                         "target's covariance, full_adapt = QuadPotentialFullAdapt (init='adapt_full'); dense: dim <= 256")
     ap.add_argument("--no-trace", action="store_true", help="do not store draws (statistics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
@@ -164,7 +174,18 @@ def main():
     start = 2 * np.random.rand(args.dim) - 1            # init_nuts jitter (sampling.py:574-584)
     seeds = seeds_all[rank * chains:(rank + 1) * chains]
 
-    pot = lmc.QuadPotentialDiagAdapt(args.dim, start, np.ones(args.dim), 10)
+    if args.mass == "diag":
+        pot = lmc.QuadPotentialDiagAdapt(args.dim, start, np.ones(args.dim), 10)
+        mass_desc = "diag mass adapt"
+    elif args.mass == "full_adapt":
+        pot = lmc.QuadPotentialFullAdapt(args.dim, start, np.eye(args.dim), 10)      # sampling.py:588-597
+        mass_desc = "dense mass adapt (one float32 %dx%d matrix per chain, refreshed + factorised every tuning iteration)" % (
+            args.dim, args.dim)
+    else:
+        idx = np.arange(args.dim)
+        cov = 0.9 ** np.abs(idx[:, None] - idx[None, :]) if args.target == "ar1" else np.eye(args.dim)
+        pot = lmc.QuadPotentialFull(cov)
+        mass_desc = "fixed dense mass (the target's covariance, one float32 matrix shared by all chains)"
     if args.kind == "nuts":
         step = lmc.NUTS(target, args.dim, potential=pot, max_treedepth=args.max_treedepth)
     else:
@@ -254,11 +275,14 @@ def main():
     if rank == 0:
         value = leap_all / wall_max
         kern_s = sum(kernel_ms) / 1e3
-        bytes_per_leap = 60 * args.dim
+        # algorithmic bytes of one reference leapfrog: the State vectors, plus for a dense mass matrix the
+        # two float32 d x d sweeps of integration.py:111,118 (the device kernel needs one)
+        bytes_per_leap = 60 * args.dim + (0 if args.mass == "diag" else 8 * args.dim * args.dim)
         achieved = leap_local * bytes_per_leap / kern_s          # this GPU's kernel, algorithmic bytes / kernel time
         traffic, traffic_src = None, None
         try:   # HBM bytes per launch from the committed PMC profile of this same workload (not measurable in-process)
-            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("%s:%d" % (args.target, args.dim))
+            tr_key = ("%s:%d" % (args.target, args.dim)) + ("" if args.mass == "diag" else ":" + args.mass)
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(tr_key)
             if tr:
                 traffic = tr["hbm_bytes_per_leapfrog"] * leap_local / K
                 traffic_src = tr["source"]
@@ -266,6 +290,8 @@ def main():
             pass
         valu_issue = None
         try:   # the limiter that actually binds (profiles/: VALU issue), as measured by the committed PMC run
+            if args.mass != "diag":
+                raise KeyError("VALU-issue figures are for the diagonal kernel")
             ps = json.load(open(os.path.join(ROOT, "profiles", "r01_default_pmc_summary.json")))
             occ = 3 if args.dim > 64 else 4   # waves per SIMD of the instantiation (168 / 128 VGPRs)
             valu_issue = {"valu_inst_per_leapfrog": ps["per_leapfrog"]["SQ_INSTS_VALU"],
@@ -280,8 +306,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "C3: %d chains/GPU x dim %d %s, %s, diag mass adapt, tune %d + draws %d in %d launches of "
-                            "%d iterations" % (chains, args.dim, target_desc, method, n_tune, n_total - n_tune, K, ips),
+                "workload": "C3: %d chains/GPU x dim %d %s, %s, %s, tune %d + draws %d in %d launches of "
+                            "%d iterations" % (chains, args.dim, target_desc, method, mass_desc, n_tune, n_total - n_tune, K, ips),
                 "chains_per_gpu": chains, "dim": args.dim, "target": args.target, "tune": n_tune,
                 "draws": n_total - n_tune, "rng": "MT19937 (numpy legacy stream, same-seed parity mode)",
                 "trace_in_hbm": not args.no_trace, "parallelism": "chain-block x%d" % world,
@@ -298,13 +324,11 @@ def main():
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "B per launch", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": leap_local * bytes_per_leap / K,
-                "kernel": "lmc::run_kernel<NS=%d>" % max(1, (args.dim + 63) // 64),
+                "kernel": ("lmc::run_kernel<NS=%d>" if args.mass == "diag" else "lmc::run_dense_kernel<NS=%d>") % max(1, (args.dim + 63) // 64),
                 "kernel_ms_avg": sum(kernel_ms) / K, "algorithmic_bytes_per_leapfrog": bytes_per_leap,
                 "read_only_frac": leap_local * 28 * args.dim / kern_s / HBM_PEAK,
                 "valu_issue": valu_issue,
-                "limiter": "measured: VALU issue (f64 at 16 lanes/clk), ~220 VALU instr per leapfrog at ~90% issue "
-                           "utilisation with 3 waves/SIMD; the trajectory lives in registers/LDS, so HBM traffic is "
-                           "a few % of the algorithmic bytes and frac can exceed 1 (profiles/, DESIGN.md section 6)",
+                "limiter": DIAG_LIMITER if args.mass == "diag" else DENSE_LIMITER,
             },
         }
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only

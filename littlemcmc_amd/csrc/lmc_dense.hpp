@@ -47,15 +47,33 @@ __device__ __forceinline__ void dense_sweep(const MatT* __restrict__ M, int d, i
     for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc[v][s] = 0.0;
-#pragma unroll 8
-    for (int j = 0; j < d; ++j) {
-        const Pack<MatT, NS> m = col[static_cast<long long>(j) * stride];
+    // Software pipeline, two batches of kSweepBatch rows: the loads of one batch are in flight while the other is
+    // consumed, so a wave always has 8..16 row loads outstanding (the sweep is latency / bandwidth bound, not ALU
+    // bound). The matrix has kSweepRows(d) rows, the extra ones zero, and the operand area is zero beyond d.
+    constexpr int B = kSweepBatch;
+    const int rows = sweep_rows(d);
+    Pack<MatT, NS> m0[B], m1[B];
+    auto fetch = [&](Pack<MatT, NS> (&m)[B], int jb) {
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const double xj = x[j * NV + v];
+        for (int b = 0; b < B; ++b) m[b] = col[static_cast<long long>(jb + b) * stride];
+    };
+    auto consume = [&](const Pack<MatT, NS> (&m)[B], int jb) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) acc[v][s] = __builtin_fma(static_cast<double>(pack_get<NS>(m, s)), xj, acc[v][s]);
-        }
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const double xj = x[(jb + b) * NV + v];
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    acc[v][s] = __builtin_fma(static_cast<double>(pack_get<NS>(m[b], s)), xj, acc[v][s]);
+            }
+    };
+    fetch(m0, 0);
+    for (int jb = 0; jb < rows; jb += 2 * B) {
+        fetch(m1, jb + B);
+        consume(m0, jb);
+        if (jb + 2 * B < rows) fetch(m0, jb + 2 * B);
+        consume(m1, jb + B);
     }
 }
 
@@ -416,8 +434,16 @@ __device__ inline void dense_hmc_transition(Team<1>& tm, const Target& tgt, cons
 // MT19937 state for the duration of the launch.
 constexpr int dense_lds_doubles(int dpad) { return 2 * dpad + kLdsMtDoubles; }
 
+#ifndef LMC_DENSE_WAVES_NS2
+#define LMC_DENSE_WAVES_NS2 2
+#endif
+#ifndef LMC_DENSE_WAVES_NS4
+#define LMC_DENSE_WAVES_NS4 2
+#endif
+constexpr int dense_waves_per_simd(int ns) { return ns <= 2 ? LMC_DENSE_WAVES_NS2 : LMC_DENSE_WAVES_NS4; }
+
 template <int NS, class MatT, template <int> class TargetT>
-__global__ __launch_bounds__(64) void run_dense_kernel(ChainArrays A, DenseArrays D, SamplerParams P, const double* tparams) {
+__global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel(ChainArrays A, DenseArrays D, SamplerParams P, const double* tparams) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int c = blockIdx.x;
     const int d = A.d, dpad = A.dpad;

@@ -9,7 +9,7 @@ enum DenseKind : int { kDenseFull = 2, kDenseFullInv = 3, kDenseFullAdapt = 4 };
 
 struct DenseArrays {
     int kind;
-    void* covT;             // MatT [P][d][dpad]: transposed inverse mass matrix (P = chains for FullAdapt, else 1)
+    void* covT;             // MatT [P][sweep_rows(d)][dpad]: transposed inverse mass matrix (P = chains for FullAdapt, else 1)
     void* fac;              // Full*: float Cholesky factor L of cov, row-major lower [P][d8][dpad] (rows >= d identity);
                             // FullInv: double LT[j][i] = L[i][j] of the mass matrix A = L L^T, [d][dpad]
     long long mat_stride;   // elements between two chains' matrices (0 = shared)
@@ -23,6 +23,10 @@ struct DenseArrays {
     int* window;            // [C]
     int* chol_failed;       // [C]  number of refreshes whose factorisation failed (old factor kept)
 };
+
+// rows of a stored (transposed) inverse mass matrix: dim rounded up to two sweep batches, extra rows zero
+constexpr int kSweepBatch = 8;
+__host__ __device__ constexpr int sweep_rows(int d) { return (d + 2 * kSweepBatch - 1) / (2 * kSweepBatch) * (2 * kSweepBatch); }
 
 // per-chain HBM scratch row of the dense kernels: 2 trajectory ends x {q, p, g, v, w} + 6 vectors per subtree level
 constexpr int dense_scratch_vectors(int max_levels) { return 10 + 6 * max_levels; }

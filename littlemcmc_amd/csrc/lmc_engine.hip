@@ -630,16 +630,17 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         D.kind = cfg->potential;
         const bool per_chain = cfg->potential == LMC_POT_FULL_ADAPT;
         const size_t P = per_chain ? C : 1;
-        D.mat_stride = per_chain ? static_cast<long long>(d * dp) : 0;
+        const size_t drows = sweep_rows(cfg->dim);
+        D.mat_stride = per_chain ? static_cast<long long>(drows * dp) : 0;
         D.fac_stride = per_chain ? static_cast<long long>(e->d8) * static_cast<long long>(dp) : 0;
         if (cfg->potential == LMC_POT_FULL_INV) {
             double *m = nullptr, *f = nullptr;
-            if ((rc = dev_alloc(e, &m, d * dp)) != LMC_OK) return bail(rc);
-            if ((rc = dev_alloc(e, &f, d * dp)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &m, drows * dp)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &f, drows * dp)) != LMC_OK) return bail(rc);
             D.covT = m; D.fac = f;
         } else {
             float *m = nullptr, *f = nullptr;
-            if ((rc = dev_alloc(e, &m, P * d * dp)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &m, P * drows * dp)) != LMC_OK) return bail(rc);
             if ((rc = dev_alloc(e, &f, P * e->d8 * dp)) != LMC_OK) return bail(rc);
             D.covT = m; D.fac = f;
         }
@@ -877,23 +878,24 @@ static int dense_state_xfer(lmc_engine* e, const lmc_dense_state* st, bool to_us
     std::vector<int> sel(C, 0);
     if (adapt) HIP_TRY(e, hipMemcpy(sel.data(), D.esel, C * sizeof(int), hipMemcpyDeviceToHost));
     if (to_user) {
-        if (st->cov && (rc = mat_to_user(st->cov, D.covT, d, inv, true)) != LMC_OK) return rc;
-        if (st->chol && (rc = mat_to_user(st->chol, D.fac, inv ? d : d8, inv, inv)) != LMC_OK) return rc;
+        const size_t drows = sweep_rows(e->cfg.dim);
+        if (st->cov && (rc = mat_to_user(st->cov, D.covT, drows, inv, true)) != LMC_OK) return rc;
+        if (st->chol && (rc = mat_to_user(st->chol, D.fac, inv ? drows : d8, inv, inv)) != LMC_OK) return rc;
     } else {
-        auto mat_from_user = [&](const float* user, float* dev, size_t rows, bool transpose) -> int {
+        auto mat_from_user = [&](const float* user, float* dev, size_t rows, bool transpose, bool identity_pad) -> int {
             std::vector<float> in(C * d * d), host(C * rows * dp, 0.0f);
             HIP_TRY(e, hipMemcpy(in.data(), user, in.size() * sizeof(float), hipMemcpyDefault));
             for (size_t c = 0; c < C; ++c) {
                 for (size_t i = 0; i < d; ++i)
                     for (size_t j = 0; j < d; ++j)
                         host[c * rows * dp + (transpose ? j * dp + i : i * dp + j)] = in[(c * d + i) * d + j];
-                for (size_t i = d; i < rows; ++i) host[c * rows * dp + i * dp + i] = 1.0f;
+                for (size_t i = d; identity_pad && i < rows; ++i) host[c * rows * dp + i * dp + i] = 1.0f;
             }
             HIP_TRY(e, hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
             return LMC_OK;
         };
-        if (st->cov && (rc = mat_from_user(st->cov, static_cast<float*>(D.covT), d, true)) != LMC_OK) return rc;
-        if (st->chol && (rc = mat_from_user(st->chol, static_cast<float*>(D.fac), d8, false)) != LMC_OK) return rc;
+        if (st->cov && (rc = mat_from_user(st->cov, static_cast<float*>(D.covT), sweep_rows(e->cfg.dim), true, false)) != LMC_OK) return rc;
+        if (st->chol && (rc = mat_from_user(st->chol, static_cast<float*>(D.fac), d8, false, true)) != LMC_OK) return rc;
     }
     if (!adapt) return LMC_OK;
     const size_t mplane = C * d * dp, plane = C * dp;
