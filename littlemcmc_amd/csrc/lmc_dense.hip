@@ -98,14 +98,12 @@ int dense_launch_momentum(int ns, hipStream_t stream, const ChainArrays& A, cons
 
 int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, double multiplier,
                        int update_window) {
-    const int lds = dense_adapt_lds_bytes(A.d);
-    if (lds > 64 * 1024) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_adapt_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (err != hipSuccess) return static_cast<int>(err);
-    }
+    const int lds = dense_adapt_lds_bytes(A.d, A.dpad);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(dense_adapt_kernel, dim3(A.chains), dim3(kAdaptThreads), lds, stream, A, D, multiplier, update_window);
+    if (dense_adapt_grid(A.d) == 16)
+        hipLaunchKernelGGL(dense_adapt_kernel<16>, dim3(A.chains), dim3(256), lds, stream, A, D, multiplier, update_window);
+    else
+        hipLaunchKernelGGL(dense_adapt_kernel<32>, dim3(A.chains), dim3(1024), lds, stream, A, D, multiplier, update_window);
     return static_cast<int>(hipGetLastError());
 }
 

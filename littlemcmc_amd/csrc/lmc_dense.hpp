@@ -621,39 +621,106 @@ __global__ __launch_bounds__(64) void dense_momentum_kernel(ChainArrays A, Dense
 }
 
 // ---- FullAdapt.update (quadpotential.py:528-552): one workgroup per chain -----------------------------------------
-// Both estimators take the new sample (Welford rank-1 updates of the d x d second moments, float64, in HBM); when
-// a refresh is due the foreground estimate becomes the float32 covariance, its lower triangle is staged in LDS
-// (packed by columns) and factorised there; the factor is written back row-major. A failed factorisation (pivot
-// <= 0 or a non-finite entry: scipy.linalg.cholesky raises) keeps the previous factor and is counted.
-constexpr int kAdaptThreads = 256;
-__device__ __forceinline__ int packed_col_start(int j, int d) { return j * d - (j * (j - 1)) / 2; }
-constexpr int dense_adapt_lds_bytes(int d) { return (d * (d + 1) / 2) * 4 + 4 * d * 8 + 16; }
+// Phase 1: both estimators take the new sample (Welford rank-1 updates of the d x d second moments, float64,
+// streamed through HBM); when a refresh is due the foreground estimate becomes the float32 covariance.
+// Phase 2 (refresh only): Cholesky of that covariance with the matrix held in REGISTERS. The workgroup is a
+// T x T grid of threads, thread (tx, ty) owns the entries (i, j) with i = tx (mod T), j = ty (mod T) -- up to
+// 8 x 8 of them -- for the whole factorisation. Step k: the threads that own column k (one wavefront; the pivot
+// reaches them by a lane shuffle) divide it by sqrt(pivot) and publish it in LDS; after ONE barrier every thread
+// reads its 8 + 8 multipliers and applies a_ij -= l_ik l_jk to the blocks that are still active. Same operation
+// order per entry as host_cholesky() in lmc_engine.hip. The factor goes back row-major through an LDS row buffer
+// (coalesced stores). A failed factorisation (pivot <= 0 or a non-finite entry: scipy.linalg.cholesky raises)
+// keeps the previous factor and is counted.
+constexpr int kCholLocals = 8;
+constexpr int dense_adapt_grid(int d) { return d <= 16 * kCholLocals ? 16 : 32; }   // T: 256 threads up to d = 128, else 1024
+constexpr int dense_adapt_lds_bytes(int d, int dpad) {
+    return 4 * d * 8 + 16 + 2 * (d + 4) * 4 + dense_adapt_grid(d) * dpad * 4;
+}
 
-__device__ inline bool cholesky_lds(float* a, int d, int tid) {   // packed-by-columns lower triangle, in place
-    const int tx = tid & 63, ty = tid >> 6;
-    for (int k = 0; k < d; ++k) {
-        __syncthreads();
-        float* ck = a + packed_col_start(k, d);   // column k: entries (k..d-1, k)
-        const float akk = ck[0];
-        if (!(akk > 0.0f) || !(akk < INFINITY)) return false;   // uniform: every thread reads the same word
-        const float lkk = sqrtf(akk);
-        __syncthreads();
-        for (int i = k + 1 + tid; i < d; i += kAdaptThreads) ck[i - k] = ck[i - k] / lkk;
-        if (tid == 0) ck[0] = lkk;
-        __syncthreads();
-        for (int j = k + 1 + ty; j < d; j += kAdaptThreads / 64) {
-            const float ljk = ck[j - k];
-            float* cj = a + packed_col_start(j, d);
-            for (int i = j + tx; i < d; i += 64) cj[i - j] = __builtin_fmaf(-ck[i - k], ljk, cj[i - j]);
+template <int T>
+__device__ inline bool cholesky_registers(const float* covT, float* fac, int d, int dpad, float* colbuf, float* rowbuf,
+                                          int tid) {
+    constexpr int R = kCholLocals;
+    const int tx = tid % T, ty = tid / T;
+    const int lane = tid & 63;
+    float a[R][R];
+#pragma unroll
+    for (int ai = 0; ai < R; ++ai)
+#pragma unroll
+        for (int bj = 0; bj < R; ++bj) {
+            const int i = tx + T * ai, j = ty + T * bj;
+            a[ai][bj] = (ai >= bj && i < d && j <= i) ? covT[static_cast<long long>(j) * dpad + i] : 0.0f;   // cov[i][j]
+        }
+    bool ok = true;
+#pragma unroll
+    for (int kb = 0; kb < R; ++kb) {
+        const int kr_end = ok ? ((d - kb * T) < T ? (d - kb * T) : T) : 0;   // uniform; <= 0 once past d or after a failure
+        for (int kr = 0; kr < kr_end; ++kr) {
+            const int k = kb * T + kr;
+            float* col = colbuf + (k & 1) * (d + 4);   // double buffered: one barrier per step
+            if (ty == kr) {   // owners of column k: T consecutive lanes of one wavefront, the pivot owner is lane-local
+                const int pivot_lane = (lane / T) * T + kr;           // the thread with tx == kr in this group
+                const float akk = __shfl(a[kb][kb], pivot_lane, 64);
+                const bool good = (akk > 0.0f) && (akk < INFINITY);
+                const float lkk = sqrtf(akk);
+#pragma unroll
+                for (int ai = kb; ai < R; ++ai) {
+                    const int i = tx + T * ai;
+                    if (i < d && i >= k) {
+                        const float v = (i == k) ? lkk : a[ai][kb] / lkk;
+                        a[ai][kb] = v;
+                        col[i] = v;
+                    }
+                }
+                if (tx == kr) col[d] = good ? 1.0f : 0.0f;
+            }
+            __syncthreads();
+            if (col[d] == 0.0f) { ok = false; break; }   // uniform
+            float li[R], lj[R];
+#pragma unroll
+            for (int ai = kb; ai < R; ++ai) {
+                const int i = tx + T * ai;
+                li[ai] = (i > k && i < d) ? col[i] : 0.0f;
+            }
+#pragma unroll
+            for (int bj = kb; bj < R; ++bj) {
+                const int j = ty + T * bj;
+                lj[bj] = (j > k && j < d) ? col[j] : 0.0f;
+            }
+#pragma unroll
+            for (int bj = kb; bj < R; ++bj)
+#pragma unroll
+                for (int ai = bj; ai < R; ++ai) {
+                    const int i = tx + T * ai, j = ty + T * bj;
+                    if (i >= j && j > k && i < d) a[ai][bj] = __builtin_fmaf(-li[ai], lj[bj], a[ai][bj]);
+                }
         }
     }
     __syncthreads();
+    if (!ok) return false;
+    // write back L row-major, T rows at a time through LDS
+#pragma unroll
+    for (int ai = 0; ai < R; ++ai) {
+        if (ai * T < d) {   // uniform
+#pragma unroll
+            for (int bj = 0; bj < R; ++bj) {
+                const int i = tx + T * ai, j = ty + T * bj;
+                if (j < dpad) rowbuf[tx * dpad + j] = (ai >= bj && j <= i && i < d) ? a[ai][bj] : 0.0f;
+            }
+            __syncthreads();
+            const int rows = (d - ai * T) < T ? (d - ai * T) : T;
+            for (int idx = tid; idx < rows * dpad; idx += T * T) fac[static_cast<long long>(ai * T) * dpad + idx] = rowbuf[idx];
+            __syncthreads();
+        }
+    }
     return true;
 }
 
-__global__ __launch_bounds__(kAdaptThreads) void dense_adapt_kernel(ChainArrays A, DenseArrays D, double multiplier,
-                                                                    int update_window) {
+template <int T>
+__global__ __launch_bounds__(T * T) void dense_adapt_kernel(ChainArrays A, DenseArrays D, double multiplier,
+                                                            int update_window) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int kThreads = T * T;
     const int c = blockIdx.x, tid = threadIdx.x;
     const int d = A.d, dpad = A.dpad;
     double* oldf = lds;            // [d] x - mean_before (foreground)
@@ -661,7 +728,8 @@ __global__ __launch_bounds__(kAdaptThreads) void dense_adapt_kernel(ChainArrays 
     double* oldb = lds + 2 * d;
     double* newb = lds + 3 * d;
     int* flag = reinterpret_cast<int*>(lds + 4 * d);
-    float* tri = reinterpret_cast<float*>(lds + 4 * d + 2);
+    float* colbuf = reinterpret_cast<float*>(lds + 4 * d + 2);
+    float* rowbuf = colbuf + 2 * (d + 4);
     const long long plane = static_cast<long long>(A.chains) * dpad;
     const long long mplane = static_cast<long long>(A.chains) * d * dpad;
     const int sel = D.esel[c];
@@ -677,7 +745,7 @@ __global__ __launch_bounds__(kAdaptThreads) void dense_adapt_kernel(ChainArrays 
     float* covT = static_cast<float*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
     float* fac = static_cast<float*>(D.fac) + static_cast<long long>(c) * D.fac_stride;
     if (tid == 0) *flag = 0;
-    for (int i = tid; i < d; i += kAdaptThreads) {   // quadpotential.py:594-599
+    for (int i = tid; i < d; i += kThreads) {   // quadpotential.py:594-599
         const double x = A.q[static_cast<long long>(c) * dpad + i];
         double m = meanf[i];
         double od = x - m;
@@ -695,7 +763,7 @@ __global__ __launch_bounds__(kAdaptThreads) void dense_adapt_kernel(ChainArrays 
     const double denom = nf - 1.0;
     bool bad = false;
     const int total = d * dpad;
-    for (int idx = tid; idx < total; idx += kAdaptThreads) {
+    for (int idx = tid; idx < total; idx += kThreads) {
         const int j = idx / dpad, i = idx - j * dpad;
         if (i >= d) continue;
         const double rf = rawf[idx] + 1.0 * newf[i] * oldf[j];   // raw_cov[i][j] += weight * new_i * old_j
@@ -705,28 +773,21 @@ __global__ __launch_bounds__(kAdaptThreads) void dense_adapt_kernel(ChainArrays 
             const float cv = static_cast<float>(rf / denom);   // np.divide(raw, n - 1, out=float32)
             covT[idx] = cv;
             bad |= !isfinite(cv);
-            if (i >= j) tri[packed_col_start(j, d) + i - j] = cv;   // cov[i][j], i >= j
         }
     }
     if (bad) *flag = 1;   // benign race: every writer stores 1
-    __syncthreads();
+    __threadfence_block();
+    __syncthreads();     // covT of this chain is complete and visible to the whole workgroup
     if (refresh) {
         bool ok = (*flag == 0);
-        if (ok) ok = cholesky_lds(tri, d, tid);
-        if (ok) {
-            for (int idx = tid; idx < total; idx += kAdaptThreads) {
-                const int i = idx / dpad, j = idx - i * dpad;   // row i of L
-                if (j < d) fac[idx] = (j <= i) ? tri[packed_col_start(j, d) + i - j] : 0.0f;
-            }
-        } else if (tid == 0) {
-            D.chol_failed[c] += 1;
-        }
+        if (ok) ok = cholesky_registers<T>(covT, fac, d, dpad, colbuf, rowbuf, tid);
+        if (!ok && tid == 0) D.chol_failed[c] += 1;
     }
     __syncthreads();
     const bool switch_window = delta >= window;   // quadpotential.py:547-552
     if (switch_window) {
-        for (int idx = tid; idx < total; idx += kAdaptThreads) rawf[idx] = 0.0;   // fresh background: eye * 0
-        for (int i = tid; i < d; i += kAdaptThreads) meanf[i] = 0.0;
+        for (int idx = tid; idx < total; idx += kThreads) rawf[idx] = 0.0;   // fresh background: eye * 0
+        for (int i = tid; i < d; i += kThreads) meanf[i] = 0.0;
     }
     if (tid == 0) {
         if (switch_window) {

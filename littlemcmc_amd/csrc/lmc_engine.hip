@@ -382,7 +382,7 @@ static int dense_fail(lmc_engine* e, int rc, const char* what) {
     return fail(e, LMC_ERR_HIP, "%s: %s", what, hipGetErrorString(static_cast<hipError_t>(rc)));
 }
 
-// In-place lower Cholesky, column by column with the operation order of the device kernel (cholesky_lds):
+// In-place lower Cholesky, column by column with the operation order of the device kernel (cholesky_registers in lmc_dense.hpp):
 // pivot sqrt, column divided by the pivot, trailing update with one fused multiply-add per entry.
 template <class T>
 static bool host_cholesky(std::vector<T>& a, int d) {   // a: [d][d] row-major, lower triangle in/out

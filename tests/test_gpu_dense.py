@@ -317,3 +317,79 @@ def test_dense_adaptation_learns_the_target_covariance():
     # a dense metric decorrelates the AR(1) target: shallower trees than the diagonal metric needs
     _, stats_diag = lmc.sample(tgt, d, draws=400, tune=600, chains=chains, random_seed=11)
     assert stats["tree_size"].mean() < 0.7 * stats_diag["tree_size"].mean()
+
+
+# ---------------------------------------------------------------------------------------------------
+# wider vectors (2 and 4 elements per thread, padded lanes): oracle chains generated on the fly
+# ---------------------------------------------------------------------------------------------------
+def _replay(ostep, dstep, start, seed, tune, draws, f32_born, label):
+    snaps, outs = _snapshots(ostep, start, seed, tune, draws)
+    tol = REPLAY_F32 if f32_born else REPLAY_F64
+    floor = DECISION if f32_born else 1e-9
+    checked = 0
+    for tune_flag in (True, False):
+        idx = [i for i, s in enumerate(snaps) if s["tune"] == tune_flag]
+        if not idx:
+            continue
+        eng = dstep._make_engine(len(idx))
+        try:
+            eng.set_position(np.stack([snaps[i]["q"] for i in idx]))
+            for c, i in enumerate(idx):
+                eng.set_rng_state(c, snaps[i]["rng"])
+            eng.set_chain_state({k: np.stack([np.asarray(snaps[i][k]) for i in idx]) for k in
+                                 ("log_step", "log_bar", "hbar", "da_count", "iter_count", "n_samples")})
+            if "cov" in snaps[idx[0]]:
+                eng.set_dense_state({k: np.stack([np.asarray(snaps[i][k]) for i in idx]) for k in
+                                     ("cov", "chol", "fore_mean", "fore_raw_cov", "fore_n", "back_mean", "back_raw_cov",
+                                      "back_n", "window", "previous_update")})
+            eng.reserve(1, keep_trace=True)
+            eng.run(1 if tune_flag else 0, 0, 1)
+            assert not eng.status().any()
+            q = eng.trace()[:, 0]
+            stats = {k: v[:, 0] for k, v in dstep._stats_from_engine(eng, 0, 1).items()}
+            dense_after = eng.get_dense_state(fields=("cov",)) if "cov" in snaps[idx[0]] else None
+            for c, i in enumerate(idx):
+                want, tag = outs[i], "%s iter %d" % (label, i)
+                if want["margin"] < floor:
+                    continue
+                for sname, val in want["stats"].items():
+                    got = stats[sname][c]
+                    if sname in INT_STATS:
+                        assert got == val, (tag, sname, got, val, want["margin"])
+                    else:
+                        assert np.isclose(got, val, rtol=tol, atol=tol * (1 + abs(want["stats"].get("energy", 0.0)))), (
+                            tag, sname, got, val)
+                np.testing.assert_allclose(q[c], want["q"], rtol=tol, atol=tol * (1 + np.abs(want["q"]).max()), err_msg=tag)
+                if dense_after is not None and i + 1 < len(snaps) and snaps[i + 1]["tune"] == tune_flag:
+                    cs = np.abs(snaps[i + 1]["cov"]).max()
+                    np.testing.assert_allclose(dense_after["cov"][c], snaps[i + 1]["cov"], rtol=0, atol=2 * tol * cs, err_msg=tag)
+                checked += 1
+        finally:
+            eng.close()
+    return checked
+
+
+@pytest.mark.parametrize("d,family", [(100, "ar1"), (130, "std_normal"), (200, "ar1"), (256, "std_normal")])
+def test_dense_adapt_wide_vectors(d, family):
+    of = otargets.make(family, d)
+    tgt = device_target(family, d, of.params())
+    seed = 900 + d
+    start, ostep = orc.init_nuts(of, d, init="jitter+adapt_full", seeds=[seed])
+    start_d, dstep = lmc.init_nuts(tgt, d, init="jitter+adapt_full", random_seed=[seed])
+    np.testing.assert_array_equal(start, start_d)
+    tune, draws = 14, 4
+    assert _replay(ostep, dstep, start, seed, tune, draws, True, "adapt_full d=%d" % d) >= tune + draws - 2
+
+
+@pytest.mark.parametrize("d,kind", [(130, "full"), (200, "inv"), (256, "full")])
+def test_dense_fixed_wide_vectors(d, kind):
+    rs = np.random.RandomState(d)
+    a = rs.randn(d, d) / np.sqrt(d)
+    mat = a @ a.T + 0.5 * np.eye(d)
+    of = otargets.make("ar1", d)
+    tgt = device_target("ar1", d, of.params())
+    ostep = orc.Step(of, d, kind="nuts", potential=orc.quad_potential(mat, kind == "full"))
+    dstep = lmc.NUTS(tgt, d, potential=_pot(kind, mat))
+    start = 0.1 * rs.randn(d)
+    n = _replay(ostep, dstep, start, 4242 + d, 10, 4, kind == "full", "%s d=%d" % (kind, d))
+    assert n >= 12
