@@ -58,10 +58,17 @@ namespace lmc {
 int dense_launch_run(int family, int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
                      const SamplerParams& P, const double* tparams) {
     const dim3 grid(A.chains), block(64);
-    const int lds = dense_lds_doubles(A.dpad) * 8;
+    const int lds = dense_lds_doubles(A.dpad) * 8 + D.cache_rows * A.dpad * (mat_f64 ? 8 : 4);
     (void)hipGetLastError();
 #define RUN_CALL(T) \
-    DENSE_SHAPE_SWITCH(ns, mat_f64, hipLaunchKernelGGL((run_dense_kernel<NS, MatT, T>), grid, block, lds, stream, A, D, P, tparams))
+    DENSE_SHAPE_SWITCH(ns, mat_f64, {                                                                               \
+        if (lds > 64 * 1024) {                                                                                      \
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&run_dense_kernel<NS, MatT, T>),     \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);                  \
+            if (err != hipSuccess) return static_cast<int>(err);                                                    \
+        }                                                                                                           \
+        hipLaunchKernelGGL((run_dense_kernel<NS, MatT, T>), grid, block, lds, stream, A, D, P, tparams);            \
+    })
     DENSE_FAMILY_SWITCH(family, RUN_CALL)
 #undef RUN_CALL
     return static_cast<int>(hipGetLastError());

@@ -34,24 +34,39 @@ template <int N, class P> __device__ __forceinline__ auto pack_get(const P& p, i
     if constexpr (N == 1) return p; else return p[s];
 }
 
+// ---- the matrix as a wave sees it -----------------------------------------------------------------------------
+// The leading `cache_rows` rows of the chain's matrix are copied to LDS once per launch (the matrix is constant
+// while a launch runs; FullAdapt refreshes it between launches): that share of every sweep costs no HBM / L2
+// traffic, and the loads of the remaining rows are already in flight while the cached rows are consumed. Each
+// lane copies and later reads only its own columns, so the copy needs no barrier.
+template <class MatT>
+struct DenseMat {
+    const MatT* glb;                                            // [sweep_rows(d)][dpad]
+    __attribute__((address_space(3))) const MatT* cache;        // [cache_rows][dpad] in LDS
+    int cache_rows;                                             // multiple of kSweepBatch, <= sweep_rows(d) - 2 * kSweepBatch or == sweep_rows(d)
+    int d, dpad;
+};
+
 // ---- one sweep over the transposed matrix: acc[v][s] = sum_j M[j][lane*NS+s] * x[j][v] --------------------------
 // x: LDS, NV operands interleaved per row index. float64 fused multiply-adds on the promoted matrix entries
 // (numpy promotes the float32 matrix and calls dgemv; only the summation order differs).
 template <int NS, int NV, class MatT>
-__device__ __forceinline__ void dense_sweep(const MatT* __restrict__ M, int d, int dpad, const lds_double* x,
-                                            double (&acc)[NV][NS]) {
+__device__ __forceinline__ void dense_sweep(const DenseMat<MatT>& mm, const lds_double* x, double (&acc)[NV][NS]) {
     typedef __attribute__((address_space(1))) const Pack<MatT, NS> glb_pack;
-    glb_pack* col = (glb_pack*)(M + lane_id() * NS);
-    const int stride = dpad / NS;   // in packs
+    typedef __attribute__((address_space(3))) const Pack<MatT, NS> lds_pack;
+    glb_pack* col = (glb_pack*)(mm.glb + lane_id() * NS);
+    lds_pack* ccol = (lds_pack*)(mm.cache + lane_id() * NS);
+    const int stride = mm.dpad / NS;   // in packs
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc[v][s] = 0.0;
     // Software pipeline, two batches of kSweepBatch rows: the loads of one batch are in flight while the other is
     // consumed, so a wave always has 8..16 row loads outstanding (the sweep is latency / bandwidth bound, not ALU
-    // bound). The matrix has kSweepRows(d) rows, the extra ones zero, and the operand area is zero beyond d.
+    // bound). The matrix has sweep_rows(d) rows, the extra ones zero, and the operand area is zero beyond d.
     constexpr int B = kSweepBatch;
-    const int rows = sweep_rows(d);
+    const int rows = sweep_rows(mm.d);
+    const int first = mm.cache_rows;
     Pack<MatT, NS> m0[B], m1[B];
     auto fetch = [&](Pack<MatT, NS> (&m)[B], int jb) {
 #pragma unroll
@@ -68,8 +83,14 @@ __device__ __forceinline__ void dense_sweep(const MatT* __restrict__ M, int d, i
                     acc[v][s] = __builtin_fma(static_cast<double>(pack_get<NS>(m[b], s)), xj, acc[v][s]);
             }
     };
-    fetch(m0, 0);
-    for (int jb = 0; jb < rows; jb += 2 * B) {
+    if (first < rows) fetch(m0, first);
+    for (int jb = 0; jb < first; jb += B) {   // LDS-resident rows
+        Pack<MatT, NS> c[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) c[b] = ccol[(jb + b) * stride];
+        consume(c, jb);
+    }
+    for (int jb = first; jb < rows; jb += 2 * B) {
         fetch(m1, jb + B);
         consume(m0, jb);
         if (jb + 2 * B < rows) fetch(m0, jb + 2 * B);
@@ -92,11 +113,11 @@ __device__ __forceinline__ void stage2(lds_double* x, const double (&a)[NS], con
 
 // v = C p and w = C g in one sweep
 template <int NS, class MatT>
-__device__ __forceinline__ void velocity2(const MatT* M, int d, int dpad, lds_double* xop, const double (&p)[NS],
+__device__ __forceinline__ void velocity2(const DenseMat<MatT>& mm, lds_double* xop, const double (&p)[NS],
                                           const double (&g)[NS], double (&v)[NS], double (&w)[NS]) {
     stage2<NS>(xop, p, g);
     double acc[2][NS];
-    dense_sweep<NS, 2, MatT>(M, d, dpad, xop, acc);
+    dense_sweep<NS, 2, MatT>(mm, xop, acc);
     vcopy(v, acc[0]);
     vcopy(w, acc[1]);
 }
@@ -159,10 +180,14 @@ __device__ inline void dense_momentum_full(const float* __restrict__ L, int d, i
 
 // quadpotential.py:411-414: p = L n in float64 (LT rows = columns of L)
 template <int NS>
-__device__ inline void dense_momentum_inv(const double* __restrict__ LT, int d, int dpad, const lds_double* z,
+__device__ inline void dense_momentum_inv(const double* __restrict__ LT, int d, int dpad, lds_double* z,
                                           double (&p0)[NS]) {
+    // the sweep runs over sweep_rows(d) rows (the extra matrix rows are zero): give it finite operands there
+    for (int e = d + lane_id(); e < sweep_rows(d); e += 64) z[e] = 0.0;
+    wave_sync();
     double acc[1][NS];
-    dense_sweep<NS, 1, double>(LT, d, dpad, z, acc);
+    DenseMat<double> mm{LT, nullptr, 0, d, dpad};
+    dense_sweep<NS, 1, double>(mm, z, acc);
     vcopy(p0, acc[0]);
 }
 
@@ -171,10 +196,11 @@ __device__ inline void dense_momentum_inv(const double* __restrict__ LT, int d, 
 // start State (float32 for the float32-momentum potentials: numpy's sgemv; we round the float64 sweep once, which
 // differs from sgemv's float32 accumulation by a few float32 ulps), e0.
 template <int NS, class MatT>
-__device__ inline double dense_start_state(Team<1>& tm, const MatT* M, int d, int dpad, double* lds, bool momentum_f32,
+__device__ inline double dense_start_state(Team<1>& tm, const DenseMat<MatT>& mm, double* lds, bool momentum_f32,
                                            int sdot_mode, const double (&p0)[NS], const double (&g0)[NS], double logp0,
                                            double (&v0)[NS], double (&w0)[NS], double (&v0s)[NS]) {
-    velocity2<NS, MatT>(M, d, dpad, (lds_double*)lds, p0, g0, v0, w0);
+    const int d = mm.d, dpad = mm.dpad;
+    velocity2<NS, MatT>(mm, (lds_double*)lds, p0, g0, v0, w0);
     if (!momentum_f32) {
         vcopy(v0s, v0);
         return first_f64(0.5 * tm.sum(pdot<NS>(p0, v0)) - logp0);
@@ -211,7 +237,7 @@ __device__ inline double dense_start_state(Team<1>& tm, const MatT* M, int d, in
 // ---- leapfrog (integration.py:100-121) with a dense mass matrix -----------------------------------------------
 // State in/out: q, p, g, v = C p, w = C g.
 template <int NS, class MatT, class Target>
-__device__ __forceinline__ void dense_leapfrog(Team<1>& tm, const Target& tgt, const MatT* M, int d, int dpad,
+__device__ __forceinline__ void dense_leapfrog(Team<1>& tm, const Target& tgt, const DenseMat<MatT>& mm,
                                                lds_double* xop, double eps, double (&q)[NS], double (&p)[NS],
                                                double (&g)[NS], double (&v)[NS], double (&w)[NS], double& energy,
                                                double& logp) {
@@ -225,7 +251,7 @@ __device__ __forceinline__ void dense_leapfrog(Team<1>& tm, const Target& tgt, c
     logp = first_f64(tgt.logp_grad(tm, q, g));
 #pragma unroll
     for (int s = 0; s < NS; ++s) p[s] = p[s] + dt * g[s];
-    velocity2<NS, MatT>(M, d, dpad, xop, p, g, v, w);
+    velocity2<NS, MatT>(mm, xop, p, g, v, w);
     energy = first_f64(0.5 * tm.sum(pdot<NS>(p, v)) - logp);
 }
 
@@ -241,7 +267,7 @@ struct DenseScratch {
 
 // ---- NUTS transition: the tree of lmc_sampler.hpp with stored velocities -------------------------------------------
 template <int NS, class MatT, class Target>
-__device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, const MatT* M, int d, int dpad,
+__device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, const DenseMat<MatT>& mm,
                                              lds_double* xop, RngState& rng, const DenseScratch& scr, double (&q)[NS],
                                              const double (&p0)[NS], const double (&g0)[NS], const double (&v0)[NS],
                                              const double (&w0)[NS], const double (&v0s)[NS], double e0, double logp0,
@@ -276,7 +302,7 @@ __device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, con
         const int n_leaves = 1 << depth;
         for (int i = 0; i < n_leaves; ++i) {
             double energy, logp;
-            dense_leapfrog<NS, MatT>(tm, tgt, M, d, dpad, xop, eps, cq, cp, cg, cv, cw, energy, logp);
+            dense_leapfrog<NS, MatT>(tm, tgt, mm, xop, eps, cq, cp, cg, cv, cw, energy, logp);
             ++n_leap;
             double de = first_f64(energy - e0);
             if (isnan(de)) de = INFINITY;
@@ -390,7 +416,7 @@ __device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, con
 
 // ---- HMC transition (hmc.py:140-182) ---------------------------------------------------------------------------
 template <int NS, class MatT, class Target>
-__device__ inline void dense_hmc_transition(Team<1>& tm, const Target& tgt, const MatT* M, int d, int dpad,
+__device__ inline void dense_hmc_transition(Team<1>& tm, const Target& tgt, const DenseMat<MatT>& mm,
                                             lds_double* xop, RngState& rng, double (&q)[NS], const double (&p0)[NS],
                                             const double (&g0)[NS], const double (&v0)[NS], const double (&w0)[NS],
                                             double e0, double logp0, double step_size, double emax, double path_length,
@@ -405,7 +431,7 @@ __device__ inline void dense_hmc_transition(Team<1>& tm, const Target& tgt, cons
     vcopy(cq, q); vcopy(cp, p0); vcopy(cg, g0); vcopy(cv, v0); vcopy(cw, w0);
     double energy = e0, logp = logp0;
     for (int i = 0; i < n_steps; ++i)
-        dense_leapfrog<NS, MatT>(tm, tgt, M, d, dpad, xop, step_size, cq, cp, cg, cv, cw, energy, logp);
+        dense_leapfrog<NS, MatT>(tm, tgt, mm, xop, step_size, cq, cp, cg, cv, cw, energy, logp);
     bool diverging = !isfinite(energy);
     double de = first_f64(e0 - energy);
     if (isnan(de)) de = -INFINITY;
@@ -432,15 +458,6 @@ __device__ inline void dense_hmc_transition(Team<1>& tm, const Target& tgt, cons
 // ---- the iteration kernel ----------------------------------------------------------------------------------------
 // LDS: [0, 2*dpad) doubles = sweep operands / normal(size=d) + its staging / float32 sdot staging; then the chain's
 // MT19937 state for the duration of the launch.
-constexpr int dense_lds_doubles(int dpad) { return 2 * dpad + kLdsMtDoubles; }
-
-#ifndef LMC_DENSE_WAVES_NS2
-#define LMC_DENSE_WAVES_NS2 2
-#endif
-#ifndef LMC_DENSE_WAVES_NS4
-#define LMC_DENSE_WAVES_NS4 2
-#endif
-constexpr int dense_waves_per_simd(int ns) { return ns <= 2 ? LMC_DENSE_WAVES_NS2 : LMC_DENSE_WAVES_NS4; }
 
 template <int NS, class MatT, template <int> class TargetT>
 __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel(ChainArrays A, DenseArrays D, SamplerParams P, const double* tparams) {
@@ -456,6 +473,12 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel
     tgt.init(tm, tparams, d);
     const MatT* M = static_cast<const MatT*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
     lds_double* xop = (lds_double*)lds;
+    MatT* mcache = reinterpret_cast<MatT*>(lds + dense_lds_doubles(dpad));
+    for (int j = 0; j < D.cache_rows; ++j) {   // every lane copies (and later reads) its own columns only
+#pragma unroll
+        for (int s = 0; s < NS; ++s) mcache[j * dpad + tid * NS + s] = M[static_cast<long long>(j) * dpad + tid * NS + s];
+    }
+    DenseMat<MatT> mm{M, (__attribute__((address_space(3))) const MatT*)mcache, D.cache_rows, d, dpad};
 
     double q[NS];
     vload<NS>(A.q + row, q);
@@ -493,7 +516,7 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel
         // ---- start state
         double g0[NS], v0[NS], w0[NS], v0s[NS];
         const double logp0 = first_f64(tgt.logp_grad(tm, q, g0));
-        const double e0 = dense_start_state<NS, MatT>(tm, M, d, dpad, lds, momentum_f32, P.sdot_mode, p0, g0, logp0, v0, w0, v0s);
+        const double e0 = dense_start_state<NS, MatT>(tm, mm, lds, momentum_f32, P.sdot_mode, p0, g0, logp0, v0, w0, v0s);
         if (!isfinite(e0)) {   // base_hmc.py:145-148
             status |= kStatusBadInitialEnergy;
             break;
@@ -504,11 +527,11 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel
         TransitionOut out;
         if (P.kind == 0) {
             const int md = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
-            dense_nuts_transition<NS, MatT>(tm, tgt, M, d, dpad, xop, rng, scr, q, p0, g0, v0, w0, v0s, e0, logp0,
+            dense_nuts_transition<NS, MatT>(tm, tgt, mm, xop, rng, scr, q, p0, g0, v0, w0, v0s, e0, logp0,
                                             step_size, P.emax, md, momentum_f32, out);
             if (out.exhausted && !tune) ++ct_maxdepth;
         } else {
-            dense_hmc_transition<NS, MatT>(tm, tgt, M, d, dpad, xop, rng, q, p0, g0, v0, w0, e0, logp0, step_size,
+            dense_hmc_transition<NS, MatT>(tm, tgt, mm, xop, rng, q, p0, g0, v0, w0, e0, logp0, step_size,
                                            P.emax, P.path_length, P.max_steps, out);
         }
         ct_leap += out.n_leapfrog;
@@ -556,6 +579,7 @@ __global__ __launch_bounds__(64) void dense_trajectory_kernel(ChainArrays A, Den
     TargetT<NS> tgt;
     tgt.init(tm, tparams, d);
     const MatT* M = static_cast<const MatT*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
+    DenseMat<MatT> mm{M, nullptr, 0, d, dpad};
     double q[NS], p[NS], g[NS], v[NS], w[NS], vs[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -566,10 +590,10 @@ __global__ __launch_bounds__(64) void dense_trajectory_kernel(ChainArrays A, Den
     }
     const int n_states = n_fwd + n_back + 1;
     double logp = first_f64(tgt.logp_grad(tm, q, g));
-    double energy = dense_start_state<NS, MatT>(tm, M, d, dpad, lds, p0_is_f32 != 0, sdot_mode, p, g, logp, v, w, vs);
+    double energy = dense_start_state<NS, MatT>(tm, mm, lds, p0_is_f32 != 0, sdot_mode, p, g, logp, v, w, vs);
     for (int k = 0; k < n_states; ++k) {
         if (k > 0) {
-            dense_leapfrog<NS, MatT>(tm, tgt, M, d, dpad, (lds_double*)lds, (k <= n_fwd) ? eps : -eps, q, p, g, v, w, energy, logp);
+            dense_leapfrog<NS, MatT>(tm, tgt, mm, (lds_double*)lds, (k <= n_fwd) ? eps : -eps, q, p, g, v, w, energy, logp);
             vcopy(vs, v);
         }
         const long long base = (static_cast<long long>(c) * n_states + k) * d;

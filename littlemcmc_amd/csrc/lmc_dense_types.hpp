@@ -14,6 +14,7 @@ struct DenseArrays {
                             // FullInv: double LT[j][i] = L[i][j] of the mass matrix A = L L^T, [d][dpad]
     long long mat_stride;   // elements between two chains' matrices (0 = shared)
     long long fac_stride;
+    int cache_rows;         // leading rows of covT every wave keeps in LDS during a launch (host-chosen, lmc_engine.hip)
     // FullAdapt estimators (slot esel[c] = foreground)
     double* rawT;           // [2][C][d][dpad]   rawT[j][i] = raw_cov[i][j]
     double* emean;          // [2][C][dpad]
@@ -27,6 +28,16 @@ struct DenseArrays {
 // rows of a stored (transposed) inverse mass matrix: dim rounded up to two sweep batches, extra rows zero
 constexpr int kSweepBatch = 8;
 __host__ __device__ constexpr int sweep_rows(int d) { return (d + 2 * kSweepBatch - 1) / (2 * kSweepBatch) * (2 * kSweepBatch); }
+
+// occupancy target of run_dense_kernel (waves per SIMD; register budget 512 / waves) and its fixed LDS carve
+#ifndef LMC_DENSE_WAVES_NS2
+#define LMC_DENSE_WAVES_NS2 2
+#endif
+#ifndef LMC_DENSE_WAVES_NS4
+#define LMC_DENSE_WAVES_NS4 2
+#endif
+constexpr int dense_waves_per_simd(int ns) { return ns <= 2 ? LMC_DENSE_WAVES_NS2 : LMC_DENSE_WAVES_NS4; }
+constexpr int dense_lds_doubles(int dpad) { return 2 * dpad + kLdsMtDoubles; }   // sweep operands / normals, MT19937 state
 
 // per-chain HBM scratch row of the dense kernels: 2 trajectory ends x {q, p, g, v, w} + 6 vectors per subtree level
 constexpr int dense_scratch_vectors(int max_levels) { return 10 + 6 * max_levels; }

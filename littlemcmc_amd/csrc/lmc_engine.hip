@@ -414,6 +414,19 @@ static int dense_run(lmc_engine* e, SamplerParams P) {
     P.momentum_f32 = e->cfg.potential != LMC_POT_FULL_INV;   // quadpotential.py:452 (float32) vs :413 (float64)
     P.adapt_mass = 0;
     const bool mat_f64 = e->cfg.potential == LMC_POT_FULL_INV;
+    {   // leading matrix rows each wave keeps in LDS (160 KiB per CU, allocation granule 1280 B):
+        // measured at d = 128 (65 536 B matrix per chain): 0 / 16 / 32 / 48 / 64 / 96 / 128 cached rows give
+        // 7.6 / 8.2 / 9.1 / 10.6 / 10.4 / 9.1 / 6.6 e7 leapfrog-steps/s -- trading waves per CU (8 -> 5) for HBM
+        // bytes pays until about 5 workgroups per CU are left
+        const int blocks_per_cu = 5;
+        const long budget = (163840L / blocks_per_cu) / 1280 * 1280 - dense_lds_doubles(e->dpad) * 8L;
+        const long row_bytes = static_cast<long>(e->dpad) * (mat_f64 ? 8 : 4);
+        long rows = budget > 0 ? budget / row_bytes : 0;
+        if (const char* env = std::getenv("LMC_DENSE_CACHE_ROWS")) rows = std::atol(env);
+        rows = rows / (2 * kSweepBatch) * (2 * kSweepBatch);
+        if (rows > sweep_rows(e->cfg.dim)) rows = sweep_rows(e->cfg.dim);
+        e->D.cache_rows = static_cast<int>(rows < 0 ? 0 : rows);
+    }
     const long long end = P.iter_begin + P.n_iters;
     long long it = P.iter_begin;
     while (it < end) {
