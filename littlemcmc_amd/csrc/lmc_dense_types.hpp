@@ -29,12 +29,14 @@ struct DenseArrays {
 constexpr int kSweepBatch = 8;
 __host__ __device__ constexpr int sweep_rows(int d) { return (d + 2 * kSweepBatch - 1) / (2 * kSweepBatch) * (2 * kSweepBatch); }
 
-// occupancy target of run_dense_kernel (waves per SIMD; register budget 512 / waves) and its fixed LDS carve
+// occupancy target of run_dense_kernel (waves per SIMD; register budget 512 / waves) and its fixed LDS carve.
+// Measured: forcing more waves than the live state allows costs more in scratch spills than it gains in latency
+// hiding (d = 128: 2 / 3 / 4 waves -> 6.6 / 6.2 / 5.7 e7 leapfrog-steps/s; d = 256: 1 / 2 waves -> 2.2 / 1.6 e7).
 #ifndef LMC_DENSE_WAVES_NS2
 #define LMC_DENSE_WAVES_NS2 2
 #endif
 #ifndef LMC_DENSE_WAVES_NS4
-#define LMC_DENSE_WAVES_NS4 2
+#define LMC_DENSE_WAVES_NS4 1
 #endif
 constexpr int dense_waves_per_simd(int ns) { return ns <= 2 ? LMC_DENSE_WAVES_NS2 : LMC_DENSE_WAVES_NS4; }
 constexpr int dense_lds_doubles(int dpad) { return 2 * dpad + kLdsMtDoubles; }   // sweep operands / normals, MT19937 state

@@ -417,8 +417,11 @@ static int dense_run(lmc_engine* e, SamplerParams P) {
     {   // leading matrix rows each wave keeps in LDS (160 KiB per CU, allocation granule 1280 B):
         // measured at d = 128 (65 536 B matrix per chain): 0 / 16 / 32 / 48 / 64 / 96 / 128 cached rows give
         // 7.6 / 8.2 / 9.1 / 10.6 / 10.4 / 9.1 / 6.6 e7 leapfrog-steps/s -- trading waves per CU (8 -> 5) for HBM
-        // bytes pays until about 5 workgroups per CU are left
-        const int blocks_per_cu = 5;
+        // bytes pays until about 5 workgroups per CU
+        // are left. A matrix shared by all chains is L2 resident and its kernel VALU bound: there only the LDS
+        // that costs no occupancy is used (5 workgroups per CU measured 1.36e8 against 1.75e8).
+        const int by_regs = 4 * dense_waves_per_simd(e->ns);
+        const int blocks_per_cu = (e->cfg.potential == LMC_POT_FULL_ADAPT && by_regs > 5) ? 5 : by_regs;
         const long budget = (163840L / blocks_per_cu) / 1280 * 1280 - dense_lds_doubles(e->dpad) * 8L;
         const long row_bytes = static_cast<long>(e->dpad) * (mat_f64 ? 8 : 4);
         long rows = budget > 0 ? budget / row_bytes : 0;
