@@ -56,6 +56,9 @@ extern "C" {
 #define LMC_TARGET_FUNNEL 3
 #define LMC_TARGET_NORMAL1D 4        /* params: {loc, scale}; dim must be 1 */
 #define LMC_TARGET_USER 5
+/* no device functor: the caller evaluates logp_dlogp_func for all chains between two lmc_engine_tick() calls
+ * (a batched callable on device memory, e.g. torch-ROCm); dim <= 256, diagonal mass matrices */
+#define LMC_TARGET_EXTERNAL 6
 
 /* Summation order of the float32 kinetic energy of the start state, 0.5f * sdot(p, v)
  * (integration.py:63-64 with float32 operands -> numpy -> OpenBLAS cblas_sdot). The value feeds the
@@ -251,6 +254,19 @@ int lmc_engine_get_dense_chain(lmc_engine* e, int32_t chain, float* cov, float* 
 /* Test entry: potential.update(sample = current position, grad, tune) for every chain (quadpotential.py:528-552).
  * During lmc_engine_run() the same kernel runs after every tuning iteration. */
 int lmc_engine_dense_update(lmc_engine* e, int32_t tune);
+
+/* ---- externally evaluated density (cfg.target_family = LMC_TARGET_EXTERNAL): the iteration loop of
+ * sampling.py:507-521 / base_hmc.py:140-190 cut at the two places the reference calls logp_dlogp_func
+ * (integration.py:62 compute_state, :115 _step). Protocol:
+ *     lmc_engine_reserve(); lmc_engine_tick_begin(n_tune, iter_begin, n_iters);
+ *     do { evaluate (logp[chains], grad[chains][dim]) at lmc_engine_tick_positions() [chains][dim];
+ *          lmc_engine_tick(logp, grad, &n_active); } while (n_active > 0);
+ * All three arrays are DEVICE memory. Every tick advances every unfinished chain by exactly one density
+ * evaluation, whatever iteration or tree depth it is in; finished chains ignore their inputs. Passing
+ * n_active = NULL skips the host synchronisation (poll every few ticks instead). */
+int lmc_engine_tick_begin(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters);
+void* lmc_engine_tick_positions(lmc_engine* e);
+int lmc_engine_tick(lmc_engine* e, const double* logp, const double* grad, int32_t* n_active);
 
 /* Running per-chain moments of the post-warm-up draws, kept on the device so that cross-chain R-hat needs no
  * trace (the only quantities the multi-GPU gather moves): mean [chains][dim], m2 = sum of squared

@@ -16,7 +16,7 @@ OK = 0
 
 KIND_NUTS, KIND_HMC = 0, 1
 POT_DIAG_ADAPT, POT_DIAG, POT_FULL, POT_FULL_INV, POT_FULL_ADAPT = range(5)
-TARGET_STD_NORMAL, TARGET_DIAG_GAUSSIAN, TARGET_AR1, TARGET_FUNNEL, TARGET_NORMAL1D, TARGET_USER = range(6)
+TARGET_STD_NORMAL, TARGET_DIAG_GAUSSIAN, TARGET_AR1, TARGET_FUNNEL, TARGET_NORMAL1D, TARGET_USER, TARGET_EXTERNAL = range(7)
 STATUS_BAD_INITIAL_ENERGY, STATUS_NAN_LOGBERN = 1, 2
 SDOT_NATIVE, SDOT_OPENBLAS_SKYLAKEX, SDOT_OPENBLAS_HASWELL = 0, 1, 2
 (STAT_STEP_SIZE, STAT_STEP_SIZE_BAR, STAT_ACCEPT, STAT_ENERGY_ERROR, STAT_ENERGY, STAT_MAX_ENERGY_ERROR,
@@ -83,6 +83,9 @@ _SIGNATURES = {
     "lmc_engine_get_dense_state": (C.c_int, [_P, C.POINTER(DenseState)]),
     "lmc_engine_set_dense_state": (C.c_int, [_P, C.POINTER(DenseState)]),
     "lmc_engine_dense_update": (C.c_int, [_P, C.c_int32]),
+    "lmc_engine_tick_begin": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32]),
+    "lmc_engine_tick_positions": (_P, [_P]),
+    "lmc_engine_tick": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int32)]),
     "lmc_engine_get_dense_chain": (C.c_int, [_P, C.c_int32, _P, _P]),
     "lmc_engine_seed": (C.c_int, [_P, _P]),
     "lmc_engine_set_rng_state": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_double]),

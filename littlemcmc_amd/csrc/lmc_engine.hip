@@ -16,6 +16,7 @@
 #include "../../include/lmc_hip.h"
 #include "lmc_sampler.hpp"
 #include "lmc_dense_launch.hpp"
+#include "lmc_tick_launch.hpp"
 #ifdef LMC_USER_TARGET_HEADER
 #include LMC_USER_TARGET_HEADER
 #endif
@@ -288,6 +289,9 @@ struct lmc_engine {
     double* mean1 = nullptr;
     double dense_weight = 1.0, dense_multiplier = 2.0;
     int dense_window = 101, dense_update_window = 1;
+    // externally evaluated density (cfg.target_family == LMC_TARGET_EXTERNAL): tick state
+    TickArrays K;
+    bool ticking = false;
     std::vector<void*> allocs;
     std::string err;
 };
@@ -469,6 +473,7 @@ int32_t lmc_has_target(int32_t family) {
 #ifdef LMC_USER_TARGET_HEADER
     if (family == LMC_TARGET_USER) return 1;
 #endif
+    if (family == LMC_TARGET_EXTERNAL) return 1;   // no device functor: the host evaluates the density between ticks
     return 0;
 }
 
@@ -527,6 +532,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         return fail(nullptr, LMC_ERR_INVALID, "unknown potential %d", cfg->potential);
     if (cfg->potential >= LMC_POT_FULL && cfg->dim > 256)
         return fail(nullptr, LMC_ERR_INVALID, "dense mass matrices are supported up to dim 256 (got %d)", cfg->dim);
+    if (cfg->target_family == LMC_TARGET_EXTERNAL && (cfg->dim > 256 || cfg->potential >= LMC_POT_FULL))
+        return fail(nullptr, LMC_ERR_INVALID, "an externally evaluated density supports dim <= 256 and diagonal mass matrices");
     if (!lmc_has_target(cfg->target_family))
         return fail(nullptr, LMC_ERR_INVALID, "target family %d is not built into this library", cfg->target_family);
     if (cfg->target_family == LMC_TARGET_NORMAL1D && cfg->dim != 1)
@@ -619,6 +626,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     A.scratch_stride = static_cast<long long>(max_levels - nlds + 1) * 4 * dp;
     const bool dense = cfg->potential >= LMC_POT_FULL;
     if (dense) A.scratch_stride = static_cast<long long>(dense_scratch_vectors(max_levels)) * dp;
+    const bool external = cfg->target_family == LMC_TARGET_EXTERNAL;
+    if (external) A.scratch_stride = static_cast<long long>(tick_scratch_vectors(max_levels)) * dp;
     TRY_ALLOC(dev_alloc(e, &A.scratch, C * static_cast<size_t>(A.scratch_stride), false));
     TRY_ALLOC(dev_alloc(e, &e->init_mean, C * dp));
     TRY_ALLOC(dev_alloc(e, &e->init_diag, C * dp));
@@ -638,6 +647,17 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         A.da_table_len = len;
     }
 #undef TRY_ALLOC
+    std::memset(&e->K, 0, sizeof(e->K));
+    if (external) {
+        TickArrays& K = e->K;
+        if ((rc = dev_alloc(e, &K.phase, C)) != LMC_OK) return bail(rc);
+        if ((rc = dev_alloc(e, &K.git, C)) != LMC_OK) return bail(rc);
+        if ((rc = dev_alloc(e, &K.ti, C * kNumTickInt)) != LMC_OK) return bail(rc);
+        if ((rc = dev_alloc(e, &K.td, C * kNumTickDbl)) != LMC_OK) return bail(rc);
+        if ((rc = dev_alloc(e, &K.lvl, C * 4 * kTickLevels)) != LMC_OK) return bail(rc);
+        if ((rc = dev_alloc(e, &K.q_eval, C * static_cast<size_t>(cfg->dim))) != LMC_OK) return bail(rc);
+        if ((rc = dev_alloc(e, &K.n_active, 1)) != LMC_OK) return bail(rc);
+    }
     std::memset(&e->D, 0, sizeof(e->D));
     if (dense) {
         DenseArrays& D = e->D;
@@ -1141,14 +1161,7 @@ int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int64_t trace_begin) {
     return LMC_OK;
 }
 
-int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters) {
-    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
-    if (e->A.cap <= 0 || !e->A.stat_f64) return fail(e, LMC_ERR_STATE, "lmc_engine_reserve() must be called before run()");
-    if (iter_begin < 0 || n_iters < 0 || iter_begin + n_iters > e->A.cap)
-        return fail(e, LMC_ERR_INVALID, "iterations [%lld, %lld) exceed reserved capacity %lld", (long long)iter_begin,
-                    (long long)(iter_begin + n_iters), (long long)e->A.cap);
-    if (n_iters == 0) return LMC_OK;
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
+static SamplerParams make_params(const lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters) {
     SamplerParams P;
     std::memset(&P, 0, sizeof(P));
     P.kind = e->cfg.kind;
@@ -1171,6 +1184,20 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
     P.nlds = e->nlds;
     P.lds_doubles = e->lds_bytes / 8;
     P.sdot_mode = e->cfg.start_energy_sdot;
+    return P;
+}
+
+int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    if (e->A.cap <= 0 || !e->A.stat_f64) return fail(e, LMC_ERR_STATE, "lmc_engine_reserve() must be called before run()");
+    if (iter_begin < 0 || n_iters < 0 || iter_begin + n_iters > e->A.cap)
+        return fail(e, LMC_ERR_INVALID, "iterations [%lld, %lld) exceed reserved capacity %lld", (long long)iter_begin,
+                    (long long)(iter_begin + n_iters), (long long)e->A.cap);
+    if (n_iters == 0) return LMC_OK;
+    if (e->cfg.target_family == LMC_TARGET_EXTERNAL)
+        return fail(e, LMC_ERR_STATE, "the density is evaluated by the caller: drive the chains with lmc_engine_tick_begin() / lmc_engine_tick()");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    SamplerParams P = make_params(e, n_tune, iter_begin, n_iters);
     if (e->cfg.potential >= LMC_POT_FULL) return dense_run(e, P);
     const int run_lds = e->lds_bytes + lds_tail_doubles(e->run_w) * 8;   // subtree stack + MT19937 + team exchange
     const dim3 grid(e->cfg.chains), block(64 * e->run_w);
@@ -1195,6 +1222,41 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
 #undef RUN_CALL
 #undef RUN_ONE
     HIP_TRY(e, hipGetLastError());
+    return LMC_OK;
+}
+
+// ---- externally evaluated density: the resumable sampler (lmc_tick.hpp) -----------------------------------
+int lmc_engine_tick_begin(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    if (e->cfg.target_family != LMC_TARGET_EXTERNAL)
+        return fail(e, LMC_ERR_STATE, "lmc_engine_tick*() needs cfg.target_family = LMC_TARGET_EXTERNAL");
+    if (e->A.cap <= 0 || !e->A.stat_f64) return fail(e, LMC_ERR_STATE, "lmc_engine_reserve() must be called before tick_begin()");
+    if (iter_begin < 0 || n_iters < 0 || iter_begin + n_iters > e->A.cap)
+        return fail(e, LMC_ERR_INVALID, "iterations [%lld, %lld) exceed reserved capacity %lld", (long long)iter_begin,
+                    (long long)(iter_begin + n_iters), (long long)e->A.cap);
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    e->K.iter_end = iter_begin + n_iters;
+    e->K.n_tune = n_tune;
+    const int rc = tick_launch_begin(e->ns, e->stream, e->A, e->K, iter_begin);
+    if (rc != 0) return fail(e, LMC_ERR_HIP, "tick_begin: %s", rc < 0 ? "unsupported vector width" : hipGetErrorString(static_cast<hipError_t>(rc)));
+    e->ticking = true;
+    return LMC_OK;
+}
+
+void* lmc_engine_tick_positions(lmc_engine* e) { return e ? e->K.q_eval : nullptr; }
+
+int lmc_engine_tick(lmc_engine* e, const double* logp, const double* grad, int32_t* n_active) {
+    if (!e || !logp || !grad) return fail(e, LMC_ERR_INVALID, "null argument");
+    if (!e->ticking) return fail(e, LMC_ERR_STATE, "lmc_engine_tick_begin() must be called first");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const SamplerParams P = make_params(e, e->K.n_tune, 0, 0);
+    HIP_TRY(e, hipMemsetAsync(e->K.n_active, 0, sizeof(int), e->stream));
+    const int rc = tick_launch(e->ns, e->stream, e->A, e->K, P, logp, grad);
+    if (rc != 0) return fail(e, LMC_ERR_HIP, "tick: %s", rc < 0 ? "unsupported vector width" : hipGetErrorString(static_cast<hipError_t>(rc)));
+    if (n_active) {
+        HIP_TRY(e, hipMemcpyAsync(n_active, e->K.n_active, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+    }
     return LMC_OK;
 }
 

@@ -695,6 +695,61 @@ __device__ __forceinline__ void write_outputs(const ChainArrays& A, int c, int t
     }
 }
 
+// diagonal mass adaptation (quadpotential.py:231-245, :324-340): both Welford estimators take the draw, the
+// foreground one becomes the float32 variance, the window switches every P.window samples
+struct MassScalars { double wsum_f, wsum_b; int wsel, n_samples; };
+template <int NS>
+__device__ __forceinline__ void diag_mass_update(const ChainArrays& A, const SamplerParams& P, long long row, int tid,
+                                                 const double (&q)[NS], float (&var)[NS], float (&inv_std)[NS],
+                                                 double (&vard)[NS], MassScalars& ms) {
+    const int d = A.d;
+    const long long plane = static_cast<long long>(A.chains) * A.dpad;
+    double* fm = A.wmean + ms.wsel * plane + row;
+    double* fr = A.wraw + ms.wsel * plane + row;
+    double* bm = A.wmean + (1 - ms.wsel) * plane + row;
+    double* br = A.wraw + (1 - ms.wsel) * plane + row;
+    ms.wsum_f += 1.0;
+    ms.wsum_b += 1.0;
+    const double prop_f = first_f64(1.0 / ms.wsum_f), prop_b = first_f64(1.0 / ms.wsum_b);
+    double m[NS], r[NS];
+    vload<NS>(fm, m); vload<NS>(fr, r);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const double od = q[s] - m[s];
+        m[s] = m[s] + prop_f * od;
+        const double nd = q[s] - m[s];
+        r[s] = r[s] + 1.0 * od * nd;
+        const int e = tid * NS + s;
+        if (e < d) {
+            var[s] = static_cast<float>(r[s] / ms.wsum_f);
+            const float sd = sqrtf(var[s]);
+            inv_std[s] = 1.0f / sd;
+            vard[s] = static_cast<double>(var[s]);
+        }
+    }
+    vstore<NS>(fm, m); vstore<NS>(fr, r);
+    vload<NS>(bm, m); vload<NS>(br, r);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const double od = q[s] - m[s];
+        m[s] = m[s] + prop_b * od;
+        const double nd = q[s] - m[s];
+        r[s] = r[s] + 1.0 * od * nd;
+    }
+    if (ms.n_samples > 0 && ms.n_samples % P.window == 0) {   // background becomes foreground
+        vstore<NS>(bm, m); vstore<NS>(br, r);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { m[s] = 0.0; r[s] = 0.0; }
+        vstore<NS>(fm, m); vstore<NS>(fr, r);             // old foreground = fresh background
+        ms.wsum_f = ms.wsum_b;
+        ms.wsum_b = 0.0;
+        ms.wsel = 1 - ms.wsel;
+    } else {
+        vstore<NS>(bm, m); vstore<NS>(br, r);
+    }
+    ++ms.n_samples;
+}
+
 template <int NS, int W, template <int> class TargetT>
 __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(ChainArrays A, SamplerParams P, const double* tparams) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -737,10 +792,11 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     DualAverage da;
     dual_average_load(A, c, da);
     int iter_count = first_i32(A.iter_count[c]);
-    int n_samples = first_i32(A.n_samples[c]);
-    int wsel = first_i32(A.wsel[c]);
-    double wsum_f = first_f64(A.wsum[c * 2 + wsel]);
-    double wsum_b = first_f64(A.wsum[c * 2 + (1 - wsel)]);
+    MassScalars ms;
+    ms.n_samples = first_i32(A.n_samples[c]);
+    ms.wsel = first_i32(A.wsel[c]);
+    ms.wsum_f = first_f64(A.wsum[c * 2 + ms.wsel]);
+    ms.wsum_b = first_f64(A.wsum[c * 2 + (1 - ms.wsel)]);
     long long ct_maxdepth = 0, ct_divs = 0, ct_after = 0, ct_leap = 0;
     int status = 0;
 
@@ -749,7 +805,6 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     stk.glb = A.scratch + static_cast<long long>(c) * A.scratch_stride;
     stk.nlds = P.nlds;
     stk.dpad = dpad;
-    const long long plane = static_cast<long long>(A.chains) * dpad;
 
     for (int it = 0; it < P.n_iters; ++it) {
         const long long git = P.iter_begin + it;
@@ -803,52 +858,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         if (adapt_step) dual_average_update(A, P, out.accept, da);
 
         // ---- diagonal mass adaptation (quadpotential.py:231-245, :324-340)
-        if (tune && P.adapt_mass) {
-            double* fm = A.wmean + wsel * plane + row;
-            double* fr = A.wraw + wsel * plane + row;
-            double* bm = A.wmean + (1 - wsel) * plane + row;
-            double* br = A.wraw + (1 - wsel) * plane + row;
-            wsum_f += 1.0;
-            wsum_b += 1.0;
-            const double prop_f = first_f64(1.0 / wsum_f), prop_b = first_f64(1.0 / wsum_b);
-            double m[NS], r[NS];
-            vload<NS>(fm, m); vload<NS>(fr, r);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const double od = q[s] - m[s];
-                m[s] = m[s] + prop_f * od;
-                const double nd = q[s] - m[s];
-                r[s] = r[s] + 1.0 * od * nd;
-                const int e = tid * NS + s;
-                if (e < d) {
-                    var[s] = static_cast<float>(r[s] / wsum_f);
-                    const float sd = sqrtf(var[s]);
-                    inv_std[s] = 1.0f / sd;
-                    vard[s] = static_cast<double>(var[s]);
-                }
-            }
-            vstore<NS>(fm, m); vstore<NS>(fr, r);
-            vload<NS>(bm, m); vload<NS>(br, r);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const double od = q[s] - m[s];
-                m[s] = m[s] + prop_b * od;
-                const double nd = q[s] - m[s];
-                r[s] = r[s] + 1.0 * od * nd;
-            }
-            if (n_samples > 0 && n_samples % P.window == 0) {   // background becomes foreground
-                vstore<NS>(bm, m); vstore<NS>(br, r);
-#pragma unroll
-                for (int s = 0; s < NS; ++s) { m[s] = 0.0; r[s] = 0.0; }
-                vstore<NS>(fm, m); vstore<NS>(fr, r);             // old foreground = fresh background
-                wsum_f = wsum_b;
-                wsum_b = 0.0;
-                wsel = 1 - wsel;
-            } else {
-                vstore<NS>(bm, m); vstore<NS>(br, r);
-            }
-            ++n_samples;
-        }
+        if (tune && P.adapt_mass) diag_mass_update<NS>(A, P, row, tid, q, var, inv_std, vard, ms);
 
         // ---- bookkeeping (base_hmc.py:164-190)
         if (out.diverging && !tune) ++ct_divs;
@@ -877,10 +887,10 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         A.da[c * 4 + 2] = da.hbar;
         A.da_count[c] = da.count;
         A.iter_count[c] = iter_count;
-        A.n_samples[c] = n_samples;
-        A.wsel[c] = wsel;
-        A.wsum[c * 2 + wsel] = wsum_f;
-        A.wsum[c * 2 + (1 - wsel)] = wsum_b;
+        A.n_samples[c] = ms.n_samples;
+        A.wsel[c] = ms.wsel;
+        A.wsum[c * 2 + ms.wsel] = ms.wsum_f;
+        A.wsum[c * 2 + (1 - ms.wsel)] = ms.wsum_b;
         A.status[c] |= status;
         A.counters[c * kNumCounters + kCtMaxTreedepth] += ct_maxdepth;
         A.counters[c * kNumCounters + kCtDivsSample] += ct_divs;

@@ -12,6 +12,13 @@ from . import _abi
 DEFAULT_SDOT = "auto"
 
 
+class _TickView:
+    """__cuda_array_interface__ shim over the engine's evaluation-point buffer (float64 [chains, dim])."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
 class Engine:
     def __init__(self, target, chains, kind="nuts", potential="diag_adapt", device=0, lib_path=None,
                  target_accept=0.8, Emax=1000.0, adapt_step_size=True, step_scale=0.25, gamma=0.05, k=0.75,
@@ -144,7 +151,52 @@ class Engine:
         self.trace_begin = max(tb, 0)
 
     def run(self, n_tune, iter_begin, n_iters):
+        if self.target.family == _abi.TARGET_EXTERNAL:
+            return self._run_ticks(int(n_tune), int(iter_begin), int(n_iters))
         self._check(self._lib.lmc_engine_run(self._h, int(n_tune), int(iter_begin), int(n_iters)))
+
+    # ---- externally evaluated density (targets.TorchTarget): the tick protocol of include/lmc_hip.h ---------
+    def tick_begin(self, n_tune, iter_begin, n_iters):
+        self._check(self._lib.lmc_engine_tick_begin(self._h, int(n_tune), int(iter_begin), int(n_iters)))
+
+    def tick_positions_ptr(self):
+        return int(self._lib.lmc_engine_tick_positions(self._h) or 0)
+
+    def tick(self, logp_ptr, grad_ptr, wait=True):
+        """One evaluation step for every unfinished chain; returns the number still running (None if not waited for)."""
+        n = C.c_int32(-1)
+        self._check(self._lib.lmc_engine_tick(self._h, C.c_void_p(int(logp_ptr)), C.c_void_p(int(grad_ptr)),
+                                              C.byref(n) if wait else None))
+        return int(n.value) if wait else None
+
+    def _run_ticks(self, n_tune, iter_begin, n_iters, poll=32):
+        """Drive n_iters iterations of every chain with the target's batched torch callable. Engine kernels and the
+        callable's kernels alternate on ONE non-default HIP stream; the host only looks every ``poll`` ticks."""
+        import torch
+
+        if n_iters == 0:
+            return
+        dev = torch.device("cuda", int(self.cfg.device))
+        if getattr(self, "_tick_stream", None) is None:
+            self._tick_stream = torch.cuda.Stream(device=dev)
+        self.synchronize()
+        self.set_stream(self._tick_stream.cuda_stream)
+        try:
+            with torch.cuda.device(dev), torch.cuda.stream(self._tick_stream):
+                self.tick_begin(n_tune, iter_begin, n_iters)
+                q = torch.as_tensor(_TickView(self.tick_positions_ptr(), (self.chains, self.dim)), device=dev)
+                ticks = 0
+                while True:
+                    logp, grad = self.target.evaluate(q)
+                    ticks += 1
+                    active = self.tick(logp.data_ptr(), grad.data_ptr(), wait=(ticks % poll == 0))
+                    self._tick_keep = (logp, grad)   # alive until the next evaluation is enqueued behind the tick
+                    if active == 0:
+                        break
+                self._tick_stream.synchronize()
+                self.ticks = getattr(self, "ticks", 0) + ticks
+        finally:
+            self.set_stream(None)
 
     def trace(self, iter_begin=None, n_iters=None):
         iter_begin = self.trace_begin if iter_begin is None else iter_begin

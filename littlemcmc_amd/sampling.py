@@ -120,6 +120,8 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
         lo = int(tune) if discard_tuned_samples else 0   # sampling.py:473-476
         eng.reserve(max(n_total, 1), keep_trace=True, trace_begin=min(lo, max(n_total - 1, 0)))
         per_launch = int(launch_iters) if launch_iters else max(1, min(n_total, 250))
+        if target.family == _abi.TARGET_EXTERNAL and not launch_iters:
+            per_launch = max(n_total, 1)   # ticks: chains never wait for each other inside one request
         it = 0
         while it < n_total:
             n = min(per_launch, n_total - it)

@@ -136,6 +136,69 @@ class UserTarget(DeviceTarget):
         self.lib_path = lib
 
 
+class TorchTarget(DeviceTarget):
+    """A log-density given as a BATCHED torch callable on the GPU, for densities that are easier to write (or
+    differentiate) in torch than as a HIP functor (reference cookbook: docs/_static/scripts/
+    sample_pytorch_logp_dlogp_func.py).
+
+        fn(q: float64 cuda tensor [chains, d]) -> (logp [chains], dlogp [chains, d])
+
+    The sampler then runs as a resumable kernel (csrc/lmc_tick.hpp): every "tick" each chain hands over the one
+    point it needs the density at, ``fn`` evaluates all chains at once, and the kernel carries every chain on to
+    its next evaluation -- finishing leapfrogs, building trees, adapting, starting new iterations -- without
+    the chains ever waiting for each other. Nothing is computed on the CPU.
+
+    ``TorchTarget.from_logp(d, logp_fn)`` builds the gradient with autograd from ``logp_fn(q) -> [chains]``.
+    Limits: d <= 256, diagonal mass matrices. A fused ``UserTarget`` is several times faster (no HBM round trip of
+    the chain state per leapfrog); this is the path for "cannot write device code".
+    """
+
+    family = _abi.TARGET_EXTERNAL
+
+    def __init__(self, d, fn):
+        super().__init__(d)
+        if not callable(fn):
+            raise TypeError("fn must be callable: q[chains, d] -> (logp[chains], dlogp[chains, d])")
+        self.fn = fn
+
+    @classmethod
+    def from_logp(cls, d, logp_fn):
+        import torch
+
+        def fn(q):
+            with torch.enable_grad():
+                x = q.detach().requires_grad_(True)
+                lp = logp_fn(x)
+                (g,) = torch.autograd.grad(lp.sum(), x)
+            return lp.detach(), g
+
+        return cls(d, fn)
+
+    def evaluate(self, q):
+        """fn on a [chains, d] tensor, results checked and made contiguous float64."""
+        import torch
+
+        logp, grad = self.fn(q)
+        if logp.shape != (q.shape[0],) and logp.numel() == q.shape[0]:
+            logp = logp.reshape(q.shape[0])
+        if logp.shape != (q.shape[0],) or grad.shape != q.shape:
+            raise ValueError("TorchTarget fn must return (logp[chains], dlogp[chains, d]); got %s and %s for q %s"
+                             % (tuple(logp.shape), tuple(grad.shape), tuple(q.shape)))
+        if not (logp.is_cuda and grad.is_cuda):
+            raise TypeError("TorchTarget fn must return CUDA (ROCm) tensors: there is no CPU path")
+        return logp.to(torch.float64).contiguous(), grad.to(torch.float64).contiguous()
+
+    def __call__(self, q):   # reference plug-in signature, one point
+        import torch
+
+        x = torch.as_tensor(np.asarray(q, dtype=np.float64).reshape(1, self.d), device="cuda")
+        logp, grad = self.evaluate(x)
+        return np.float64(logp[0].item()), grad[0].cpu().numpy()
+
+    def __getstate__(self):
+        return dict(self.__dict__)
+
+
 _SEPARABLE_TEMPLATE = r"""
 #include "lmc_team.hpp"
 namespace lmc {
