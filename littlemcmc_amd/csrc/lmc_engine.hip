@@ -1250,10 +1250,12 @@ int lmc_engine_tick(lmc_engine* e, const double* logp, const double* grad, int32
     if (!e->ticking) return fail(e, LMC_ERR_STATE, "lmc_engine_tick_begin() must be called first");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     const SamplerParams P = make_params(e, e->K.n_tune, 0, 0);
-    HIP_TRY(e, hipMemsetAsync(e->K.n_active, 0, sizeof(int), e->stream));
     const int rc = tick_launch(e->ns, e->stream, e->A, e->K, P, logp, grad);
     if (rc != 0) return fail(e, LMC_ERR_HIP, "tick: %s", rc < 0 ? "unsupported vector width" : hipGetErrorString(static_cast<hipError_t>(rc)));
     if (n_active) {
+        HIP_TRY(e, hipMemsetAsync(e->K.n_active, 0, sizeof(int), e->stream));
+        const int rc2 = tick_launch_count(e->stream, e->K, e->cfg.chains);
+        if (rc2 != 0) return fail(e, LMC_ERR_HIP, "tick count: %s", hipGetErrorString(static_cast<hipError_t>(rc2)));
         HIP_TRY(e, hipMemcpyAsync(n_active, e->K.n_active, sizeof(int), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
     }

@@ -31,4 +31,10 @@ int tick_launch_begin(int ns, hipStream_t stream, const ChainArrays& A, const Ti
     return static_cast<int>(hipGetLastError());
 }
 
+int tick_launch_count(hipStream_t stream, const TickArrays& K, int chains) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(tick_count_kernel, dim3((chains + 255) / 256), dim3(256), 0, stream, K, chains);
+    return static_cast<int>(hipGetLastError());
+}
+
 }  // namespace lmc

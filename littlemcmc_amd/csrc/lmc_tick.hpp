@@ -36,8 +36,11 @@ __device__ __forceinline__ void store_rows(double* dst, int d, int lane, const d
     }
 }
 
+#ifndef LMC_TICK_WAVES
+#define LMC_TICK_WAVES 4
+#endif
 template <int NS>
-__global__ __launch_bounds__(64) void tick_kernel(ChainArrays A, TickArrays K, SamplerParams P, const double* logp_in,
+__global__ __launch_bounds__(64, LMC_TICK_WAVES) void tick_kernel(ChainArrays A, TickArrays K, SamplerParams P, const double* logp_in,
                                                   const double* grad_in) {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // 2 * dpad doubles: normals + staging / sdot staging
     const int c = blockIdx.x;
@@ -407,7 +410,21 @@ __global__ __launch_bounds__(64) void tick_kernel(ChainArrays A, TickArrays K, S
         A.da_count[c] = da.count;
         A.iter_count[c] = iter_count;
         A.status[c] |= status;
-        if (phase != kTickDone) atomicAdd(K.n_active, 1);
+    }
+}
+
+// chains that still want evaluations (only launched when the host asks: one atomic per 256 chains, not per chain
+// per tick -- 65 536 atomics on one address cost more than the rest of the tick)
+__global__ __launch_bounds__(256) void tick_count_kernel(TickArrays K, int chains) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const bool active = c < chains && K.phase[c] != kTickDone;
+    const unsigned long long m = __ballot(active);
+    __shared__ int part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int n = part[0] + part[1] + part[2] + part[3];
+        if (n) atomicAdd(K.n_active, n);
     }
 }
 

@@ -31,5 +31,6 @@ constexpr int tick_scratch_vectors(int max_levels) { return 9 + 4 * max_levels; 
 int tick_launch(int ns, hipStream_t stream, const ChainArrays& A, const TickArrays& K, const SamplerParams& P,
                 const double* logp, const double* grad);
 int tick_launch_begin(int ns, hipStream_t stream, const ChainArrays& A, const TickArrays& K, long long iter_begin);
+int tick_launch_count(hipStream_t stream, const TickArrays& K, int chains);   // K.n_active += chains not yet done
 
 }  // namespace lmc
