@@ -393,3 +393,58 @@ def test_dense_fixed_wide_vectors(d, kind):
     start = 0.1 * rs.randn(d)
     n = _replay(ostep, dstep, start, 4242 + d, 10, 4, kind == "full", "%s d=%d" % (kind, d))
     assert n >= 12
+
+
+# ---------------------------------------------------------------------------------------------------
+# size-independent properties at scale: chains are independent, so chain c of a large run IS chain c of a small one
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("init,d", [("jitter+adapt_full", 128), ("adapt_full", 40)])
+def test_dense_chains_are_prefix_stable_at_scale(init, d):
+    """Per-chain matrices, estimators, scratch rows and RNG streams are indexed by chain: the first 48 chains of a
+    3000-chain run must equal a 48-chain run bit for bit (same seeds by construction, sampling.py:131-136)."""
+    tgt = lmc.targets.AR1(d, 0.9)
+    kw = dict(draws=12, tune=40, init=init, random_seed=77, discard_tuned_samples=False)
+    big_tr, big_st = lmc.sample(tgt, d, chains=3000, **kw)
+    small_tr, small_st = lmc.sample(tgt, d, chains=48, **kw)
+    np.testing.assert_array_equal(big_tr[:48], small_tr)
+    np.testing.assert_array_equal(big_st["tree_size"][:48], small_st["tree_size"])
+    np.testing.assert_array_equal(big_st["energy"][:48], small_st["energy"])
+    assert np.isfinite(big_tr).all() and not big_st["diverging"][:, 40:].any()
+
+
+def test_dense_checkpoint_resume_is_exact():
+    """A FullAdapt run split into two engine lifetimes (chain state + dense state + RNG saved and restored) equals
+    the uninterrupted run bit for bit."""
+    d, chains, tune, draws = 9, 10, 70, 20
+    tgt = lmc.targets.AR1(d, 0.9)
+    start, step = lmc.init_nuts(tgt, d, init="jitter+adapt_full", random_seed=[5])
+    seeds = np.arange(chains, dtype=np.uint32) + 100
+
+    def fresh():
+        eng = step._make_engine(chains)
+        eng.seed(seeds)
+        eng.set_position(start)
+        eng.reset_tuning()
+        eng.reserve(tune + draws, keep_trace=True)
+        return eng
+
+    with fresh() as eng:
+        eng.run(tune, 0, tune + draws)
+        want = eng.trace()
+    cut = 33
+    with fresh() as eng:
+        eng.run(tune, 0, cut)
+        q = eng.get_position()
+        chain_state = eng.get_chain_state()
+        dense_state = eng.get_dense_state()
+        rng = [eng.get_rng_state(c) for c in range(chains)]
+        first = eng.trace(0, cut)
+    with fresh() as eng:
+        eng.set_position(q)
+        eng.set_chain_state(chain_state)
+        eng.set_dense_state({k: v for k, v in dense_state.items() if k != "chol_failures"})
+        for c in range(chains):
+            eng.set_rng_state(c, rng[c])
+        eng.run(tune, cut, tune + draws - cut)
+        second = eng.trace(cut, tune + draws - cut)
+    np.testing.assert_array_equal(np.concatenate([first, second], axis=1), want)

@@ -164,3 +164,14 @@ def test_tick_protocol_through_the_c_abi_directly():
         leap = eng.stat_i32(lmc._abi.STAT_TREE_SIZE, 0, n)
         assert ticks == (leap.sum(axis=1) + n).max()       # one evaluation per leapfrog + one per iteration start
         assert eng.counters()[:, lmc._abi.CT_LEAPFROGS].sum() == leap.sum()
+
+
+def test_tick_chains_are_prefix_stable_at_scale():
+    """Chains driven through ticks are independent of how many other chains share the launch: the first 32 chains
+    of a 5000-chain run equal a 32-chain run bit for bit (the callable is evaluated row by row)."""
+    d = 20
+    kw = dict(draws=10, tune=30, random_seed=31, discard_tuned_samples=False)
+    big_tr, big_st = lmc.sample(torch_std_normal(d), d, chains=5000, **kw)
+    small_tr, small_st = lmc.sample(torch_std_normal(d), d, chains=32, **kw)
+    np.testing.assert_array_equal(big_st["tree_size"][:32], small_st["tree_size"])
+    np.testing.assert_array_equal(big_tr[:32], small_tr)
