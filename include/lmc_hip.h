@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LMC_ABI_VERSION 1
+#define LMC_ABI_VERSION 2
 
 /* status codes */
 #define LMC_OK 0
@@ -124,6 +124,7 @@ typedef struct lmc_config {
     int32_t adaptation_window;    /* 101 (quadpotential.py:156) */
     int32_t lds_levels;           /* subtree-stack levels kept in LDS; 0 = choose automatically */
     int32_t start_energy_sdot;    /* LMC_SDOT_*: summation order of the float32 start-state kinetic energy */
+    double adaptation_window_multiplier; /* 1.0: QuadPotentialDiagAdapt's window grows by this factor at every switch (quadpotential.py:243) */
 } lmc_config;
 
 /* Fill *cfg with the reference's defaults for the given shape. */
@@ -228,6 +229,7 @@ typedef struct lmc_chain_state {
     double* hbar;           /* step_adapt._hbar */
     int32_t* da_count;      /* step_adapt._count */
     int32_t* iter_count;    /* step.iter_count */
+    int32_t* window;        /* potential.adaptation_window (grows by the multiplier at every switch) */
 } lmc_chain_state;
 int lmc_engine_get_chain_state(lmc_engine* e, const lmc_chain_state* dst);
 int lmc_engine_set_chain_state(lmc_engine* e, const lmc_chain_state* src);

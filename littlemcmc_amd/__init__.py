@@ -12,8 +12,7 @@ from .hmc import HamiltonianMC
 from .nuts import NUTS
 from .sampling import init_nuts, sample
 
-# mass matrices: the diagonal family runs on the device; the dense classes exist for API completeness and
-# raise NotImplementedError (outside the hot-path scope)
+# mass matrices: diagonal (the hot path) and dense (model_ndim <= 256), all on the device
 quad_potential = _qp.quad_potential
 QuadPotentialDiag, QuadPotentialDiagAdapt = _qp.QuadPotentialDiag, _qp.QuadPotentialDiagAdapt
 QuadPotentialFull, QuadPotentialFullInv, QuadPotentialFullAdapt = (

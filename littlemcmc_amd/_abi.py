@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LMC_HIP_LIB") or os.path.join(_HERE, "liblmc_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK = 0
 
 KIND_NUTS, KIND_HMC = 0, 1
@@ -38,7 +38,7 @@ class Config(C.Structure):
         ("gamma", C.c_double), ("k", C.c_double), ("t0", C.c_double),
         ("max_treedepth", C.c_int32), ("early_max_treedepth", C.c_int32),
         ("path_length", C.c_double), ("max_steps", C.c_int32), ("adaptation_window", C.c_int32),
-        ("lds_levels", C.c_int32), ("start_energy_sdot", C.c_int32),
+        ("lds_levels", C.c_int32), ("start_energy_sdot", C.c_int32), ("adaptation_window_multiplier", C.c_double),
     ]
 
 
@@ -52,7 +52,7 @@ class ChainState(C.Structure):
               ("back_mean", np.float64, True), ("back_raw_var", np.float64, True), ("fore_w_sum", np.float64, False),
               ("back_w_sum", np.float64, False), ("n_samples", np.int32, False), ("log_step", np.float64, False),
               ("log_bar", np.float64, False), ("hbar", np.float64, False), ("da_count", np.int32, False),
-              ("iter_count", np.int32, False))
+              ("iter_count", np.int32, False), ("window", np.int32, False))
     _fields_ = [(name, C.c_void_p) for name, _dt, _vec in FIELDS]
 
 

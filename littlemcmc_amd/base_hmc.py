@@ -87,7 +87,8 @@ class BaseHMC:
             kind=self._kind, potential=self.potential._engine_kind, target_accept=self.target_accept,
             Emax=self.Emax, adapt_step_size=self.adapt_step_size, step_scale=self._step_scale,
             gamma=self._gamma, k=self._k, t0=self._t0,
-            adaptation_window=getattr(self.potential, "adaptation_window", 101),
+            adaptation_window=getattr(self.potential, "_initial_adaptation_window", 101),
+            adaptation_window_multiplier=getattr(self.potential, "adaptation_window_multiplier", 1.0),
         )
 
     def _make_engine(self, chains, device=0):

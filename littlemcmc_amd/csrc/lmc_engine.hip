@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void trajectory_kernel(ChainArrays A, const dou
 // QuadPotentialDiagAdapt.reset() (quadpotential.py:195-204) / QuadPotentialDiag.__init__ (:349-365)
 // + DualAverageAdaptation.reset() (step_sizes.py:49-56) + iter_count = 0.
 __global__ void reset_kernel(ChainArrays A, const double* init_mean, const float* init_diag, double init_weight,
-                             int adapt, double log_step0, double mu, int reset_step, int reset_mass) {
+                             int adapt, double log_step0, double mu, int reset_step, int reset_mass, int window) {
     const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     const long long n = static_cast<long long>(A.chains) * A.dpad;
     if (idx >= n) return;
@@ -224,6 +224,7 @@ __global__ void reset_kernel(ChainArrays A, const double* init_mean, const float
             A.wsum[c * 2 + 1] = 0.0;
             A.wsel[c] = 0;
             A.n_samples[c] = 0;
+            A.awindow[c] = window;
         }
     }
     if (reset_step && A.mom_mean != nullptr) {
@@ -503,6 +504,7 @@ void lmc_config_defaults(lmc_config* cfg, int32_t chains, int32_t dim) {
     cfg->path_length = 2.0;
     cfg->max_steps = 1024;
     cfg->adaptation_window = 101;
+    cfg->adaptation_window_multiplier = 1.0;
     cfg->lds_levels = 0;
     cfg->start_energy_sdot = LMC_SDOT_OPENBLAS_SKYLAKEX;
 }
@@ -515,7 +517,7 @@ static int launch_reset(lmc_engine* e, int reset_step, int reset_mass) {
     const double mu = std::log(10 * e->initial_step);           // step_sizes.py:55
     LMC_LAUNCH(reset_kernel, dim3(blocks), dim3(threads), 0, e->stream, e->A, e->init_mean, e->init_diag,
                        e->init_weight, e->cfg.potential == LMC_POT_DIAG_ADAPT ? 1 : 0, log_step0, mu, reset_step,
-                       reset_mass);
+                       reset_mass, e->cfg.adaptation_window);
     HIP_TRY(e, hipGetLastError());
     return LMC_OK;
 }
@@ -542,6 +544,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         return fail(nullptr, LMC_ERR_INVALID, "unknown step kind %d", cfg->kind);
     if (cfg->start_energy_sdot < LMC_SDOT_NATIVE || cfg->start_energy_sdot > LMC_SDOT_OPENBLAS_HASWELL)
         return fail(nullptr, LMC_ERR_INVALID, "unknown start_energy_sdot mode %d", cfg->start_energy_sdot);
+    if (cfg->adaptation_window < 1 || !(cfg->adaptation_window_multiplier > 0.0))
+        return fail(nullptr, LMC_ERR_INVALID, "adaptation_window must be >= 1 and its multiplier > 0");
     if (cfg->max_treedepth < 1 || cfg->max_treedepth > 20 || cfg->early_max_treedepth < 1 ||
         cfg->early_max_treedepth > 20)
         return fail(nullptr, LMC_ERR_INVALID, "max_treedepth must be in [1, 20]");
@@ -614,6 +618,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     TRY_ALLOC(dev_alloc(e, &A.wsum, C * 2));
     TRY_ALLOC(dev_alloc(e, &A.wsel, C));
     TRY_ALLOC(dev_alloc(e, &A.n_samples, C));
+    TRY_ALLOC(dev_alloc(e, &A.awindow, C));
     TRY_ALLOC(dev_alloc(e, &A.da, C * 4));
     TRY_ALLOC(dev_alloc(e, &A.da_count, C));
     TRY_ALLOC(dev_alloc(e, &A.iter_count, C));
@@ -1178,6 +1183,7 @@ static SamplerParams make_params(const lmc_engine* e, int64_t n_tune, int64_t it
     P.path_length = e->cfg.path_length;
     P.max_steps = e->cfg.max_steps;
     P.window = e->cfg.adaptation_window;
+    P.window_multiplier = e->cfg.adaptation_window_multiplier;
     P.n_tune = n_tune;
     P.iter_begin = iter_begin;
     P.n_iters = n_iters;
@@ -1472,6 +1478,7 @@ static int chain_state_xfer(lmc_engine* e, const lmc_chain_state* st, bool to_us
     if ((rc = ints(st->n_samples, A.n_samples)) != LMC_OK) return rc;
     if ((rc = ints(st->da_count, A.da_count)) != LMC_OK) return rc;
     if ((rc = ints(st->iter_count, A.iter_count)) != LMC_OK) return rc;
+    if ((rc = ints(st->window, A.awindow)) != LMC_OK) return rc;
     if (!to_user && st->var) {
         const long long n = static_cast<long long>(C) * e->dpad;
         LMC_LAUNCH(derive_inv_std_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, e->stream, e->A);

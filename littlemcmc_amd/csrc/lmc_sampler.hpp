@@ -55,6 +55,7 @@ struct ChainArrays {
     double* wsum;         // [C][2]
     int* wsel;            // [C]
     int* n_samples;       // [C]
+    int* awindow;         // [C] current adaptation window (grows by P.window_multiplier at every switch)
     double* da;           // [C][4] log_step, log_bar, hbar, mu
     const double* da_sqrt; // [da_table_len] sqrt(count)        (host libm)
     const double* da_mk;   // [da_table_len] count ** -k        (host libm)
@@ -90,7 +91,8 @@ struct SamplerParams {
     int max_treedepth, early_max_treedepth;
     double path_length;
     int max_steps;
-    int window;           // adaptation_window (101)
+    int window;           // adaptation_window (101): initial value, the current one is per chain (A.awindow)
+    double window_multiplier;   // adaptation_window_multiplier (quadpotential.py:243)
     long long n_tune;     // iterations with index < n_tune are tuning iterations
     long long iter_begin; // global index of the first iteration of this launch
     int n_iters;
@@ -697,7 +699,7 @@ __device__ __forceinline__ void write_outputs(const ChainArrays& A, int c, int t
 
 // diagonal mass adaptation (quadpotential.py:231-245, :324-340): both Welford estimators take the draw, the
 // foreground one becomes the float32 variance, the window switches every P.window samples
-struct MassScalars { double wsum_f, wsum_b; int wsel, n_samples; };
+struct MassScalars { double wsum_f, wsum_b; int wsel, n_samples, window; };
 template <int NS>
 __device__ __forceinline__ void diag_mass_update(const ChainArrays& A, const SamplerParams& P, long long row, int tid,
                                                  const double (&q)[NS], float (&var)[NS], float (&inv_std)[NS],
@@ -736,7 +738,7 @@ __device__ __forceinline__ void diag_mass_update(const ChainArrays& A, const Sam
         const double nd = q[s] - m[s];
         r[s] = r[s] + 1.0 * od * nd;
     }
-    if (ms.n_samples > 0 && ms.n_samples % P.window == 0) {   // background becomes foreground
+    if (ms.n_samples > 0 && ms.n_samples % ms.window == 0) {   // background becomes foreground
         vstore<NS>(bm, m); vstore<NS>(br, r);
 #pragma unroll
         for (int s = 0; s < NS; ++s) { m[s] = 0.0; r[s] = 0.0; }
@@ -744,6 +746,7 @@ __device__ __forceinline__ void diag_mass_update(const ChainArrays& A, const Sam
         ms.wsum_f = ms.wsum_b;
         ms.wsum_b = 0.0;
         ms.wsel = 1 - ms.wsel;
+        ms.window = static_cast<int>(static_cast<double>(ms.window) * P.window_multiplier);   // quadpotential.py:243
     } else {
         vstore<NS>(bm, m); vstore<NS>(br, r);
     }
@@ -797,6 +800,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     ms.wsel = first_i32(A.wsel[c]);
     ms.wsum_f = first_f64(A.wsum[c * 2 + ms.wsel]);
     ms.wsum_b = first_f64(A.wsum[c * 2 + (1 - ms.wsel)]);
+    ms.window = first_i32(A.awindow[c]);
     long long ct_maxdepth = 0, ct_divs = 0, ct_after = 0, ct_leap = 0;
     int status = 0;
 
@@ -889,6 +893,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         A.iter_count[c] = iter_count;
         A.n_samples[c] = ms.n_samples;
         A.wsel[c] = ms.wsel;
+        A.awindow[c] = ms.window;
         A.wsum[c * 2 + ms.wsel] = ms.wsum_f;
         A.wsum[c * 2 + (1 - ms.wsel)] = ms.wsum_b;
         A.status[c] |= status;

@@ -356,10 +356,12 @@ __global__ __launch_bounds__(64, LMC_TICK_WAVES) void tick_kernel(ChainArrays A,
             ms.wsel = first_i32(A.wsel[c]);
             ms.wsum_f = first_f64(A.wsum[c * 2 + ms.wsel]);
             ms.wsum_b = first_f64(A.wsum[c * 2 + (1 - ms.wsel)]);
+            ms.window = first_i32(A.awindow[c]);
             diag_mass_update<NS>(A, P, row, lane, q, var, inv_std, vard, ms);
             if (lane == 0) {
                 A.n_samples[c] = ms.n_samples;
                 A.wsel[c] = ms.wsel;
+                A.awindow[c] = ms.window;
                 A.wsum[c * 2 + ms.wsel] = ms.wsum_f;
                 A.wsum[c * 2 + (1 - ms.wsel)] = ms.wsum_b;
             }

@@ -23,7 +23,7 @@ class Engine:
     def __init__(self, target, chains, kind="nuts", potential="diag_adapt", device=0, lib_path=None,
                  target_accept=0.8, Emax=1000.0, adapt_step_size=True, step_scale=0.25, gamma=0.05, k=0.75,
                  t0=10, path_length=2.0, max_treedepth=10, early_max_treedepth=8, max_steps=1024,
-                 adaptation_window=101, lds_levels=0, sdot=None):
+                 adaptation_window=101, adaptation_window_multiplier=1.0, lds_levels=0, sdot=None):
         self._lib = _abi.load(lib_path or getattr(target, "lib_path", None))
         self._h = C.c_void_p()
         self.target = target
@@ -50,6 +50,7 @@ class Engine:
         cfg.path_length = float(path_length)
         cfg.max_steps = int(max_steps)
         cfg.adaptation_window = int(adaptation_window)
+        cfg.adaptation_window_multiplier = float(adaptation_window_multiplier)
         cfg.lds_levels = int(lds_levels)
         if sdot is None:
             sdot = DEFAULT_SDOT
@@ -242,11 +243,13 @@ class Engine:
         return {"var": var, "log_step": da[:, 0], "log_bar": da[:, 1], "hbar": da[:, 2], "mu": da[:, 3],
                 "count": cnt, "n_samples": ns}
 
-    def get_chain_state(self):
-        """Full adaptation state of every chain as a dict of host arrays (checkpoint)."""
+    def get_chain_state(self, fields=None):
+        """Full adaptation state of every chain as a dict of host arrays (checkpoint); ``fields`` restricts the copy."""
         st = _abi.ChainState()
         out = {}
         for name, dt, vec in _abi.ChainState.FIELDS:
+            if fields is not None and name not in fields:
+                continue
             out[name] = np.empty((self.chains, self.dim) if vec else (self.chains,), dtype=dt)
             setattr(st, name, out[name].ctypes.data)
         self._check(self._lib.lmc_engine_get_chain_state(self._h, C.byref(st)))

@@ -165,8 +165,6 @@ class QuadPotentialDiagAdapt(QuadPotential):
             raise ValueError("Wrong shape for initial_mean: expected %s got %s" % (n, len(initial_mean)))
         if dtype not in (None, "float32", np.float32):
             raise NotImplementedError("the device mass matrix is float32, like the reference's default")
-        if adaptation_window_multiplier != 1:
-            raise NotImplementedError("adaptation_window_multiplier != 1 is not implemented on the device")
         super().__init__(n)
         self.dtype = "float32"
         if initial_diag is None:  # quadpotential.py:178-180
@@ -176,14 +174,21 @@ class QuadPotentialDiagAdapt(QuadPotential):
         self._initial_diag = initial_diag.astype("float32")
         self._initial_weight = initial_weight
         self.adaptation_window = int(adaptation_window)
+        self._initial_adaptation_window = int(adaptation_window)
         self.adaptation_window_multiplier = float(adaptation_window_multiplier)
         self._var = np.array(self._initial_diag, copy=True)
         self._stds = np.sqrt(self._initial_diag)
         self._inv_stds = 1.0 / self._stds
         self._n_samples = 0
 
+    def _pull(self, engine, chain=0):
+        super()._pull(engine, chain)
+        if self.adaptation_window_multiplier != 1.0:
+            self.adaptation_window = int(engine.get_chain_state(fields=("window",))["window"][chain])
+
     def _push_initial(self, engine):
         engine.set_potential(self._initial_mean, self._initial_diag.astype("d"), float(self._initial_weight))
+        self.adaptation_window = self._initial_adaptation_window
         self._var = np.array(self._initial_diag, copy=True)
         self._stds = np.sqrt(self._initial_diag)
         self._inv_stds = 1.0 / self._stds

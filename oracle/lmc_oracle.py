@@ -52,7 +52,7 @@ class DiagAdaptPotential:
 
     momentum_f32 = True
 
-    def __init__(self, n, initial_mean, initial_diag=None, initial_weight=0, window=101):
+    def __init__(self, n, initial_mean, initial_diag=None, initial_weight=0, window=101, multiplier=1):
         self.n = n
         if initial_diag is None:  # quadpotential.py:178-180
             initial_diag = np.ones(n, dtype="float32")
@@ -62,7 +62,8 @@ class DiagAdaptPotential:
         self._initial_mean = np.array(initial_mean, dtype="d")
         self._initial_diag = initial_diag
         self._initial_weight = initial_weight
-        self.window = window
+        self._initial_window = window
+        self.multiplier = float(multiplier)
         self.reset()
 
     def reset(self):  # quadpotential.py:195-204
@@ -72,6 +73,9 @@ class DiagAdaptPotential:
         self.fore = _Welford(self.n, self._initial_mean, self._initial_diag, self._initial_weight)
         self.back = _Welford(self.n)
         self.n_samples = 0
+        # the reference's reset() leaves a grown adaptation_window in place (it only matters for multiplier != 1 and
+        # for chains after the first of its sequential driver); every chain here starts like the reference's first
+        self.window = self._initial_window
 
     def velocity(self, x):  # :206-208
         return np.multiply(self.var, x)
@@ -94,6 +98,7 @@ class DiagAdaptPotential:
         if self.n_samples > 0 and self.n_samples % self.window == 0:
             self.fore = self.back
             self.back = _Welford(self.n)
+            self.window = int(self.window * self.multiplier)  # :243
         self.n_samples += 1
 
 

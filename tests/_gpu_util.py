@@ -108,7 +108,8 @@ def oracle_chain_snapshots(ostep, start, seed, tune, draws):
                     hbar=float(np.ravel(ad.hbar)[0]), da_count=ad.count, n_samples=pot.n_samples)
         if adaptive:
             snap.update(fore_mean=pot.fore.mean.copy(), fore_raw_var=pot.fore.raw_var.copy(), fore_w_sum=pot.fore.w_sum,
-                        back_mean=pot.back.mean.copy(), back_raw_var=pot.back.raw_var.copy(), back_w_sum=pot.back.w_sum)
+                        back_mean=pot.back.mean.copy(), back_raw_var=pot.back.raw_var.copy(), back_w_sum=pot.back.w_sum,
+                        window=pot.window)
         q, st = ostep.astep(q, rng)
         snaps.append(snap)
         outs.append(dict(q=q.copy(), stats={k: np.ravel(v)[0] for k, v in st.items()}, margin=ostep.last_margins.lb,
@@ -135,7 +136,7 @@ def replay_iterations_on_device(step, snaps, outs, label=""):
             state = {k: np.stack([np.asarray(snaps[i][k]) for i in idx]) for k in
                      ("var", "log_step", "log_bar", "hbar", "da_count", "iter_count", "n_samples")}
             if "fore_mean" in snaps[idx[0]]:
-                for k in ("fore_mean", "fore_raw_var", "back_mean", "back_raw_var", "fore_w_sum", "back_w_sum"):
+                for k in ("fore_mean", "fore_raw_var", "back_mean", "back_raw_var", "fore_w_sum", "back_w_sum", "window"):
                     state[k] = np.stack([np.asarray(snaps[i][k]) for i in idx])
             eng.set_chain_state(state)
             eng.reserve(1, keep_trace=True)
@@ -168,6 +169,7 @@ def replay_iterations_on_device(step, snaps, outs, label=""):
                         for k in ("fore_mean", "fore_raw_var", "back_mean", "back_raw_var"):
                             np.testing.assert_allclose(after[k][c], nxt[k], rtol=1e-11, atol=1e-13, err_msg=tag + " " + k)
                         assert after["fore_w_sum"][c] == nxt["fore_w_sum"] and after["back_w_sum"][c] == nxt["back_w_sum"], tag
+                        assert after["window"][c] == nxt["window"], (tag, after["window"][c], nxt["window"])
                 checked += 1
         finally:
             eng.close()

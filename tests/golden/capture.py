@@ -445,9 +445,47 @@ def capture_dense_e2e():
         save(name, **arrays)
 
 
+# ---------------------------------------------------------------------------------------
+# 8. QuadPotentialDiagAdapt with a growing adaptation window (adaptation_window_multiplier != 1)
+# ---------------------------------------------------------------------------------------
+def capture_diag_window_multiplier():
+    out = {}
+    rs = np.random.RandomState(21)
+    d = 6
+    samples = rs.randn(150, d) * np.linspace(0.3, 4.0, d) + 1.0
+    pot = QuadPotentialDiagAdapt(d, np.full(d, 0.5), np.ones(d), 10, adaptation_window=15, adaptation_window_multiplier=2)
+    rows = {k: [] for k in ("var", "ns", "window", "fw", "bw")}
+    for x in samples:
+        pot.update(x, None, True)
+        rows["var"].append(np.array(pot._var, dtype="d"))
+        rows["ns"].append(pot._n_samples)
+        rows["window"].append(pot.adaptation_window)
+        rows["fw"].append(pot._foreground_var.w_sum)
+        rows["bw"].append(pot._background_var.w_sum)
+    for k, v in rows.items():
+        out["seq_" + k] = np.array(v)
+    out["samples"] = samples
+    # one chain end to end (one chain: the reference's reset() keeps the grown window for the next chain)
+    d2, tune, draws, seed = 8, 220, 40, 424242
+    f = targets.make("ar1", d2)
+    np.random.seed(seed)
+    start = 2 * np.random.rand(d2) - 1
+    pot2 = QuadPotentialDiagAdapt(d2, start, np.ones(d2), 10, adaptation_window=20, adaptation_window_multiplier=2)
+    step = ref.NUTS(f, d2, potential=pot2)
+    trace, stats = ref.sample(f, d2, draws=draws, tune=tune, step=step, start=start, chains=1, cores=1, progressbar=False,
+                              random_seed=[seed], discard_tuned_samples=False)
+    out.update(e2e_d=np.array(d2), e2e_tune=np.array(tune), e2e_draws=np.array(draws), e2e_seed=np.array(seed),
+               e2e_start=start, e2e_trace=trace, e2e_final_window=np.array(pot2.adaptation_window),
+               e2e_final_var=np.array(pot2._var, dtype="d"))
+    for k, v in stats.items():
+        out["e2e_stat_" + k] = v
+    save("diag_window_multiplier", **out)
+
+
 CAPTURES = {"leapfrog": capture_leapfrog, "transitions": capture_transitions, "adapt": capture_adapt,
             "e2e": capture_e2e, "seeds": capture_seeds, "dense_units": capture_dense_units,
-            "dense_adapt": capture_dense_adapt, "dense_e2e": capture_dense_e2e}
+            "dense_adapt": capture_dense_adapt, "dense_e2e": capture_dense_e2e,
+            "diag_window_multiplier": capture_diag_window_multiplier}
 
 if __name__ == "__main__":
     for which in (sys.argv[1:] or list(CAPTURES)):

@@ -181,3 +181,28 @@ def test_every_iteration_replay_on_wide_and_multi_wave_shapes(family, d, kw):
     snaps, outs = oracle_chain_snapshots(ostep, start, seeds[1], tune, draws)
     checked, fragile = replay_iterations_on_device(step, snaps, outs, label="%s d=%d" % (family, d))
     assert checked >= tune + draws - 1, (checked, fragile)
+
+
+def test_growing_adaptation_window_replays_the_reference(golden_dir):
+    """QuadPotentialDiagAdapt(adaptation_window=20, adaptation_window_multiplier=2): the window doubles at every
+    switch (quadpotential.py:239-243); every iteration of the captured reference chain replayed on the device, the
+    per-chain window included, and whole sample() runs agree on the final window."""
+    from tests._gpu_util import oracle_chain_snapshots, replay_iterations_on_device
+
+    g = np.load(os.path.join(golden_dir, "diag_window_multiplier.npz"))
+    d, tune, draws, seed = int(g["e2e_d"]), int(g["e2e_tune"]), int(g["e2e_draws"]), int(g["e2e_seed"])
+    start = g["e2e_start"]
+    opot = orc.DiagAdaptPotential(d, start, np.ones(d), 10, window=20, multiplier=2)
+    ostep = orc.Step(OT.make("ar1", d), d, kind="nuts", potential=opot)
+    pot = lmc.QuadPotentialDiagAdapt(d, start, np.ones(d), 10, adaptation_window=20, adaptation_window_multiplier=2)
+    step = lmc.NUTS(lmc.targets.AR1(d), d, potential=pot)
+    snaps, outs = oracle_chain_snapshots(ostep, start, seed, tune, draws)
+    np.testing.assert_allclose(np.array([o["q"] for o in outs]), g["e2e_trace"][0], rtol=1e-9, atol=1e-300)
+    final = int(g["e2e_final_window"])
+    assert sorted(set(s["window"] for s in snaps)) == [20, 40, 80, 160, 320] and final == 320
+    checked, fragile = replay_iterations_on_device(step, snaps, outs, label="growing window")
+    assert checked >= tune + draws - 2, (checked, fragile)
+    trace, stats = lmc.sample(lmc.targets.AR1(d), d, draws=draws, tune=tune, step=step, start=start, chains=3,
+                              random_seed=[seed, seed + 1, seed + 2], discard_tuned_samples=False)
+    assert step.potential.adaptation_window == final
+    np.testing.assert_array_equal(stats["tree_size"][0, :12, 0], g["e2e_stat_tree_size"][0, :12, 0])

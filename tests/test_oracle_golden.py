@@ -148,3 +148,27 @@ def test_e2e_golden(golden_dir, name):
         else:
             np.testing.assert_allclose(stats[name_], want, rtol=RTOL, atol=1e-12, err_msg=name_)
     np.testing.assert_allclose(trace, g["trace"], rtol=RTOL, atol=1e-300)
+
+
+def test_diag_adapt_growing_window_golden(golden_dir):
+    """QuadPotentialDiagAdapt(adaptation_window_multiplier=2) (quadpotential.py:239-243): estimator sequence and one
+    end-to-end chain."""
+    g = _load(golden_dir, "diag_window_multiplier")
+    d = g["samples"].shape[1]
+    pot = orc.DiagAdaptPotential(d, np.full(d, 0.5), np.ones(d), 10, window=15, multiplier=2)
+    for i, x in enumerate(g["samples"]):
+        pot.update(x, True)
+        np.testing.assert_array_equal(np.asarray(pot.var, dtype="d"), g["seq_var"][i])
+        assert pot.n_samples == g["seq_ns"][i] and pot.window == g["seq_window"][i]
+        assert pot.fore.w_sum == g["seq_fw"][i] and pot.back.w_sum == g["seq_bw"][i]
+    assert pot.window > 15
+    d2, tune, draws, seed = int(g["e2e_d"]), int(g["e2e_tune"]), int(g["e2e_draws"]), int(g["e2e_seed"])
+    f = targets.make("ar1", d2)
+    pot2 = orc.DiagAdaptPotential(d2, g["e2e_start"], np.ones(d2), 10, window=20, multiplier=2)
+    step = orc.Step(f, d2, kind="nuts", potential=pot2)
+    trace, stats = orc.sample(f, d2, draws=draws, tune=tune, step=step, start=g["e2e_start"], chains=1,
+                              random_seed=[seed], discard_tuned_samples=False)
+    np.testing.assert_allclose(trace, g["e2e_trace"], rtol=RTOL, atol=1e-300)
+    np.testing.assert_array_equal(stats["tree_size"], g["e2e_stat_tree_size"])
+    assert pot2.window == int(g["e2e_final_window"])
+    np.testing.assert_array_equal(np.asarray(pot2.var, dtype="d"), g["e2e_final_var"])
