@@ -534,8 +534,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         return fail(nullptr, LMC_ERR_INVALID, "unknown potential %d", cfg->potential);
     if (cfg->potential >= LMC_POT_FULL && cfg->dim > 256)
         return fail(nullptr, LMC_ERR_INVALID, "dense mass matrices are supported up to dim 256 (got %d)", cfg->dim);
-    if (cfg->target_family == LMC_TARGET_EXTERNAL && (cfg->dim > 256 || cfg->potential >= LMC_POT_FULL))
-        return fail(nullptr, LMC_ERR_INVALID, "an externally evaluated density supports dim <= 256 and diagonal mass matrices");
+    if (cfg->target_family == LMC_TARGET_EXTERNAL && cfg->potential >= LMC_POT_FULL)
+        return fail(nullptr, LMC_ERR_INVALID, "an externally evaluated density supports diagonal mass matrices only");
     if (!lmc_has_target(cfg->target_family))
         return fail(nullptr, LMC_ERR_INVALID, "target family %d is not built into this library", cfg->target_family);
     if (cfg->target_family == LMC_TARGET_NORMAL1D && cfg->dim != 1)

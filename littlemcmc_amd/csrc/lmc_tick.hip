@@ -14,6 +14,8 @@ int tick_launch(int ns, hipStream_t stream, const ChainArrays& A, const TickArra
         case 1: hipLaunchKernelGGL((tick_kernel<1>), grid, block, lds, stream, A, K, P, logp, grad); break;
         case 2: hipLaunchKernelGGL((tick_kernel<2>), grid, block, lds, stream, A, K, P, logp, grad); break;
         case 4: hipLaunchKernelGGL((tick_kernel<4>), grid, block, lds, stream, A, K, P, logp, grad); break;
+        case 8: hipLaunchKernelGGL((tick_kernel<8>), grid, block, lds, stream, A, K, P, logp, grad); break;
+        case 16: hipLaunchKernelGGL((tick_kernel<16>), grid, block, lds, stream, A, K, P, logp, grad); break;
         default: return -1;
     }
     return static_cast<int>(hipGetLastError());
@@ -26,6 +28,8 @@ int tick_launch_begin(int ns, hipStream_t stream, const ChainArrays& A, const Ti
         case 1: hipLaunchKernelGGL((tick_begin_kernel<1>), grid, block, 0, stream, A, K, iter_begin); break;
         case 2: hipLaunchKernelGGL((tick_begin_kernel<2>), grid, block, 0, stream, A, K, iter_begin); break;
         case 4: hipLaunchKernelGGL((tick_begin_kernel<4>), grid, block, 0, stream, A, K, iter_begin); break;
+        case 8: hipLaunchKernelGGL((tick_begin_kernel<8>), grid, block, 0, stream, A, K, iter_begin); break;
+        case 16: hipLaunchKernelGGL((tick_begin_kernel<16>), grid, block, 0, stream, A, K, iter_begin); break;
         default: return -1;
     }
     return static_cast<int>(hipGetLastError());

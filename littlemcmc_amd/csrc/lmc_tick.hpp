@@ -36,11 +36,11 @@ __device__ __forceinline__ void store_rows(double* dst, int d, int lane, const d
     }
 }
 
-#ifndef LMC_TICK_WAVES
-#define LMC_TICK_WAVES 4
-#endif
+// register budget per vector width (waves per SIMD): the tick kernel is latency / bandwidth bound and insensitive to
+// occupancy (4 / 6 / 8 waves measured equal at NS = 2), so wide vectors simply get the registers they need
+constexpr int tick_waves_per_simd(int ns) { return ns <= 2 ? 4 : ns == 4 ? 2 : 1; }
 template <int NS>
-__global__ __launch_bounds__(64, LMC_TICK_WAVES) void tick_kernel(ChainArrays A, TickArrays K, SamplerParams P, const double* logp_in,
+__global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(ChainArrays A, TickArrays K, SamplerParams P, const double* logp_in,
                                                   const double* grad_in) {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // 2 * dpad doubles: normals + staging / sdot staging
     const int c = blockIdx.x;
