@@ -175,3 +175,19 @@ def test_tick_chains_are_prefix_stable_at_scale():
     small_tr, small_st = lmc.sample(torch_std_normal(d), d, chains=32, **kw)
     np.testing.assert_array_equal(big_st["tree_size"][:32], small_st["tree_size"])
     np.testing.assert_array_equal(big_tr[:32], small_tr)
+
+
+@pytest.mark.parametrize("kind", ["nuts", "hmc"])
+def test_ticks_with_a_fixed_diagonal_scaling(kind):
+    """QuadPotentialDiag (scaling=..., float64 momentum draw, no mass adaptation) through ticks == fused kernel."""
+    d, chains = 9, 16
+    scaling = np.linspace(0.5, 2.0, d)
+    cls = lmc.NUTS if kind == "nuts" else lmc.HamiltonianMC
+    out = []
+    for tgt in (torch_ar1(d), lmc.targets.AR1(d)):
+        step = cls(tgt, d, scaling=scaling, is_cov=True)
+        out.append(lmc.sample(tgt, d, draws=10, tune=15, step=step, chains=chains, random_seed=4, discard_tuned_samples=False))
+    (a_tr, a_st), (b_tr, b_st) = out
+    key = "tree_size" if kind == "nuts" else "n_steps"
+    np.testing.assert_array_equal(a_st[key][:, :10], b_st[key][:, :10])
+    np.testing.assert_allclose(a_tr[:, :10], b_tr[:, :10], rtol=1e-7, atol=1e-9)
