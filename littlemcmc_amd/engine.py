@@ -186,9 +186,24 @@ class Engine:
             with torch.cuda.device(dev), torch.cuda.stream(self._tick_stream):
                 self.tick_begin(n_tune, iter_begin, n_iters)
                 q = torch.as_tensor(_TickView(self.tick_positions_ptr(), (self.chains, self.dim)), device=dev)
+                graph = None
+                if getattr(self.target, "graph", False):
+                    graph = getattr(self, "_tick_graph", None)
+                    if graph is None:   # warm up (allocator, lazy init), then capture fn(q) once
+                        for _ in range(3):
+                            self.target.evaluate(q)
+                        self._tick_stream.synchronize()
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=self._tick_stream):
+                            out = self.target.evaluate(q)
+                        graph = self._tick_graph = (g, out)
                 ticks = 0
                 while True:
-                    logp, grad = self.target.evaluate(q)
+                    if graph is not None:
+                        graph[0].replay()
+                        logp, grad = graph[1]
+                    else:
+                        logp, grad = self.target.evaluate(q)
                     ticks += 1
                     active = self.tick(logp.data_ptr(), grad.data_ptr(), wait=(ticks % poll == 0))
                     self._tick_keep = (logp, grad)   # alive until the next evaluation is enqueued behind the tick

@@ -155,14 +155,19 @@ class TorchTarget(DeviceTarget):
 
     family = _abi.TARGET_EXTERNAL
 
-    def __init__(self, d, fn):
+    def __init__(self, d, fn, graph=False):
         super().__init__(d)
         if not callable(fn):
             raise TypeError("fn must be callable: q[chains, d] -> (logp[chains], dlogp[chains, d])")
         self.fn = fn
+        # graph=True: capture fn once into a HIP graph (torch.cuda.CUDAGraph) and replay it every tick. The points
+        # always live in the same engine-owned buffer, so the capture is valid for the whole run; it removes the
+        # host-side launch cost of fn's kernels (what bounds small batches). fn must be capturable: no host
+        # synchronisation, no data-dependent shapes.
+        self.graph = bool(graph)
 
     @classmethod
-    def from_logp(cls, d, logp_fn):
+    def from_logp(cls, d, logp_fn, graph=False):
         import torch
 
         def fn(q):
@@ -172,7 +177,7 @@ class TorchTarget(DeviceTarget):
                 (g,) = torch.autograd.grad(lp.sum(), x)
             return lp.detach(), g
 
-        return cls(d, fn)
+        return cls(d, fn, graph=graph)
 
     def evaluate(self, q):
         """fn on a [chains, d] tensor, results checked and made contiguous float64."""

@@ -28,10 +28,11 @@ def torch_ar1(d, rho=0.9):
     c = 1.0 / (1.0 - rho * rho)
     c_end, c_mid, off = c, (1.0 + rho * rho) * c, -rho * c
 
+    diag = torch.full((d,), c_mid, dtype=torch.float64, device="cuda")   # built once: fn itself stays graph-capturable
+    diag[0] = c_end
+    diag[d - 1] = c_end
+
     def fn(q):
-        diag = torch.full((d,), c_mid, dtype=q.dtype, device=q.device)
-        diag[0] = c_end
-        diag[d - 1] = c_end
         pq = diag * q
         if d > 1:
             pq[:, 1:] += off * q[:, :-1]
@@ -191,3 +192,15 @@ def test_ticks_with_a_fixed_diagonal_scaling(kind):
     key = "tree_size" if kind == "nuts" else "n_steps"
     np.testing.assert_array_equal(a_st[key][:, :10], b_st[key][:, :10])
     np.testing.assert_allclose(a_tr[:, :10], b_tr[:, :10], rtol=1e-7, atol=1e-9)
+
+
+def test_graph_replay_of_the_callable_gives_the_same_chains():
+    """TorchTarget(graph=True): fn captured once into a HIP graph and replayed every tick == eager evaluation."""
+    d, chains = 10, 40
+    kw = dict(draws=12, tune=25, chains=chains, random_seed=13, discard_tuned_samples=False)
+    eager_tr, eager_st = lmc.sample(torch_ar1(d), d, **kw)
+    t = torch_ar1(d)
+    t.graph = True
+    graph_tr, graph_st = lmc.sample(t, d, **kw)
+    np.testing.assert_array_equal(graph_st["tree_size"], eager_st["tree_size"])
+    np.testing.assert_array_equal(graph_tr, eager_tr)

@@ -32,7 +32,8 @@ def ar1(q):
 
 
 ar1_compiled = None
-for name, tgt in (("fused AR1Target", lmc.targets.AR1(d, rho)), ("TorchTarget (eager, 7 torch kernels / tick)", TorchTarget(d, ar1))):
+for name, tgt in (("fused AR1Target", lmc.targets.AR1(d, rho)), ("TorchTarget (eager, 7 torch kernels / tick)", TorchTarget(d, ar1)),
+                  ("TorchTarget (graph=True: fn replayed as a HIP graph)", TorchTarget(d, ar1, graph=True))):
     step = lmc.NUTS(tgt, d)
     eng = step._make_engine(chains)
     eng.seed(np.arange(chains, dtype=np.uint32) + 1)
@@ -50,6 +51,6 @@ for name, tgt in (("fused AR1Target", lmc.targets.AR1(d, rho)), ("TorchTarget (e
     dt = time.perf_counter() - t0
     leaps = eng.counters()[:, _abi.CT_LEAPFROGS].sum() - base
     ticks = getattr(eng, "ticks", 0)
-    print("%-46s %9.3e leapfrog-steps/s  (%.2f s, %d chains x d=%d x %d iterations%s)" % (
+    print("%-54s %9.3e leapfrog-steps/s  (%.2f s, %d chains x d=%d x %d iterations%s)" % (
         name, leaps / dt, dt, chains, d, iters - 5, (", %d ticks, %.0f us/tick" % (ticks, 1e6 * dt / max(ticks, 1))) if ticks else ""))
     eng.close()
