@@ -150,3 +150,26 @@ def test_bench_and_entry_modules_import_without_gpu():
     assert bench.usable_cores() >= 1 and bench.HBM_PEAK == 8.0e12
     entry = importlib.import_module("__graft_entry__")
     assert callable(entry.build) and callable(entry.smoke)
+
+
+def test_torch_target_host_contract_without_a_gpu():
+    """TorchTarget is a host object around a callable: construction, shape checking and the refusal of CPU tensors
+    need no GPU (the sampler itself does)."""
+    import torch
+
+    from littlemcmc_amd.targets import TorchTarget, require_device_target
+
+    t = TorchTarget(3, lambda q: (-0.5 * (q * q).sum(dim=1), -q))
+    assert t.family == lmc._abi.TARGET_EXTERNAL and t.d == 3 and not t.graph
+    assert require_device_target(t, 3) is t
+    with pytest.raises(TypeError, match="no CPU path"):
+        t.evaluate(torch.zeros(2, 3, dtype=torch.float64))
+    bad = TorchTarget(3, lambda q: (q.sum(dim=1), q[:, :2]))
+    with pytest.raises(ValueError, match="must return"):
+        bad.evaluate(torch.zeros(2, 3, dtype=torch.float64))
+    with pytest.raises(TypeError):
+        TorchTarget(3, None)
+    auto = TorchTarget.from_logp(3, lambda q: -0.5 * (q * q).sum(dim=1), graph=True)
+    assert auto.graph
+    lp, g = auto.fn(torch.ones(2, 3, dtype=torch.float64))          # the autograd wrapper itself is device agnostic
+    assert torch.allclose(lp, torch.full((2,), -1.5, dtype=torch.float64)) and torch.allclose(g, -torch.ones(2, 3, dtype=torch.float64))
