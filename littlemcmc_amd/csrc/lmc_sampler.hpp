@@ -713,8 +713,9 @@ __device__ __forceinline__ void diag_mass_update(const ChainArrays& A, const Sam
     ms.wsum_f += 1.0;
     ms.wsum_b += 1.0;
     const double prop_f = first_f64(1.0 / ms.wsum_f), prop_b = first_f64(1.0 / ms.wsum_b);
-    double m[NS], r[NS];
-    vload<NS>(fm, m); vload<NS>(fr, r);
+    // all four estimator rows are requested before any is used: one HBM round trip per update instead of two
+    double m[NS], r[NS], mb[NS], rb[NS];
+    vload<NS>(fm, m); vload<NS>(fr, r); vload<NS>(bm, mb); vload<NS>(br, rb);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const double od = q[s] - m[s];
@@ -730,13 +731,13 @@ __device__ __forceinline__ void diag_mass_update(const ChainArrays& A, const Sam
         }
     }
     vstore<NS>(fm, m); vstore<NS>(fr, r);
-    vload<NS>(bm, m); vload<NS>(br, r);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const double od = q[s] - m[s];
-        m[s] = m[s] + prop_b * od;
-        const double nd = q[s] - m[s];
-        r[s] = r[s] + 1.0 * od * nd;
+        const double od = q[s] - mb[s];
+        mb[s] = mb[s] + prop_b * od;
+        const double nd = q[s] - mb[s];
+        rb[s] = rb[s] + 1.0 * od * nd;
+        m[s] = mb[s]; r[s] = rb[s];
     }
     if (ms.n_samples > 0 && ms.n_samples % ms.window == 0) {   // background becomes foreground
         vstore<NS>(bm, m); vstore<NS>(br, r);
