@@ -107,7 +107,9 @@ int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArra
                        int update_window) {
     const int lds = dense_adapt_lds_bytes(A.d, A.dpad);
     (void)hipGetLastError();
-    if (dense_adapt_grid(A.d) == 16)
+    if (dense_adapt_grid(A.d) == 8)
+        hipLaunchKernelGGL(dense_adapt_kernel<8>, dim3(A.chains), dim3(64), lds, stream, A, D, multiplier, update_window);
+    else if (dense_adapt_grid(A.d) == 16)
         hipLaunchKernelGGL(dense_adapt_kernel<16>, dim3(A.chains), dim3(256), lds, stream, A, D, multiplier, update_window);
     else
         hipLaunchKernelGGL(dense_adapt_kernel<32>, dim3(A.chains), dim3(1024), lds, stream, A, D, multiplier, update_window);

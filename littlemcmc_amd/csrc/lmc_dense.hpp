@@ -656,7 +656,8 @@ __global__ __launch_bounds__(64) void dense_momentum_kernel(ChainArrays A, Dense
 // (coalesced stores). A failed factorisation (pivot <= 0 or a non-finite entry: scipy.linalg.cholesky raises)
 // keeps the previous factor and is counted.
 constexpr int kCholLocals = 8;
-constexpr int dense_adapt_grid(int d) { return d <= 16 * kCholLocals ? 16 : 32; }   // T: 256 threads up to d = 128, else 1024
+// T: one wavefront (8 x 8 threads) per chain up to d = 64, 256 threads up to d = 128, else 1024
+constexpr int dense_adapt_grid(int d) { return d <= 8 * kCholLocals ? 8 : d <= 16 * kCholLocals ? 16 : 32; }
 constexpr int dense_adapt_lds_bytes(int d, int dpad) {
     return 4 * d * 8 + 16 + 2 * (d + 4) * 4 + dense_adapt_grid(d) * dpad * 4;
 }
