@@ -58,7 +58,7 @@ namespace lmc {
 int dense_launch_run(int family, int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
                      const SamplerParams& P, const double* tparams) {
     const dim3 grid(A.chains), block(64);
-    const int lds = dense_lds_doubles(A.dpad) * 8 + D.cache_rows * A.dpad * (mat_f64 ? 8 : 4);
+    const int lds = dense_lds_doubles(A.dpad) * 8 + D.cache_rows * A.dpad * (mat_f64 ? 8 : 4) + D.lds_slots * A.dpad * 8;
     (void)hipGetLastError();
 #define RUN_CALL(T) \
     DENSE_SHAPE_SWITCH(ns, mat_f64, {                                                                               \

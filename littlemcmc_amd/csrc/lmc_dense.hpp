@@ -257,12 +257,22 @@ __device__ __forceinline__ void dense_leapfrog(Team<1>& tm, const Target& tgt, c
 
 // ---- per-chain HBM rows: trajectory ends and subtree stack -------------------------------------------------------
 struct DenseScratch {
-    glb_double* base;
+    glb_double* base;      // HBM row of the chain: every slot has a home here
+    lds_double* lbase;     // the first `nlds` slots live in LDS instead (host-chosen: what is left after the matrix cache)
+    int nlds;
     int dpad;
-    // k: 0 q, 1 p, 2 g, 3 v, 4 w
-    __device__ __forceinline__ glb_double* end(int right, int k) const { return base + (right * 5 + k) * dpad; }
-    // k: 0 lp, 1 lv, 2 rp, 3 rv, 4 psum, 5 proposal q
-    __device__ __forceinline__ glb_double* level(int j, int k) const { return base + (10 + 6 * j + k) * dpad; }
+    // slots: 0-4 left end {q, p, g, v, w}, 5-9 right end, then 6 per subtree level {lp, lv, rp, rv, psum, proposal q}.
+    // Level j is touched with frequency 2^-j, so the low slots are the hot ones.
+    static __device__ __forceinline__ int end(int right, int k) { return right * 5 + k; }
+    static __device__ __forceinline__ int level(int j, int k) { return 10 + 6 * j + k; }
+    template <int NS>
+    __device__ __forceinline__ void ld(int slot, double (&x)[NS]) const {
+        if (slot < nlds) vload_as<NS>(lbase + slot * dpad, x); else vload_as<NS>(base + slot * dpad, x);
+    }
+    template <int NS>
+    __device__ __forceinline__ void st(int slot, const double (&x)[NS]) const {
+        if (slot < nlds) vstore_as<NS>(lbase + slot * dpad, x); else vstore_as<NS>(base + slot * dpad, x);
+    }
 };
 
 // ---- NUTS transition: the tree of lmc_sampler.hpp with stored velocities -------------------------------------------
@@ -275,8 +285,8 @@ __device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, con
                                              TransitionOut& out) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        vstore_as<NS>(scr.end(r, 0), q); vstore_as<NS>(scr.end(r, 1), p0); vstore_as<NS>(scr.end(r, 2), g0);
-        vstore_as<NS>(scr.end(r, 3), v0); vstore_as<NS>(scr.end(r, 4), w0);
+        scr.st<NS>(DenseScratch::end(r, 0), q); scr.st<NS>(DenseScratch::end(r, 1), p0); scr.st<NS>(DenseScratch::end(r, 2), g0);
+        scr.st<NS>(DenseScratch::end(r, 3), v0); scr.st<NS>(DenseScratch::end(r, 4), w0);
     }
     double psum[NS], propq[NS];
     vcopy(psum, p0); vcopy(propq, q);
@@ -294,8 +304,8 @@ __device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, con
         const double eps = right ? step_size : -step_size;
         const int side = right ? 1 : 0;
         double cq[NS], cp[NS], cg[NS], cv[NS], cw[NS];
-        vload_as<NS>(scr.end(side, 0), cq); vload_as<NS>(scr.end(side, 1), cp); vload_as<NS>(scr.end(side, 2), cg);
-        vload_as<NS>(scr.end(side, 3), cv); vload_as<NS>(scr.end(side, 4), cw);
+        scr.ld<NS>(DenseScratch::end(side, 0), cq); scr.ld<NS>(DenseScratch::end(side, 1), cp); scr.ld<NS>(DenseScratch::end(side, 2), cg);
+        scr.ld<NS>(DenseScratch::end(side, 3), cv); scr.ld<NS>(DenseScratch::end(side, 4), cw);
 
         double tlp[NS], tlv[NS], trp[NS], trv[NS], tps[NS], tq[NS];   // in-flight node
         double tw = 0.0, ta = 0.0, tpe = 0.0, tplogp = 0.0;
@@ -324,9 +334,9 @@ __device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, con
             while ((i >> j) & 1) {   // merge stack[j] (a, earlier) with t (b); nuts.py:377-417
                 double alp[NS], alv[NS], arp[NS], arv[NS], aps[NS], aq[NS];
                 double aw, aa, ape, aplogp;
-                vload_as<NS>(scr.level(j, 0), alp); vload_as<NS>(scr.level(j, 1), alv);
-                vload_as<NS>(scr.level(j, 2), arp); vload_as<NS>(scr.level(j, 3), arv);
-                vload_as<NS>(scr.level(j, 4), aps); vload_as<NS>(scr.level(j, 5), aq);
+                scr.ld<NS>(DenseScratch::level(j, 0), alp); scr.ld<NS>(DenseScratch::level(j, 1), alv);
+                scr.ld<NS>(DenseScratch::level(j, 2), arp); scr.ld<NS>(DenseScratch::level(j, 3), arv);
+                scr.ld<NS>(DenseScratch::level(j, 4), aps); scr.ld<NS>(DenseScratch::level(j, 5), aq);
                 lsc.get(j, aw, aa, ape, aplogp);
                 double ps[NS];
 #pragma unroll
@@ -353,9 +363,9 @@ __device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, con
             }
             if (turning) break;
             if (i + 1 < n_leaves) {
-                vstore_as<NS>(scr.level(j, 0), tlp); vstore_as<NS>(scr.level(j, 1), tlv);
-                vstore_as<NS>(scr.level(j, 2), trp); vstore_as<NS>(scr.level(j, 3), trv);
-                vstore_as<NS>(scr.level(j, 4), tps); vstore_as<NS>(scr.level(j, 5), tq);
+                scr.st<NS>(DenseScratch::level(j, 0), tlp); scr.st<NS>(DenseScratch::level(j, 1), tlv);
+                scr.st<NS>(DenseScratch::level(j, 2), trp); scr.st<NS>(DenseScratch::level(j, 3), trv);
+                scr.st<NS>(DenseScratch::level(j, 4), tps); scr.st<NS>(DenseScratch::level(j, 5), tq);
                 lsc.put(j, tw, ta, tpe, tplogp);
             }
         }
@@ -374,9 +384,9 @@ __device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, con
             psum[s] = momentum_f32 ? static_cast<double>(static_cast<float>(t)) : t;
         }
         double oLv[NS], oRv[NS], oP[NS];
-        if (l_start) vcopy(oLv, v0s); else vload_as<NS>(scr.end(0, 3), oLv);
-        if (r_start) vcopy(oRv, v0s); else vload_as<NS>(scr.end(1, 3), oRv);
-        vload_as<NS>(scr.end(side, 1), oP);   // momentum of the end that is being replaced
+        if (l_start) vcopy(oLv, v0s); else scr.ld<NS>(DenseScratch::end(0, 3), oLv);
+        if (r_start) vcopy(oRv, v0s); else scr.ld<NS>(DenseScratch::end(1, 3), oRv);
+        scr.ld<NS>(DenseScratch::end(side, 1), oP);   // momentum of the end that is being replaced
         double dots[6];
         double p1[NS], p2[NS];
         if (right) {
@@ -394,8 +404,8 @@ __device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, con
             dots[4] = pdot<NS>(p2, tlv);   dots[5] = pdot<NS>(p2, oRv);
             l_start = false;
         }
-        vstore_as<NS>(scr.end(side, 0), cq); vstore_as<NS>(scr.end(side, 1), cp); vstore_as<NS>(scr.end(side, 2), cg);
-        vstore_as<NS>(scr.end(side, 3), cv); vstore_as<NS>(scr.end(side, 4), cw);
+        scr.st<NS>(DenseScratch::end(side, 0), cq); scr.st<NS>(DenseScratch::end(side, 1), cp); scr.st<NS>(DenseScratch::end(side, 2), cg);
+        scr.st<NS>(DenseScratch::end(side, 3), cv); scr.st<NS>(DenseScratch::end(side, 4), cw);
         if (tm.any_nonpositive6(dots)) { turning = true; exhausted = false; break; }
     }
 
@@ -498,6 +508,8 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel
     int status = 0;
     DenseScratch scr;
     scr.base = (glb_double*)(A.scratch + static_cast<long long>(c) * A.scratch_stride);
+    scr.lbase = (lds_double*)(lds + dense_lds_doubles(dpad)) + (static_cast<long long>(D.cache_rows) * dpad * sizeof(MatT)) / 8;
+    scr.nlds = D.lds_slots;
     scr.dpad = dpad;
     const bool momentum_f32 = P.momentum_f32 != 0;
 

@@ -15,6 +15,7 @@ struct DenseArrays {
     long long mat_stride;   // elements between two chains' matrices (0 = shared)
     long long fac_stride;
     int cache_rows;         // leading rows of covT every wave keeps in LDS during a launch (host-chosen, lmc_engine.hip)
+    int lds_slots;          // leading tree slots (trajectory ends, low subtree levels) kept in LDS instead of the HBM row
     // FullAdapt estimators (slot esel[c] = foreground)
     double* rawT;           // [2][C][d][dpad]   rawT[j][i] = raw_cov[i][j]
     double* emean;          // [2][C][dpad]
