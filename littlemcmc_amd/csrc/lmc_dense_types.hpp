@@ -39,7 +39,10 @@ __host__ __device__ constexpr int sweep_rows(int d) { return (d + 2 * kSweepBatc
 #ifndef LMC_DENSE_WAVES_NS4
 #define LMC_DENSE_WAVES_NS4 1
 #endif
-constexpr int dense_waves_per_simd(int ns) { return ns <= 2 ? LMC_DENSE_WAVES_NS2 : LMC_DENSE_WAVES_NS4; }
+#ifndef LMC_DENSE_WAVES_NS1
+#define LMC_DENSE_WAVES_NS1 2
+#endif
+constexpr int dense_waves_per_simd(int ns) { return ns <= 1 ? LMC_DENSE_WAVES_NS1 : ns == 2 ? LMC_DENSE_WAVES_NS2 : LMC_DENSE_WAVES_NS4; }
 constexpr int dense_lds_doubles(int dpad) { return 2 * dpad + kLdsMtDoubles; }   // sweep operands / normals, MT19937 state
 
 // per-chain HBM scratch row of the dense kernels: 2 trajectory ends x {q, p, g, v, w} + 6 vectors per subtree level
