@@ -4,6 +4,7 @@
 
 #include "../../include/lmc_hip.h"
 #include "lmc_dense.hpp"
+#include "lmc_tick_dense.hpp"
 #include "lmc_dense_launch.hpp"
 #ifdef LMC_USER_TARGET_HEADER
 #include LMC_USER_TARGET_HEADER
@@ -104,15 +105,25 @@ int dense_launch_momentum(int ns, hipStream_t stream, const ChainArrays& A, cons
 }
 
 int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, double multiplier,
-                       int update_window) {
+                       int update_window, int* mask) {
     const int lds = dense_adapt_lds_bytes(A.d, A.dpad);
     (void)hipGetLastError();
     if (dense_adapt_grid(A.d) == 8)
-        hipLaunchKernelGGL(dense_adapt_kernel<8>, dim3(A.chains), dim3(64), lds, stream, A, D, multiplier, update_window);
+        hipLaunchKernelGGL(dense_adapt_kernel<8>, dim3(A.chains), dim3(64), lds, stream, A, D, multiplier, update_window, mask);
     else if (dense_adapt_grid(A.d) == 16)
-        hipLaunchKernelGGL(dense_adapt_kernel<16>, dim3(A.chains), dim3(256), lds, stream, A, D, multiplier, update_window);
+        hipLaunchKernelGGL(dense_adapt_kernel<16>, dim3(A.chains), dim3(256), lds, stream, A, D, multiplier, update_window, mask);
     else
-        hipLaunchKernelGGL(dense_adapt_kernel<32>, dim3(A.chains), dim3(1024), lds, stream, A, D, multiplier, update_window);
+        hipLaunchKernelGGL(dense_adapt_kernel<32>, dim3(A.chains), dim3(1024), lds, stream, A, D, multiplier, update_window, mask);
+    return static_cast<int>(hipGetLastError());
+}
+
+int tick_dense_launch(int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
+                      const TickArrays& K, const SamplerParams& P, const double* logp, const double* grad, int* adapt_mask) {
+    const dim3 grid(A.chains), block(64);
+    const int lds = 2 * A.dpad * 8;
+    (void)hipGetLastError();
+    DENSE_SHAPE_SWITCH(ns, mat_f64, hipLaunchKernelGGL((tick_dense_kernel<NS, MatT>), grid, block, lds, stream, A, D, K, P, logp,
+                                                       grad, adapt_mask))
     return static_cast<int>(hipGetLastError());
 }
 

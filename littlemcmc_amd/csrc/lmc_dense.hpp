@@ -755,10 +755,12 @@ __device__ inline bool cholesky_registers(const float* covT, float* fac, int d, 
 
 template <int T>
 __global__ __launch_bounds__(T * T) void dense_adapt_kernel(ChainArrays A, DenseArrays D, double multiplier,
-                                                            int update_window) {
+                                                            int update_window, int* mask) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int kThreads = T * T;
     const int c = blockIdx.x, tid = threadIdx.x;
+    // mask != nullptr (tick path): only the chains that finished a tuning iteration in the last tick take part
+    if (mask != nullptr && mask[c] == 0) return;
     const int d = A.d, dpad = A.dpad;
     double* oldf = lds;            // [d] x - mean_before (foreground)
     double* newf = lds + d;        // [d] x - mean_after
@@ -838,6 +840,7 @@ __global__ __launch_bounds__(T * T) void dense_adapt_kernel(ChainArrays A, Dense
             D.en[c * 2 + 1 - sel] = nb;
         }
         A.n_samples[c] = n_samples + 1;
+        if (mask != nullptr) mask[c] = 0;   // every thread read it before the first barrier
     }
 }
 

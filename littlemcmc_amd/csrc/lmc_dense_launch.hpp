@@ -17,7 +17,11 @@ int dense_launch_trajectory(int family, int ns, bool mat_f64, hipStream_t stream
                             double* ov, double* og, double* oe, double* ol);
 int dense_launch_momentum(int ns, hipStream_t stream, const ChainArrays& A, const DenseArrays& D, double* out);
 int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, double multiplier,
-                       int update_window);
+                       int update_window, int* mask = nullptr);
+// the tick kernel with a dense mass matrix (lmc_tick_dense.hpp)
+struct TickArrays;
+int tick_dense_launch(int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
+                      const TickArrays& K, const SamplerParams& P, const double* logp, const double* grad, int* adapt_mask);
 int dense_launch_reset(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, const float* cov1T,
                        const float* fac1, const double* raw1T, const double* mean1, double weight, int window, int d8);
 

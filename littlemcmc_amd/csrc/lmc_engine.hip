@@ -293,6 +293,7 @@ struct lmc_engine {
     // externally evaluated density (cfg.target_family == LMC_TARGET_EXTERNAL): tick state
     TickArrays K;
     bool ticking = false;
+    int* adapt_mask = nullptr;     // [C] chains whose FullAdapt.update is due after the current tick
     std::vector<void*> allocs;
     std::string err;
 };
@@ -546,8 +547,6 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         return fail(nullptr, LMC_ERR_INVALID, "unknown potential %d", cfg->potential);
     if (cfg->potential >= LMC_POT_FULL && cfg->dim > 256)
         return fail(nullptr, LMC_ERR_INVALID, "dense mass matrices are supported up to dim 256 (got %d)", cfg->dim);
-    if (cfg->target_family == LMC_TARGET_EXTERNAL && cfg->potential >= LMC_POT_FULL)
-        return fail(nullptr, LMC_ERR_INVALID, "an externally evaluated density supports diagonal mass matrices only");
     if (!lmc_has_target(cfg->target_family))
         return fail(nullptr, LMC_ERR_INVALID, "target family %d is not built into this library", cfg->target_family);
     if (cfg->target_family == LMC_TARGET_NORMAL1D && cfg->dim != 1)
@@ -644,7 +643,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     const bool dense = cfg->potential >= LMC_POT_FULL;
     if (dense) A.scratch_stride = static_cast<long long>(dense_scratch_vectors(max_levels)) * dp;
     const bool external = cfg->target_family == LMC_TARGET_EXTERNAL;
-    if (external) A.scratch_stride = static_cast<long long>(tick_scratch_vectors(max_levels)) * dp;
+    if (external) A.scratch_stride = static_cast<long long>(dense ? tick_dense_scratch_vectors(max_levels) : tick_scratch_vectors(max_levels)) * dp;
     TRY_ALLOC(dev_alloc(e, &A.scratch, C * static_cast<size_t>(A.scratch_stride), false));
     TRY_ALLOC(dev_alloc(e, &e->init_mean, C * dp));
     TRY_ALLOC(dev_alloc(e, &e->init_diag, C * dp));
@@ -674,6 +673,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         if ((rc = dev_alloc(e, &K.lvl, C * 4 * kTickLevels)) != LMC_OK) return bail(rc);
         if ((rc = dev_alloc(e, &K.q_eval, C * static_cast<size_t>(cfg->dim))) != LMC_OK) return bail(rc);
         if ((rc = dev_alloc(e, &K.n_active, 1)) != LMC_OK) return bail(rc);
+        if ((rc = dev_alloc(e, &e->adapt_mask, C)) != LMC_OK) return bail(rc);
     }
     std::memset(&e->D, 0, sizeof(e->D));
     if (dense) {
@@ -1267,9 +1267,21 @@ int lmc_engine_tick(lmc_engine* e, const double* logp, const double* grad, int32
     if (!e || !logp || !grad) return fail(e, LMC_ERR_INVALID, "null argument");
     if (!e->ticking) return fail(e, LMC_ERR_STATE, "lmc_engine_tick_begin() must be called first");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    const SamplerParams P = make_params(e, e->K.n_tune, 0, 0);
-    const int rc = tick_launch(e->ns, e->stream, e->A, e->K, P, logp, grad);
-    if (rc != 0) return fail(e, LMC_ERR_HIP, "tick: %s", rc < 0 ? "unsupported vector width" : hipGetErrorString(static_cast<hipError_t>(rc)));
+    SamplerParams P = make_params(e, e->K.n_tune, 0, 0);
+    if (e->cfg.potential >= LMC_POT_FULL) {
+        P.momentum_f32 = e->cfg.potential != LMC_POT_FULL_INV;
+        P.adapt_mass = 0;
+        int rc = tick_dense_launch(e->ns, e->cfg.potential == LMC_POT_FULL_INV, e->stream, e->A, e->D, e->K, P, logp, grad,
+                                   e->adapt_mask);
+        if (rc != 0) return dense_fail(e, rc, "tick");
+        if (e->cfg.potential == LMC_POT_FULL_ADAPT) {   // update() of the chains that finished a tuning iteration in this tick
+            rc = dense_launch_adapt(e->stream, e->A, e->D, e->dense_multiplier, e->dense_update_window, e->adapt_mask);
+            if (rc != 0) return dense_fail(e, rc, "dense update");
+        }
+    } else {
+        const int rc = tick_launch(e->ns, e->stream, e->A, e->K, P, logp, grad);
+        if (rc != 0) return fail(e, LMC_ERR_HIP, "tick: %s", rc < 0 ? "unsupported vector width" : hipGetErrorString(static_cast<hipError_t>(rc)));
+    }
     if (n_active) {
         HIP_TRY(e, hipMemsetAsync(e->K.n_active, 0, sizeof(int), e->stream));
         const int rc2 = tick_launch_count(e->stream, e->K, e->cfg.chains);

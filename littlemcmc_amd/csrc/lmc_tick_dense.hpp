@@ -1,30 +1,20 @@
-// Externally evaluated log-densities ("a batched callable adapter"): the sampler as a
-// resumable state machine. The plug-in `logp_dlogp_func` stays on the host side of the C ABI -- any batched
-// function (chains x d) -> (chains), (chains x d) on device memory, e.g. a torch-ROCm callable -- and the
-// transition kernel is cut at the one place the reference calls it (integration.py:62 and :115):
-//
-//   tick_kernel:  consume (logp, grad) of the point each chain asked for  ->  advance that chain's iteration
-//                 (finish the leapfrog, leaf, merges, doublings, end of transition, adaptation, next iteration's
-//                 momentum draw ...) until it needs the density again  ->  write the next point, return.
-//
-// Chains do not wait for each other: every tick every unfinished chain performs exactly one density evaluation,
-// whatever iteration / tree depth it is in. All per-chain state lives in HBM between ticks (ends of the
-// trajectory, subtree stack, p_sum, proposal, scalars); the arithmetic is the one of lmc_sampler.hpp, statement for
-// statement, so a chain driven through ticks and a chain inside run_kernel agree to the rounding of the density.
-//
-//   leapfrog  <- /root/reference/littlemcmc/integration.py:100-121 (split at line 115)
-//   NUTS      <- nuts.py:204-435        HMC <- hmc.py:140-182        iteration <- base_hmc.py:140-190
+// The tick kernel (lmc_tick.hpp) with a dense mass matrix: densities evaluated by the caller (targets.TorchTarget)
+// sampled with QuadPotentialFull / FullInv / FullAdapt. Same state machine, cut at the density evaluation; the
+// differences are the ones between lmc_sampler.hpp and lmc_dense.hpp: velocities are matrix sweeps and therefore
+// stored with the trajectory ends and tree nodes, one sweep per leapfrog forms v = C p and w = C g, the momentum is
+// a triangular solve (or L n), and FullAdapt's update of a chain that finished a tuning iteration in this tick runs
+// in dense_adapt_kernel, launched masked by the host between two ticks. GENERATED from lmc_tick.hpp by
+// tools/gen_tick_dense.py so that the two state machines stay statement-parallel; do not edit by hand.
 #pragma once
+#include "lmc_dense.hpp"
 #include "lmc_tick_launch.hpp"
 
 namespace lmc {
 
-// register budget per vector width (waves per SIMD): the tick kernel is latency / bandwidth bound and insensitive to
-// occupancy (4 / 6 / 8 waves measured equal at NS = 2), so wide vectors simply get the registers they need
-constexpr int tick_waves_per_simd(int ns) { return ns <= 2 ? 4 : ns == 4 ? 2 : 1; }
-template <int NS>
-__global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(ChainArrays A, TickArrays K, SamplerParams P, const double* logp_in,
-                                                  const double* grad_in) {
+template <int NS, class MatT>
+__global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void tick_dense_kernel(ChainArrays A, DenseArrays D, TickArrays K,
+                                                                                  SamplerParams P, const double* logp_in,
+                                                                                  const double* grad_in, int* adapt_mask) {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // 2 * dpad doubles: normals + staging / sdot staging
     const int c = blockIdx.x;
     const int lane = lane_id();
@@ -35,19 +25,14 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
     Team<1> tm{nullptr, 0};
     glb_double* scr = (glb_double*)(A.scratch + static_cast<long long>(c) * A.scratch_stride);
     auto slot = [&](int k) { return scr + k * dpad; };
-    auto level = [&](int j, int k) { return scr + (9 + 4 * j + k) * dpad; };
+    auto level = [&](int j, int k) { return scr + (kTickDenseFixedSlots + 6 * j + k) * dpad; };
+    const MatT* M = static_cast<const MatT*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
+    DenseMat<MatT> mm{M, nullptr, 0, d, dpad};
+    lds_double* xop = (lds_double*)lds;
 
     // ---- persistent chain state
     long long git = K.git[c];
     const bool tune = git < K.n_tune;
-    float var[NS], inv_std[NS];
-    double vard[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        var[s] = A.var[row + lane * NS + s];
-        inv_std[s] = A.inv_std[row + lane * NS + s];
-        vard[s] = static_cast<double>(var[s]);
-    }
     RngState rng;
     rng.mt = A.mt + static_cast<long long>(c) * kMtN;   // in place in HBM / L2: a tick touches a few words
     rng.pos = first_i32(A.rng_pos[c]);
@@ -80,9 +65,9 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
     // what this tick decides
     bool begin_doubling = false, subtree_done = false, end_transition = false, need_leap = false;
     bool diverging = false, turning = false, exhausted = false, accepted = false;
-    double cq[NS], cp[NS], cg[NS];          // the state the next leapfrog starts from
+    double cq[NS], cp[NS], cg[NS], cv[NS], cw[NS];   // the state the next leapfrog starts from: q, p, g, v = C p, w = C g
     double q[NS];                           // the chain's position (start of the iteration / its result)
-    double tlp[NS], trp[NS], tps[NS], tq[NS];
+    double tlp[NS], tlv[NS], trp[NS], trv[NS], tps[NS], tq[NS];
     double tw = 0.0, ta = 0.0, tpe = 0.0, tplogp = 0.0;
     const double logp_new = first_f64(logp_in[c]);
 
@@ -93,20 +78,13 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
         load_rows<NS>(grad_in + static_cast<long long>(c) * d, d, lane, g0);
         rng_normals(rng, d, lds, lds + dpad);
         double p0[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int e = lane * NS + s;
-            const double z = (e < d) ? lds[e] : 0.0;
-            p0[s] = momentum_f32 ? static_cast<double>(inv_std[s] * static_cast<float>(z)) : z * static_cast<double>(inv_std[s]);
-        }
-        wave_sync();
+        if (D.kind == kDenseFullInv)
+            dense_momentum_inv<NS>(static_cast<const double*>(D.fac), d, dpad, xop, p0);
+        else
+            dense_momentum_full<NS>(static_cast<const float*>(D.fac) + static_cast<long long>(c) * D.fac_stride, d, dpad, xop, p0);
         logp0 = logp_new;
-        if (momentum_f32) {
-            const float kin = start_kinetic_f32<NS>(tm, p0, var, d, P.sdot_mode, reinterpret_cast<float*>(lds), dpad);
-            e0 = first_f64(static_cast<double>(kin) - logp0);
-        } else {
-            e0 = first_f64(0.5 * tm.sum(pdot_v<NS>(p0, vard, p0)) - logp0);
-        }
+        double v0[NS], w0[NS], v0s[NS];
+        e0 = dense_start_state<NS, MatT>(tm, mm, lds, momentum_f32, P.sdot_mode, p0, g0, logp0, v0, w0, v0s);
         if (!isfinite(e0)) {   // base_hmc.py:145-148
             if (lane == 0) { A.status[c] |= kStatusBadInitialEnergy; K.phase[c] = kTickDone; }
             return;
@@ -118,10 +96,11 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
             max_depth = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                vstore_as<NS>(slot(3 * r + 0), q); vstore_as<NS>(slot(3 * r + 1), p0); vstore_as<NS>(slot(3 * r + 2), g0);
+                vstore_as<NS>(slot(5 * r + 0), q); vstore_as<NS>(slot(5 * r + 1), p0); vstore_as<NS>(slot(5 * r + 2), g0);
+                vstore_as<NS>(slot(5 * r + 3), v0); vstore_as<NS>(slot(5 * r + 4), w0);
             }
-            vstore_as<NS>(slot(6), p0); vstore_as<NS>(slot(7), q);
-            l_start = momentum_f32; r_start = momentum_f32;
+            vstore_as<NS>(slot(kSlotPsum), p0); vstore_as<NS>(slot(kSlotProp), q); vstore_as<NS>(slot(kSlotV0s), v0s);
+            l_start = true; r_start = true;   // the end still is the start state: its stored velocity is v0s
             prop_e = e0; prop_logp = logp0;
             coff = 0.0; w_start = 1.0; wn = 0.0; an = 0.0; max_de = 0.0;
             depth = 0;
@@ -133,7 +112,7 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
             n_steps = n_steps < 1 ? 1 : n_steps;
             n_steps = n_steps > P.max_steps ? P.max_steps : n_steps;
             eps = step_size;
-            vcopy(cq, q); vcopy(cp, p0); vcopy(cg, g0);
+            vcopy(cq, q); vcopy(cp, p0); vcopy(cg, g0); vcopy(cv, v0); vcopy(cw, w0);
             need_leap = true;
         }
     } else {
@@ -141,15 +120,12 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
         double half[NS];
         load_rows<NS>(K.q_eval + static_cast<long long>(c) * d, d, lane, cq);
         load_rows<NS>(grad_in + static_cast<long long>(c) * d, d, lane, cg);
-        vload_as<NS>(slot(8), half);
+        vload_as<NS>(slot(kSlotHalf), half);
         const double dt = 0.5 * eps;
-        double kin = 0.0;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            cp[s] = half[s] + dt * cg[s];
-            kin = __builtin_fma(cp[s], vard[s] * cp[s], kin);
-        }
-        const double energy = first_f64(0.5 * tm.sum(kin) - logp_new);
+        for (int s = 0; s < NS; ++s) cp[s] = half[s] + dt * cg[s];
+        velocity2<NS, MatT>(mm, xop, cp, cg, cv, cw);   // the one matrix sweep of this leapfrog: v = C p, w = C g
+        const double energy = first_f64(0.5 * tm.sum(pdot<NS>(cp, cv)) - logp_new);
         ++n_leap;
         if (P.kind == 0) {
             // ---- leaf (nuts.py:344-375) and the merges it closes (nuts.py:377-417)
@@ -169,14 +145,14 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
                 tw = exp_uniform_fast(x - coff);
                 const double sat = (coff == 0.0) ? fmin(1.0, tw) : ((x >= 0.0) ? 1.0 : exp_uniform(x));
                 ta = tw * sat;
-                vcopy(tlp, cp); vcopy(trp, cp); vcopy(tps, cp); vcopy(tq, cq);
+                vcopy(tlp, cp); vcopy(trp, cp); vcopy(tps, cp); vcopy(tlv, cv); vcopy(trv, cv); vcopy(tq, cq);
                 tpe = energy; tplogp = logp_new;
                 int j = 0;
                 while ((leaf >> j) & 1) {
-                    double alp[NS], arp[NS], aps[NS], aq[NS];
+                    double alp[NS], alv[NS], arp[NS], arv[NS], aps[NS], aq[NS];
                     double aw, aa, ape, aplogp;
-                    vload_as<NS>(level(j, 0), alp); vload_as<NS>(level(j, 1), arp);
-                    vload_as<NS>(level(j, 2), aps); vload_as<NS>(level(j, 3), aq);
+                    vload_as<NS>(level(j, 0), alp); vload_as<NS>(level(j, 1), alv); vload_as<NS>(level(j, 2), arp);
+                    vload_as<NS>(level(j, 3), arv); vload_as<NS>(level(j, 4), aps); vload_as<NS>(level(j, 5), aq);
                     lsc.get(j, aw, aa, ape, aplogp);
                     double ps[NS];
 #pragma unroll
@@ -186,16 +162,16 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
                         double p1[NS], p2[NS];
 #pragma unroll
                         for (int s = 0; s < NS; ++s) { p1[s] = aps[s] + tlp[s]; p2[s] = arp[s] + tps[s]; }
-                        double dots[6] = {pdot_v<NS>(ps, vard, alp), pdot_v<NS>(ps, vard, trp), pdot_v<NS>(p1, vard, alp),
-                                          pdot_v<NS>(p1, vard, tlp), pdot_v<NS>(p2, vard, arp), pdot_v<NS>(p2, vard, trp)};
+                        double dots[6] = {pdot<NS>(ps, alv), pdot<NS>(ps, trv), pdot<NS>(p1, alv),
+                                          pdot<NS>(p1, tlv), pdot<NS>(p2, arv), pdot<NS>(p2, trv)};
                         turn = tm.any_nonpositive6(dots);
                     } else {
-                        turn = tm.any_nonpositive2(pdot_v<NS>(ps, vard, alp), pdot_v<NS>(ps, vard, trp));
+                        turn = tm.any_nonpositive2(pdot<NS>(ps, alv), pdot<NS>(ps, trv));
                     }
                     const double wsum = aw + tw;
                     const double asum = aa + ta;
                     const bool take_b = uniform_true(window_next(rng, win) * wsum < tw);
-                    vcopy(tlp, alp); vcopy(tps, ps);
+                    vcopy(tlp, alp); vcopy(tlv, alv); vcopy(tps, ps);
                     if (!take_b) { vcopy(tq, aq); tpe = ape; tplogp = aplogp; }
                     tw = wsum; ta = asum;
                     ++j;
@@ -203,8 +179,8 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
                 }
                 if (!turning) {
                     if (leaf + 1 < (1 << depth)) {   // park the node, continue the subtree from (cq, cp, cg)
-                        vstore_as<NS>(level(j, 0), tlp); vstore_as<NS>(level(j, 1), trp);
-                        vstore_as<NS>(level(j, 2), tps); vstore_as<NS>(level(j, 3), tq);
+                        vstore_as<NS>(level(j, 0), tlp); vstore_as<NS>(level(j, 1), tlv); vstore_as<NS>(level(j, 2), trp);
+                        vstore_as<NS>(level(j, 3), trv); vstore_as<NS>(level(j, 4), tps); vstore_as<NS>(level(j, 5), tq);
                         lsc.put(j, tw, ta, tpe, tplogp);
                         ++leaf;
                         need_leap = true;
@@ -218,10 +194,10 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
                 // ---- accepted subtree: merge into the trajectory (nuts.py:315-340)
                 ++depth;
                 double psum[NS], propq[NS];
-                vload_as<NS>(slot(6), psum); vload_as<NS>(slot(7), propq);
+                vload_as<NS>(slot(kSlotPsum), psum); vload_as<NS>(slot(kSlotProp), propq);
                 if (uniform_true(window_next(rng, win) * (w_start + wn) < tw)) {
                     vcopy(propq, tq); prop_e = tpe; prop_logp = tplogp;
-                    vstore_as<NS>(slot(7), propq);
+                    vstore_as<NS>(slot(kSlotProp), propq);
                 }
                 wn = first_f64(wn + tw);
                 an = first_f64(an + ta);
@@ -230,13 +206,12 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
                     const double t = psum[s] + tps[s];
                     psum[s] = momentum_f32 ? static_cast<double>(static_cast<float>(t)) : t;
                 }
-                vstore_as<NS>(slot(6), psum);
+                vstore_as<NS>(slot(kSlotPsum), psum);
                 double Lp[NS], Rp[NS], oLv[NS], oRv[NS], vtl[NS], vtr[NS];
-                vload_as<NS>(slot(1), Lp); vload_as<NS>(slot(4), Rp);
-                end_velocity<NS>(oLv, vard, Lp, l_start);
-                end_velocity<NS>(oRv, vard, Rp, r_start);
-#pragma unroll
-                for (int s = 0; s < NS; ++s) { vtl[s] = vard[s] * tlp[s]; vtr[s] = vard[s] * trp[s]; }
+                vload_as<NS>(slot(1), Lp); vload_as<NS>(slot(6), Rp);
+                vload_as<NS>(slot(l_start ? kSlotV0s : 3), oLv);
+                vload_as<NS>(slot(r_start ? kSlotV0s : 8), oRv);
+                vcopy(vtl, tlv); vcopy(vtr, trv);
                 double dots[6], p1[NS], p2[NS];
                 const int side = right ? 1 : 0;
                 if (right) {
@@ -254,7 +229,8 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
                     dots[4] = pdot<NS>(p2, vtl);   dots[5] = pdot<NS>(p2, oRv);
                     l_start = false;
                 }
-                vstore_as<NS>(slot(3 * side + 0), cq); vstore_as<NS>(slot(3 * side + 1), cp); vstore_as<NS>(slot(3 * side + 2), cg);
+                vstore_as<NS>(slot(5 * side + 0), cq); vstore_as<NS>(slot(5 * side + 1), cp); vstore_as<NS>(slot(5 * side + 2), cg);
+                vstore_as<NS>(slot(5 * side + 3), cv); vstore_as<NS>(slot(5 * side + 4), cw);
                 if (tm.any_nonpositive6(dots)) { turning = true; end_transition = true; }
                 else if (depth >= max_depth) { exhausted = true; end_transition = true; }
                 else begin_doubling = true;
@@ -283,7 +259,8 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
         right = window_next(rng, win) < 0.5;
         eps = right ? step_size : -step_size;
         const int side = right ? 1 : 0;
-        vload_as<NS>(slot(3 * side + 0), cq); vload_as<NS>(slot(3 * side + 1), cp); vload_as<NS>(slot(3 * side + 2), cg);
+        vload_as<NS>(slot(5 * side + 0), cq); vload_as<NS>(slot(5 * side + 1), cp); vload_as<NS>(slot(5 * side + 2), cg);
+        vload_as<NS>(slot(5 * side + 3), cv); vload_as<NS>(slot(5 * side + 4), cw);
         leaf = 0;
         need_leap = true;
     }
@@ -295,10 +272,10 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             half[s] = cp[s] + dt * cg[s];
-            const double v = vard[s] * half[s];
+            const double v = cv[s] + dt * cw[s];   // C (p + dt g)
             qn[s] = cq[s] + eps * v;
         }
-        vstore_as<NS>(slot(8), half);
+        vstore_as<NS>(slot(kSlotHalf), half);
         store_rows<NS>(K.q_eval + static_cast<long long>(c) * d, d, lane, qn);
         phase = kTickLeap;
     }
@@ -307,7 +284,7 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
         // ---- statistics, adaptation, outputs (base_hmc.py:155-190), then the next iteration asks for its start density
         TransitionOut out;
         if (P.kind == 0) {
-            vload_as<NS>(slot(7), q);
+            vload_as<NS>(slot(kSlotProp), q);
             out.accept = (wn > 0.0) ? first_f64(an / wn) : 0.0;   // nuts.py:421-425
             out.energy = prop_e;
             out.energy_error = first_f64(prop_e - e0);
@@ -333,27 +310,8 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
         long long ct_maxdepth = (P.kind == 0 && exhausted && !tune) ? 1 : 0;
         const bool adapt_step = tune && P.adapt_step_size;
         if (adapt_step) dual_average_update(A, P, out.accept, da);
-        if (tune && P.adapt_mass) {
-            MassScalars ms;
-            ms.n_samples = first_i32(A.n_samples[c]);
-            ms.wsel = first_i32(A.wsel[c]);
-            ms.wsum_f = first_f64(A.wsum[c * 2 + ms.wsel]);
-            ms.wsum_b = first_f64(A.wsum[c * 2 + (1 - ms.wsel)]);
-            ms.window = first_i32(A.awindow[c]);
-            diag_mass_update<NS>(A, P, row, lane, q, var, inv_std, vard, ms);
-            if (lane == 0) {
-                A.n_samples[c] = ms.n_samples;
-                A.wsel[c] = ms.wsel;
-                A.awindow[c] = ms.window;
-                A.wsum[c * 2 + ms.wsel] = ms.wsum_f;
-                A.wsum[c * 2 + (1 - ms.wsel)] = ms.wsum_b;
-            }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                A.var[row + lane * NS + s] = var[s];
-                A.inv_std[row + lane * NS + s] = inv_std[s];
-            }
-        }
+        // FullAdapt.update for this chain runs in dense_adapt_kernel right after this tick (the host launches it masked)
+        if (tune && D.kind == kDenseFullAdapt && lane == 0) adapt_mask[c] = 1;
         ++iter_count;
         if (A.mom_mean != nullptr && !tune) moments_update<NS>(A, tm, c, row, q);
         write_outputs<NS>(A, c, lane, git, q, out, da.step_now, da.step_bar_now, tune);
@@ -395,36 +353,6 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
         A.da_count[c] = da.count;
         A.iter_count[c] = iter_count;
         A.status[c] |= status;
-    }
-}
-
-// chains that still want evaluations (only launched when the host asks: one atomic per 256 chains, not per chain
-// per tick -- 65 536 atomics on one address cost more than the rest of the tick)
-__global__ __launch_bounds__(256) void tick_count_kernel(TickArrays K, int chains) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    const bool active = c < chains && K.phase[c] != kTickDone;
-    const unsigned long long m = __ballot(active);
-    __shared__ int part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = __popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int n = part[0] + part[1] + part[2] + part[3];
-        if (n) atomicAdd(K.n_active, n);
-    }
-}
-
-// lmc_engine_tick_begin(): every chain asks for the density at its current position
-template <int NS>
-__global__ __launch_bounds__(64) void tick_begin_kernel(ChainArrays A, TickArrays K, long long iter_begin) {
-    const int c = blockIdx.x;
-    const int lane = lane_id();
-    double q[NS];
-    vload<NS>(A.q + static_cast<long long>(c) * A.dpad, q);
-    store_rows<NS>(K.q_eval + static_cast<long long>(c) * A.d, A.d, lane, q);
-    if (lane == 0) {
-        const bool dead = (A.status[c] & kStatusBadInitialEnergy) != 0 || iter_begin >= K.iter_end;
-        K.phase[c] = dead ? kTickDone : kTickStart;
-        K.git[c] = iter_begin;
     }
 }
 

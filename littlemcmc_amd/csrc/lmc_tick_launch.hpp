@@ -28,9 +28,32 @@ struct TickArrays {
 // then 4 vectors per subtree level {lp, rp, psum, proposal q}
 constexpr int tick_scratch_vectors(int max_levels) { return 9 + 4 * max_levels; }
 
+// rows of the caller's [chains][d] (unpadded) arrays <-> a thread's slice of a padded vector
+template <int NS>
+__device__ __forceinline__ void load_rows(const double* src, int d, int lane, double (&x)[NS]) {   // [d] unpadded
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = lane * NS + s;
+        x[s] = (e < d) ? src[e] : 0.0;
+    }
+}
+template <int NS>
+__device__ __forceinline__ void store_rows(double* dst, int d, int lane, const double (&x)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = lane * NS + s;
+        if (e < d) dst[e] = x[s];
+    }
+}
+
 int tick_launch(int ns, hipStream_t stream, const ChainArrays& A, const TickArrays& K, const SamplerParams& P,
                 const double* logp, const double* grad);
 int tick_launch_begin(int ns, hipStream_t stream, const ChainArrays& A, const TickArrays& K, long long iter_begin);
 int tick_launch_count(hipStream_t stream, const TickArrays& K, int chains);   // K.n_active += chains not yet done
+
+// per-chain HBM row of the dense tick kernel (lmc_tick_dense.hpp): 0-4 left end {q, p, g, v, w}, 5-9 right end, p_sum,
+// proposal q, half-stepped momentum, the start state's stored velocity, then 6 vectors per subtree level
+constexpr int kSlotPsum = 10, kSlotProp = 11, kSlotHalf = 12, kSlotV0s = 13, kTickDenseFixedSlots = 14;
+constexpr int tick_dense_scratch_vectors(int max_levels) { return kTickDenseFixedSlots + 6 * max_levels; }
 
 }  // namespace lmc

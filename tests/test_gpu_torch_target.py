@@ -130,8 +130,8 @@ def test_torch_target_contract_errors():
         lmc.sample(on_cpu, d, draws=2, tune=2, chains=2, random_seed=1)
     with pytest.raises(TypeError):
         TorchTarget(d, "not callable")
-    with pytest.raises(lmc._abi.HipLibraryError, match="diagonal mass"):
-        lmc.sample(torch_std_normal(d), d, draws=2, tune=2, chains=2, random_seed=1, init="adapt_full")
+    with pytest.raises(NotImplementedError, match="up to model_ndim = 256"):
+        lmc.sample(torch_std_normal(300), 300, draws=2, tune=2, chains=2, random_seed=1, init="adapt_full")
     # reference plug-in signature on one point
     logp, grad = torch_std_normal(d)(np.arange(4.0))
     assert np.isclose(logp, -7.0) and np.allclose(grad, -np.arange(4.0))
@@ -204,3 +204,54 @@ def test_graph_replay_of_the_callable_gives_the_same_chains():
     graph_tr, graph_st = lmc.sample(t, d, **kw)
     np.testing.assert_array_equal(graph_st["tree_size"], eager_st["tree_size"])
     np.testing.assert_array_equal(graph_tr, eager_tr)
+
+
+# ---------------------------------------------------------------------------------------------------
+# torch-callable density x dense mass matrix: csrc/lmc_tick_dense.hpp (generated from lmc_tick.hpp)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["e2e_nuts_full_ar1_12", "e2e_nuts_fullinv_ar1_12", "e2e_hmc_full_std10",
+                                  "e2e_nuts_adaptfull_ar1_10_b", "e2e_nuts_adaptfull_std70"])
+def test_dense_mass_through_ticks_replays_the_reference_chain(golden_dir, name):
+    """The captured dense-mass reference chains (tests/golden/e2e_*full*.npz) replayed iteration by iteration with the
+    density evaluated by a torch callable: same bar as the fused dense kernel (tests/test_gpu_dense.py)."""
+    from tests.test_gpu_dense import _pot, _replay
+
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    d, tune, draws = int(g["d"]), int(g["tune"]), int(g["draws"])
+    potk, kind, fam = str(g["potential"]), str(g["kind"]), str(g["family"])
+    of = OT.make(fam, d)
+    tgt = torch_ar1(d) if fam == "ar1" else torch_std_normal(d)
+    seed = int(g["seeds"][0])
+    if potk in ("full", "inv"):
+        ostep = orc.Step(of, d, kind=kind, potential=orc.quad_potential(g["matrix"], potk == "full"))
+        dstep = (lmc.HamiltonianMC if kind == "hmc" else lmc.NUTS)(tgt, d, potential=_pot("full" if potk == "full" else "inv", g["matrix"]))
+        start = orc.jitter_start(seed, d)
+    else:
+        start, ostep = orc.init_nuts(of, d, init=potk, seeds=[seed])
+        start_d, dstep = lmc.init_nuts(tgt, d, init=potk, random_seed=[seed])
+        np.testing.assert_array_equal(start, start_d)
+    checked = _replay(ostep, dstep, start, seed, tune, draws, potk != "inv", name + " (ticks)")
+    assert checked >= 0.97 * (tune + draws)
+
+
+def test_sample_torch_target_with_dense_adaptation():
+    """sample(TorchTarget, init="adapt_full"): chains finish their tuning iterations in different ticks and each gets
+    its FullAdapt.update right after its own iteration (masked launch of dense_adapt_kernel); the run starts identical
+    to the fused dense kernel and learns the target's covariance."""
+    d, chains = 8, 64
+    kw = dict(draws=200, tune=500, chains=chains, init="adapt_full", random_seed=11, discard_tuned_samples=False)
+    t_tr, t_st, eng = lmc.sample(torch_ar1(d), d, return_engine=True, **kw)
+    try:
+        cov = eng.get_dense_state(fields=("cov",))["cov"]
+        ns = eng.adapt_state()["n_samples"]
+    finally:
+        eng.close()
+    assert (ns == 500).all()                                  # exactly one update per tuning iteration per chain
+    f_tr, f_st = lmc.sample(lmc.targets.AR1(d), d, **kw)
+    np.testing.assert_array_equal(t_st["tree_size"][:, :10], f_st["tree_size"][:, :10])
+    np.testing.assert_allclose(t_tr[:, :10], f_tr[:, :10], rtol=1e-6, atol=1e-8)
+    idx = np.arange(d)
+    true_cov = 0.9 ** np.abs(idx[:, None] - idx[None, :])
+    assert np.abs(cov.mean(axis=0) - true_cov).max() < 0.15
+    x = t_tr[:, 500:].reshape(-1, d)
+    assert np.abs(np.cov(x.T) - true_cov).max() < 0.1
