@@ -173,3 +173,16 @@ def test_torch_target_host_contract_without_a_gpu():
     assert auto.graph
     lp, g = auto.fn(torch.ones(2, 3, dtype=torch.float64))          # the autograd wrapper itself is device agnostic
     assert torch.allclose(lp, torch.full((2,), -1.5, dtype=torch.float64)) and torch.allclose(g, -torch.ones(2, 3, dtype=torch.float64))
+
+
+def test_generated_dense_tick_kernel_is_current():
+    """csrc/lmc_tick_dense.hpp is generated from csrc/lmc_tick.hpp (tools/gen_tick_dense.py): the committed file must be
+    what the generator produces from the committed source."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_tick_dense", os.path.join(root, "tools", "gen_tick_dense.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert open(gen.OUT).read() == gen.TEXT

@@ -6,6 +6,7 @@ silently different kernel. Run from the repo root: python tools/gen_tick_dense.p
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "littlemcmc_amd/csrc/lmc_tick_dense.hpp")
 src = open(os.path.join(ROOT, "littlemcmc_amd/csrc/lmc_tick.hpp")).read()
 body = src[src.index("// register budget per vector width"):src.index("// chains that still want evaluations")]
 
@@ -159,5 +160,8 @@ hdr = '''// The tick kernel (lmc_tick.hpp) with a dense mass matrix: densities e
 namespace lmc {
 
 '''
-open(os.path.join(ROOT, "littlemcmc_amd/csrc/lmc_tick_dense.hpp"), "w").write(hdr + body + "}  // namespace lmc\n")
-print("wrote lmc_tick_dense.hpp")
+TEXT = hdr + body + "}  // namespace lmc\n"
+
+if __name__ == "__main__":
+    open(OUT, "w").write(TEXT)
+    print("wrote", OUT)
