@@ -103,3 +103,30 @@ def test_results_do_not_depend_on_where_the_tree_stack_lives():
         else:
             for a, b in zip(ref, out):
                 np.testing.assert_array_equal(a, b)
+
+
+def test_degenerate_shapes_on_the_dense_and_tick_paths():
+    """d = 1 and 2, one chain, tune = 0 / draws = 0, max_treedepth = 1: the widened paths (dense mass, torch-callable
+    density, both together) at the smallest sizes the reference accepts."""
+    import torch
+
+    from littlemcmc_amd.targets import TorchTarget
+
+    def torch_normal(d):
+        return TorchTarget(d, lambda q: (-0.5 * (q * q).sum(dim=1), -q))
+
+    for d in (1, 2):
+        for tgt in (lmc.targets.StdNormal(d), torch_normal(d)):
+            for init in ("adapt_diag", "adapt_full"):
+                tr, st = lmc.sample(tgt, d, draws=6, tune=9, chains=1, init=init, random_seed=3)
+                assert tr.shape == (1, 6, d) and np.isfinite(tr).all() and st["tree_size"].min() >= 1
+                tr, st = lmc.sample(tgt, d, draws=0, tune=5, chains=2, init=init, random_seed=3)
+                assert tr.shape == (2, 0, d) and st["depth"].shape == (2, 0, 1)
+                tr, st = lmc.sample(tgt, d, draws=5, tune=0, chains=2, init=init, random_seed=3, max_treedepth=1)
+                assert tr.shape == (2, 5, d) and (st["depth"] == 1).all() and (st["tree_size"] == 1).all()
+    # a 1 x 1 "dense" matrix is a diagonal one: same chain as QuadPotentialDiag... up to the float32 / float64 momentum
+    # dtype, so compare the two dense classes with each other instead (cov = 1 / A)
+    a = lmc.sample(lmc.targets.StdNormal(1), 1, draws=20, tune=0, chains=3, random_seed=8,
+                   step=lmc.HamiltonianMC(lmc.targets.StdNormal(1), 1, potential=lmc.QuadPotentialFullInv(np.array([[4.0]]))))[0]
+    assert np.isfinite(a).all() and a.std() > 0
+    assert torch.cuda.is_available()
