@@ -57,7 +57,7 @@ extern "C" {
 #define LMC_TARGET_NORMAL1D 4        /* params: {loc, scale}; dim must be 1 */
 #define LMC_TARGET_USER 5
 /* no device functor: the caller evaluates logp_dlogp_func for all chains between two lmc_engine_tick() calls
- * (a batched callable on device memory, e.g. torch-ROCm); diagonal mass matrices */
+ * (a batched callable on device memory, e.g. torch-ROCm); all potentials (dense ones up to dim 256) */
 #define LMC_TARGET_EXTERNAL 6
 
 /* Summation order of the float32 kinetic energy of the start state, 0.5f * sdot(p, v)
