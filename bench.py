@@ -47,7 +47,7 @@ def make_target(lmc, name, dim):
 
 def cpu_baseline_worker(args):
     """One oracle chain (a port of the reference's sequential path) -> (leapfrogs, seconds)."""
-    name, dim, tune, draws, seed, start = args
+    name, dim, tune, draws, seed, start, mass = args
     sys.path.insert(0, ROOT)
     try:   # one BLAS thread per chain process: the reference's chain-per-process model, no oversubscription
         from threadpoolctl import threadpool_limits
@@ -60,7 +60,13 @@ def cpu_baseline_worker(args):
 
     f = {"ar1": lambda: OT.AR1(dim, 0.9), "std_normal": lambda: OT.StdNormal(dim), "funnel": lambda: OT.Funnel(dim),
          "diag": lambda: OT.DiagGaussian.ill_conditioned(dim, 1e4)}[name]()
-    pot = orc.DiagAdaptPotential(dim, start, np.ones(dim), 10)
+    if mass == "full_adapt":
+        pot = orc.FullAdaptPotential(dim, start, np.eye(dim), 10)
+    elif mass == "full":
+        idx = np.arange(dim)
+        pot = orc.FullPotential(0.9 ** np.abs(idx[:, None] - idx[None, :]) if name == "ar1" else np.eye(dim))
+    else:
+        pot = orc.DiagAdaptPotential(dim, start, np.ones(dim), 10)
     step = orc.Step(f, dim, kind="nuts", potential=pot)
     t0 = time.perf_counter()
     _tr, st = orc.sample(f, dim, draws=draws, tune=tune, step=step, chains=1, start=start, random_seed=[seed],
@@ -86,13 +92,13 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(name, dim, seeds, start, budget_iters):
+def cpu_baseline(name, dim, seeds, start, budget_iters, mass="diag"):
     import multiprocessing as mp
 
     cores = usable_cores()
     tune = draws = budget_iters // 2
     n_chains = 3 * cores   # ~15 s of CPU work on the GPU box (41 k leapfrogs/s per EPYC core)
-    jobs = [(name, dim, tune, draws, int(seeds[i % len(seeds)]), start) for i in range(n_chains)]
+    jobs = [(name, dim, tune, draws, int(seeds[i % len(seeds)]), start, mass) for i in range(n_chains)]
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(cores) as pool:
         res = pool.map(cpu_baseline_worker, jobs)
@@ -100,9 +106,9 @@ def cpu_baseline(name, dim, seeds, start, budget_iters):
     leap = sum(r[0] for r in res)
     return {
         "value": leap / wall, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
-        "sample": "%d chains on %d worker processes (1 per usable core) x (tune %d + draws %d), %s d=%d, numpy oracle "
-                  "(port of the reference's sequential path); %.0f leapfrogs in %.1f s"
-                  % (n_chains, cores, tune, draws, name, dim, leap, wall),
+        "sample": "%d chains on %d worker processes (1 per usable core) x (tune %d + draws %d), %s d=%d, %s mass, numpy "
+                  "oracle (port of the reference's sequential path); %.0f leapfrogs in %.1f s"
+                  % (n_chains, cores, tune, draws, name, dim, mass, leap, wall),
         "per_core": leap / wall / cores,
     }
 
@@ -332,7 +338,7 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args.target, args.dim, seeds_all[:64], start, args.cpu_iters)
+            out["cpu_baseline"] = cpu_baseline(args.target, args.dim, seeds_all[:64], start, args.cpu_iters, args.mass)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
