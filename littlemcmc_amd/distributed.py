@@ -30,7 +30,7 @@ def env_rank_world():
 
 
 def sample_distributed(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, chains=None, random_seed=None,
-                       start=None, group=None, diagnostics=True, **kwargs):
+                       start=None, group=None, diagnostics=True, **kwargs):   # diagnostics: True | False | "moments"
     """``sample()`` for a job of ``chains`` chains spread over the ranks of the current process group.
 
     Returns (trace, stats, diag): this rank's block of the trace/stats (same layouts as ``sample``) and, if
@@ -54,9 +54,18 @@ def sample_distributed(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, 
         kwargs["step"] = step
     kwargs.setdefault("device", local_rank)
     trace, stats, eng = sample(logp_dlogp_func, model_ndim, draws=draws, tune=tune, chains=hi - lo,
-                               random_seed=seeds[lo:hi], start=start, return_engine=True, **kwargs)
+                               random_seed=seeds[lo:hi], start=start, return_engine=True,
+                               keep_moments=(diagnostics == "moments"), **kwargs)
     diag = None
-    if diagnostics:
+    if diagnostics == "moments":
+        # trace-free cross-chain R-hat: the kernel kept (mean, M2, n) per chain; ranks exchange
+        # 3 x d doubles
+        from . import diagnostics as dg
+
+        mean, m2, n = eng.moments()
+        rhat = dg.rhat_from_moments(mean, m2, n, group=group)
+        diag = {"rhat": rhat.cpu().numpy(), "n_chains": float(chains)}
+    elif diagnostics:
         from . import diagnostics as dg
 
         x = dg.trace_tensor(eng)

@@ -72,12 +72,13 @@ def init_nuts(logp_dlogp_func, model_ndim=None, init="auto", random_seed=None, s
 def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, init="auto", chains=None,
            cores=None, start=None, progressbar=True, random_seed=None, discard_tuned_samples=True,
            chain_idx=0, callback=None, mp_ctx=None, pickle_backend="pickle", size=None, device=0,
-           launch_iters=None, return_engine=False, **kwargs):
+           launch_iters=None, return_engine=False, keep_moments=False, **kwargs):
     """Draw samples with many chains on one MI355X (reference signature: sampling.py:35-53).
 
     Extra keywords: ``size`` (alias of ``model_ndim``), ``device`` (HIP ordinal), ``launch_iters``
     (iterations per kernel launch; default: the whole run in at most a few launches),
-    ``return_engine`` (also return the live Engine, e.g. to read device pointers).
+    ``return_engine`` (also return the live Engine, e.g. to read device pointers), ``keep_moments`` (the kernel
+    also keeps every chain's running mean / M2 of the post-warm-up draws: ``Engine.moments()``).
     """
     if model_ndim is None:
         model_ndim = size if size is not None else getattr(logp_dlogp_func, "d", None)
@@ -116,6 +117,8 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
     try:
         eng.seed(seeds)                       # np.random.seed(random_seed[i]) per chain (sampling.py:496-497)
         eng.set_position(np.ascontiguousarray(starts))
+        if keep_moments:
+            eng.keep_moments(True)
         eng.reset_tuning()                    # step.reset_tuning(); iter_count = 0 (sampling.py:503-509)
         lo = int(tune) if discard_tuned_samples else 0   # sampling.py:473-476
         eng.reserve(max(n_total, 1), keep_trace=True, trace_begin=min(lo, max(n_total - 1, 0)))

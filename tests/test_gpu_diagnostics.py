@@ -81,3 +81,15 @@ def test_moments_require_opt_in():
     with lmc.Engine(lmc.targets.StdNormal(4), chains=2) as eng:
         with pytest.raises(lmc._abi.HipLibraryError, match="keep_moments"):
             eng.moments()
+
+
+def test_sample_distributed_with_moment_diagnostics():
+    """diagnostics="moments": R-hat from the running moments the kernel keeps, no trace involved; equals the plain
+    (non-split) R-hat of the returned draws."""
+    d = 7
+    tgt = lmc.targets.AR1(d, 0.5)
+    tr, st, diag = lmc.distributed.sample_distributed(tgt, d, draws=120, tune=100, chains=12, random_seed=3,
+                                                      diagnostics="moments")
+    want, _ = odg.rhat_ess(tr, do_split=False)
+    np.testing.assert_allclose(diag["rhat"], want, rtol=1e-9)
+    assert diag["n_chains"] == 12.0
