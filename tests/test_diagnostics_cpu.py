@@ -79,6 +79,14 @@ assert seeds[:4] == global_seeds(20260928, 4)          # prefix stable: blocks d
 out = [None] * world
 dist.all_gather_object(out, seeds[lo:hi])
 assert sum(out, []) == seeds
+# trace-free R-hat from per-chain running moments (what lmc_engine_get_moments hands out), block per rank
+blk = x[lo:hi]
+mean = blk.mean(axis=1)
+m2 = ((blk - mean[:, None, :]) ** 2).sum(axis=1)
+rh = dg.rhat_from_moments(mean, m2, np.full(hi - lo, blk.shape[1])).numpy()
+from oracle import diagnostics_oracle as odg
+want, _ = odg.rhat_ess(x, do_split=False)
+np.testing.assert_allclose(rh, want, rtol=1e-10)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
