@@ -86,9 +86,10 @@ struct DiagGaussianTarget {
 template <int NS>
 struct AR1Target {
     static constexpr bool kLanePartial = true;
-    // per-thread coefficient slices, fixed for the whole kernel: diagonal, coupling to e-1 and to e+1.
-    // Boundary / padding elements simply carry a 0 coefficient, so the hot loop has no selects.
-    double diag[NS], lo[NS], hi[NS];
+    // per-thread coefficient slices, fixed for the whole kernel: diagonal and coupling. Padding elements carry 0
+    // coefficients, so the hot loop has no selects; ONE coupling slice serves both neighbours: the element below
+    // e = 0 and the one above e = d-1 are exact zeros (team edge / padding), so their products vanish by themselves.
+    double diag[NS], cpl[NS];
     template <class Team>
     __device__ void init(Team& tm, const double* params, int d) {
         const double c_end = params[0], c_mid = params[1], off = params[2];
@@ -96,8 +97,7 @@ struct AR1Target {
         for (int s = 0; s < NS; ++s) {
             const int e = tm.tid() * NS + s;
             diag[s] = (e >= d) ? 0.0 : ((e == 0 || e == d - 1) ? c_end : c_mid);
-            lo[s] = (e > 0 && e < d) ? off : 0.0;
-            hi[s] = (e < d - 1) ? off : 0.0;
+            cpl[s] = (e < d) ? off : 0.0;
         }
     }
     template <class Team>
@@ -114,7 +114,7 @@ struct AR1Target {
             const double prev = (s == 0) ? below : q[s - 1];
             const double next = (s == NS - 1) ? above : q[s + 1];
             // (diag q + off q_{e-1}) + off q_{e+1}; a zero coefficient adds +0.0, which leaves the sum unchanged
-            const double pq = (diag[s] * q[s] + lo[s] * prev) + hi[s] * next;
+            const double pq = (diag[s] * q[s] + cpl[s] * prev) + cpl[s] * next;
             g[s] = -pq;
             part = __builtin_fma(q[s], g[s], part);
         }
