@@ -4,18 +4,28 @@
     python bench.py --gpus N --steps K --warmup W            (N = 1: this process)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2] / SURVEY.md 8d "C3"): 65 536 chains per GPU x dim 128, AR(1) rho=0.9
-correlated Gaussian, NUTS defaults, diagonal mass adaptation, init jitter+adapt_diag; the timed job is
-the reference recipe ``sample(tune=T, draws=D)`` cut into K equal launches ("steps") of the one persistent
-kernel (tune = first half; the default K = 20 x 100 iterations is exactly SURVEY 8d's tune=1000, draws=1000). W warm-up steps run first on a throw-away copy of the job (same kernel, same
-shapes) and are not timed. Chains are independent: with N GPUs every rank owns its own block of
-65 536 chains (weak scaling, no data-path collective); ranks only meet in the barrier and in the
-max/sum reductions of the timing.
+Workload (BASELINE.json configs[2] / SURVEY.md 8d "C3"): 65 536 chains x dim 128, AR(1) rho=0.9 correlated
+Gaussian, NUTS defaults, diagonal mass adaptation, init jitter+adapt_diag; the timed job is the reference recipe
+``sample(tune=T, draws=D)`` cut into K equal launches ("steps") of the one persistent kernel (tune = first half;
+the default K = 20 x 100 iterations is SURVEY 8d's tune=1000, draws=1000). W warm-up steps run first on a
+throw-away copy of the job (same kernel, same shapes) and are not timed.
 
-value  = leapfrog steps of ALL chains on ALL GPUs in the timed region (sum of tree_size) / wall seconds
-roofline.achieved = algorithmic bytes (60*d per leapfrog step) / kernel time by HIP events
-cpu_baseline      = the numpy oracle (a port of the reference, oracle/lmc_oracle.py) on this box's host
-                    cores, one chain per core, same recipe, bounded sample.
+Multi-GPU (``--scaling strong``, the default, is C3 as BASELINE states it: "65 536 chains ... 1 -> 8 MI355X"): the
+65 536 chains are dealt to the ranks in contiguous blocks (littlemcmc_amd.distributed.chain_block) with the seeds of
+the GLOBAL chain index space, so the union of the blocks is the N = 1 job chain for chain; ``--scaling weak`` gives
+every rank its own 65 536 chains. Chains are independent: no data-path collective, ranks meet in the barrier, in the
+max/sum reductions of the timing and in ONE all-reduce of diagnostics statistics.
+
+value            = leapfrog steps of ALL chains on ALL GPUs in the timed region (sum of tree_size) / wall seconds
+roofline         = the bound that binds the kernel: FP64 vector issue. achieved = leapfrogs/s x 26*d flop (SURVEY 8d's
+                   flop count of one leapfrog incl. amortised U-turn dots) against 78.6 TFLOP/s; the HBM contract
+                   figures (60*d and 28*d bytes per leapfrog) are side fields -- the State never leaves registers/LDS,
+                   so they are not a bound. Counter-derived fields (HBM traffic, VALU instructions per leapfrog) are
+                   quoted from profiles/pmc_counters.json ONLY if that profile was taken on this very build
+                   (source hash match); otherwise they are null.
+secondary        = north_star's named shape (standard normal, d = 128, same chains / recipe) timed the same way.
+cpu_baseline     = the numpy oracle (a port of the reference, oracle/lmc_oracle.py) on this box's host cores, one chain
+                   per core, same recipe, bounded sample.
 """
 import argparse
 import json
@@ -29,7 +39,9 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK = 8.0e12      # B/s, MI355X spec (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.3 TB/s achievable)
+HBM_PEAK = 8.0e12        # B/s, MI355X spec (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.3 TB/s achievable)
+FP64_VALU_PEAK = 78.6e12  # flop/s: 256 CUs x 4 SIMDs x 16 lanes x 2 (FMA) x 2.4 GHz
+FLOP_PER_LEAPFROG_PER_DIM = 26   # SURVEY.md 8d "Bound": ~26*d FP64 flop per leapfrog incl. amortised U-turn dots
 SEED = 20260928
 
 
@@ -43,6 +55,22 @@ def make_target(lmc, name, dim):
     if name == "diag":
         return lmc.targets.DiagGaussian.ill_conditioned(dim, 1e4), "ill-conditioned diagonal Gaussian kappa=1e4"
     raise SystemExit("unknown target %s" % name)
+
+
+def config_label(target, dim, chains_total, max_treedepth, kind, mass):
+    """BASELINE.json's name for the workload when it is one of its configurations, else a neutral label."""
+    if kind == "nuts" and mass == "diag":
+        if (target, dim, chains_total, max_treedepth) == ("ar1", 128, 65536, 10):
+            return "C3"
+        if (target, dim, chains_total, max_treedepth) == ("std_normal", 64, 4096, 10):
+            return "C2"
+        if (target, dim, chains_total, max_treedepth) == ("diag", 1000, 8192, 10):
+            return "C4"
+        if (target, dim, chains_total, max_treedepth) == ("funnel", 256, 16384, 12):
+            return "C5"
+        if (target, dim, chains_total, max_treedepth) == ("std_normal", 128, 65536, 10):
+            return "north_star shape"
+    return "custom"
 
 
 def cpu_baseline_worker(args):
@@ -113,11 +141,15 @@ def cpu_baseline(name, dim, seeds, start, budget_iters, mass="diag"):
     }
 
 
-DIAG_LIMITER = ("measured: VALU issue (f64 at 16 lanes/clk), ~220 VALU instr per leapfrog at ~90% issue "
-                "utilisation with 3 waves/SIMD; the trajectory lives in registers/LDS, so HBM traffic is "
-                "a few % of the algorithmic bytes and frac can exceed 1 (profiles/, DESIGN.md section 6)")
-DENSE_LIMITER = ("one float32 d x d matrix sweep per leapfrog (4 d^2 B; the reference does two): per-chain matrices "
-                 "(full_adapt) stream from HBM / Infinity Cache, a shared matrix (full) from L2; DESIGN.md section 9")
+def pmc_profile(key, source_hash):
+    """Counter-derived figures of this workload, if profiles/pmc_counters.json holds a profile of THIS build."""
+    try:
+        entry = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters.json"))).get(key)
+    except Exception:
+        return None
+    if not entry or entry.get("source_hash") != source_hash:
+        return None
+    return entry
 
 
 def main():
@@ -125,7 +157,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chains", type=int, default=65536, help="chains PER GPU")
+    ap.add_argument("--chains", type=int, default=65536, help="chains of the job (strong scaling) / per GPU (weak scaling)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: --chains is the whole job, dealt to the ranks in contiguous blocks (C3 as BASELINE "
+                         "states it); weak: every rank owns --chains chains")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--target", default="ar1", choices=["ar1", "std_normal", "funnel", "diag"])
     ap.add_argument("--iters-per-step", type=int, default=100, help="NUTS iterations per chain per launch")
@@ -137,6 +172,7 @@ def main():
     ap.add_argument("--no-trace", action="store_true", help="do not store draws (statistics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the standard-normal d=128 secondary workload")
     ap.add_argument("--cpu-iters", type=int, default=2000, help="iterations per oracle chain in the CPU baseline")
     ap.add_argument("--lds-levels", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -165,180 +201,225 @@ def main():
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     import littlemcmc_amd as lmc
-    from littlemcmc_amd import _abi
+    from littlemcmc_amd import _abi, _build
+    from littlemcmc_amd.distributed import chain_block
 
     K, W, ips = args.steps, args.warmup, args.iters_per_step
     n_total = K * ips
     n_tune = n_total // 2
-    chains = args.chains
-    target, target_desc = make_target(lmc, args.target, args.dim)
+    chains_total = args.chains if args.scaling == "strong" else args.chains * world
+    if args.scaling == "strong":
+        lo, hi = chain_block(chains_total, rank, world)
+    else:
+        lo, hi = rank * args.chains, (rank + 1) * args.chains
+    chains = hi - lo
+    if chains < 1:
+        raise SystemExit("rank %d owns no chain (%d chains over %d ranks)" % (rank, chains_total, world))
+    stream = torch.cuda.Stream()        # a real (non-null) HIP stream: the engine launches on it, the events time it
 
     # seeds: sample()'s own derivation over the GLOBAL chain index space (prefix stable), block per rank
     np.random.seed(SEED)
-    seeds_all = np.array([np.random.randint(2 ** 30) for _ in range(chains * world)], dtype=np.uint32)
-    np.random.seed(int(seeds_all[0]))
-    start = 2 * np.random.rand(args.dim) - 1            # init_nuts jitter (sampling.py:574-584)
-    seeds = seeds_all[rank * chains:(rank + 1) * chains]
+    seeds_all = np.array([np.random.randint(2 ** 30) for _ in range(chains_total)], dtype=np.uint32)
+    seeds = seeds_all[lo:hi]
 
-    if args.mass == "diag":
-        pot = lmc.QuadPotentialDiagAdapt(args.dim, start, np.ones(args.dim), 10)
-        mass_desc = "diag mass adapt"
-    elif args.mass == "full_adapt":
-        pot = lmc.QuadPotentialFullAdapt(args.dim, start, np.eye(args.dim), 10)      # sampling.py:588-597
-        mass_desc = "dense mass adapt (one float32 %dx%d matrix per chain, refreshed + factorised every tuning iteration)" % (
-            args.dim, args.dim)
-    else:
-        idx = np.arange(args.dim)
-        cov = 0.9 ** np.abs(idx[:, None] - idx[None, :]) if args.target == "ar1" else np.eye(args.dim)
-        pot = lmc.QuadPotentialFull(cov)
-        mass_desc = "fixed dense mass (the target's covariance, one float32 matrix shared by all chains)"
-    if args.kind == "nuts":
-        step = lmc.NUTS(target, args.dim, potential=pot, max_treedepth=args.max_treedepth)
-    else:
-        step = lmc.HamiltonianMC(target, args.dim, potential=pot, path_length=2.0)
-    kw = step._engine_kwargs()
-    kw["lds_levels"] = args.lds_levels
-    stream = torch.cuda.Stream()        # a real (non-null) HIP stream: the engine launches on it, the events time it
+    def all_reduce(vals, op):
+        t = torch.tensor(vals, dtype=torch.float64, device=red_dev)
+        if world > 1:
+            dist.all_reduce(t, op=op)
+        return [float(v) for v in t]
 
-    def new_job(capacity, trace_from, keep_trace):
-        eng = lmc.Engine(target, chains=chains, device=local_rank, **kw)
-        step.potential._push_initial(eng)
-        eng.set_stream(stream.cuda_stream)
-        eng.seed(seeds)
-        eng.set_position(start)
-        eng.reset_tuning()
-        eng.reserve(capacity, keep_trace=keep_trace, trace_begin=trace_from)
-        return eng
+    def run_job(target_name, dim, with_ess):
+        """The timed job on this rank's chain block -> dict of measurements (wall / leapfrogs reduced over ranks)."""
+        target, target_desc = make_target(lmc, target_name, dim)
+        np.random.seed(int(seeds_all[0]))
+        start = 2 * np.random.rand(dim) - 1            # init_nuts jitter (sampling.py:574-584)
+        if args.mass == "diag":
+            pot = lmc.QuadPotentialDiagAdapt(dim, start, np.ones(dim), 10)
+            mass_desc = "diag mass adapt"
+        elif args.mass == "full_adapt":
+            pot = lmc.QuadPotentialFullAdapt(dim, start, np.eye(dim), 10)      # sampling.py:588-597
+            mass_desc = ("dense mass adapt (one float32 %dx%d matrix per chain, refreshed + factorised every tuning "
+                         "iteration)" % (dim, dim))
+        else:
+            idx = np.arange(dim)
+            cov = 0.9 ** np.abs(idx[:, None] - idx[None, :]) if target_name == "ar1" else np.eye(dim)
+            pot = lmc.QuadPotentialFull(cov)
+            mass_desc = "fixed dense mass (the target's covariance, one float32 matrix shared by all chains)"
+        if args.kind == "nuts":
+            step = lmc.NUTS(target, dim, potential=pot, max_treedepth=args.max_treedepth)
+        else:
+            step = lmc.HamiltonianMC(target, dim, potential=pot, path_length=2.0)
+        kw = step._engine_kwargs()
+        kw["lds_levels"] = args.lds_levels
 
-    # ---- warm-up: W launches of a throw-away copy of the job
-    if W > 0:
-        warm = new_job(W * ips, (W * ips) // 2, keep_trace=False)
-        for s in range(W):
-            warm.run((W * ips) // 2, s * ips, ips)
-        warm.synchronize()
-        warm.close()
+        def new_job(capacity, trace_from, keep_trace):
+            eng = lmc.Engine(target, chains=chains, device=local_rank, **kw)
+            step.potential._push_initial(eng)
+            eng.set_stream(stream.cuda_stream)
+            eng.seed(seeds)
+            eng.set_position(start)
+            eng.reset_tuning()
+            eng.reserve(capacity, keep_trace=keep_trace, trace_begin=trace_from)
+            return eng
 
-    # draws stay in HBM; if the requested job is longer than the memory allows, keep the most recent draws only
-    trace_begin = n_tune
-    if not args.no_trace:
-        free_b, _tot = torch.cuda.mem_get_info()
-        per_draw = chains * args.dim * 8
-        fit = int(0.6 * free_b // per_draw)
-        if n_total - n_tune > fit:
-            trace_begin = n_total - max(fit, 1)
-    eng = new_job(n_total, trace_begin, keep_trace=not args.no_trace)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(K):
-        ev[s][0].record(stream)
-        eng.run(n_tune, s * ips, ips)
-        ev[s][1].record(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+        if W > 0:   # warm-up: W launches of a throw-away copy of the job
+            warm = new_job(W * ips, (W * ips) // 2, keep_trace=False)
+            for s in range(W):
+                warm.run((W * ips) // 2, s * ips, ips)
+            warm.synchronize()
+            warm.close()
 
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    ct = eng.counters()
-    leap_local = float(ct[:, _abi.CT_LEAPFROGS].sum())
-    status = eng.status()
-    if status.any():
-        raise SystemExit("chains reported failure status bits: %s" % np.unique(status))
-    depth_mean = float(eng.stat_i32(_abi.STAT_DEPTH, n_total - min(ips, n_total - n_tune), min(ips, n_total - n_tune)).mean()) \
-        if n_total > n_tune else 0.0
-    div_after = int(ct[:, _abi.CT_DIVS_AFTER_TUNE].sum())
-
-    # ---- ESS/sec (the second half of BASELINE.json's metric): split-R-hat / Geyer ESS of the post-warm-up
-    #      draws, computed where they live (HBM) and reduced across ranks with ONE all-reduce (RCCL) of
-    #      per-dimension sufficient statistics -- the only collective of the multi-GPU path.
-    ess = None
-    if not args.no_trace and not args.no_ess and n_total - n_tune >= 8:
-        from littlemcmc_amd import diagnostics as dg
-
-        t_ess = time.perf_counter()
-        diag = dg.summarize(dg.trace_tensor(eng), chunk=1024, reduce_device=red_dev)
+        # draws stay in HBM; if the requested job is longer than the memory allows, keep the most recent draws only
+        trace_begin = n_tune
+        keep_trace = with_ess and not args.no_trace
+        if keep_trace:
+            free_b, _tot = torch.cuda.mem_get_info()
+            per_draw = chains * dim * 8
+            fit = int(0.6 * free_b // per_draw)
+            if n_total - n_tune > fit:
+                trace_begin = n_total - max(fit, 1)
+        eng = new_job(n_total, trace_begin, keep_trace=keep_trace)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
         torch.cuda.synchronize()
-        draw_steps = [s for s in range(K) if s * ips >= trace_begin]
-        draw_s = sum(kernel_ms[s] for s in draw_steps) / 1e3
-        e = diag["ess"]
-        ess = {"min": float(e.min()), "median": float(e.median()), "rhat_max": float(diag["rhat"].max()),
-               "draw_seconds_this_rank": draw_s, "chains_total": diag["n_chains"] / 2, "draws": n_total - trace_begin,
-               "diagnostics_seconds": time.perf_counter() - t_ess}
-    eng.close()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(K):
+            ev[s][0].record(stream)
+            eng.run(n_tune, s * ips, ips)
+            ev[s][1].record(stream)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
 
-    wall_t = torch.tensor([wall], dtype=torch.float64, device=red_dev)
-    leap_t = torch.tensor([leap_local], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(leap_t, op=dist.ReduceOp.SUM)
-    wall_max, leap_all = float(wall_t.item()), float(leap_t.item())
+        kernel_ms = [a.elapsed_time(b) for a, b in ev]
+        ct = eng.counters()
+        leap_local = float(ct[:, _abi.CT_LEAPFROGS].sum())
+        status = eng.status()
+        if status.any():
+            raise SystemExit("chains reported failure status bits: %s" % np.unique(status))
+        n_last = min(ips, n_total - n_tune)
+        depth_mean = float(eng.stat_i32(_abi.STAT_DEPTH, n_total - n_last, n_last).mean()) if n_last > 0 else 0.0
+        div_after = int(ct[:, _abi.CT_DIVS_AFTER_TUNE].sum())
+
+        # ESS/sec (the second half of BASELINE.json's metric): split-R-hat / ESS of the post-warm-up draws, computed
+        # where they live (HBM) and reduced across ranks with ONE all-reduce (RCCL) of per-dimension sufficient
+        # statistics -- the only collective of the multi-GPU path.
+        ess = None
+        if keep_trace and not args.no_ess and n_total - n_tune >= 8:
+            from littlemcmc_amd import diagnostics as dg
+
+            torch.cuda.synchronize()
+            t_ess = time.perf_counter()
+            diag = dg.summarize(dg.trace_tensor(eng), reduce_device=red_dev)
+            torch.cuda.synchronize()
+            diag_s = time.perf_counter() - t_ess
+            draw_s = sum(kernel_ms[s] for s in range(K) if s * ips >= trace_begin) / 1e3
+            e = diag["ess"]
+            ess = {"min": float(e.min()), "median": float(e.median()), "rhat_max": float(diag["rhat"].max()),
+                   "draw_seconds": draw_s, "chains_total": int(diag["n_chains"] / 2), "draws": n_total - trace_begin,
+                   "diagnostics_seconds": diag_s, "definition": diag.get("definition", "")}
+        eng.close()
+
+        wall_max, = all_reduce([wall], dist.ReduceOp.MAX)
+        leap_all, div_all = all_reduce([leap_local, float(div_after)], dist.ReduceOp.SUM)
+        if ess is not None:   # post-warm-up time of the slowest rank
+            ess["draw_seconds"], ess["diagnostics_seconds"] = all_reduce([ess["draw_seconds"], ess["diagnostics_seconds"]],
+                                                                         dist.ReduceOp.MAX)
+        method = ("NUTS max_treedepth=%d" % args.max_treedepth) if args.kind == "nuts" else "HMC path_length=2"
+        label = config_label(target_name, dim, chains_total, args.max_treedepth, args.kind, args.mass)
+        part = ("%d chains on this GPU" % chains) if world == 1 else ("%d chains in blocks of ~%d per GPU" % (chains_total, chains))
+        return {
+            "label": label, "target": target_name, "dim": dim, "start": start, "mass_desc": mass_desc,
+            "workload": "%s: %d chains x dim %d %s, %s, %s, tune %d + draws %d in %d launches of %d iterations; %s" % (
+                label, chains_total, dim, target_desc, method, mass_desc, n_tune, n_total - n_tune, K, ips, part),
+            "wall": wall_max, "leap_all": leap_all, "leap_local": leap_local, "kernel_ms": kernel_ms,
+            "depth_mean": depth_mean, "div_after": int(div_all), "ess": ess,
+        }
+
+    src_hash = _build.source_hash()
+
+    def roofline(job):
+        kern_s = sum(job["kernel_ms"]) / 1e3
+        dim = job["dim"]
+        rate_local = job["leap_local"] / kern_s                  # this GPU's kernel: leapfrogs per second of kernel time
+        flop = FLOP_PER_LEAPFROG_PER_DIM * dim
+        extra = 0 if args.mass == "diag" else 8 * dim * dim      # dense: the reference's two float32 d x d sweeps
+        key = ("%s:%d" % (job["target"], dim)) + ("" if args.mass == "diag" else ":" + args.mass)
+        prof = pmc_profile(key, src_hash)
+        r = {
+            "kernel": ("lmc::run_kernel<NS=%d>" if args.mass == "diag" else "lmc::run_dense_kernel<NS=%d>") % max(1, (dim + 63) // 64),
+            "kernel_ms_avg": sum(job["kernel_ms"]) / K, "leapfrogs_per_launch": job["leap_local"] / K,
+            "flop_per_leapfrog": flop, "flop_model": "26*d FP64 flop per leapfrog incl. amortised U-turn dots (SURVEY.md 8d)",
+            "hbm_contract_60d": {"bytes_per_leapfrog": 60 * dim + extra, "GB_per_s": rate_local * (60 * dim + extra) / 1e9,
+                                 "frac_of_8TBps": rate_local * (60 * dim + extra) / HBM_PEAK},
+            "hbm_contract_28d_read_only": {"bytes_per_leapfrog": 28 * dim, "GB_per_s": rate_local * 28 * dim / 1e9,
+                                           "frac_of_8TBps": rate_local * 28 * dim / HBM_PEAK},
+            "traffic": None, "traffic_unit": "B per launch", "valu_inst_per_leapfrog": None, "simd_valu_busy": None,
+            "pmc_source": None,
+        }
+        if args.mass == "diag":
+            r.update({"bound": "fp64_valu", "achieved": rate_local * flop / 1e12, "peak": FP64_VALU_PEAK / 1e12,
+                      "unit": "TFLOP/s", "frac": rate_local * flop / FP64_VALU_PEAK,
+                      "note": "the leapfrog State lives in registers/LDS, HBM carries draws and adaptation state only, so "
+                              "the HBM contract figures are not a bound (they may exceed the 8 TB/s peak); the kernel is "
+                              "limited by per-wave instruction issue at 3-4 waves per SIMD (DESIGN.md section 6)"})
+        else:
+            r.update({"bound": "hbm", "achieved": rate_local * (60 * dim + extra) / 1e9, "peak": HBM_PEAK / 1e9,
+                      "unit": "GB/s", "frac": rate_local * (60 * dim + extra) / HBM_PEAK,
+                      "note": "one float32 d x d matrix sweep per leapfrog (4 d^2 B; the reference does two): per-chain "
+                              "matrices stream from HBM / Infinity Cache, a shared matrix from L2 (DESIGN.md section 9)"})
+        if prof:   # measured on this very build (source hash match)
+            r["traffic"] = prof["hbm_bytes_per_leapfrog"] * job["leap_local"] / K
+            r["valu_inst_per_leapfrog"] = prof.get("valu_inst_per_leapfrog")
+            r["simd_valu_busy"] = prof.get("simd_valu_busy")
+            r["pmc_source"] = prof.get("source")
+        return r
+
+    primary = run_job(args.target, args.dim, with_ess=True)
+    secondary = None
+    if not args.no_secondary and args.mass == "diag" and args.kind == "nuts" and (args.target, args.dim) != ("std_normal", 128):
+        secondary = run_job("std_normal", 128, with_ess=False)
 
     if rank == 0:
-        value = leap_all / wall_max
-        kern_s = sum(kernel_ms) / 1e3
-        # algorithmic bytes of one reference leapfrog: the State vectors, plus for a dense mass matrix the
-        # two float32 d x d sweeps of integration.py:111,118 (the device kernel needs one)
-        bytes_per_leap = 60 * args.dim + (0 if args.mass == "diag" else 8 * args.dim * args.dim)
-        achieved = leap_local * bytes_per_leap / kern_s          # this GPU's kernel, algorithmic bytes / kernel time
-        traffic, traffic_src = None, None
-        try:   # HBM bytes per launch from the committed PMC profile of this same workload (not measurable in-process)
-            tr_key = ("%s:%d" % (args.target, args.dim)) + ("" if args.mass == "diag" else ":" + args.mass)
-            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(tr_key)
-            if tr:
-                traffic = tr["hbm_bytes_per_leapfrog"] * leap_local / K
-                traffic_src = tr["source"]
-        except Exception:
-            pass
-        valu_issue = None
-        try:   # the limiter that actually binds (profiles/: VALU issue), as measured by the committed PMC run
-            if args.mass != "diag":
-                raise KeyError("VALU-issue figures are for the diagonal kernel")
-            ps = json.load(open(os.path.join(ROOT, "profiles", "r01_default_pmc_summary.json")))
-            occ = 3 if args.dim > 64 else 4   # waves per SIMD of the instantiation (168 / 128 VGPRs)
-            valu_issue = {"valu_inst_per_leapfrog": ps["per_leapfrog"]["SQ_INSTS_VALU"],
-                          "simd_issue_utilisation": min(1.0, occ * ps["wave_time_split"]["valu_active"]),
-                          "source": "profiles/r01_default_pmc_summary.json (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves per SIMD)"}
-        except Exception:
-            pass
-        method = ("NUTS max_treedepth=%d" % args.max_treedepth) if args.kind == "nuts" else "HMC path_length=2"
+        value = primary["leap_all"] / primary["wall"]
+        ess = primary["ess"]
         out = {
             "metric": "leapfrog-steps/sec (all chains)", "value": value, "unit": "leapfrog-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall_max * 1e3 / K,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": primary["wall"] * 1e3 / K,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "C3: %d chains/GPU x dim %d %s, %s, %s, tune %d + draws %d in %d launches of "
-                            "%d iterations" % (chains, args.dim, target_desc, method, mass_desc, n_tune, n_total - n_tune, K, ips),
-                "chains_per_gpu": chains, "dim": args.dim, "target": args.target, "tune": n_tune,
-                "draws": n_total - n_tune, "rng": "MT19937 (numpy legacy stream, same-seed parity mode)",
-                "trace_in_hbm": not args.no_trace, "parallelism": "chain-block x%d" % world,
+                "workload": primary["workload"], "chains_total": chains_total, "chains_this_gpu": chains,
+                "dim": args.dim, "target": args.target, "tune": n_tune, "draws": n_total - n_tune,
+                "rng": "MT19937 (numpy legacy stream, same-seed parity mode)",
+                "trace_in_hbm": not args.no_trace, "parallelism": "chain-block x%d (%s scaling)" % (world, args.scaling),
             },
-            "leapfrogs": leap_all, "wall_s": wall_max, "mean_depth_draws": depth_mean,
+            "leapfrogs": primary["leap_all"], "wall_s": primary["wall"], "mean_depth_draws": primary["depth_mean"],
             "ess_per_sec": None if ess is None else {
-                "min": ess["min"] / ess["draw_seconds_this_rank"], "median": ess["median"] / ess["draw_seconds_this_rank"],
+                "min": ess["min"] / ess["draw_seconds"], "median": ess["median"] / ess["draw_seconds"],
+                "min_including_diagnostics": ess["min"] / (ess["draw_seconds"] + ess["diagnostics_seconds"]),
+                "median_including_diagnostics": ess["median"] / (ess["draw_seconds"] + ess["diagnostics_seconds"]),
                 "ess_min": ess["min"], "ess_median": ess["median"], "rhat_max": ess["rhat_max"],
-                "definition": "multi-chain split-R-hat / Geyer ESS over all %d chains x %d post-warm-up draws, "
-                              "divided by the post-warm-up kernel time" % (int(ess["chains_total"]), ess["draws"]),
-                "diagnostics_seconds": ess["diagnostics_seconds"]},
-            "divergences_after_tune": div_after,
-            "roofline": {
-                "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "B per launch", "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": leap_local * bytes_per_leap / K,
-                "kernel": ("lmc::run_kernel<NS=%d>" if args.mass == "diag" else "lmc::run_dense_kernel<NS=%d>") % max(1, (args.dim + 63) // 64),
-                "kernel_ms_avg": sum(kernel_ms) / K, "algorithmic_bytes_per_leapfrog": bytes_per_leap,
-                "read_only_frac": leap_local * 28 * args.dim / kern_s / HBM_PEAK,
-                "valu_issue": valu_issue,
-                "limiter": DIAG_LIMITER if args.mass == "diag" else DENSE_LIMITER,
-            },
+                "definition": "%s over all %d chains x %d post-warm-up draws; per second of post-warm-up kernel time "
+                              "(slowest rank), and per second of kernel + diagnostics time" % (
+                                  ess["definition"], ess["chains_total"], ess["draws"]),
+                "draw_seconds": ess["draw_seconds"], "diagnostics_seconds": ess["diagnostics_seconds"]},
+            "divergences_after_tune": primary["div_after"],
+            "roofline": roofline(primary),
+            "source_hash": src_hash,
         }
+        if secondary is not None:
+            out["secondary"] = [{
+                "workload": secondary["workload"], "value": secondary["leap_all"] / secondary["wall"],
+                "unit": "leapfrog-steps/s", "ms_per_step": secondary["wall"] * 1e3 / K, "leapfrogs": secondary["leap_all"],
+                "wall_s": secondary["wall"], "mean_depth_draws": secondary["depth_mean"],
+                "divergences_after_tune": secondary["div_after"], "roofline": roofline(secondary)}]
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args.target, args.dim, seeds_all[:64], start, args.cpu_iters, args.mass)
+            out["cpu_baseline"] = cpu_baseline(args.target, args.dim, seeds_all[:64], primary["start"], args.cpu_iters, args.mass)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

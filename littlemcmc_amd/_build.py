@@ -24,6 +24,19 @@ def sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))]
 
 
+def source_hash():
+    """Identity of a build: sha256 over the kernel sources, the C header and the compiler flags (16 hex digits).
+    Profiles under profiles/ record it, so a measurement is only quoted for the build it was taken on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sources() + [os.path.join(os.path.dirname(HERE), "include", "lmc_hip.h")]:
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def lib_path():
     return os.path.join(HERE, LIB_NAME)
 

@@ -130,6 +130,9 @@ class BaseHMC:
         eng = self._engine()
         eng.set_position(np.asarray(q0, dtype="d").reshape(1, self.model_ndim))
         eng.set_rng_state(0, np.random.get_state())
+        # the step size this iteration integrates with (base_hmc.py:151-153), from the adaptation state before the update
+        self.step_size = float(np.exp(self.step_adapt._log_step if (self.tune and self.adapt_step_size)
+                                      else self.step_adapt._log_bar))
         eng.run(1 if self.tune else 0, 0, 1)
         np.random.set_state(eng.get_rng_state(0))
         raise_for_status(eng.status())
@@ -139,8 +142,6 @@ class BaseHMC:
             self.step_adapt._tuned_stats.append(stats["mean_tree_accept" if self._kind == "nuts" else "accept"])
         self.step_adapt._pull(eng)
         self.potential._pull(eng)
-        self.step_size = float(np.exp(self.step_adapt._log_step if (self.tune and self.adapt_step_size)
-                                      else self.step_adapt._log_bar))
         if stats["diverging"]:
             if self.tune:
                 kind = WarningType.TUNING_DIVERGENCE

@@ -233,6 +233,7 @@ __global__ void reset_kernel(ChainArrays A, const double* init_mean, const float
         if (e == 0) A.mom_n[c] = 0;
     }
     if (reset_step && e == 0) {
+        A.status[c] = 0;   // a chain stopped by "Bad initial energy" starts afresh (the reference raises per call and recovers)
         A.da[c * 4 + 0] = log_step0;
         A.da[c * 4 + 1] = log_step0;
         A.da[c * 4 + 2] = 0.0;
@@ -717,6 +718,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         std::vector<double> ones(cfg->dim, 1.0), zeros(cfg->dim, 0.0);
         rc = lmc_engine_set_potential(e, zeros.data(), ones.data(), 10.0, 0);
         if (rc != LMC_OK) return bail(rc);
+        rc = launch_reset(e, 1, 0);   // DualAverageAdaptation.__init__ -> reset() (step_sizes.py:41-56), iter_count = 0
+        if (rc != LMC_OK) return bail(rc);
         if (dense) {
             std::vector<double> eye(static_cast<size_t>(cfg->dim) * cfg->dim, 0.0);
             for (int i = 0; i < cfg->dim; ++i) eye[static_cast<size_t>(i) * cfg->dim + i] = 1.0;
@@ -803,7 +806,9 @@ int lmc_engine_set_potential(lmc_engine* e, const double* initial_mean, const do
     HIP_TRY(e, hipMemcpyAsync(e->init_mean, fmean.data(), fmean.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
     e->init_weight = initial_weight;
     e->potential_set = true;
-    int rc = launch_reset(e, 1, 1);
+    // only the mass state: the reference's potential.reset() / BaseHMC.reset() leave the step-size adaptation alone
+    // (base_hmc.py:196-200); create() and reset_tuning() initialise the dual averaging
+    int rc = launch_reset(e, 0, 1);
     if (rc != LMC_OK) return rc;
     HIP_TRY(e, hipStreamSynchronize(e->stream));   // host staging buffers go out of scope
     return LMC_OK;
@@ -1082,6 +1087,9 @@ int lmc_engine_set_rng_state(lmc_engine* e, int32_t chain, const uint32_t* key, 
                              double gauss) {
     if (!e || !key || chain < 0 || chain >= e->cfg.chains || pos < 0 || pos > kMtN)
         return fail(e, LMC_ERR_INVALID, "bad rng state");
+    if ((pos & 1) && e->run_w > 1)   // the team kernels twist between barriers at even positions only
+        return fail(e, LMC_ERR_INVALID, "odd MT19937 position %d (a 32-bit legacy draw, e.g. np.random.randint, came before): "
+                    "chains of more than 256 dimensions need an even position -- draw one more 32-bit value first", pos);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     HIP_TRY(e, hipMemcpy(e->A.mt + static_cast<size_t>(chain) * kMtN, key, kMtN * sizeof(uint32_t), hipMemcpyDefault));
@@ -1108,6 +1116,7 @@ int lmc_engine_set_position(lmc_engine* e, const double* q, int32_t per_chain) {
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     const size_t C = e->cfg.chains, d = e->cfg.dim, dp = e->dpad;
     HIP_TRY(e, hipMemsetAsync(e->A.q, 0, C * dp * sizeof(double), e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->A.status, 0, C * sizeof(int), e->stream));   // new positions: per-chain failure bits start clean
     if (per_chain) {
         HIP_TRY(e, hipMemcpy2DAsync(e->A.q, dp * sizeof(double), q, d * sizeof(double), d * sizeof(double), C,
                                     hipMemcpyDefault, e->stream));

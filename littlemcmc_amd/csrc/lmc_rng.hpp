@@ -121,11 +121,17 @@ __device__ __forceinline__ double mt_words_to_double(uint32_t w0, uint32_t w1) {
     return (static_cast<double>(a) * 67108864.0 + static_cast<double>(b)) / 9007199254740992.0;
 }
 
+// Word-granular like numpy's rk_double (two rk_random calls, each of which twists when the state is exhausted):
+// a chain stream of this library only ever sits at even positions, but a state handed over from the host
+// (lmc_engine_set_rng_state <- np.random.get_state()) is odd after any 32-bit legacy draw (np.random.randint),
+// and then one double straddles the twist.
 __device__ inline double rng_uniform(RngState& r) {
-    if (r.pos >= kMtN) mt_regen(r);   // pos is always even inside a chain stream, so pos+1 < 624
+    if (r.pos >= kMtN) mt_regen(r);
     const uint32_t w0 = first_u32(r.mt[r.pos]);
-    const uint32_t w1 = first_u32(r.mt[r.pos + 1]);
-    r.pos += 2;
+    r.pos += 1;
+    if (r.pos >= kMtN) mt_regen(r);
+    const uint32_t w1 = first_u32(r.mt[r.pos]);
+    r.pos += 1;
     return first_f64(mt_words_to_double(w0, w1));
 }
 
@@ -144,6 +150,10 @@ __device__ inline double window_next(RngState& r, UniformWindow& w) {
     if (w.idx == w.n) {   // (re)fill from the current stream position
         if (r.pos >= kMtN) mt_regen(r);
         int n = (kMtN - r.pos) >> 1;
+        if (n == 0) {          // one word left (odd position inherited from the host): this double straddles the twist
+            w.n = 0; w.idx = 0;
+            return rng_uniform(r);
+        }
         n = n > 64 ? 64 : n;
         const int lane = lane_id();
         double v = 0.0;
@@ -179,7 +189,7 @@ __device__ inline void rng_normals(RngState& r, int d, double* out, double* stag
     int have = 0;
     while (have < need_pairs) {
         const int avail = (kMtN - r.pos) >> 2;   // whole attempts left in this generation
-        if (avail == 0) {                         // 0 or 2 words left: one attempt across the twist
+        if (avail == 0) {                         // fewer than 4 words left: one attempt across the twist
             const double x1 = 2.0 * rng_uniform(r) - 1.0;
             const double x2 = 2.0 * rng_uniform(r) - 1.0;
             const double r2 = x1 * x1 + x2 * x2;

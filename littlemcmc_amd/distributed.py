@@ -37,6 +37,8 @@ def sample_distributed(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, 
     requested, R-hat/ESS over ALL chains of ALL ranks. With the same ``random_seed`` the union of the blocks
     equals a single-GPU run of ``chains`` chains, chain for chain.
     """
+    import inspect
+
     import torch.distributed as dist
 
     from .sampling import init_nuts, sample
@@ -44,32 +46,58 @@ def sample_distributed(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, 
     rank, world, local_rank = env_rank_world()
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if chains is None:   # sample()'s own default (sampling.py:124-129) per rank would make the job size depend on the launch
+        raise ValueError("sample_distributed needs the TOTAL number of chains (chains=...)")
+    chains = int(chains)
+    if chains < 1:
+        raise ValueError("chains must be >= 1")
     seeds = global_seeds(random_seed, chains)
     lo, hi = chain_block(chains, rank, world)
-    if start is None and kwargs.get("step") is None:
+    # keyword routing as in sample(): its own parameters stay with sample(), everything else configures the step method
+    sample_names = set(inspect.signature(sample).parameters) - {"kwargs"}
+    sample_kw = {k: v for k, v in kwargs.items() if k in sample_names}
+    step_kw = {k: v for k, v in kwargs.items() if k not in sample_names}
+    if start is None and sample_kw.get("step") is None:
         # init_nuts must see the GLOBAL first seed so every rank jitters from the same start (sampling.py:574-584)
-        start, step = init_nuts(logp_dlogp_func, model_ndim, init=kwargs.pop("init", "auto"), random_seed=seeds,
-                                **{k: v for k, v in kwargs.items() if k not in ("device", "launch_iters")})
-        kwargs = {k: v for k, v in kwargs.items() if k in ("device", "launch_iters")}
-        kwargs["step"] = step
-    kwargs.setdefault("device", local_rank)
-    trace, stats, eng = sample(logp_dlogp_func, model_ndim, draws=draws, tune=tune, chains=hi - lo,
-                               random_seed=seeds[lo:hi], start=start, return_engine=True,
-                               keep_moments=(diagnostics == "moments"), **kwargs)
+        start, step = init_nuts(logp_dlogp_func, model_ndim, init=sample_kw.pop("init", "auto"), random_seed=seeds, **step_kw)
+        sample_kw["step"] = step
+        step_kw = {}
+    sample_kw.setdefault("device", local_rank)
+    eng = None
+    if hi > lo:
+        trace, stats, eng = sample(logp_dlogp_func, model_ndim, draws=draws, tune=tune, chains=hi - lo,
+                                   random_seed=seeds[lo:hi], start=start, return_engine=True,
+                                   keep_moments=(diagnostics == "moments"), **sample_kw, **step_kw)
+    else:   # more ranks than chains: this rank owns nothing but still joins the diagnostics reduction
+        d = int(model_ndim)
+        n_keep = draws if sample_kw.get("discard_tuned_samples", True) else draws + tune
+        trace, stats = np.zeros((0, n_keep, d)), {}
     diag = None
     if diagnostics == "moments":
         # trace-free cross-chain R-hat: the kernel kept (mean, M2, n) per chain; ranks exchange
         # 3 x d doubles
         from . import diagnostics as dg
 
-        mean, m2, n = eng.moments()
+        if eng is not None:
+            mean, m2, n = eng.moments()
+        else:
+            import torch
+
+            mean = m2 = torch.zeros((0, int(model_ndim)), dtype=torch.float64)
+            n = torch.zeros((0,), dtype=torch.int32)
         rhat = dg.rhat_from_moments(mean, m2, n, group=group)
         diag = {"rhat": rhat.cpu().numpy(), "n_chains": float(chains)}
     elif diagnostics:
         from . import diagnostics as dg
 
-        x = dg.trace_tensor(eng)
+        if eng is not None:
+            x = dg.trace_tensor(eng)
+        else:
+            import torch
+
+            x = torch.zeros((0, draws, int(model_ndim)), dtype=torch.float64)
         diag = dg.summarize(x, group=group)
         diag = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in diag.items()}
-    eng.close()
+    if eng is not None:
+        eng.close()
     return trace, stats, diag

@@ -124,15 +124,33 @@ class UserTarget(DeviceTarget):
     def __init__(self, d, source, params=()):
         super().__init__(d, params)
         self.source = source
-        digest = hashlib.sha256(source.encode()).hexdigest()[:16]
+        # the cache key covers everything the binary depends on: the snippet, the kernel sources and the compiler flags
+        h = hashlib.sha256(source.encode())
+        for path in _build.sources():
+            with open(path, "rb") as fh:
+                h.update(fh.read())
+        h.update(" ".join(_build.HIPCC_FLAGS).encode())
+        digest = h.hexdigest()[:16]
         cache = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_user_targets")
         os.makedirs(cache, exist_ok=True)
         header = os.path.join(cache, "user_%s.hpp" % digest)
         lib = os.path.join(cache, "liblmc_hip_user_%s.so" % digest)
         if not os.path.exists(lib):
-            with open(header, "w") as fh:
+            # several ranks may build the same target at once: private temporaries, atomic rename into place
+            tmp_tag = "%d_%s" % (os.getpid(), digest)
+            tmp_header = os.path.join(cache, "user_%s.tmp.hpp" % tmp_tag)
+            tmp_lib = os.path.join(cache, "liblmc_hip_user_%s.tmp.so" % tmp_tag)
+            with open(tmp_header, "w") as fh:
                 fh.write(source)
-            _build.build(out=lib, extra_flags=["-DLMC_USER_TARGET_HEADER=\"%s\"" % header, "-DLMC_ONLY_USER"], force=True)
+            try:
+                _build.build(out=tmp_lib, extra_flags=["-DLMC_USER_TARGET_HEADER=\"%s\"" % tmp_header, "-DLMC_ONLY_USER"],
+                             force=True)
+                os.replace(tmp_lib, lib)
+                os.replace(tmp_header, header)
+            finally:
+                for f in (tmp_lib, tmp_header):
+                    if os.path.exists(f):
+                        os.remove(f)
         self.lib_path = lib
 
 

@@ -205,7 +205,7 @@ def capture_adapt():
 # ---------------------------------------------------------------------------------------
 # 4/5. end-to-end sample() runs (sequential path)
 # ---------------------------------------------------------------------------------------
-def capture_e2e():
+def capture_e2e(only=None):
     runs = [
         # name, family, d, kind, chains, tune, draws, kwargs
         ("e2e_hmc_c1", "std_normal", 10, "hmc", 4, 300, 200, {"path_length": 2.0}),
@@ -215,8 +215,12 @@ def capture_e2e():
         ("e2e_nuts_funnel8", "funnel", 8, "nuts", 4, 250, 150, {"max_treedepth": 12}),
         ("e2e_nuts_diag50", "diag_gaussian", 50, "nuts", 2, 250, 100, {}),
         ("e2e_nuts_normal1d", "normal1d", 1, "nuts", 2, 120, 80, {}),
+        # the benchmarked instantiation (BASELINE config C3's shape: AR(1) at d = 128, two elements per lane)
+        ("e2e_nuts_ar1_128", "ar1", 128, "nuts", 2, 250, 50, {}),
     ]
     for name, fam, d, kind, chains, tune, draws, kw in runs:
+        if only and name not in only:
+            continue
         f = targets.make(fam, d)
         if kind == "hmc":
             step = ref.HamiltonianMC(f, d, **kw)
@@ -488,5 +492,9 @@ CAPTURES = {"leapfrog": capture_leapfrog, "transitions": capture_transitions, "a
             "diag_window_multiplier": capture_diag_window_multiplier}
 
 if __name__ == "__main__":
+    # capture.py [group | e2e:<name>[,<name>...]] ...   (no argument: everything)
     for which in (sys.argv[1:] or list(CAPTURES)):
-        CAPTURES[which]()
+        if which.startswith("e2e:"):
+            capture_e2e(only=which[4:].split(","))
+        else:
+            CAPTURES[which]()

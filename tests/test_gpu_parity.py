@@ -83,7 +83,7 @@ def test_transitions_golden(golden_dir):
 
 
 E2E = ["e2e_hmc_c1", "e2e_nuts_std64", "e2e_nuts_std128", "e2e_nuts_ar1_16", "e2e_nuts_funnel8",
-       "e2e_nuts_diag50", "e2e_nuts_normal1d"]
+       "e2e_nuts_diag50", "e2e_nuts_normal1d", "e2e_nuts_ar1_128"]
 
 
 @pytest.mark.parametrize("name", E2E)
@@ -119,8 +119,11 @@ def test_e2e_golden_through_sample_api(golden_dir, name):
         want = {n_: g["stat_" + n_][c, :, 0] for n_ in stats}
         verified += assert_chain_matches(trace[c], got, g["trace"][c], want, margins[c, :, 0],
                                          label="%s chain %d" % (name, c))
-    # whole tuned chains are chaotic (see test_every_iteration_of_the_golden_runs): require a solid prefix
-    assert verified >= chains * min(15, tune + draws), "%s: only %d iterations verified" % (name, verified)
+    # whole tuned chains are chaotic (see test_every_iteration_of_the_golden_runs, which checks EVERY iteration from
+    # the oracle's own state): require a solid prefix. Deep trees at d = 128 amplify the float32 start-energy
+    # rounding faster (60+ leapfrogs per iteration feeding dual averaging), so their prefix is shorter.
+    need = 10 if name == "e2e_nuts_ar1_128" else 15
+    assert verified >= chains * min(need, tune + draws), "%s: only %d iterations verified" % (name, verified)
 
 
 @pytest.mark.parametrize("name", E2E)
@@ -142,7 +145,7 @@ def test_every_iteration_of_the_golden_runs(golden_dir, name):
     seeds = [int(s) for s in g["seeds"]]
     start = g["start"]
     total_checked = total_fragile = 0
-    for c in range(min(chains, 2)):
+    for c in range(chains):   # every captured chain
         if str(g["kind"]) == "hmc":
             ostep = orc.Step(f, d, kind="hmc", **kw)
             step = lmc.HamiltonianMC(tgt, d, **kw)
@@ -160,7 +163,7 @@ def test_every_iteration_of_the_golden_runs(golden_dir, name):
         if same:
             np.testing.assert_array_equal(np.array([o["stats"]["diverging"] for o in outs]),
                                           g["stat_diverging"][c, :, 0])
-    assert total_checked >= 0.99 * (min(chains, 2) * (tune + draws)), (total_checked, total_fragile)
+    assert total_checked >= 0.99 * (chains * (tune + draws)), (total_checked, total_fragile)
 
 
 @pytest.mark.parametrize("family,d,kw", [("ar1", 200, {}), ("ar1", 300, {}), ("funnel", 600, {"max_treedepth": 9}),

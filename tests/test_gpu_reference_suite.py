@@ -152,10 +152,75 @@ def test_astep_protocol_matches_oracle():
     assert st[0]["tune"] is np.False_ or not st[0]["tune"]
 
 
+def test_astep_after_a_32_bit_legacy_draw():
+    """np.random.randint leaves the MT19937 position odd; the device stream must stay word-exact with numpy's
+    (rk_double twists between its two words), through uniforms, normals and a whole NUTS iteration."""
+    from oracle import lmc_oracle as orc
+    from oracle import targets as OT
+
+    # raw stream: position 1 after the randint, 311 doubles bring it to 623 -> the next double straddles the twist
+    with lmc.Engine(lmc.targets.StdNormal(3), chains=1) as eng:
+        rs = np.random.RandomState(7)
+        rs.randint(2 ** 30)
+        assert rs.get_state()[2] % 2 == 1
+        eng.set_rng_state(0, rs.get_state())
+        got = eng.rng_draw([-311, -3, 5, -1, 129])[0]
+        want = np.concatenate([rs.random_sample(311), rs.random_sample(3), rs.normal(size=5), rs.random_sample(1),
+                               rs.normal(size=129)])
+        npt.assert_allclose(got, want, rtol=5e-16, atol=0)
+        st, ws = eng.get_rng_state(0), rs.get_state()
+        assert st[2] == ws[2] and st[3] == ws[3]
+        npt.assert_array_equal(st[1], ws[1])
+    # the step-method protocol from an odd position, across the twist inside a tree (window refill with one word left)
+    d = 5
+    step = lmc.NUTS(lmc.targets.StdNormal(d), d)
+    ostep = orc.Step(OT.StdNormal(d), d, kind="nuts")
+    np.random.seed(5)
+    np.random.randint(10)
+    rng = np.random.RandomState(5)
+    rng.randint(10)
+    q = oq = np.full(d, -0.2)
+    for i in range(60):   # ~60 iterations x (5 normals + tree uniforms) consume well over 624 words
+        q, st = step._astep(q)
+        oq, ost = ostep.astep(oq, rng)
+        assert st[0]["depth"] == ost["depth"] and st[0]["tree_size"] == ost["tree_size"], i
+        npt.assert_allclose(q, oq, rtol=1e-8, atol=1e-11)
+    assert np.random.get_state()[2] == rng.get_state()[2]
+    npt.assert_array_equal(np.random.get_state()[1], rng.get_state()[1])
+
+
+def test_astep_reports_the_step_size_it_used_and_reset_keeps_the_step_adaptation():
+    d = 4
+    step = lmc.NUTS(lmc.targets.StdNormal(d), d)
+    np.random.seed(11)
+    q = np.zeros(d)
+    eps0 = 0.25 / d ** 0.25
+    q, st = step._astep(q)
+    assert step.step_size == pytest.approx(eps0, rel=1e-15)        # base_hmc.py:151-153: the step of THIS iteration
+    used_next = float(st[0]["step_size"])
+    q, st = step._astep(q)
+    assert step.step_size == pytest.approx(used_next, rel=1e-12)
+    count, log_step = step.step_adapt._count, step.step_adapt._log_step
+    step.reset()                                                   # base_hmc.py:197-200: potential only
+    q, st = step._astep(q)
+    assert step.step_adapt._count == count + 1                     # the device's dual averaging went on, not back to 1
+    assert step.potential._n_samples == 1
+    step.potential.reset()
+    q, st = step._astep(q)
+    assert step.step_adapt._count == count + 2 and step.step_adapt._log_step != log_step
+
+
 def test_bad_initial_energy_raises_value_error():
     step = lmc.NUTS(lmc.targets.StdNormal(2), 2)
     with pytest.raises(ValueError, match="Bad initial energy"):
         step._astep(np.array([np.inf, 0.0]))
+    # the reference raises per call and recovers: a good position afterwards samples normally
+    np.random.seed(3)
+    q, st = step._astep(np.array([0.1, -0.2]))
+    assert np.isfinite(q).all() and st[0]["tree_size"] >= 1
+    step.reset_tuning()
+    q, st = step._astep(q)
+    assert np.isfinite(q).all()
     with pytest.raises(ValueError, match="Bad initial energy"):
         lmc.sample(lmc.targets.StdNormal(2), 2, draws=2, tune=2, chains=3, start=np.array([np.nan, 0.0]), random_seed=1)
 

@@ -177,6 +177,90 @@ def test_headline_shape_65536_chains_dim128_moments_on_device():
         eng.close()
 
 
+def _pooled_moments(mean, m2, n):
+    """Pooled mean / variance per dimension from per-chain running moments (mean[c, d], M2[c, d], n[c])."""
+    n = np.asarray(n, dtype="d")[:, None]
+    tot = n.sum()
+    grand = (mean * n).sum(axis=0) / tot
+    ss = m2.sum(axis=0) + (n * (mean - grand) ** 2).sum(axis=0)
+    return grand, ss / (tot - 1.0)
+
+
+def test_c3_full_size_65536_chains_dim128_ar1():
+    """configs[2] at its one-GPU size, through the kernel the benchmark times (run_kernel<2, 1, AR1Target>):
+    65 536 chains x d = 128 AR(1) rho = 0.9, NUTS defaults, diagonal mass adaptation. Pooled posterior mean and
+    marginal variance within 1e-3 (north_star) of the truth (0 and 1 -- what the CPU reference converges to),
+    cross-chain R-hat < 1.01, no divergences, trees as deep as the reference's (mean depth 6.3)."""
+    from littlemcmc_amd import diagnostics as dg
+
+    d, chains, tune, draws = 128, 65536, 400, 1000
+    tgt = T.AR1(d, 0.9)
+    seeds = lmc.distributed.global_seeds(20260928, chains)
+    start, step = lmc.init_nuts(tgt, d, random_seed=seeds)
+    eng = step._make_engine(chains)
+    try:
+        eng.seed(seeds)
+        eng.set_position(start)
+        eng.reset_tuning()
+        eng.keep_moments(True)                         # running per-chain moments in the kernel: no 67 GB trace
+        eng.reserve(tune + draws, keep_trace=False)
+        eng.run(tune, 0, tune + draws)
+        eng.synchronize()
+        assert not eng.status().any()
+        mean, m2, n = eng.moments()
+        assert (np.asarray(n) == draws).all()
+        gmean, gvar = _pooled_moments(np.asarray(mean), np.asarray(m2), n)
+        assert np.abs(gmean).max() < 1e-3, np.abs(gmean).max()
+        assert np.abs(gvar - 1.0).max() < 1e-3, np.abs(gvar - 1.0).max()
+        rhat = dg.rhat_from_moments(mean, m2, n).cpu().numpy()
+        assert rhat.max() < 1.01
+        depth = eng.stat_i32(_abi.STAT_DEPTH, tune, draws)
+        size = eng.stat_i32(_abi.STAT_TREE_SIZE, tune, draws)
+        assert 5.8 < depth.mean() < 6.6, depth.mean()
+        assert np.all(size <= 2 ** depth.astype(np.int64) - 1) and np.all(size >= 2 ** (depth.astype(np.int64) - 1))
+        ct = eng.counters()
+        assert ct[:, _abi.CT_DIVS_AFTER_TUNE].sum() == 0
+        assert ct[:, _abi.CT_LEAPFROGS].sum() == eng.stat_i32(_abi.STAT_TREE_SIZE, 0, tune + draws).astype(np.int64).sum()
+    finally:
+        eng.close()
+
+
+def test_c4_per_gpu_size_1024_chains_dim1000():
+    """configs[3] at its per-GPU size (8192 chains over 8 GPUs): 1024 chains x d = 1000, kappa = 1e4 diagonal
+    Gaussian, QuadPotentialDiagAdapt warm-up -- the team-of-4-wavefronts kernel."""
+    d, chains, tune, draws = 1000, 1024, 500, 200
+    tgt = T.DiagGaussian.ill_conditioned(d, 1e4)
+    trace, stats, eng = lmc.sample(tgt, d, draws=draws, tune=tune, chains=chains, random_seed=20260928, return_engine=True)
+    var = eng.adapt_state()["var"]
+    eng.close()
+    tree_invariants(stats, 10)
+    sigma2 = 1.0 / tgt.params
+    # the adapted mass matrix learnt every scale over four orders of magnitude (500 tuning draws: ~9 % noise per entry)
+    assert np.abs(np.median(var / sigma2, axis=0) - 1.0).max() < 0.15
+    pooled = trace.var(axis=(0, 1)) / sigma2                      # 2e5 draws per dimension
+    assert np.abs(pooled - 1.0).max() < 0.03, np.abs(pooled - 1.0).max()
+    assert np.abs(trace.mean(axis=(0, 1)) / np.sqrt(sigma2)).max() < 0.02
+    assert stats["diverging"].sum() == 0
+    assert abs(stats["mean_tree_accept"].mean() - 0.8) < 0.05
+
+
+def test_c5_per_gpu_size_2048_chains_dim256_funnel():
+    """configs[4] at its per-GPU size (16 384 chains over 8 GPUs): 2048 chains x d = 256 Neal's funnel,
+    max_treedepth = 12 -- divergence-heavy, ragged trees of 1 ... 4095 leapfrogs side by side."""
+    d, chains, tune, draws = 256, 2048, 300, 200
+    trace, stats = lmc.sample(T.Funnel(d), d, draws=draws, tune=tune, chains=chains, random_seed=20260928,
+                              max_treedepth=12)
+    depth, size, div = tree_invariants(stats, 12)
+    assert div.sum() > 0 and depth.max() >= depth.min() + 3
+    assert np.isfinite(trace).all()
+    # every divergent transition reports an energy error beyond Emax or a non-finite one (nuts.py:358)
+    mee = np.abs(stats["max_energy_error"][..., 0])
+    assert np.all((mee[div] >= 1000.0) | ~np.isfinite(mee[div]))
+    assert np.all(mee[~div] < 1000.0)
+    v = trace[..., 0]
+    assert abs(v.mean()) < 1.0 and 1.0 < v.std() < 4.0          # q_0 ~ N(0, 3^2): the mouth is explored, the neck under-sampled
+
+
 def test_same_seed_chains_agree_statistically_with_the_oracle():
     """Whole tuned chains decorrelate from the reference after a few dozen iterations, so
     long same-seed runs are compared as samples: per-chain means of the device and of the oracle (32 chains,

@@ -11,7 +11,7 @@ for lib in "$@"; do
   for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
              "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE"; do
     i=$((i+1))
-    LMC_HIP_LIB=$lib timeout 900 rocprofv3 --pmc $set --output-format csv -d $out/$tag -o pmc$i -- python bench.py --no-cpu-baseline --no-ess $args > $out/$tag.pmc$i.log 2>&1
+    LMC_HIP_LIB=$lib timeout 900 rocprofv3 --pmc $set --output-format csv -d $out/$tag -o pmc$i -- python bench.py --no-cpu-baseline --no-ess --no-secondary $args > $out/$tag.pmc$i.log 2>&1
     grep '"metric"' $out/$tag.pmc$i.log | tail -1 > $out/$tag.pmc$i.json
   done
   python - $out $tag <<'PY'

@@ -5,7 +5,7 @@ set -u
 out=gpurun_out/$1; shift
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-BENCH="python bench.py --no-cpu-baseline --no-ess $*"
+BENCH="python bench.py --no-cpu-baseline --no-ess --no-secondary $*"
 echo "== stats"; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o stats -- $BENCH > $out/bench_stats.log 2>&1
 grep '"metric"' $out/bench_stats.log > $out/bench_stats.json
 echo "== pmc sq"; timeout 900 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $out -o pmc_sq -- $BENCH > $out/bench_pmc_sq.log 2>&1

@@ -4,7 +4,7 @@ set -u
 out=gpurun_out/$1; shift
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o stats -- python bench.py --no-cpu-baseline --no-ess $* > $out/bench.log 2>&1
+timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o stats -- python bench.py --no-cpu-baseline --no-ess --no-secondary $* > $out/bench.log 2>&1
 grep '"metric"' $out/bench.log > $out/bench.json
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
