@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LMC_ABI_VERSION 2
+#define LMC_ABI_VERSION 3
 
 /* status codes */
 #define LMC_OK 0
@@ -293,6 +293,20 @@ int lmc_engine_logp_dlogp(lmc_engine* e, const double* q, double* logp, double* 
 int lmc_engine_rng_draw(lmc_engine* e, const int32_t* ops, int32_t n_ops, double* out);
 /* potential.random() for every chain (quadpotential.py:221-224 / :374-376): out [chains][dim]. */
 int lmc_engine_draw_momentum(lmc_engine* e, double* out);
+
+/* ---- cross-chain diagnostics on the draws in HBM (the reference has none: ArviZ recipe only,
+ * docs/tutorials/framework_cookbook.rst:201-213) -------------------------------------------------------------------
+ * Per-dimension sufficient statistics of the sub-series [t0, t0 + n) of every chain of a trace block
+ * x[chains][draws_stride][dim] (DEVICE pointer, e.g. lmc_engine_trace_device_ptr()):
+ *   out[0][dim] = sum over chains of the chain mean          out[1][dim] = sum of squared chain means
+ *   out[2][dim] = sum of unbiased within-chain variances (lag0 == 0 only, else 0)
+ *   out[3 + k][dim] = sum of biased (1/n) autocovariances at lag lag0 + k, k < lmc_diag_lags_per_pass()
+ * out is a DEVICE pointer to (3 + lags_per_pass) * dim doubles. The work is enqueued on `stream` (a hipStream_t, NULL =
+ * default stream) of the current device; the result is bit-reproducible (no floating-point atomics). The statistics add
+ * over chains, chain halves and ranks: split R-hat and the Geyer ESS follow from their sums (littlemcmc_amd/diagnostics.py). */
+int lmc_diag_lags_per_pass(void);
+int lmc_diag_chain_stats(const double* x, int64_t chains, int64_t draws_stride, int32_t dim, int64_t t0, int64_t n,
+                         int32_t lag0, double* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LMC_HIP_LIB") or os.path.join(_HERE, "liblmc_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK = 0
 
 KIND_NUTS, KIND_HMC = 0, 1
@@ -118,6 +118,8 @@ _SIGNATURES = {
     "lmc_engine_logp_dlogp": (C.c_int, [_P, _P, _P, _P]),
     "lmc_engine_rng_draw": (C.c_int, [_P, _P, C.c_int32, _P]),
     "lmc_engine_draw_momentum": (C.c_int, [_P, _P]),
+    "lmc_diag_lags_per_pass": (C.c_int, []),
+    "lmc_diag_chain_stats": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

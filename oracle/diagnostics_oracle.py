@@ -12,7 +12,21 @@ def split(x):
     return np.concatenate([x[:, :h], x[:, n - h:]], axis=0)
 
 
-def rhat_ess(x, do_split=True):
+def rank_normalize(x):
+    """Vehtari et al. (2021) eq. 14: z = Phi^-1((r - 3/8) / (S + 1/4)), r = rank among ALL S draws of the dimension."""
+    from scipy.stats import norm, rankdata
+
+    c, n, d = x.shape
+    z = np.empty_like(x, dtype="d")
+    for j in range(d):
+        r = rankdata(x[:, :, j].ravel(), method="average")
+        z[:, :, j] = norm.ppf((r - 0.375) / (c * n + 0.25)).reshape(c, n)
+    return z
+
+
+def rhat_ess(x, do_split=True, rank_normalized=False):
+    if rank_normalized:
+        x = rank_normalize(x)
     if do_split:
         x = split(x)
     m, n, d = x.shape

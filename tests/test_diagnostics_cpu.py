@@ -42,11 +42,27 @@ def test_ess_recovers_known_autocorrelation_time():
     assert np.all(np.abs(got["rhat"].numpy() - 1) < 0.01)
 
 
-def test_chunking_does_not_change_the_statistics():
-    x = torch.from_numpy(ar1_chains(10, 64, 4, 0.3, 5))
-    a = dg.summarize(x, chunk=3)
-    b = dg.summarize(x, chunk=1000)
-    np.testing.assert_allclose(a["ess"].numpy(), b["ess"].numpy(), rtol=1e-12)
+def test_lag_passes_follow_the_autocorrelation_length():
+    """16 lags per pass; passes stop once Geyer's initial positive sequence has ended in every dimension."""
+    fast = dg.summarize(torch.from_numpy(ar1_chains(10, 400, 4, 0.3, 5)))
+    slow = dg.summarize(torch.from_numpy(ar1_chains(10, 400, 4, 0.95, 5)))
+    assert fast["lag_passes"] == 1 and slow["lag_passes"] >= 3
+    x = ar1_chains(10, 400, 4, 0.95, 5)
+    rhat, ess = odg.rhat_ess(x)
+    np.testing.assert_allclose(slow["ess"].numpy(), ess, rtol=1e-8)
+    capped = dg.summarize(torch.from_numpy(x), max_lag=16)
+    assert capped["lag_passes"] == 1 and np.all(capped["ess"].numpy() >= slow["ess"].numpy())
+
+
+@pytest.mark.parametrize("rho", [0.0, 0.7])
+def test_rank_normalised_variant_matches_numpy_restatement(rho):
+    x = np.exp(ar1_chains(5, 90, 3, rho, 11))          # heavy right tail: rank normalisation matters
+    got = dg.summarize(torch.from_numpy(x), rank_normalized=True)
+    rhat, ess = odg.rhat_ess(x, rank_normalized=True)
+    np.testing.assert_allclose(got["rhat"].numpy(), rhat, rtol=1e-9)
+    np.testing.assert_allclose(got["ess"].numpy(), ess, rtol=1e-7)
+    plain = dg.summarize(torch.from_numpy(x))
+    assert not np.allclose(plain["ess"].numpy(), got["ess"].numpy(), rtol=1e-3)
 
 
 def test_chain_blocks_partition_the_chains():

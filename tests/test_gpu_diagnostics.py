@@ -27,6 +27,53 @@ def test_device_diagnostics_match_numpy_on_real_draws():
         eng.close()
 
 
+@pytest.mark.parametrize("chains,n,d,rho", [(7, 61, 5, 0.2), (33, 200, 130, 0.6), (12, 300, 64, 0.97), (3, 16, 1, -0.5)])
+def test_hip_chain_statistics_kernel_against_numpy(chains, n, d, rho):
+    """lmc_diag_chain_stats (csrc/lmc_diag.hip) on synthetic AR(1) series: ragged sizes (n not a multiple of the 16-draw
+    block, d over several 64-lane slabs), slow mixing (several lag passes), split and unsplit, rank-normalised."""
+    import torch
+
+    from tests.test_diagnostics_cpu import ar1_chains
+
+    x = ar1_chains(chains, n, d, rho, 21)
+    xd = torch.from_numpy(x).cuda()
+    for split in (True, False):
+        got = dg.summarize(xd, split=split)
+        rhat, ess = odg.rhat_ess(x, do_split=split)
+        np.testing.assert_allclose(got["rhat"].cpu().numpy(), rhat, rtol=1e-9)
+        np.testing.assert_allclose(got["ess"].cpu().numpy(), ess, rtol=1e-7)
+        host = dg.summarize(torch.from_numpy(x), split=split)        # the FFT mirror used by the gloo tests
+        assert host["lag_passes"] == got["lag_passes"]
+        np.testing.assert_allclose(got["ess"].cpu().numpy(), host["ess"].numpy(), rtol=1e-9)
+    if rho > 0.9:
+        assert got["lag_passes"] > 2
+    # one pass of the raw statistics, lags 16..31, against direct sums
+    blk = dg.chain_stats_pass(xd, [(3, n - 5)], 16).cpu().numpy()
+    sub = x[:, 3:3 + n - 5]
+    cen = sub - sub.mean(axis=1, keepdims=True)
+    m = n - 5
+    for k in (0, 5, 15):
+        lag = 16 + k
+        want = (cen[:, :m - lag] * cen[:, lag:]).sum(axis=(0, 1)) / m if lag < m else np.zeros(d)
+        np.testing.assert_allclose(blk[3 + k], want, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(blk[0], sub.mean(axis=1).sum(axis=0), rtol=1e-12)
+    z = dg.summarize(xd, rank_normalized=True)
+    rhat, ess = odg.rhat_ess(x, rank_normalized=True)
+    np.testing.assert_allclose(z["rhat"].cpu().numpy(), rhat, rtol=1e-8)
+    np.testing.assert_allclose(z["ess"].cpu().numpy(), ess, rtol=1e-6)
+
+
+def test_hip_chain_statistics_are_bit_reproducible():
+    import torch
+
+    from tests.test_diagnostics_cpu import ar1_chains
+
+    xd = torch.from_numpy(ar1_chains(5000, 64, 70, 0.4, 2)).cuda()
+    a = dg.chain_stats_pass(xd, [(0, 32), (32, 32)], 0)
+    b = dg.chain_stats_pass(xd, [(0, 32), (32, 32)], 0)
+    assert torch.equal(a, b)
+
+
 def test_sample_distributed_single_rank_equals_sample():
     d = 5
     tgt = lmc.targets.StdNormal(d)
