@@ -70,7 +70,9 @@ extern "C" {
 
 /* per-chain status bits (lmc_engine_get_status) */
 #define LMC_STATUS_BAD_INITIAL_ENERGY 1   /* base_hmc.py:145-148 (ValueError in the reference) */
-#define LMC_STATUS_NAN_LOGBERN 2          /* math.py:23-24 (FloatingPointError in the reference) */
+/* (No bit for math.py:23-24's FloatingPointError: logbern() only sees log-weights of leaves that passed the divergence
+ * test |dE| < Emax (nuts.py:358; a NaN dE becomes +inf first, and inf < Emax is false even for Emax = inf), so every
+ * log_size entering a merge is finite and log_p cannot be NaN -- the error is unreachable through this path.) */
 
 /* per-draw statistics. f64 slots */
 #define LMC_STAT_STEP_SIZE 0        /* "step_size": exp(log_step) after the update (step_sizes.py:94-99) */
@@ -293,6 +295,17 @@ int lmc_engine_logp_dlogp(lmc_engine* e, const double* q, double* logp, double* 
 int lmc_engine_rng_draw(lmc_engine* e, const int32_t* ops, int32_t n_ops, double* out);
 /* potential.random() for every chain (quadpotential.py:221-224 / :374-376): out [chains][dim]. */
 int lmc_engine_draw_momentum(lmc_engine* e, double* out);
+
+/* ---- a user-written density compiled at run time (cfg.target_family = LMC_TARGET_USER in the stock library) ------------
+ * The kernels that depend on the density functor -- run_kernel<run_ns, run_w, UserTarget>, trajectory_kernel<unit_ns,
+ * UserTarget>, logp_kernel<unit_ns, UserTarget> (csrc/lmc_sampler.hpp, csrc/lmc_unit_kernels.hpp) -- are compiled by the
+ * caller with hiprtc for the shape lmc_engine_kernel_shape() reports, and handed over as a code object plus the three
+ * (lowered) kernel names; everything else stays the prebuilt library. This is how `logp_dlogp_func` (integration.py:
+ * 40,62,115) becomes a device function linked into the leapfrog kernel without hipcc on the machine. Diagonal mass
+ * matrices only; littlemcmc_amd.targets.UserTarget drives it. */
+int lmc_engine_kernel_shape(lmc_engine* e, int32_t* unit_ns, int32_t* run_ns, int32_t* run_w);
+int lmc_engine_load_user_kernels(lmc_engine* e, const void* code_object, const char* run_name, const char* trajectory_name,
+                                 const char* logp_name);
 
 /* ---- cross-chain diagnostics on the draws in HBM (the reference has none: ArviZ recipe only,
  * docs/tutorials/framework_cookbook.rst:201-213) -------------------------------------------------------------------

@@ -17,7 +17,7 @@ OK = 0
 KIND_NUTS, KIND_HMC = 0, 1
 POT_DIAG_ADAPT, POT_DIAG, POT_FULL, POT_FULL_INV, POT_FULL_ADAPT = range(5)
 TARGET_STD_NORMAL, TARGET_DIAG_GAUSSIAN, TARGET_AR1, TARGET_FUNNEL, TARGET_NORMAL1D, TARGET_USER, TARGET_EXTERNAL = range(7)
-STATUS_BAD_INITIAL_ENERGY, STATUS_NAN_LOGBERN = 1, 2
+STATUS_BAD_INITIAL_ENERGY = 1
 SDOT_NATIVE, SDOT_OPENBLAS_SKYLAKEX, SDOT_OPENBLAS_HASWELL = 0, 1, 2
 (STAT_STEP_SIZE, STAT_STEP_SIZE_BAR, STAT_ACCEPT, STAT_ENERGY_ERROR, STAT_ENERGY, STAT_MAX_ENERGY_ERROR,
  STAT_MODEL_LOGP) = range(7)
@@ -118,6 +118,8 @@ _SIGNATURES = {
     "lmc_engine_logp_dlogp": (C.c_int, [_P, _P, _P, _P]),
     "lmc_engine_rng_draw": (C.c_int, [_P, _P, C.c_int32, _P]),
     "lmc_engine_draw_momentum": (C.c_int, [_P, _P]),
+    "lmc_engine_kernel_shape": (C.c_int, [_P, _P, _P, _P]),
+    "lmc_engine_load_user_kernels": (C.c_int, [_P, _P, C.c_char_p, C.c_char_p, C.c_char_p]),
     "lmc_diag_lags_per_pass": (C.c_int, []),
     "lmc_diag_chain_stats": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _P, _P]),
 }

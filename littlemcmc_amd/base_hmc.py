@@ -28,9 +28,8 @@ def raise_for_status(status, what="chain"):
     if len(bad):  # base_hmc.py:145-148
         raise ValueError("Bad initial energy (non-finite) in %s %s. The model might be misspecified."
                          % (what, bad[:8].tolist()))
-    bad = np.nonzero(status & _abi.STATUS_NAN_LOGBERN)[0]
-    if len(bad):  # math.py:23-24
-        raise FloatingPointError("log_p can't be nan. (%s %s)" % (what, bad[:8].tolist()))
+    # math.py:23-24 (FloatingPointError for a NaN log_p) has no device counterpart: every leaf that reaches a merge
+    # passed |dE| < Emax (nuts.py:358), so all log-weights are finite and log_p cannot be NaN (include/lmc_hip.h)
 
 
 class _StepIntegrator(HipLeapfrogIntegrator):

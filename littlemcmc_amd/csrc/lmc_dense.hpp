@@ -315,7 +315,7 @@ __device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, con
             dense_leapfrog<NS, MatT>(tm, tgt, mm, xop, eps, cq, cp, cg, cv, cw, energy, logp);
             ++n_leap;
             double de = first_f64(energy - e0);
-            if (isnan(de)) de = INFINITY;
+            if (isnan(de)) de = __builtin_inf();
             if (fabs(de) > fabs(max_de)) max_de = de;
             if (!(fabs(de) < emax)) { diverging = true; break; }   // nuts.py:358,370-375
             const double x = -de;
@@ -421,7 +421,6 @@ __device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, con
     out.diverging = diverging;
     out.exhausted = exhausted;
     out.accepted = 0;
-    out.nan_logbern = 0;
 }
 
 // ---- HMC transition (hmc.py:140-182) ---------------------------------------------------------------------------
@@ -444,7 +443,7 @@ __device__ inline void dense_hmc_transition(Team<1>& tm, const Target& tgt, cons
         dense_leapfrog<NS, MatT>(tm, tgt, mm, xop, step_size, cq, cp, cg, cv, cw, energy, logp);
     bool diverging = !isfinite(energy);
     double de = first_f64(e0 - energy);
-    if (isnan(de)) de = -INFINITY;
+    if (isnan(de)) de = -__builtin_inf();
     if (fabs(de) > emax) diverging = true;
     const double accept = first_f64(fmin(1.0, exp_uniform(de)));
     bool accepted = false;
@@ -462,7 +461,6 @@ __device__ inline void dense_hmc_transition(Team<1>& tm, const Target& tgt, cons
     out.diverging = diverging;
     out.exhausted = 0;
     out.accepted = accepted;
-    out.nan_logbern = 0;
 }
 
 // ---- the iteration kernel ----------------------------------------------------------------------------------------
@@ -698,7 +696,7 @@ __device__ inline bool cholesky_registers(const float* covT, float* fac, int d, 
             if (ty == kr) {   // owners of column k: T consecutive lanes of one wavefront, the pivot owner is lane-local
                 const int pivot_lane = (lane / T) * T + kr;           // the thread with tx == kr in this group
                 const float akk = __shfl(a[kb][kb], pivot_lane, 64);
-                const bool good = (akk > 0.0f) && (akk < INFINITY);
+                const bool good = (akk > 0.0f) && (akk < __builtin_inf());
                 const float lkk = sqrtf(akk);
 #pragma unroll
                 for (int ai = kb; ai < R; ++ai) {

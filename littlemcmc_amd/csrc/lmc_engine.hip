@@ -15,6 +15,7 @@
 
 #include "../../include/lmc_hip.h"
 #include "lmc_sampler.hpp"
+#include "lmc_unit_kernels.hpp"
 #include "lmc_dense_launch.hpp"
 #include "lmc_tick_launch.hpp"
 #ifdef LMC_USER_TARGET_HEADER
@@ -108,96 +109,6 @@ __global__ __launch_bounds__(64) void momentum_kernel(ChainArrays A, int momentu
     }
 }
 
-template <int NS, template <int> class TargetT>
-__global__ __launch_bounds__(64) void logp_kernel(ChainArrays A, const double* tparams, const double* qin,
-                                                  double* logp_out, double* grad_out) {
-    const int c = blockIdx.x;
-    const int lane = lane_id();
-    const int d = A.d;
-    Team<1> tm{nullptr, 0};
-    TargetT<NS> tgt;
-    tgt.init(tm, tparams, d);
-    double q[NS], g[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int e = lane * NS + s;
-        q[s] = (e < d) ? qin[static_cast<long long>(c) * d + e] : 0.0;
-    }
-    const double logp = tgt.logp_grad(tm, q, g);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int e = lane * NS + s;
-        if (e < d) grad_out[static_cast<long long>(c) * d + e] = g[s];
-    }
-    if (lane == 0) logp_out[c] = logp;
-}
-
-// compute_state + n_fwd steps (+eps) + n_back steps (-eps); all states written out.
-template <int NS, template <int> class TargetT>
-__global__ __launch_bounds__(64) void trajectory_kernel(ChainArrays A, const double* tparams, const double* q0,
-                                                        const double* p0, int p0_is_f32, int sdot_mode, double eps,
-                                                        int n_fwd, int n_back, double* oq, double* op, double* ov,
-                                                        double* og, double* oe, double* ol) {
-    const int c = blockIdx.x;
-    const int lane = lane_id();
-    const int d = A.d;
-    const long long row = static_cast<long long>(c) * A.dpad;
-    Team<1> tm{nullptr, 0};
-    TargetT<NS> tgt;
-    tgt.init(tm, tparams, d);
-    double q[NS], p[NS], g[NS];
-    float var[NS];
-    double vard[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int e = lane * NS + s;
-        q[s] = (e < d) ? q0[static_cast<long long>(c) * d + e] : 0.0;
-        p[s] = (e < d) ? p0[static_cast<long long>(c) * d + e] : 0.0;
-        var[s] = A.var[row + e];
-        vard[s] = static_cast<double>(var[s]);
-    }
-    const int n_states = n_fwd + n_back + 1;
-    double logp = tgt.logp_grad(tm, q, g);
-    double energy;
-    double v[NS];
-    if (p0_is_f32) {
-        extern __shared__ __attribute__((aligned(16))) double lds[];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            p[s] = static_cast<double>(static_cast<float>(p[s]));
-            v[s] = static_cast<double>(var[s] * static_cast<float>(p[s]));
-        }
-        const float kin = start_kinetic_f32<NS>(tm, p, var, d, sdot_mode, reinterpret_cast<float*>(lds), A.dpad);
-        energy = static_cast<double>(kin) - logp;
-    } else {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) v[s] = static_cast<double>(var[s]) * p[s];
-        energy = 0.5 * wave_sum(pdot_v<NS>(p, vard, p)) - logp;
-    }
-    for (int k = 0; k < n_states; ++k) {
-        if (k > 0) {
-            leapfrog<NS>(tm, tgt, vard, (k <= n_fwd) ? eps : -eps, q, p, g, energy, logp);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) v[s] = static_cast<double>(var[s]) * p[s];
-        }
-        const long long base = (static_cast<long long>(c) * n_states + k) * d;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int e = lane * NS + s;
-            if (e < d) {
-                oq[base + e] = q[s];
-                op[base + e] = p[s];
-                ov[base + e] = v[s];
-                og[base + e] = g[s];
-            }
-        }
-        if (lane == 0) {
-            oe[static_cast<long long>(c) * n_states + k] = energy;
-            ol[static_cast<long long>(c) * n_states + k] = logp;
-        }
-    }
-}
-
 // QuadPotentialDiagAdapt.reset() (quadpotential.py:195-204) / QuadPotentialDiag.__init__ (:349-365)
 // + DualAverageAdaptation.reset() (step_sizes.py:49-56) + iter_count = 0.
 __global__ void reset_kernel(ChainArrays A, const double* init_mean, const float* init_diag, double init_weight,
@@ -270,7 +181,7 @@ static thread_local std::string g_last_error;
 
 struct lmc_engine {
     lmc_config cfg;
-    int ns = 0, dpad = 0, nlds = 1, lds_bytes = 0;   // ns: vector width of the W = 1 unit kernels (dpad = 64 * ns)
+    int ns = 0, dpad = 0, nlds = 1, ncold_lds = 0, lds_bytes = 0;   // ns: vector width of the W = 1 unit kernels (dpad = 64 * ns)
     int run_ns = 0, run_w = 1;                       // shape of the sampling kernel: dpad = 64 * run_ns * run_w
     hipStream_t own_stream = nullptr, stream = nullptr;
     ChainArrays A;
@@ -295,6 +206,10 @@ struct lmc_engine {
     TickArrays K;
     bool ticking = false;
     int* adapt_mask = nullptr;     // [C] chains whose FullAdapt.update is due after the current tick
+    // run-time compiled user density (cfg.target_family == LMC_TARGET_USER in the stock library): the three kernels that
+    // depend on the density functor come from a code object the caller compiled with hiprtc
+    hipModule_t user_module = nullptr;
+    hipFunction_t user_run = nullptr, user_trajectory = nullptr, user_logp = nullptr;
     std::vector<void*> allocs;
     std::string err;
 };
@@ -485,9 +400,7 @@ int32_t lmc_has_target(int32_t family) {
 #if !(defined(LMC_USER_TARGET_HEADER) && defined(LMC_ONLY_USER))
     if (family >= LMC_TARGET_STD_NORMAL && family <= LMC_TARGET_NORMAL1D) return 1;
 #endif
-#ifdef LMC_USER_TARGET_HEADER
-    if (family == LMC_TARGET_USER) return 1;
-#endif
+    if (family == LMC_TARGET_USER) return 1;       // compiled in (LMC_USER_TARGET_HEADER build) or loaded at run time
     if (family == LMC_TARGET_EXTERNAL) return 1;   // no device functor: the host evaluates the density between ticks
     return 0;
 }
@@ -612,6 +525,30 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     if (nlds < 1) nlds = 1;
     e->nlds = nlds;
     e->lds_bytes = (2 + 4 * (nlds - 1)) * e->dpad * 8;
+    e->ncold_lds = 0;
+    if (e->run_w == 1 && LMC_NUTS_ONE_WAVE_FORM) {
+        // one-wave form (nuts_transition2): reduction buffer + exp table + level scalars, then the cold slots (other
+        // trajectory end, running momentum sum, ...), stack level 1 (3 vectors) and levels 2.. (4 vectors each); level 0
+        // lives in registers. What does not fit goes to the chain's HBM scratch row. lds_levels < 0: nothing but the head.
+        const int waves_per_cu = 4 * run_waves_per_simd(e->run_ns);
+        long budget = (163840L / waves_per_cu) / 1280 * 1280 - lds_tail_doubles(1) * 8L - stack2_head_doubles(e->dpad) * 8L;
+        const long vec = e->dpad * 8L;
+        int ncold = 0;
+        if (cfg->lds_levels >= 0) {
+            if ((kNumColdSlots + 3) * vec <= budget) ncold = kNumColdSlots;      // all cold slots + level 1
+            else if ((3 + 3) * vec <= budget) ncold = 3;                         // {aold, psum, op} + level 1
+        }
+        budget -= ncold * vec;
+        nlds = cfg->lds_levels;
+        if (nlds == 0) {
+            while (nlds < max_levels && stack2_level_doubles(nlds + 1, e->dpad) * 8L <= budget) ++nlds;
+        }
+        if (nlds > max_levels) nlds = max_levels;
+        if (nlds < 0) nlds = 0;
+        e->nlds = nlds;
+        e->ncold_lds = ncold;
+        e->lds_bytes = (stack2_head_doubles(e->dpad) + ncold * e->dpad + stack2_level_doubles(nlds, e->dpad)) * 8;
+    }
     if (e->lds_bytes > 160 * 1024) return bail(fail(nullptr, LMC_ERR_INVALID, "lds_levels too large"));
 
     const size_t C = cfg->chains, dp = e->dpad;
@@ -640,7 +577,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     TRY_ALLOC(dev_alloc(e, &A.rng_gauss, C));
     TRY_ALLOC(dev_alloc(e, &A.status, C));
     TRY_ALLOC(dev_alloc(e, &A.counters, C * kNumCounters));
-    A.scratch_stride = static_cast<long long>(max_levels - nlds + 1) * 4 * dp;
+    A.scratch_stride = static_cast<long long>(max_levels - nlds + 1) * 4 * dp + static_cast<long long>(kNumColdSlots) * dp;
     const bool dense = cfg->potential >= LMC_POT_FULL;
     if (dense) A.scratch_stride = static_cast<long long>(dense_scratch_vectors(max_levels)) * dp;
     const bool external = cfg->target_family == LMC_TARGET_EXTERNAL;
@@ -743,8 +680,53 @@ void lmc_engine_destroy(lmc_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (void* p : e->allocs)
         if (p) (void)hipFree(p);
+    if (e->user_module) (void)hipModuleUnload(e->user_module);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
+}
+
+// ---- run-time compiled user density ------------------------------------------------------------------------------
+#ifdef LMC_USER_TARGET_HEADER
+static const bool kUserCompiledIn = true;
+#else
+static const bool kUserCompiledIn = false;
+#endif
+
+int lmc_engine_kernel_shape(lmc_engine* e, int32_t* unit_ns, int32_t* run_ns, int32_t* run_w) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    if (unit_ns) *unit_ns = e->ns;
+    if (run_ns) *run_ns = e->run_ns;
+    if (run_w) *run_w = e->run_w;
+    return LMC_OK;
+}
+
+int lmc_engine_load_user_kernels(lmc_engine* e, const void* code_object, const char* run_name, const char* trajectory_name,
+                                 const char* logp_name) {
+    if (!e || !code_object || !run_name || !trajectory_name || !logp_name) return fail(e, LMC_ERR_INVALID, "null argument");
+    if (e->cfg.target_family != LMC_TARGET_USER)
+        return fail(e, LMC_ERR_STATE, "lmc_engine_load_user_kernels() needs cfg.target_family = LMC_TARGET_USER");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->user_module) { (void)hipModuleUnload(e->user_module); e->user_module = nullptr; }
+    e->user_run = e->user_trajectory = e->user_logp = nullptr;
+    HIP_TRY(e, hipModuleLoadData(&e->user_module, code_object));
+    HIP_TRY(e, hipModuleGetFunction(&e->user_run, e->user_module, run_name));
+    HIP_TRY(e, hipModuleGetFunction(&e->user_trajectory, e->user_module, trajectory_name));
+    HIP_TRY(e, hipModuleGetFunction(&e->user_logp, e->user_module, logp_name));
+    return LMC_OK;
+}
+
+// launch one of the module's kernels: the arguments are the very values the compiled-in kernels take
+static int user_launch(lmc_engine* e, hipFunction_t f, unsigned grid, unsigned block, unsigned lds, void** args) {
+    if (!f)
+        return fail(e, LMC_ERR_STATE, "the user density's kernels are not loaded: call lmc_engine_load_user_kernels() "
+                                      "(littlemcmc_amd.targets.UserTarget does)");
+    if (e->cfg.potential >= LMC_POT_FULL)
+        return fail(e, LMC_ERR_INVALID, "a run-time compiled user density runs with diagonal mass matrices; dense ones need "
+                                        "the density compiled in (UserTarget(..., jit=\"hipcc\"))");
+    (void)hipGetLastError();
+    HIP_TRY(e, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, lds, e->stream, args, nullptr));
+    return LMC_OK;
 }
 
 int lmc_engine_set_stream(lmc_engine* e, void* hip_stream) {
@@ -1209,6 +1191,7 @@ static SamplerParams make_params(const lmc_engine* e, int64_t n_tune, int64_t it
     P.iter_begin = iter_begin;
     P.n_iters = n_iters;
     P.nlds = e->nlds;
+    P.ncold_lds = e->ncold_lds;
     P.lds_doubles = e->lds_bytes / 8;
     P.sdot_mode = e->cfg.start_energy_sdot;
     return P;
@@ -1234,6 +1217,10 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
             HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NSV, WV, T>),             \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));              \
         LMC_LAUNCH((run_kernel<NSV, WV, T>), grid, block, run_lds, e->stream, e->A, P, e->tparams);    \
+    }
+    if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledIn) {
+        void* args[] = {&e->A, &P, &e->tparams};
+        return user_launch(e, e->user_run, grid.x, block.x, static_cast<unsigned>(run_lds), args);
     }
 #define RUN_CALL(T)                                                                                            \
     {                                                                                                          \
@@ -1547,6 +1534,13 @@ int lmc_engine_trajectory(lmc_engine* e, const double* q0, const double* p0, int
         if (rc != 0) return dense_fail(e, rc, "trajectory");
     } else {
     const dim3 grid(e->cfg.chains), block(64);
+    if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledIn) {
+        int sdot = e->cfg.start_energy_sdot, p32 = p0_is_f32, nf = n_fwd, nb = n_back;
+        double eps_ = eps;
+        void* args[] = {&e->A, &e->tparams, &dq0.p, &dp0.p, &p32, &sdot, &eps_, &nf, &nb, &oq.p, &op.p, &ov.p, &og.p, &oe.p, &ol.p};
+        const int rc = user_launch(e, e->user_trajectory, grid.x, block.x, static_cast<unsigned>(e->dpad * 8), args);
+        if (rc != LMC_OK) return rc;
+    } else {
 #define TRAJ_CALL(T)                                                                                          \
     LMC_NS_SWITCH(e, e->ns, LMC_LAUNCH((trajectory_kernel<NS, T>), grid, block, e->dpad * 8, e->stream, e->A,   \
                                                e->tparams, dq0.p, dp0.p, p0_is_f32, e->cfg.start_energy_sdot, eps, n_fwd, n_back, oq.p, \
@@ -1554,6 +1548,7 @@ int lmc_engine_trajectory(lmc_engine* e, const double* q0, const double* p0, int
     LMC_FAMILY_SWITCH(e, e->cfg.target_family, TRAJ_CALL)
 #undef TRAJ_CALL
     HIP_TRY(e, hipGetLastError());
+    }
     }
     HIP_TRY(e, hipMemcpyAsync(out_q, oq.p, C * ns * d * sizeof(double), hipMemcpyDefault, e->stream));
     HIP_TRY(e, hipMemcpyAsync(out_p, op.p, C * ns * d * sizeof(double), hipMemcpyDefault, e->stream));
@@ -1573,11 +1568,17 @@ int lmc_engine_logp_dlogp(lmc_engine* e, const double* q, double* logp, double* 
     HIP_TRY(e, dq.alloc(C * d)); HIP_TRY(e, dl.alloc(C)); HIP_TRY(e, dg.alloc(C * d));
     HIP_TRY(e, hipMemcpyAsync(dq.p, q, C * d * sizeof(double), hipMemcpyDefault, e->stream));
     const dim3 grid(e->cfg.chains), block(64);
+    if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledIn) {
+        void* args[] = {&e->A, &e->tparams, &dq.p, &dl.p, &dg.p};
+        const int rc = user_launch(e, e->user_logp, grid.x, block.x, 0, args);
+        if (rc != LMC_OK) return rc;
+    } else {
 #define LOGP_CALL(T) \
     LMC_NS_SWITCH(e, e->ns, LMC_LAUNCH((logp_kernel<NS, T>), grid, block, 0, e->stream, e->A, e->tparams, dq.p, dl.p, dg.p))
     LMC_FAMILY_SWITCH(e, e->cfg.target_family, LOGP_CALL)
 #undef LOGP_CALL
     HIP_TRY(e, hipGetLastError());
+    }
     HIP_TRY(e, hipMemcpyAsync(logp, dl.p, C * sizeof(double), hipMemcpyDefault, e->stream));
     HIP_TRY(e, hipMemcpyAsync(grad, dg.p, C * d * sizeof(double), hipMemcpyDefault, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));

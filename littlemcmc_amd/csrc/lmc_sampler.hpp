@@ -27,7 +27,6 @@ namespace lmc {
 
 // ---- status bits (per chain) ------------------------------------------------------------------
 constexpr int kStatusBadInitialEnergy = 1;   // base_hmc.py:145-148 -> ValueError on the host
-constexpr int kStatusNanLogbern = 2;         // math.py:23-24 -> FloatingPointError on the host
 
 // ---- per-draw statistic slots -------------------------------------------------------------------
 enum StatF64 : int {
@@ -96,6 +95,7 @@ struct SamplerParams {
     long long n_tune;     // iterations with index < n_tune are tuning iterations
     long long iter_begin; // global index of the first iteration of this launch
     int n_iters;
+    int ncold_lds;        // pair form: cold slots kept in LDS (the rest at the head of the scratch row)
     int nlds;             // subtree levels kept in LDS (>= 1)
     int lds_doubles;      // LDS doubles used by the subtree stack; the MT19937 state (624 words) follows
     int sdot_mode;        // SdotMode for the float32 start-state kinetic energy
@@ -400,7 +400,6 @@ struct TransitionOut {
     int diverging;
     int exhausted;         // NUTS: loop ran to max_treedepth without turning/diverging
     int accepted;          // HMC
-    int nan_logbern;
 };
 
 // ---- NUTS transition -----------------------------------------------------------------------------------
@@ -443,7 +442,7 @@ __device__ inline void nuts_transition(TeamT& tm, const Target& tgt, const doubl
             leapfrog<NS>(tm, tgt, var, eps, cq, cp, cg, energy, logp);
             ++n_leap;
             double de = first_f64(energy - e0);
-            if (isnan(de)) de = INFINITY;
+            if (isnan(de)) de = __builtin_inf();
             if (fabs(de) > fabs(max_de)) max_de = de;
             if (!(fabs(de) < emax)) { diverging = true; break; }   // nuts.py:358,370-375
             const double x = -de;
@@ -551,7 +550,6 @@ __device__ inline void nuts_transition(TeamT& tm, const Target& tgt, const doubl
     out.diverging = diverging;
     out.exhausted = exhausted;
     out.accepted = 0;
-    out.nan_logbern = 0;
 }
 
 // ---- HMC transition (hmc.py:140-182) -------------------------------------------------------------------
@@ -572,7 +570,7 @@ __device__ inline void hmc_transition(TeamT& tm, const Target& tgt, const double
     for (int i = 0; i < n_steps; ++i) leapfrog<NS>(tm, tgt, var, step_size, cq, cp, cg, energy, logp);
     bool diverging = !isfinite(energy);
     double de = first_f64(e0 - energy);
-    if (isnan(de)) de = -INFINITY;
+    if (isnan(de)) de = -__builtin_inf();
     if (fabs(de) > emax) diverging = true;
     const double accept = first_f64(fmin(1.0, exp_uniform(de)));
     bool accepted = false;
@@ -590,13 +588,472 @@ __device__ inline void hmc_transition(TeamT& tm, const Target& tgt, const double
     out.diverging = diverging;
     out.exhausted = 0;
     out.accepted = accepted;
-    out.nan_logbern = 0;
+}
+
+// ---- NUTS transition, one-wave form (W == 1): batched LDS-transposed reductions, leaf pairs ---------------
+// Same algorithm and decisions as nuts_transition() above (which stays the team form for W > 1); what changes is
+// where the issue slots go. Measured on gfx950 (tools/ubench/valu_cost.hip): a wave issues at most one instruction
+// of ANY kind every ~10 cycles, a DPP move costs as much VALU time as a float64 operation, a permlane swap ~1.9x,
+// a v_readlane with an SGPR index ~1.8x -- so at 3 waves per SIMD every instruction of the per-leaf path counts.
+//   * leaves are processed in PAIRS (2k, 2k+1): the even leaf's {p, q} stays in registers, so subtree-stack
+//     level 0 is never written to or read from LDS;
+//   * every length-d reduction of a pair -- two kinetic energies, two log-densities, the two level-0 U-turn dots --
+//     goes through ONE transposed reduction: each lane drops its partials into LDS columns, lane l adds the eight
+//     partials [8l, 8l+8) and three DPP steps finish the sums (16 VALU instead of 22 + 22 + 20); every further
+//     cascade level is one more such flush of its six dots (16 VALU instead of 42);
+//   * the per-leaf scalars are evaluated on lanes: energies of both leaves with one DPP shift, and the four
+//     weights (w_A, w_A min(1,e^-dE_A), w_B, ...) with ONE table-driven exp on four lanes instead of two to four
+//     wave-uniform exps (each ~25 VALU + ~20 s_mov + a scalar-cache round trip);
+//   * the second leaf of a pair is integrated before the first one's energy is known (speculation): a diverging
+//     first leaf discards it; leapfrog count and random stream are those of the sequential algorithm;
+//   * per-level subtree scalars live in LDS (lane 0 writes, broadcast reads) instead of VGPR lanes read with
+//     v_readlane; the proposal position of a merged node is tracked by its SOURCE (this pair or a stack level)
+//     and copied once when the node is parked; a level-1 node stores {lp, rp, q} only (its psum is lp + rp);
+//   * stack loads of the next cascade level are issued before the current level's reduction is waited for;
+//   * the trajectory is extended in place: {cq, cp, cg} is the end being extended, {oq, op, og} the other one.
+// LDS plan (doubles): [0, red) reduction buffer (also the normals / float32-dot staging area between transitions),
+// 64-entry exp table, 4 scalars per level, stack level 1 (3*dpad), levels 2..nlds (4*dpad each), [MT19937 state].
+constexpr int kRedValues = 6;
+constexpr int kExpTableDoubles = 64;
+constexpr int kLevelScalDoubles = 80;   // 4 per level, levels < 20
+constexpr int red_doubles(int dpad) { return 2 * dpad > 64 * kRedValues ? 2 * dpad : 64 * kRedValues; }
+constexpr int stack2_head_doubles(int dpad) { return red_doubles(dpad) + kExpTableDoubles + kLevelScalDoubles; }
+constexpr int stack2_level_doubles(int nlds, int dpad) { return nlds <= 0 ? 0 : 3 * dpad + 4 * dpad * (nlds - 1); }
+constexpr int kNumColdSlots = 5;   // == kNumCold
+
+struct TreeStack2 {
+    double* levels;     // LDS: level 1 at offset 0 (3 vectors), level j >= 2 at 3*dpad + (j-2)*4*dpad
+    double* glb;        // this chain's scratch row: levels > nlds, 4*dpad apart
+    double* scal;       // LDS: 4 doubles per level
+    double* exptab;     // LDS copy of kExp2Table
+    double* cold;       // LDS: cold slots [0, ncold_lds)
+    double* glb_cold;   // scratch row: cold slots [ncold_lds, kNumCold)
+    int nlds;           // levels 1..nlds live in LDS
+    int ncold_lds;
+    int dpad;
+    __device__ __forceinline__ int lds_off(int j) const { return j == 1 ? 0 : (4 * j - 5) * dpad; }
+    __device__ __forceinline__ unsigned glb_off(int j) const { return static_cast<unsigned>(j - nlds - 1) * static_cast<unsigned>(4 * dpad); }
+};
+
+struct RedBuf {
+    lds_double* buf;
+    int wofs;           // this lane's column (doubles)
+    int r0, r1, r2, r3; // the four 16-byte pieces of this lane's 64-byte row, rotated so that a ds_read_b128 of 16
+                        // lanes covers all 64 banks (lane stride is 64 B = 16 banks)
+    __device__ __forceinline__ void init(double* lds) {
+        const int lane = lane_id();
+        buf = (lds_double*)lds;
+        wofs = lane;
+        const int rot = (lane >> 2) & 3;
+        const int row = lane < 8 * kRedValues ? lane : 0;   // rows beyond the buffer re-read row 0 (their sums are never used)
+        r0 = row * 8 + 2 * rot; r1 = row * 8 + 2 * (rot ^ 1); r2 = row * 8 + 2 * (rot ^ 2); r3 = row * 8 + 2 * (rot ^ 3);
+    }
+    __device__ __forceinline__ void put(int v, double x) const { buf[v * 64 + wofs] = x; }
+    // lane 8k+7 of the result holds the wave sum of value k (k < kRedValues); other lanes hold partial scans
+    __device__ __forceinline__ double gather() const {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) d2 lds_d2;
+        asm volatile("" ::: "memory");   // DS operations of one wave execute in issue order: no wait, only no reordering
+        const d2 a = *(const lds_d2*)(buf + r0), b = *(const lds_d2*)(buf + r1);   // ds_read_b128 each
+        const d2 c = *(const lds_d2*)(buf + r2), d = *(const lds_d2*)(buf + r3);
+        asm volatile("" ::: "memory");
+        double s = ((a.x + a.y) + (b.x + b.y)) + ((c.x + c.y) + (d.x + d.y));
+        s += dpp_f64<0x111>(s);
+        s += dpp_f64<0x112>(s);
+        s += dpp_f64<0x114>(s);
+        return s;
+    }
+};
+__device__ __forceinline__ double red_value(double s, int k) { return readlane_f64(s, 8 * k + 7); }
+// any of the sums k in [k0, k0 + n) <= 0 ?
+__device__ __forceinline__ bool red_any_nonpositive(double s, int k0, int n) {
+    const unsigned long long m = __ballot(s <= 0.0);
+    unsigned long long sel = 0ull;
+    for (int k = k0; k < k0 + n; ++k) sel |= 1ull << (8 * k + 7);
+    return (m & sel) != 0ull;
+}
+
+// exp on lanes (arguments <= ~700; very negative ones underflow to 0): exp_uniform_fast's algorithm with the
+// 2^(j/64) table read from LDS by every lane
+__device__ __forceinline__ double exp_lanes(double x, const double* table_lds) {
+    const double kf = rint(x * LMC_SC(92.332482616893656));            // 64 / ln 2
+    double r = __builtin_fma(-kf, LMC_SC(1.08304246932675596327e-02), x);   // ln2/64 hi
+    r = __builtin_fma(-kf, LMC_SC(2.98158582698529328128e-12), r);          // ln2/64 lo
+    const int ki = static_cast<int>(kf);
+    const double t = ((const lds_double*)table_lds)[ki & 63];
+    double p = fma_sgpr_addend(r, LMC_SC(1.0 / 120.0), LMC_SC(1.0 / 24.0));
+    p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 6.0));
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return ldexp(p * t, ki >> 6);
+}
+
+template <int NS>
+__device__ __forceinline__ void stack2_load3(const TreeStack2& stk, int j, double (&lp)[NS], double (&rp)[NS], double (&ps)[NS]) {
+    const int dp = stk.dpad;
+    if (j <= stk.nlds) {
+        lds_double* b = (lds_double*)(stk.levels) + stk.lds_off(j);
+        vload_as<NS>(b, lp); vload_as<NS>(b + dp, rp);
+        if (j > 1) vload_as<NS>(b + 2 * dp, ps);
+    } else {
+        glb_double* b = (glb_double*)(stk.glb) + stk.glb_off(j);
+        vload_as<NS>(b, lp); vload_as<NS>(b + dp, rp);
+        if (j > 1) vload_as<NS>(b + 2 * dp, ps);
+    }
+    if (j == 1) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) ps[s] = lp[s] + rp[s];   // the very sum the pair formed (nuts.py:386)
+    }
+}
+template <int NS>
+__device__ __forceinline__ void stack2_load_lp(const TreeStack2& stk, int j, double (&lp)[NS]) {
+    if (j <= stk.nlds) vload_as<NS>((lds_double*)(stk.levels) + stk.lds_off(j), lp);
+    else vload_as<NS>((glb_double*)(stk.glb) + stk.glb_off(j), lp);
+}
+template <int NS>
+__device__ __forceinline__ void stack2_load_q(const TreeStack2& stk, int j, double (&pq)[NS]) {
+    const int dp = stk.dpad;
+    const int qo = (j == 1 ? 2 : 3) * dp;
+    if (j <= stk.nlds) vload_as<NS>((lds_double*)(stk.levels) + stk.lds_off(j) + qo, pq);
+    else vload_as<NS>((glb_double*)(stk.glb) + stk.glb_off(j) + qo, pq);
+}
+template <int NS>
+__device__ __forceinline__ void stack2_store(const TreeStack2& stk, int j, const double (&lp)[NS], const double (&rp)[NS],
+                                             const double (&ps)[NS], const double (&pq)[NS]) {
+    const int dp = stk.dpad;
+    if (j <= stk.nlds) {
+        lds_double* b = (lds_double*)(stk.levels) + stk.lds_off(j);
+        vstore_as<NS>(b, lp); vstore_as<NS>(b + dp, rp);
+        if (j == 1) { vstore_as<NS>(b + 2 * dp, pq); } else { vstore_as<NS>(b + 2 * dp, ps); vstore_as<NS>(b + 3 * dp, pq); }
+    } else {
+        glb_double* b = (glb_double*)(stk.glb) + stk.glb_off(j);
+        vstore_as<NS>(b, lp); vstore_as<NS>(b + dp, rp);
+        if (j == 1) { vstore_as<NS>(b + 2 * dp, pq); } else { vstore_as<NS>(b + 2 * dp, ps); vstore_as<NS>(b + 3 * dp, pq); }
+    }
+}
+__device__ __forceinline__ void level_scal_put(const TreeStack2& stk, int j, double w, double a, double pe, double plogp) {
+    if (lane_id() == 0) {
+        lds_double* s = (lds_double*)(stk.scal) + 4 * j;
+        s[0] = w; s[1] = a; s[2] = pe; s[3] = plogp;
+    }
+}
+__device__ __forceinline__ void level_scal_get(const TreeStack2& stk, int j, double& w, double& a, double& pe, double& plogp) {
+    const lds_double* s = (const lds_double*)(stk.scal) + 4 * j;   // same address in every lane: LDS broadcast
+    w = s[0]; a = s[1]; pe = s[2]; plogp = s[3];
+}
+
+// first half of integration.py:100-121 plus the elementwise part of the second: leaves the per-lane partials of the
+// kinetic energy and of the log-density for a batched reduction (a target that reduces its log-density itself
+// contributes it from lane 0). v = var (.) p' on return.
+template <int NS, class Target, class TeamT>
+__device__ __forceinline__ void leapfrog_partial(TeamT& tm, const Target& tgt, const double (&var)[NS], double eps,
+                                                 double (&q)[NS], double (&p)[NS], double (&g)[NS], double (&v)[NS],
+                                                 double& kin_part, double& lp_part) {
+    const double dt = 0.5 * eps;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        p[s] = p[s] + dt * g[s];
+        const double vh = var[s] * p[s];
+        q[s] = q[s] + eps * vh;
+    }
+    if constexpr (Target::kLanePartial) {
+        lp_part = tgt.logp_grad_partial(tm, q, g);
+    } else {
+        const double lp = first_f64(tgt.logp_grad(tm, q, g));
+        lp_part = (lane_id() == 0) ? lp : 0.0;
+    }
+    double kin = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        p[s] = p[s] + dt * g[s];
+        v[s] = var[s] * p[s];
+        kin = __builtin_fma(p[s], v[s], kin);
+    }
+    kin_part = kin;
+}
+
+// Cold per-transition vectors (touched once per doubling, not per leaf) live in memory by design, so that the
+// register allocator has nothing to spill around the pair loop: slot order = hotness; the first stk.ncold_lds slots
+// are LDS, the others sit at the head of the chain's HBM scratch row. The proposal of the trajectory itself lives in
+// the chain's row of A.q (written when a subtree is accepted, read back once at the end of the transition).
+enum ColdSlot : int { kColdAold = 0, kColdPsum = 1, kColdOp = 2, kColdOq = 3, kColdOg = 4, kNumCold = kNumColdSlots };
+template <int NS>
+__device__ __forceinline__ void cold_load(const TreeStack2& stk, int slot, double (&x)[NS]) {
+    if (slot < stk.ncold_lds) vload_as<NS>((lds_double*)(stk.cold) + slot * stk.dpad, x);
+    else vload_as<NS>((glb_double*)(stk.glb_cold) + (slot - stk.ncold_lds) * stk.dpad, x);
+}
+template <int NS>
+__device__ __forceinline__ void cold_store(const TreeStack2& stk, int slot, const double (&x)[NS]) {
+    if (slot < stk.ncold_lds) vstore_as<NS>((lds_double*)(stk.cold) + slot * stk.dpad, x);
+    else vstore_as<NS>((glb_double*)(stk.glb_cold) + (slot - stk.ncold_lds) * stk.dpad, x);
+}
+
+// On return the chain's row of A.q (qrow) holds the proposal; q is NOT updated (the caller reloads it).
+template <int NS, class Target, class TeamT>
+__device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const double (&var)[NS], RngState& rng,
+                                        const TreeStack2& stk, const RedBuf& rb, double* qrow, const double (&q)[NS],
+                                        const double (&p0)[NS], const double (&g0)[NS], double e0, double logp0,
+                                        double step_size, double emax, int max_depth, bool momentum_f32,
+                                        TransitionOut& out) {
+    static_assert(TeamT::kWaves == 1, "one-wave form");
+    // {cq, cp, cg}: the trajectory end that is being (or was last) extended (registers); the other end, the running
+    // momentum sum and the extended end's momentum before the doubling are cold slots
+    double cq[NS], cp[NS], cg[NS];
+    vcopy(cq, q); vcopy(cp, p0); vcopy(cg, g0);
+    cold_store<NS>(stk, kColdOq, q); cold_store<NS>(stk, kColdOp, p0); cold_store<NS>(stk, kColdOg, g0);
+    cold_store<NS>(stk, kColdPsum, p0);
+    bool c_right = true;                                    // which end {c*} is
+    bool c_start = momentum_f32, o_start = momentum_f32;    // end still is the float32 start state
+    double prop_e = e0, prop_logp = logp0;
+    double coff = 0.0, w_start = 1.0, wn = 0.0, an = 0.0, max_de = 0.0;
+    int depth = 0, n_leap = 0;
+    bool diverging = false, turning = false, exhausted = true;
+    const bool odd_lane = (lane_id() & 1) != 0;
+    UniformWindow win;
+    window_reset(win);
+
+    // Scalars of the n (1 or 2) leaves whose kinetic energy / log-density sums sit in lanes 7 / 15 (first leaf) and
+    // 23 / 31 (second) of s (nuts.py:344-375): energy errors, divergence, linear-domain weights. On return lanes
+    // 15 / 31 of en hold the energies, of ev the weights w = e^{-dE - c}, lanes 14 / 30 of ev w * min(1, e^{-dE}).
+    // Returns the number of leaves accepted into the subtree (a diverging leaf stops the count).
+    auto leaf_scalars = [&](double s, int n, double& en, double& ev) -> int {
+        en = 0.5 * dpp_f64<0x118>(s) - s;                      // row_shr:8 brings the kinetic sum next to the log-density
+        double de = en - e0;
+        int ok = 0;
+        for (int i = 0; i < n; ++i) {
+            double dei = readlane_f64(de, 15 + 16 * i);
+            ++n_leap;
+            if (isnan(dei)) dei = __builtin_inf();
+            if (fabs(dei) > fabs(max_de)) max_de = dei;
+            if (!(fabs(dei) < emax)) { diverging = true; break; }   // nuts.py:358,370-375
+            const double x = -dei;
+            if (x - coff > 600.0) {   // cold path: move the offset, rescale every stored weight
+                const double f = exp_uniform(coff - x);
+                const int lane = lane_id();
+                if (lane >= 1 && lane < 20) {
+                    lds_double* sc = (lds_double*)(stk.scal) + 4 * lane;
+                    sc[0] = sc[0] * f; sc[1] = sc[1] * f;
+                }
+                wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
+                coff = x;
+            }
+            ++ok;
+        }
+        // lanes 15 / 31: x - c; lanes 14 / 30: (x - c) + min(x, 0), i.e. log of w * min(1, e^{-dE})
+        const double x = -de;
+        const double xn = dpp_f64<0x101>(x);                   // row_shl:1: lane l <- lane l+1
+        const double arg = odd_lane ? (x - coff) : ((xn - coff) + fmin(xn, 0.0));
+        ev = exp_lanes(arg, stk.exptab);
+        return ok;
+    };
+
+    for (int dd = 0; dd < max_depth; ++dd) {
+        const bool right = team_uniform(tm, rng, win) < 0.5;   // nuts.py:213
+        const double eps = right ? step_size : -step_size;
+        if (right != c_right) {   // the other end becomes the one that is extended
+            double t[NS];
+            cold_load<NS>(stk, kColdOq, t); cold_store<NS>(stk, kColdOq, cq); vcopy(cq, t);
+            cold_load<NS>(stk, kColdOp, t); cold_store<NS>(stk, kColdOp, cp); vcopy(cp, t);
+            cold_load<NS>(stk, kColdOg, t); cold_store<NS>(stk, kColdOg, cg); vcopy(cg, t);
+            const bool tb = c_start; c_start = o_start; o_start = tb;
+            c_right = right;
+        }
+        cold_store<NS>(stk, kColdAold, cp);   // momentum of the extended end before this doubling (nuts.py:332-338 operands)
+        const bool aold_start = c_start;
+
+        // subtree node under construction: momentum sum tps, weights; its right-end momentum is always the current cp,
+        // its left-end momentum and proposal position are identified by their sources
+        double tps[NS], eq[NS], ep[NS];
+        double tw = 0.0, ta = 0.0, tpe = 0.0, tplogp = 0.0;
+        int qsrc = -1;   // proposal position: -2 first leaf of the last pair (eq), -1 the current state (cq), j >= 1 stack level j
+        const int D = depth;
+        if (D == 0) {
+            double v[NS], kinp, lp, en, ev;
+            leapfrog_partial<NS>(tm, tgt, var, eps, cq, cp, cg, v, kinp, lp);
+            rb.put(0, kinp); rb.put(1, lp);
+            const double s0 = rb.gather();
+            if (leaf_scalars(s0, 1, en, ev) == 1) {
+                tw = readlane_f64(ev, 15); ta = readlane_f64(ev, 14);
+                tpe = readlane_f64(en, 15); tplogp = readlane_f64(s0, 15);
+                vcopy(tps, cp);
+            }
+        } else {
+            const int n_pairs = 1 << (D - 1);
+            for (int k = 0; k < n_pairs; ++k) {
+                double v[NS], kinA, lpA, kinB, lpB;
+                leapfrog_partial<NS>(tm, tgt, var, eps, cq, cp, cg, v, kinA, lpA);
+                rb.put(0, kinA); rb.put(1, lpA);
+                vcopy(eq, cq); vcopy(ep, cp);
+                leapfrog_partial<NS>(tm, tgt, var, eps, cq, cp, cg, v, kinB, lpB);   // speculative w.r.t. the first leaf's divergence test
+                rb.put(2, kinB); rb.put(3, lpB);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) tps[s] = ep[s] + cp[s];
+                rb.put(4, pdot_v<NS>(tps, var, ep));   // var (.) ep is the first leaf's velocity, re-formed (same rounded product)
+                rb.put(5, pdot<NS>(tps, v));
+                const double s0 = rb.gather();
+                // this pair closes m right children (levels 1..m); level 1's node is requested now and arrives while
+                // the leaf scalars are evaluated
+                const int m = __builtin_ctz(~static_cast<unsigned>(k) | (1u << (D - 1)));
+                double alp[NS], arp[NS], aps[NS];
+                double aw = 0.0, aa = 0.0, ape = 0.0, aplogp = 0.0;
+#if LMC_V2_PREFETCH
+                if (m >= 1) { stack2_load3<NS>(stk, 1, alp, arp, aps); level_scal_get(stk, 1, aw, aa, ape, aplogp); }
+#endif
+                double en, ev;
+                if (leaf_scalars(s0, 2, en, ev) != 2) break;
+                // ---- level-0 merge (nuts.py:384-417 with depth 1: only the span check)
+                {
+                    const double wA = readlane_f64(ev, 15), aA = readlane_f64(ev, 14);
+                    const double wB = readlane_f64(ev, 31), aB = readlane_f64(ev, 30);
+                    const bool turn = red_any_nonpositive(s0, 4, 2);
+                    const double wsum = wA + wB;
+                    const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < wB);   // drawn even if turning
+                    qsrc = take_b ? -1 : -2;
+                    const int pl = take_b ? 31 : 15;
+                    tpe = readlane_f64(en, pl); tplogp = readlane_f64(s0, pl);
+                    tw = wsum; ta = aA + aB;
+                    if (turn) { turning = true; break; }
+                }
+                // ---- cascade level 1 (peeled: its operands were requested above; left end of the pair node = ep)
+                if (m >= 1) {
+#if !LMC_V2_PREFETCH
+                    stack2_load3<NS>(stk, 1, alp, arp, aps); level_scal_get(stk, 1, aw, aa, ape, aplogp);
+#endif
+                    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0, d4 = 0.0, d5 = 0.0;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const double p1 = aps[s] + ep[s];
+                        const double p2 = arp[s] + tps[s];
+                        const double ps = aps[s] + tps[s];
+                        const double valp = var[s] * alp[s], vtlp = var[s] * ep[s], varp = var[s] * arp[s];
+                        d0 = __builtin_fma(ps, valp, d0); d1 = __builtin_fma(ps, v[s], d1);
+                        d2 = __builtin_fma(p1, valp, d2); d3 = __builtin_fma(p1, vtlp, d3);
+                        d4 = __builtin_fma(p2, varp, d4); d5 = __builtin_fma(p2, v[s], d5);
+                        tps[s] = ps;
+                    }
+                    rb.put(0, d0); rb.put(1, d1); rb.put(2, d2); rb.put(3, d3); rb.put(4, d4); rb.put(5, d5);
+                    const double sj = rb.gather();
+                    const bool turn = red_any_nonpositive(sj, 0, 6);
+                    const double wsum = aw + tw;
+                    const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < tw);
+                    if (!take_b) { qsrc = 1; tpe = ape; tplogp = aplogp; }
+                    tw = wsum; ta = aa + ta;
+                    if (turn) { turning = true; break; }
+                }
+                // ---- cascade levels 2..m: node a = stack[j]; the in-flight node's left end is stack[j-1]'s
+                for (int j = 2; j <= m; ++j) {
+                    double blp[NS], brp[NS], bps[NS], tl[NS];
+                    stack2_load3<NS>(stk, j, blp, brp, bps);
+                    stack2_load_lp<NS>(stk, j - 1, tl);
+                    double bw, ba, bpe, bplogp;
+                    level_scal_get(stk, j, bw, ba, bpe, bplogp);
+                    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0, d4 = 0.0, d5 = 0.0;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const double p1 = bps[s] + tl[s];
+                        const double p2 = brp[s] + tps[s];
+                        const double ps = bps[s] + tps[s];
+                        const double valp = var[s] * blp[s], vtlp = var[s] * tl[s], varp = var[s] * brp[s];
+                        d0 = __builtin_fma(ps, valp, d0); d1 = __builtin_fma(ps, v[s], d1);
+                        d2 = __builtin_fma(p1, valp, d2); d3 = __builtin_fma(p1, vtlp, d3);
+                        d4 = __builtin_fma(p2, varp, d4); d5 = __builtin_fma(p2, v[s], d5);
+                        tps[s] = ps;
+                    }
+                    rb.put(0, d0); rb.put(1, d1); rb.put(2, d2); rb.put(3, d3); rb.put(4, d4); rb.put(5, d5);
+                    const double sj = rb.gather();
+                    const bool turn = red_any_nonpositive(sj, 0, 6);
+                    const double wsum = bw + tw;
+                    const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < tw);
+                    if (!take_b) { qsrc = j; tpe = bpe; tplogp = bplogp; }
+                    tw = wsum; ta = ba + ta;
+                    if (turn) { turning = true; break; }
+                }
+                if (turning) break;
+                if (k + 1 < n_pairs) {   // park the node at level m + 1 (the last pair's cascade result stays in flight)
+                    double tl[NS], tqv[NS];
+                    if (m == 0) vcopy(tl, ep); else stack2_load_lp<NS>(stk, m, tl);
+                    if (qsrc == -1) vcopy(tqv, cq);
+                    else if (qsrc == -2) vcopy(tqv, eq);
+                    else stack2_load_q<NS>(stk, qsrc, tqv);
+                    stack2_store<NS>(stk, m + 1, tl, cp, tps, tqv);
+                    level_scal_put(stk, m + 1, tw, ta, tpe, tplogp);
+                }
+            }
+        }
+        ++depth;   // nuts.py:315
+        if (diverging || turning) { exhausted = false; break; }
+
+        // ---- accepted subtree: merge into the trajectory (nuts.py:321-340)
+        if (uniform_true(team_uniform(tm, rng, win) * (w_start + wn) < tw)) {   // biased progressive
+            double tqv[NS];
+            if (qsrc == -1) vcopy(tqv, cq);
+            else if (qsrc == -2) vcopy(tqv, eq);
+            else stack2_load_q<NS>(stk, qsrc, tqv);
+            vstore_as<NS>((glb_double*)qrow, tqv);
+            prop_e = tpe; prop_logp = tplogp;
+        }
+        wn = first_f64(wn + tw);
+        an = first_f64(an + ta);
+        double tlp[NS], psum[NS], op[NS], aold[NS];
+        if (D == 0) vcopy(tlp, cp);
+        else if (D == 1) vcopy(tlp, ep);
+        else stack2_load_lp<NS>(stk, D - 1, tlp);
+        cold_load<NS>(stk, kColdPsum, psum); cold_load<NS>(stk, kColdOp, op); cold_load<NS>(stk, kColdAold, aold);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {   // in place; float32 storage when the start momentum is float32
+            const double t = psum[s] + tps[s];
+            psum[s] = momentum_f32 ? static_cast<double>(static_cast<float>(t)) : t;
+        }
+        cold_store<NS>(stk, kColdPsum, psum);
+        double ov[NS], av[NS];   // velocities of the untouched end and of the extended end as it was before this doubling
+        end_velocity<NS>(ov, var, op, o_start);
+        end_velocity<NS>(av, var, aold, aold_start);
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0, d4 = 0.0, d5 = 0.0;
+        if (right) {   // L = other end, old R = aold, subtree left end = tlp (adjacent to old R), right end = cp
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double vtl = var[s] * tlp[s], vtr = var[s] * cp[s];
+                const double p1 = psum[s] + tlp[s], p2 = aold[s] + tps[s];
+                d0 = __builtin_fma(psum[s], ov[s], d0); d1 = __builtin_fma(psum[s], vtr, d1);
+                d2 = __builtin_fma(p1, ov[s], d2);      d3 = __builtin_fma(p1, vtl, d3);
+                d4 = __builtin_fma(p2, av[s], d4);      d5 = __builtin_fma(p2, vtr, d5);
+            }
+        } else {       // R = other end, old L = aold, subtree "left" end tlp is adjacent to old L, far end = cp
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double vtl = var[s] * tlp[s], vtr = var[s] * cp[s];
+                const double p1 = tps[s] + aold[s], p2 = tlp[s] + psum[s];
+                d0 = __builtin_fma(psum[s], vtr, d0);   d1 = __builtin_fma(psum[s], ov[s], d1);
+                d2 = __builtin_fma(p1, vtr, d2);        d3 = __builtin_fma(p1, av[s], d3);
+                d4 = __builtin_fma(p2, vtl, d4);        d5 = __builtin_fma(p2, ov[s], d5);
+            }
+        }
+        c_start = false;
+        rb.put(0, d0); rb.put(1, d1); rb.put(2, d2); rb.put(3, d3); rb.put(4, d4); rb.put(5, d5);
+        if (red_any_nonpositive(rb.gather(), 0, 6)) { turning = true; exhausted = false; break; }
+    }
+
+    const double mean_accept = (wn > 0.0) ? first_f64(an / wn) : 0.0;
+    out.accept = mean_accept;
+    out.energy = prop_e;
+    out.energy_error = first_f64(prop_e - e0);
+    out.max_energy_error = max_de;
+    out.model_logp = prop_logp;
+    out.depth = depth;
+    out.n_leapfrog = n_leap;
+    out.diverging = diverging;
+    out.exhausted = exhausted;
+    out.accepted = 0;
 }
 
 // ---- the iteration kernel: n_iters x _astep for every chain, no host round trips ------------------------
 // Occupancy target per vector width (waves per SIMD; the VGPR budget is 512 / waves): the per-chain state
 // is register resident, so wider per-thread slices trade occupancy for registers. Chains longer than
 // 128 elements are spread over W waves (dpad = 64 * NS * W) instead of growing NS further.
+#ifndef LMC_NUTS_ONE_WAVE_FORM
+#define LMC_NUTS_ONE_WAVE_FORM 0   // 1: W == 1 kernels use nuts_transition2 (pair form) and its LDS plan
+#endif
 #ifndef LMC_WAVES_NS1
 #define LMC_WAVES_NS1 4
 #endif
@@ -611,7 +1068,13 @@ constexpr int run_waves_per_simd(int ns) {
 }
 // LDS carve (doubles) behind the subtree stack: MT19937 state (624 words), team exchange area, RNG re-broadcast
 constexpr int kLdsMtDoubles = 320;
-constexpr int lds_tail_doubles(int w) { return w == 1 ? kLdsMtDoubles : kLdsMtDoubles + 2 * w * kTeamSlots + 4; }
+#ifndef LMC_MT_IN_LDS_W1
+#define LMC_MT_IN_LDS_W1 0   // pair-form kernels: 1 keeps the MT19937 state in LDS for the launch, 0 uses it in place (L2)
+#endif
+constexpr bool run_mt_in_lds(int w) { return w > 1 || !LMC_NUTS_ONE_WAVE_FORM || LMC_MT_IN_LDS_W1; }
+constexpr int lds_tail_doubles(int w) {
+    return w == 1 ? (run_mt_in_lds(1) ? kLdsMtDoubles : 0) : kLdsMtDoubles + 2 * w * kTeamSlots + 4;
+}
 
 // ---- pieces of the iteration body shared by the diagonal and the dense-mass kernels ---------------------------
 struct DualAverage {   // step_sizes.py:49-99, wave-uniform
@@ -787,9 +1250,14 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     RngState rng;
     uint32_t* mt_glb = A.mt + static_cast<long long>(c) * kMtN;
     uint32_t* mt_lds = reinterpret_cast<uint32_t*>(lds + P.lds_doubles);
-    for (int i = tid; i < kMtN; i += 64 * W) mt_lds[i] = mt_glb[i];
-    tm.sync();
-    rng.mt = mt_lds;
+    constexpr bool kMtInLds = run_mt_in_lds(W);
+    if constexpr (kMtInLds) {
+        for (int i = tid; i < kMtN; i += 64 * W) mt_lds[i] = mt_glb[i];
+        tm.sync();
+        rng.mt = mt_lds;
+    } else {
+        rng.mt = mt_glb;   // used in place (L2): the LDS it would take holds subtree-stack data instead
+    }
     rng.pos = first_i32(A.rng_pos[c]);
     rng.has_gauss = first_i32(A.rng_has_gauss[c]);
     rng.gauss = first_f64(A.rng_gauss[c]);
@@ -810,6 +1278,22 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     stk.glb = A.scratch + static_cast<long long>(c) * A.scratch_stride;
     stk.nlds = P.nlds;
     stk.dpad = dpad;
+    // pair form (nuts_transition2): reduction buffer, exp table, level scalars, cold slots, stack levels 1..nlds
+    TreeStack2 stk2;
+    stk2.exptab = lds + red_doubles(dpad);
+    stk2.scal = stk2.exptab + kExpTableDoubles;
+    stk2.cold = stk2.scal + kLevelScalDoubles;
+    stk2.levels = stk2.cold + P.ncold_lds * dpad;
+    stk2.glb_cold = stk.glb;
+    stk2.glb = stk.glb + kNumCold * dpad;
+    stk2.nlds = P.nlds;
+    stk2.ncold_lds = P.ncold_lds;
+    stk2.dpad = dpad;
+    RedBuf rb;
+    rb.init(lds);
+    if constexpr (W == 1 && LMC_NUTS_ONE_WAVE_FORM) {
+        if (tid < kExpTableDoubles) stk2.exptab[tid] = kExp2Table[tid];
+    }
 
     for (int it = 0; it < P.n_iters; ++it) {
         const long long git = P.iter_begin + it;
@@ -849,14 +1333,18 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         TransitionOut out;
         if (P.kind == 0) {
             const int md = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
-            nuts_transition<NS>(tm, tgt, vard, rng, stk, q, p0, g0, e0, logp0, step_size, P.emax, md,
-                                P.momentum_f32 != 0, out);
+            if constexpr (W == 1 && LMC_NUTS_ONE_WAVE_FORM) {
+                nuts_transition2<NS>(tm, tgt, vard, rng, stk2, rb, A.q + row, q, p0, g0, e0, logp0, step_size, P.emax, md,
+                                     P.momentum_f32 != 0, out);
+                vload<NS>(A.q + row, q);   // the proposal was written to the chain's row of A.q
+            } else
+                nuts_transition<NS>(tm, tgt, vard, rng, stk, q, p0, g0, e0, logp0, step_size, P.emax, md,
+                                    P.momentum_f32 != 0, out);
             if (out.exhausted && !tune) ++ct_maxdepth;
         } else {
             hmc_transition<NS>(tm, tgt, vard, rng, q, p0, g0, e0, logp0, step_size, P.emax, P.path_length,
                                P.max_steps, out);
         }
-        if (out.nan_logbern) status |= kStatusNanLogbern;
         ct_leap += out.n_leapfrog;
 
         // ---- dual averaging (step_sizes.py:71-92)
@@ -876,7 +1364,9 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
 
     // ---- store persistent chain state
     tm.sync();
-    for (int i = tid; i < kMtN; i += 64 * W) mt_glb[i] = mt_lds[i];
+    if constexpr (kMtInLds) {
+        for (int i = tid; i < kMtN; i += 64 * W) mt_glb[i] = mt_lds[i];
+    }
     vstore<NS>(A.q + row, q);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {

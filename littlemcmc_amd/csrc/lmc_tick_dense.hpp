@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void tick_dense_kerne
         if (P.kind == 0) {
             // ---- leaf (nuts.py:344-375) and the merges it closes (nuts.py:377-417)
             double de = first_f64(energy - e0);
-            if (isnan(de)) de = INFINITY;
+            if (isnan(de)) de = __builtin_inf();
             if (fabs(de) > fabs(max_de)) max_de = de;
             if (!(fabs(de) < P.emax)) {
                 diverging = true;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void tick_dense_kerne
             } else {
                 diverging = !isfinite(energy);
                 double de = first_f64(e0 - energy);
-                if (isnan(de)) de = -INFINITY;
+                if (isnan(de)) de = -__builtin_inf();
                 if (fabs(de) > P.emax) diverging = true;
                 const double accept = first_f64(fmin(1.0, exp_uniform(de)));
                 if (!diverging) {
@@ -306,7 +306,6 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void tick_dense_kerne
         out.n_leapfrog = n_leap;
         out.diverging = diverging;
         out.exhausted = exhausted;
-        out.nan_logbern = 0;
         long long ct_maxdepth = (P.kind == 0 && exhausted && !tune) ? 1 : 0;
         const bool adapt_step = tune && P.adapt_step_size;
         if (adapt_step) dual_average_update(A, P, out.accept, da);

@@ -29,6 +29,15 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def _reduce_device(group):
+    """Where the diagnostics all-reduce runs: on the GPUs for RCCL ("nccl"), on the host for gloo."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and str(dist.get_backend(group)) == "gloo":
+        return "cpu"
+    return None
+
+
 def sample_distributed(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, chains=None, random_seed=None,
                        start=None, group=None, diagnostics=True, **kwargs):   # diagnostics: True | False | "moments"
     """``sample()`` for a job of ``chains`` chains spread over the ranks of the current process group.
@@ -85,7 +94,7 @@ def sample_distributed(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, 
 
             mean = m2 = torch.zeros((0, int(model_ndim)), dtype=torch.float64)
             n = torch.zeros((0,), dtype=torch.int32)
-        rhat = dg.rhat_from_moments(mean, m2, n, group=group)
+        rhat = dg.rhat_from_moments(mean, m2, n, group=group, reduce_device=_reduce_device(group))
         diag = {"rhat": rhat.cpu().numpy(), "n_chains": float(chains)}
     elif diagnostics:
         from . import diagnostics as dg
@@ -96,7 +105,7 @@ def sample_distributed(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, 
             import torch
 
             x = torch.zeros((0, draws, int(model_ndim)), dtype=torch.float64)
-        diag = dg.summarize(x, group=group)
+        diag = dg.summarize(x, group=group, reduce_device=_reduce_device(group))
         diag = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in diag.items()}
     if eng is not None:
         eng.close()

@@ -66,6 +66,8 @@ class Engine:
         self._h = h
         params = np.ascontiguousarray(target.params, dtype=np.float64)
         self._check(self._lib.lmc_engine_set_target_params(self._h, _abi.ptr(params), params.size))
+        if hasattr(target, "_attach"):   # a run-time compiled density hands its kernels to the engine (targets.UserTarget)
+            target._attach(self)
         self.capacity = 0
         self.keep_trace = False
         self.trace_begin = 0
@@ -205,7 +207,8 @@ class Engine:
                     else:
                         logp, grad = self.target.evaluate(q)
                     ticks += 1
-                    active = self.tick(logp.data_ptr(), grad.data_ptr(), wait=(ticks % poll == 0))
+                    active = self.tick(logp.data_ptr(), grad.data_ptr(),
+                                       wait=(ticks % getattr(self.target, "tick_poll", poll) == 0))
                     self._tick_keep = (logp, grad)   # alive until the next evaluation is enqueued behind the tick
                     if active == 0:
                         break

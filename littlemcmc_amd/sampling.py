@@ -41,7 +41,7 @@ def init_nuts(logp_dlogp_func, model_ndim=None, init="auto", random_seed=None, s
     "adapt_full", "jitter+adapt_full" (dense modes: model_ndim <= 256)."""
     if model_ndim is None:
         model_ndim = size if size is not None else getattr(logp_dlogp_func, "d", None)
-    require_device_target(logp_dlogp_func, model_ndim)
+    logp_dlogp_func = require_device_target(logp_dlogp_func, model_ndim)
     if not isinstance(init, str):
         raise TypeError("init must be a string.")
     init = init.lower()
@@ -122,7 +122,9 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
         eng.reset_tuning()                    # step.reset_tuning(); iter_count = 0 (sampling.py:503-509)
         lo = int(tune) if discard_tuned_samples else 0   # sampling.py:473-476
         eng.reserve(max(n_total, 1), keep_trace=True, trace_begin=min(lo, max(n_total - 1, 0)))
-        per_launch = int(launch_iters) if launch_iters else max(1, min(n_total, 250))
+        # one launch for the whole job unless asked otherwise: every launch ends with a tail in which the chains with
+        # the longest trees run alone (ragged targets: DESIGN.md section 6), so fewer, longer launches are faster
+        per_launch = int(launch_iters) if launch_iters else max(1, min(n_total, 4000))
         if target.family == _abi.TARGET_EXTERNAL and not launch_iters:
             per_launch = max(n_total, 1)   # ticks: chains never wait for each other inside one request
         it = 0

@@ -7,9 +7,10 @@ The objects here name such a functor plus its parameters; they are ALSO callable
 reference's signature -- the call evaluates the device functor on the GPU for one point -- so
 they can be passed wherever the reference expects ``logp_dlogp_func``.
 
-A plain Python callable cannot run inside a HIP kernel; passing one raises ``TypeError`` (there is
-no CPU fallback). Arbitrary densities are supported through :class:`UserTarget`, which compiles a
-user-supplied HIP snippet into a private build of the library.
+Arbitrary densities are supported three ways: :class:`UserTarget` compiles a user-supplied HIP snippet into the
+kernels (the fast path), :class:`TorchTarget` takes a batched torch callable on the GPU, and a plain per-point
+Python callable -- the reference's own plug-in signature -- is wrapped in :class:`CallableTarget`: the sampler still
+runs in the HIP tick kernel, the user's function is evaluated on the host between ticks (compatibility path).
 """
 import hashlib
 import os
@@ -105,7 +106,7 @@ class Normal1D(DeviceTarget):
 
 
 class UserTarget(DeviceTarget):
-    """A user-written device log-density, compiled with hipcc and linked into the kernels.
+    """A user-written device log-density, compiled at run time and linked into the kernels.
 
     ``source`` must define, in namespace ``lmc``::
 
@@ -115,22 +116,94 @@ class UserTarget(DeviceTarget):
             template <class Team> __device__ double logp_grad(Team& tm, const double (&q)[NS], double (&g)[NS]) const;
         };
 
-    following the thread-distributed contract documented in csrc/lmc_targets.hpp. The library is
-    rebuilt once per distinct source (cached by content hash next to the package).
-    """
+    following the thread-distributed contract documented in csrc/lmc_targets.hpp.
+
+    ``jit="hiprtc"`` (default): when an engine is created, the three kernels that depend on the functor -- the
+    transition kernel of the engine's shape, the trajectory and the log-density unit kernels -- are compiled in
+    process with hiprtc (about 2 s, cached by content under ``_user_targets/``) and handed to the stock library
+    (``lmc_engine_load_user_kernels``); no compiler is needed on the machine. Diagonal mass matrices.
+    ``jit="hipcc"``: a private build of the whole library around the functor (about 10 s, needs hipcc); this is the
+    path for dense mass matrices with a user density."""
 
     family = _abi.TARGET_USER
 
-    def __init__(self, d, source, params=()):
+    def __init__(self, d, source, params=(), jit="hiprtc"):
         super().__init__(d, params)
         self.source = source
+        if jit not in ("hiprtc", "hipcc"):
+            raise ValueError("jit must be 'hiprtc' or 'hipcc'")
+        self.jit = jit
+        self._code = {}   # (unit_ns, run_ns, run_w) -> (code object bytes, lowered names)
+        if jit == "hipcc":
+            self.lib_path = self._build_private_library()
+
+    # ---- hiprtc: the target-dependent kernels only ---------------------------------------------------------
+    def _digest(self, extra=""):
         # the cache key covers everything the binary depends on: the snippet, the kernel sources and the compiler flags
-        h = hashlib.sha256(source.encode())
+        h = hashlib.sha256(self.source.encode())
         for path in _build.sources():
             with open(path, "rb") as fh:
                 h.update(fh.read())
         h.update(" ".join(_build.HIPCC_FLAGS).encode())
-        digest = h.hexdigest()[:16]
+        h.update(extra.encode())
+        return h.hexdigest()[:16]
+
+    def kernels_for(self, unit_ns, run_ns, run_w):
+        """(code object, run name, trajectory name, logp name) for one engine shape, compiled once and cached."""
+        key = (int(unit_ns), int(run_ns), int(run_w))
+        if key in self._code:
+            return self._code[key]
+        names = ["lmc::run_kernel<%d, %d, lmc::UserTarget>" % (key[1], key[2]),
+                 "lmc::trajectory_kernel<%d, lmc::UserTarget>" % key[0],
+                 "lmc::logp_kernel<%d, lmc::UserTarget>" % key[0]]
+        tu = ('#include "lmc_sampler.hpp"\n#include "lmc_unit_kernels.hpp"\n' + self.source +
+              "\nnamespace lmc {\n"
+              "template __global__ void run_kernel<%d, %d, UserTarget>(ChainArrays, SamplerParams, const double*);\n"
+              "template __global__ void trajectory_kernel<%d, UserTarget>(ChainArrays, const double*, const double*, const double*, "
+              "int, int, double, int, int, double*, double*, double*, double*, double*, double*);\n"
+              "template __global__ void logp_kernel<%d, UserTarget>(ChainArrays, const double*, const double*, double*, double*);\n"
+              "}\n" % (key[1], key[2], key[0], key[0]))
+        cache = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_user_targets")
+        os.makedirs(cache, exist_ok=True)
+        path = os.path.join(cache, "user_%s_%d_%d_%d.hsaco" % (self._digest("hiprtc"), key[0], key[1], key[2]))
+        lowered = None
+        if os.path.exists(path) and os.path.exists(path + ".names"):
+            with open(path, "rb") as fh:
+                code = fh.read()
+            with open(path + ".names") as fh:
+                lowered = fh.read().split("\n")[:3]
+        else:
+            code, lowered = _hiprtc_compile(tu, names)
+            tmp = "%s.%d.tmp" % (path, os.getpid())     # several ranks may compile the same target at once
+            with open(tmp, "wb") as fh:
+                fh.write(code)
+            os.replace(tmp, path)
+            with open(tmp, "w") as fh:
+                fh.write("\n".join(lowered))
+            os.replace(tmp, path + ".names")
+        self._code[key] = (code, lowered[0], lowered[1], lowered[2])
+        return self._code[key]
+
+    def _attach(self, engine):
+        """Called by Engine after lmc_engine_create: compile (or fetch) the kernels of the engine's shape and load them."""
+        if self.jit != "hiprtc":
+            return
+        import ctypes as C
+
+        ns, rns, rw = C.c_int32(), C.c_int32(), C.c_int32()
+        engine._check(engine._lib.lmc_engine_kernel_shape(engine._h, C.byref(ns), C.byref(rns), C.byref(rw)))
+        code, run, traj, logp = self.kernels_for(ns.value, rns.value, rw.value)
+        buf = C.create_string_buffer(code, len(code))
+        engine._check(engine._lib.lmc_engine_load_user_kernels(engine._h, buf, run.encode(), traj.encode(), logp.encode()))
+
+    def __getstate__(self):
+        st = super().__getstate__()
+        st["_code"] = {}
+        return st
+
+    # ---- hipcc: private build of the library ------------------------------------------------------------------
+    def _build_private_library(self):
+        digest = self._digest("hipcc")
         cache = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_user_targets")
         os.makedirs(cache, exist_ok=True)
         header = os.path.join(cache, "user_%s.hpp" % digest)
@@ -141,7 +214,7 @@ class UserTarget(DeviceTarget):
             tmp_header = os.path.join(cache, "user_%s.tmp.hpp" % tmp_tag)
             tmp_lib = os.path.join(cache, "liblmc_hip_user_%s.tmp.so" % tmp_tag)
             with open(tmp_header, "w") as fh:
-                fh.write(source)
+                fh.write(self.source)
             try:
                 _build.build(out=tmp_lib, extra_flags=["-DLMC_USER_TARGET_HEADER=\"%s\"" % tmp_header, "-DLMC_ONLY_USER"],
                              force=True)
@@ -151,7 +224,50 @@ class UserTarget(DeviceTarget):
                 for f in (tmp_lib, tmp_header):
                     if os.path.exists(f):
                         os.remove(f)
-        self.lib_path = lib
+        return lib
+
+
+def _hiprtc_compile(source, name_expressions):
+    """Compile a translation unit for gfx950 with hiprtc -> (code object bytes, lowered kernel names)."""
+    import ctypes as C
+
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    try:
+        rtc = C.CDLL(os.path.join(rocm, "lib", "libhiprtc.so"))
+    except OSError as err:
+        raise _abi.HipLibraryError("cannot load libhiprtc.so (%s): UserTarget(jit='hiprtc') needs the ROCm runtime compiler; "
+                                   "use jit='hipcc' where hipcc is installed" % err)
+    rtc.hiprtcGetErrorString.restype = C.c_char_p
+    prog = C.c_void_p()
+
+    def check(rc, what):
+        if rc != 0:
+            n = C.c_size_t()
+            rtc.hiprtcGetProgramLogSize(prog, C.byref(n))
+            log = C.create_string_buffer(n.value + 1)
+            rtc.hiprtcGetProgramLog(prog, log)
+            raise RuntimeError("hiprtc %s failed (%s):\n%s" % (what, rtc.hiprtcGetErrorString(rc).decode(), log.value.decode()[-4000:]))
+
+    check(rtc.hiprtcCreateProgram(C.byref(prog), source.encode(), b"lmc_user_target.hip", 0, None, None), "create")
+    try:
+        for n in name_expressions:
+            check(rtc.hiprtcAddNameExpression(prog, n.encode()), "name expression")
+        flags = [f for f in _build.HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
+        opts = [f.encode() for f in flags] + [("-I" + _build.CSRC).encode(), ("-I" + os.path.join(rocm, "include")).encode()]
+        arr = (C.c_char_p * len(opts))(*opts)
+        check(rtc.hiprtcCompileProgram(prog, len(opts), arr), "compile")
+        size = C.c_size_t()
+        check(rtc.hiprtcGetCodeSize(prog, C.byref(size)), "code size")
+        code = C.create_string_buffer(size.value)
+        check(rtc.hiprtcGetCode(prog, code), "code")
+        lowered = []
+        for n in name_expressions:
+            p = C.c_char_p()
+            check(rtc.hiprtcGetLoweredName(prog, n.encode(), C.byref(p)), "lowered name")
+            lowered.append(p.value.decode())
+        return code.raw, lowered
+    finally:
+        rtc.hiprtcDestroyProgram(C.byref(prog))
 
 
 class TorchTarget(DeviceTarget):
@@ -198,6 +314,15 @@ class TorchTarget(DeviceTarget):
 
         return cls(d, fn, graph=graph)
 
+    @classmethod
+    def from_pointwise(cls, d, fn, graph=False):
+        """``fn(q: tensor[d]) -> (logp: scalar tensor, dlogp: tensor[d])`` written in torch ops for ONE point -- the
+        reference's plug-in signature (integration.py:40,62,115) -- batched over the chains with ``torch.vmap``."""
+        import torch
+
+        batched = torch.vmap(fn)
+        return cls(d, lambda q: batched(q), graph=graph)
+
     def evaluate(self, q):
         """fn on a [chains, d] tensor, results checked and made contiguous float64."""
         import torch
@@ -221,6 +346,47 @@ class TorchTarget(DeviceTarget):
 
     def __getstate__(self):
         return dict(self.__dict__)
+
+
+class CallableTarget(TorchTarget):
+    """The reference's own plug-in, unchanged: a per-point Python callable ``fn(q: ndarray[d]) -> (logp, dlogp[d])``
+    (integration.py:40,62,115; e.g. tests/test_utils.py:19-28 or docs/_static/scripts/
+    sample_pytorch_logp_dlogp_func.py:35-45 with CPU tensors).
+
+    The sampler itself -- leapfrog, trees, adaptation, RNG -- still runs in the HIP tick kernel (csrc/lmc_tick.hpp);
+    only the user's density is evaluated where the user's code lives: every tick the points of all chains are copied
+    to the host, ``fn`` is called once per chain, and the values go back for the next tick. This is the compatibility
+    path (C1-sized jobs: a handful of chains); a :class:`UserTarget` or a batched :class:`TorchTarget` is what the
+    many-chain configurations need. ``sample()`` / ``NUTS`` / ``HamiltonianMC`` wrap a plain callable in it."""
+
+    tick_poll = 1   # look at the number of unfinished chains after every tick: no wasted host evaluations
+
+    def __init__(self, d, fn):
+        if not callable(fn):
+            raise TypeError("fn must be callable: q[d] -> (logp, dlogp[d])")
+        self.pointwise = fn
+        super().__init__(d, self._batched, graph=False)
+
+    @staticmethod
+    def _host(x):
+        if hasattr(x, "detach"):   # a torch tensor (CPU or device)
+            x = x.detach().cpu().numpy()
+        return np.asarray(x, dtype=np.float64)
+
+    def _batched(self, q):
+        import torch
+
+        host = q.detach().cpu().numpy()
+        logp = np.empty(host.shape[0])
+        grad = np.empty_like(host)
+        for c in range(host.shape[0]):
+            lp, dlp = self.pointwise(host[c].copy())
+            logp[c] = self._host(lp).reshape(-1)[0]          # scalar or shape-(1,) array (tests/test_utils.py:27-28)
+            grad[c] = self._host(dlp).reshape(self.d)
+        return torch.from_numpy(logp).to(q.device), torch.from_numpy(grad).to(q.device)
+
+    def __call__(self, q):   # the callable itself, as the reference would call it
+        return self.pointwise(np.asarray(q, dtype=np.float64))
 
 
 _SEPARABLE_TEMPLATE = r"""
@@ -274,12 +440,17 @@ UserTarget.separable = classmethod(_separable)
 
 
 def require_device_target(logp_dlogp_func, model_ndim=None):
-    """The product path runs the density inside HIP kernels: reject anything else, loudly."""
+    """What the step methods and ``sample()`` accept as ``logp_dlogp_func``: a device functor (inlined into the
+    leapfrog kernel), a batched torch callable (TorchTarget) or -- the reference's own signature -- a plain per-point
+    Python callable, which is wrapped in a :class:`CallableTarget` (sampler on the GPU, density evaluated by the
+    caller's code between ticks). Anything else is rejected, loudly."""
     if not isinstance(logp_dlogp_func, DeviceTarget):
+        if callable(logp_dlogp_func) and model_ndim is not None:
+            return CallableTarget(int(model_ndim), logp_dlogp_func)
         raise TypeError(
-            "littlemcmc_amd runs logp_dlogp_func inside the GPU leapfrog kernel: pass a "
-            "littlemcmc_amd.targets.DeviceTarget (StdNormal, DiagGaussian, AR1, Funnel, Normal1D or a "
-            "UserTarget built from a HIP snippet), not %r. There is no CPU fallback." % (logp_dlogp_func,))
+            "logp_dlogp_func must be a littlemcmc_amd.targets.DeviceTarget (StdNormal, DiagGaussian, AR1, Funnel, "
+            "Normal1D, UserTarget, TorchTarget) or a callable q[d] -> (logp, dlogp[d]) together with model_ndim; got %r"
+            % (logp_dlogp_func,))
     if model_ndim is not None and int(model_ndim) != logp_dlogp_func.d:
         raise ValueError("model_ndim=%s does not match the target's dimension %d" % (model_ndim, logp_dlogp_func.d))
     return logp_dlogp_func

@@ -37,7 +37,7 @@ def test_header_constants_match_binding():
                  "TARGET_AR1", "TARGET_FUNNEL", "TARGET_NORMAL1D", "TARGET_USER", "STAT_STEP_SIZE", "STAT_ACCEPT",
                  "STAT_MODEL_LOGP", "STAT_DEPTH", "STAT_TREE_SIZE", "STAT_DIVERGING", "STAT_TUNE", "STAT_ACCEPTED",
                  "CT_LEAPFROGS", "NUM_COUNTERS", "SDOT_NATIVE", "SDOT_OPENBLAS_SKYLAKEX", "SDOT_OPENBLAS_HASWELL",
-                 "STATUS_BAD_INITIAL_ENERGY", "STATUS_NAN_LOGBERN"):
+                 "STATUS_BAD_INITIAL_ENERGY"):
         assert int(consts["LMC_" + name]) == getattr(_abi, name), name
 
 
@@ -54,9 +54,29 @@ def test_config_struct_layout_and_defaults():
     assert [f for f, _ in _abi.Config._fields_] == fields[: len(_abi.Config._fields_)]
 
 
-def test_built_in_targets_present_user_absent():
+def test_built_in_targets_and_the_run_time_user_family():
     lib = _abi.load()
-    assert [lib.lmc_has_target(i) for i in range(6)] == [1, 1, 1, 1, 1, 0]
+    # 0..4 compiled in; 5 = LMC_TARGET_USER: its kernels are loaded at run time (lmc_engine_load_user_kernels);
+    # 6 = LMC_TARGET_EXTERNAL (ticks); nothing beyond
+    assert [lib.lmc_has_target(i) for i in range(8)] == [1, 1, 1, 1, 1, 1, 1, 0]
+
+
+def test_user_target_compiles_with_hiprtc_without_a_gpu():
+    """The run-time compiler needs no device: the three functor-dependent kernels of an engine shape come out of
+    hiprtc as a gfx950 code object with the lowered names the engine looks up; the result is cached by content."""
+    from littlemcmc_amd.targets import UserTarget
+
+    t = UserTarget.separable(70, logp="-0.5*q*q", grad="-q")
+    assert t.jit == "hiprtc" and t.lib_path is None
+    code, run, traj, logp = t.kernels_for(2, 2, 1)
+    assert code[:4] == b"\x7fELF" and len(code) > 10000
+    assert "run_kernel" in run and "UserTarget" in run and "trajectory_kernel" in traj and "logp_kernel" in logp
+    assert t.kernels_for(2, 2, 1)[0] is code                      # in-memory cache
+    assert UserTarget.separable(70, logp="-0.5*q*q", grad="-q").kernels_for(2, 2, 1)[0] == code   # disk cache
+    with pytest.raises(RuntimeError, match="hiprtc compile failed"):
+        UserTarget(3, "namespace lmc { this is not C++ }").kernels_for(1, 1, 1)
+    with pytest.raises(ValueError):
+        UserTarget(3, "", jit="nvcc")
 
 
 def test_no_cpu_fallback_without_device():
@@ -70,14 +90,30 @@ def test_no_cpu_fallback_without_device():
         lmc.sample(T.StdNormal(4), 4, draws=3, tune=3, chains=2, random_seed=1)
 
 
-def test_plain_python_callable_is_rejected():
+def test_plain_python_callable_is_wrapped_not_evaluated_on_a_cpu_sampler():
+    """The reference's plug-in signature (integration.py:40,62,115) is accepted: a per-point callable becomes a
+    CallableTarget (sampler in the HIP tick kernel, density evaluated by the caller's code). Non-callables and
+    dimension mismatches are rejected; without a GPU the engine still fails loudly -- there is no CPU sampler."""
+    from littlemcmc_amd.targets import CallableTarget, require_device_target
+
     f = lambda q: (-0.5 * np.dot(q, q), -q)   # noqa: E731
+    t = require_device_target(f, 3)
+    assert isinstance(t, CallableTarget) and t.family == lmc._abi.TARGET_EXTERNAL and t.d == 3 and t.tick_poll == 1
+    lp, g = t(np.array([1.0, 2.0, 3.0]))
+    assert lp == -7.0 and np.array_equal(g, [-1.0, -2.0, -3.0])
+    step = lmc.NUTS(f, 3)
+    assert isinstance(step._logp_dlogp_func, CallableTarget)
     with pytest.raises(TypeError, match="DeviceTarget"):
-        lmc.NUTS(f, 3)
+        lmc.NUTS("not callable", 3)
     with pytest.raises(TypeError, match="DeviceTarget"):
-        lmc.sample(f, 3)
+        require_device_target(f)                      # a bare callable needs model_ndim
     with pytest.raises(ValueError, match="model_ndim"):
         lmc.NUTS(T.StdNormal(4), 5)
+    import torch
+
+    if not torch.cuda.is_available():
+        with pytest.raises(_abi.HipLibraryError):
+            lmc.sample(f, 3, draws=2, tune=2, chains=2, random_seed=1)
 
 
 def test_reference_argument_errors():

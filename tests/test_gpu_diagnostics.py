@@ -140,3 +140,63 @@ def test_sample_distributed_with_moment_diagnostics():
     want, _ = odg.rhat_ess(tr, do_split=False)
     np.testing.assert_allclose(diag["rhat"], want, rtol=1e-9)
     assert diag["n_chains"] == 12.0
+
+
+TWO_RANK_WORKER = """
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+import littlemcmc_amd as lmc
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank = dist.get_rank()
+d, chains = 16, 11                                   # 11 chains over 2 ranks: blocks of 6 and 5
+tgt = lmc.targets.AR1(d, 0.9)
+tr, st, diag = lmc.distributed.sample_distributed(tgt, d, draws=60, tune=80, chains=chains, random_seed=20260928, device=0)
+tr2, st2, diag2 = lmc.distributed.sample_distributed(tgt, d, draws=60, tune=80, chains=chains, random_seed=20260928,
+                                                     device=0, diagnostics="moments", discard_tuned_samples=False)
+np.savez({out!r} + "/rank%d.npz" % rank, trace=tr, tree_size=st["tree_size"], depth=st["depth"], rhat=diag["rhat"],
+         ess=diag["ess"], n_chains=diag["n_chains"], rhat_m=diag2["rhat"], trace_all=tr2)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_ranks_on_one_gpu_equal_the_single_process_run(tmp_path):
+    """The multi-GPU path end to end with 2 ranks (gloo) sharing this GPU: sample_distributed's chain blocks,
+    concatenated, ARE the single-process run -- draws and statistics bit for bit -- and the all-reduced R-hat / ESS
+    equal the single-process diagnostics of all chains."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(TWO_RANK_WORKER.format(root=root, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+    parts = [np.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(2)]
+    d, chains = 16, 11
+    tgt = lmc.targets.AR1(d, 0.9)
+    seeds = lmc.distributed.global_seeds(20260928, chains)
+    start, step = lmc.init_nuts(tgt, d, random_seed=seeds)
+    trace, stats, eng = lmc.sample(tgt, d, draws=60, tune=80, chains=chains, random_seed=seeds, start=start, step=step,
+                                   return_engine=True)
+    try:
+        assert [p["trace"].shape[0] for p in parts] == [6, 5]
+        np.testing.assert_array_equal(np.concatenate([p["trace"] for p in parts]), trace)
+        np.testing.assert_array_equal(np.concatenate([p["tree_size"] for p in parts]), stats["tree_size"])
+        np.testing.assert_array_equal(np.concatenate([p["depth"] for p in parts]), stats["depth"])
+        want = dg.summarize(dg.trace_tensor(eng))
+        for p in parts:          # every rank holds the diagnostics of ALL chains
+            assert float(p["n_chains"]) == 2.0 * chains
+            np.testing.assert_allclose(p["rhat"], want["rhat"].cpu().numpy(), rtol=1e-12)
+            np.testing.assert_allclose(p["ess"], want["ess"].cpu().numpy(), rtol=1e-10)
+        rhat_m, _ = odg.rhat_ess(trace, do_split=False)
+        np.testing.assert_allclose(parts[0]["rhat_m"], rhat_m, rtol=1e-9)
+        assert parts[0]["trace_all"].shape == (6, 140, d)          # sample()'s own keywords reach sample()
+    finally:
+        eng.close()

@@ -152,6 +152,80 @@ def test_astep_protocol_matches_oracle():
     assert st[0]["tune"] is np.False_ or not st[0]["tune"]
 
 
+# ---- the reference's own plug-in signature: a plain per-point Python callable ----------------------------------
+def test_plain_python_callable_reproduces_the_reference_chain(golden_dir):
+    """tests/test_utils.py:19-28's function, passed to sample() as it is (numpy, per point, logp of shape (1,)):
+    wrapped in a CallableTarget, sampled by the HIP tick kernel with the density evaluated by the caller's code --
+    and the chain is the reference's (golden e2e_nuts_normal1d, captured from the reference with this density)."""
+    import os
+
+    from oracle import lmc_oracle as orc
+    from oracle import targets as OT
+    from tests._gpu_util import assert_chain_matches
+
+    import scipy.stats
+
+    # tests/test_utils.py:19-28's density as the golden capture states it (oracle/targets.py: Normal1D, a plain numpy
+    # per-point callable -- analytic log-density, so that far tuning excursions do not underflow norm.pdf to -inf)
+    plain = OT.make("normal1d", 1)
+    assert not isinstance(plain, lmc.targets.DeviceTarget)
+
+    def scipy_plain(x, loc=0, scale=1):   # the reference's literal spelling: log(norm.pdf(x)) of shape (1,), -(x-loc)/scale
+        return np.log(scipy.stats.norm.pdf(x, loc=loc, scale=scale)), -(x - loc) / scale
+
+    g = np.load(os.path.join(golden_dir, "e2e_nuts_normal1d.npz"))
+    chains, tune, draws = int(g["chains"]), int(g["tune"]), int(g["draws"])
+    calls = []
+
+    def counted(x):
+        calls.append(1)
+        return plain(x)
+
+    trace, stats = lmc.sample(counted, 1, draws=draws, tune=tune, chains=chains, cores=1, progressbar=False,
+                              random_seed=int(g["random_seed"]), discard_tuned_samples=False)
+    assert trace.shape == g["trace"].shape and len(calls) > chains * (tune + draws)
+    _t, _s, margins = orc.sample(OT.make("normal1d", 1), 1, draws=draws, tune=tune, chains=chains,
+                                 random_seed=int(g["random_seed"]), discard_tuned_samples=False, record_margins=True)
+    verified = 0
+    for c in range(chains):
+        got = {n_: stats[n_][c, :, 0] for n_ in stats}
+        want = {n_: g["stat_" + n_][c, :, 0] for n_ in stats}
+        verified += assert_chain_matches(trace[c], got, g["trace"][c], want, margins[c, :, 0], label="callable chain %d" % c)
+    assert verified >= chains * 15
+    # the step-method protocol with a plain callable, and a callable returning CPU torch tensors
+    import torch
+
+    step = lmc.NUTS(scipy_plain, 1)
+    assert isinstance(step._logp_dlogp_func, lmc.targets.CallableTarget)
+    np.random.seed(4)
+    q, st = step._astep(np.array([0.3]))
+    assert np.isfinite(q).all() and st[0]["tree_size"] >= 1
+
+    def torch_fn(x):
+        t = torch.tensor(x, requires_grad=True)
+        lp = -0.5 * (t * t).sum()
+        lp.backward()
+        return lp, t.grad
+
+    tr, _st = lmc.sample(torch_fn, 3, draws=30, tune=30, chains=2, random_seed=2, progressbar=False)
+    assert tr.shape == (2, 30, 3) and np.isfinite(tr).all()
+    with pytest.raises(TypeError):
+        lmc.sample("not a callable", 2, draws=2, tune=2)
+
+
+def test_pointwise_torch_callable_is_batched_with_vmap():
+    import torch
+
+    d = 7
+    tgt = lmc.targets.TorchTarget.from_pointwise(d, lambda q: (-0.5 * (q * q).sum(), -q))
+    kw = dict(draws=40, tune=60, chains=64, random_seed=5, progressbar=False, discard_tuned_samples=False)
+    tr, st = lmc.sample(tgt, d, **kw)
+    tr2, st2 = lmc.sample(lmc.targets.StdNormal(d), d, **kw)        # the fused device functor of the same density
+    np.testing.assert_array_equal(st["tree_size"][:, :10], st2["tree_size"][:, :10])
+    npt.assert_allclose(tr[:, :5], tr2[:, :5], rtol=1e-9, atol=1e-12)
+    assert abs(tr[:, 60:].var() - 1.0) < 0.15
+
+
 def test_astep_after_a_32_bit_legacy_draw():
     """np.random.randint leaves the MT19937 position odd; the device stream must stay word-exact with numpy's
     (rk_double twists between its two words), through uniforms, normals and a whole NUTS iteration."""

@@ -186,13 +186,54 @@ def _pooled_moments(mean, m2, n):
     return grand, ss / (tot - 1.0)
 
 
-def test_c3_full_size_65536_chains_dim128_ar1():
+def _many_chain_moments(tgt, d, chains, tune, draws):
+    """Pooled moments of a many-chain NUTS run from the kernel's running per-chain moments (no trace in HBM)."""
+    seeds = lmc.distributed.global_seeds(20260928, chains)
+    start, step = lmc.init_nuts(tgt, d, random_seed=seeds)
+    eng = step._make_engine(chains)
+    try:
+        eng.seed(seeds)
+        eng.set_position(start)
+        eng.reset_tuning()
+        eng.keep_moments(True)
+        eng.reserve(tune + draws, keep_trace=False)
+        eng.run(tune, 0, tune + draws)
+        eng.synchronize()
+        assert not eng.status().any()
+        mean, m2, n = eng.moments()
+        return _pooled_moments(np.asarray(mean), np.asarray(m2), n)
+    finally:
+        eng.close()
+
+
+def test_stationary_moments_are_the_references_not_the_targets(golden_dir):
+    """north_star: "posterior moments within 1e-3 of the CPU reference". The reference's NUTS does not leave a
+    correlated Gaussian exactly invariant (``_Tree.extend`` aliases p_sum): on AR(1) rho = 0.9 at
+    d = 32 its pooled marginal variance is 1.0195 +- 0.0007 (tests/golden/stationary_moments.npz, 3.6e6 draws of the
+    imported reference), not 1. The device reproduces THAT number -- the same algorithm, quirk included -- which a
+    sampler that merely targets N(0, Sigma) correctly would not."""
+    import os
+
+    g = np.load(os.path.join(golden_dir, "stationary_moments.npz"))
+    gmean, gvar = _many_chain_moments(T.AR1(32, 0.9), 32, 65536, 400, 600)
+    ref, se = float(g["ar1_32_var_avg"]), float(g["ar1_32_var_avg_se"])
+    assert abs(gvar.mean() - ref) < 1e-3 + 3 * se, (gvar.mean(), ref, se)
+    assert gvar.mean() - 1.0 > 0.015                       # far outside the Monte-Carlo error of an unbiased sampler
+    assert np.abs(gmean).max() < 1e-3 + 3 * float(np.abs(g["ar1_32_mean"]).max())
+
+
+def test_c3_full_size_65536_chains_dim128_ar1(golden_dir):
     """configs[2] at its one-GPU size, through the kernel the benchmark times (run_kernel<2, 1, AR1Target>):
-    65 536 chains x d = 128 AR(1) rho = 0.9, NUTS defaults, diagonal mass adaptation. Pooled posterior mean and
-    marginal variance within 1e-3 (north_star) of the truth (0 and 1 -- what the CPU reference converges to),
+    65 536 chains x d = 128 AR(1) rho = 0.9, NUTS defaults, diagonal mass adaptation. Pooled posterior mean within
+    1e-3 of 0 and dimension-averaged marginal variance within 1e-3 (north_star; plus the golden value's own Monte-Carlo
+    error) of the CPU reference's stationary value -- which is 1.003, not 1 (tests/golden/capture_moments.py) --,
     cross-chain R-hat < 1.01, no divergences, trees as deep as the reference's (mean depth 6.3)."""
+    import os
+
     from littlemcmc_amd import diagnostics as dg
 
+    g = np.load(os.path.join(golden_dir, "stationary_moments.npz"))
+    ref_var, ref_se = float(g["ar1_128_var_avg"]), float(g["ar1_128_var_avg_se"])
     d, chains, tune, draws = 128, 65536, 400, 1000
     tgt = T.AR1(d, 0.9)
     seeds = lmc.distributed.global_seeds(20260928, chains)
@@ -211,7 +252,8 @@ def test_c3_full_size_65536_chains_dim128_ar1():
         assert (np.asarray(n) == draws).all()
         gmean, gvar = _pooled_moments(np.asarray(mean), np.asarray(m2), n)
         assert np.abs(gmean).max() < 1e-3, np.abs(gmean).max()
-        assert np.abs(gvar - 1.0).max() < 1e-3, np.abs(gvar - 1.0).max()
+        assert abs(gvar.mean() - ref_var) < 1e-3 + 3 * ref_se, (gvar.mean(), ref_var, ref_se)
+        assert np.abs(gvar - gvar.mean()).max() < 1.5e-3          # every dimension sits at that level (edges slightly lower)
         rhat = dg.rhat_from_moments(mean, m2, n).cpu().numpy()
         assert rhat.max() < 1.01
         depth = eng.stat_i32(_abi.STAT_DEPTH, tune, draws)

@@ -35,7 +35,9 @@ with open("profiles/%s_kernel_trace.csv" % tag, "w", newline="") as fh:
     w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
     w.writeheader()
     w.writerows(keep)
-vgpr = int(keep[0]["VGPR_Count"]) + int(keep[0].get("Accum_VGPR_Count", 0) or 0)
+# rocprofv3 on gfx950 reports VGPR_Count per 32 lanes (84 for the 168-register wave64 kernel that
+# -Rpass-analysis=kernel-resource-usage and the ISA metadata show): double it
+vgpr = 2 * (int(keep[0]["VGPR_Count"]) + int(keep[0].get("Accum_VGPR_Count", 0) or 0))
 alloc = (vgpr + 7) // 8 * 8
 waves_per_simd = min(8, 512 // alloc)
 dur_ns = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in keep]
