@@ -181,7 +181,7 @@ static thread_local std::string g_last_error;
 
 struct lmc_engine {
     lmc_config cfg;
-    int ns = 0, dpad = 0, nlds = 1, ncold_lds = 0, lds_bytes = 0;   // ns: vector width of the W = 1 unit kernels (dpad = 64 * ns)
+    int ns = 0, dpad = 0, nlds = 1, lds_bytes = 0;   // ns: vector width of the W = 1 unit kernels (dpad = 64 * ns)
     int run_ns = 0, run_w = 1;                       // shape of the sampling kernel: dpad = 64 * run_ns * run_w
     hipStream_t own_stream = nullptr, stream = nullptr;
     ChainArrays A;
@@ -525,29 +525,20 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     if (nlds < 1) nlds = 1;
     e->nlds = nlds;
     e->lds_bytes = (2 + 4 * (nlds - 1)) * e->dpad * 8;
-    e->ncold_lds = 0;
     if (e->run_w == 1 && LMC_NUTS_ONE_WAVE_FORM) {
-        // one-wave form (nuts_transition2): reduction buffer + exp table + level scalars, then the cold slots (other
-        // trajectory end, running momentum sum, ...), stack level 1 (3 vectors) and levels 2.. (4 vectors each); level 0
-        // lives in registers. What does not fit goes to the chain's HBM scratch row. lds_levels < 0: nothing but the head.
+        // pair form (nuts_transition2): compile-time plan PairLds<NS> -- reduction buffer, exp table, level scalars, cold
+        // slots, stack level 1 -- plus as many further levels as fit without lowering the occupancy; the rest of the
+        // stack goes to the chain's scratch row
         const int waves_per_cu = 4 * run_waves_per_simd(e->run_ns);
-        long budget = (163840L / waves_per_cu) / 1280 * 1280 - lds_tail_doubles(1) * 8L - stack2_head_doubles(e->dpad) * 8L;
-        const long vec = e->dpad * 8L;
-        int ncold = 0;
-        if (cfg->lds_levels >= 0) {
-            if ((kNumColdSlots + 3) * vec <= budget) ncold = kNumColdSlots;      // all cold slots + level 1
-            else if ((3 + 3) * vec <= budget) ncold = 3;                         // {aold, psum, op} + level 1
-        }
-        budget -= ncold * vec;
-        nlds = cfg->lds_levels;
-        if (nlds == 0) {
-            while (nlds < max_levels && stack2_level_doubles(nlds + 1, e->dpad) * 8L <= budget) ++nlds;
-        }
+        const long budget = (163840L / waves_per_cu) / 1280 * 1280 - lds_tail_doubles(1) * 8L;
+        if (pair_min_doubles(e->run_ns) * 8L > budget)
+            return bail(fail(nullptr, LMC_ERR_INVALID, "pair form does not fit the LDS budget"));
+        nlds = cfg->lds_levels > 0 ? cfg->lds_levels : 1;
+        if (cfg->lds_levels <= 0)
+            while (nlds < max_levels && pair_total_doubles(e->run_ns, nlds + 1) * 8L <= budget) ++nlds;
         if (nlds > max_levels) nlds = max_levels;
-        if (nlds < 0) nlds = 0;
         e->nlds = nlds;
-        e->ncold_lds = ncold;
-        e->lds_bytes = (stack2_head_doubles(e->dpad) + ncold * e->dpad + stack2_level_doubles(nlds, e->dpad)) * 8;
+        e->lds_bytes = pair_total_doubles(e->run_ns, nlds) * 8;
     }
     if (e->lds_bytes > 160 * 1024) return bail(fail(nullptr, LMC_ERR_INVALID, "lds_levels too large"));
 
@@ -1191,7 +1182,6 @@ static SamplerParams make_params(const lmc_engine* e, int64_t n_tune, int64_t it
     P.iter_begin = iter_begin;
     P.n_iters = n_iters;
     P.nlds = e->nlds;
-    P.ncold_lds = e->ncold_lds;
     P.lds_doubles = e->lds_bytes / 8;
     P.sdot_mode = e->cfg.start_energy_sdot;
     return P;

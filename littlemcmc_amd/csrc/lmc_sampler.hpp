@@ -95,7 +95,6 @@ struct SamplerParams {
     long long n_tune;     // iterations with index < n_tune are tuning iterations
     long long iter_begin; // global index of the first iteration of this launch
     int n_iters;
-    int ncold_lds;        // pair form: cold slots kept in LDS (the rest at the head of the scratch row)
     int nlds;             // subtree levels kept in LDS (>= 1)
     int lds_doubles;      // LDS doubles used by the subtree stack; the MT19937 state (624 words) follows
     int sdot_mode;        // SdotMode for the float32 start-state kinetic energy
@@ -590,11 +589,12 @@ __device__ inline void hmc_transition(TeamT& tm, const Target& tgt, const double
     out.accepted = accepted;
 }
 
-// ---- NUTS transition, one-wave form (W == 1): batched LDS-transposed reductions, leaf pairs ---------------
-// Same algorithm and decisions as nuts_transition() above (which stays the team form for W > 1); what changes is
-// where the issue slots go. Measured on gfx950 (tools/ubench/valu_cost.hip): a wave issues at most one instruction
-// of ANY kind every ~10 cycles, a DPP move costs as much VALU time as a float64 operation, a permlane swap ~1.9x,
-// a v_readlane with an SGPR index ~1.8x -- so at 3 waves per SIMD every instruction of the per-leaf path counts.
+// ---- NUTS transition, pair form (one-wave kernels): batched LDS-transposed reductions, leaf pairs ---------------
+// Same algorithm and decisions as nuts_transition() above (the leaf form; it stays the team form for W > 1 and the
+// form for shallow trees); what changes is where the issue slots go. Measured on gfx950 (tools/ubench/valu_cost.hip):
+// a wave issues at most one instruction of ANY kind every ~10 cycles, a DPP move costs as much VALU time as a float64
+// operation, a permlane swap ~1.9x, a v_readlane with an SGPR index ~1.8x -- at 3 waves per SIMD every instruction of
+// the per-leaf path counts.
 //   * leaves are processed in PAIRS (2k, 2k+1): the even leaf's {p, q} stays in registers, so subtree-stack
 //     level 0 is never written to or read from LDS;
 //   * every length-d reduction of a pair -- two kinetic energies, two log-densities, the two level-0 U-turn dots --
@@ -609,62 +609,74 @@ __device__ inline void hmc_transition(TeamT& tm, const Target& tgt, const double
 //   * per-level subtree scalars live in LDS (lane 0 writes, broadcast reads) instead of VGPR lanes read with
 //     v_readlane; the proposal position of a merged node is tracked by its SOURCE (this pair or a stack level)
 //     and copied once when the node is parked; a level-1 node stores {lp, rp, q} only (its psum is lp + rp);
-//   * stack loads of the next cascade level are issued before the current level's reduction is waited for;
-//   * the trajectory is extended in place: {cq, cp, cg} is the end being extended, {oq, op, og} the other one.
-// LDS plan (doubles): [0, red) reduction buffer (also the normals / float32-dot staging area between transitions),
-// 64-entry exp table, 4 scalars per level, stack level 1 (3*dpad), levels 2..nlds (4*dpad each), [MT19937 state].
+//   * cold per-transition vectors (other trajectory end, running momentum sum, ...) live in LDS slots and the
+//     trajectory proposal in the chain's row of A.q, so nothing but the hot set occupies registers in the pair loop;
+//   * the whole LDS plan is compile-time (dpad = 64 * NS): every LDS access is one lane-offset register plus an
+//     immediate, no per-slot address registers.
 constexpr int kRedValues = 6;
-constexpr int kExpTableDoubles = 64;
-constexpr int kLevelScalDoubles = 80;   // 4 per level, levels < 20
-constexpr int red_doubles(int dpad) { return 2 * dpad > 64 * kRedValues ? 2 * dpad : 64 * kRedValues; }
-constexpr int stack2_head_doubles(int dpad) { return red_doubles(dpad) + kExpTableDoubles + kLevelScalDoubles; }
-constexpr int stack2_level_doubles(int nlds, int dpad) { return nlds <= 0 ? 0 : 3 * dpad + 4 * dpad * (nlds - 1); }
-constexpr int kNumColdSlots = 5;   // == kNumCold
+constexpr int kExpTableDoubles = 32;    // 2^(j/32): the even entries of kExp2Table
+constexpr int kLevelScalDoubles = 96;   // 4 per parked level, levels < 24 (max_treedepth <= 20)
+#ifndef LMC_PAIR_COLD_LDS
+#define LMC_PAIR_COLD_LDS 3   // cold slots kept in LDS: {aold, psum, op}; {oq, og} (touched only when the direction flips) head
+#endif                        // the scratch row -- measured: with the MT19937 state in LDS instead, C3 is unchanged and depth-3 trees gain 9 %
+enum ColdSlot : int { kColdAold = 0, kColdPsum = 1, kColdOp = 2, kColdOq = 3, kColdOg = 4, kNumCold = 5 };
+constexpr int kNumColdSlots = kNumCold;
 
-struct TreeStack2 {
-    double* levels;     // LDS: level 1 at offset 0 (3 vectors), level j >= 2 at 3*dpad + (j-2)*4*dpad
-    double* glb;        // this chain's scratch row: levels > nlds, 4*dpad apart
-    double* scal;       // LDS: 4 doubles per level
-    double* exptab;     // LDS copy of kExp2Table
-    double* cold;       // LDS: cold slots [0, ncold_lds)
-    double* glb_cold;   // scratch row: cold slots [ncold_lds, kNumCold)
-    int nlds;           // levels 1..nlds live in LDS
-    int ncold_lds;
-    int dpad;
-    __device__ __forceinline__ int lds_off(int j) const { return j == 1 ? 0 : (4 * j - 5) * dpad; }
-    __device__ __forceinline__ unsigned glb_off(int j) const { return static_cast<unsigned>(j - nlds - 1) * static_cast<unsigned>(4 * dpad); }
+template <int NS>
+struct PairLds {   // offsets in doubles from the start of the block's dynamic LDS
+    static constexpr int DP = 64 * NS;
+    static constexpr int kRedSize = (2 * DP > 64 * kRedValues) ? 2 * DP : 64 * kRedValues;   // also normals / sdot staging
+    static constexpr int kExp = kRedSize;
+    static constexpr int kScal = kExp + kExpTableDoubles;
+    static constexpr int kCold = kScal + kLevelScalDoubles;
+    static constexpr int kColdLds = LMC_PAIR_COLD_LDS;           // cold slots in LDS; the others head the scratch row
+    static constexpr int kL1 = kCold + kColdLds * DP;             // level 1: {lp, rp, q}
+    static constexpr int kL2 = kL1 + 3 * DP;                      // levels 2..nlds: {lp, rp, psum, q}
+    static constexpr int kMinDoubles = kL2;                       // head + cold + level 1: what the form needs at least
+    static constexpr int kGlbLevels = (kNumCold - kColdLds) * DP; // scratch row: cold slots not in LDS, then levels > nlds
+    __host__ __device__ static constexpr int total_doubles(int nlds) { return kL2 + (nlds > 1 ? (nlds - 1) * 4 * DP : 0); }
+};
+constexpr int pair_min_doubles(int ns) { return ns == 1 ? PairLds<1>::kMinDoubles : ns == 2 ? PairLds<2>::kMinDoubles : PairLds<4>::kMinDoubles; }
+constexpr int pair_total_doubles(int ns, int nlds) {
+    return ns == 1 ? PairLds<1>::total_doubles(nlds) : ns == 2 ? PairLds<2>::total_doubles(nlds) : PairLds<4>::total_doubles(nlds);
+}
+
+struct PairCtx {
+    double* lds;        // block's dynamic LDS
+    double* glb;        // this chain's scratch row
+    int nlds;           // stack levels 1..nlds live in LDS (>= 1)
+    int red_lane;       // lane * 8: this lane's 64-byte row of the reduction buffer (doubles)
 };
 
-struct RedBuf {
-    lds_double* buf;
-    int wofs;           // this lane's column (doubles)
-    int r0, r1, r2, r3; // the four 16-byte pieces of this lane's 64-byte row, rotated so that a ds_read_b128 of 16
-                        // lanes covers all 64 banks (lane stride is 64 B = 16 banks)
-    __device__ __forceinline__ void init(double* lds) {
-        const int lane = lane_id();
-        buf = (lds_double*)lds;
-        wofs = lane;
-        const int rot = (lane >> 2) & 3;
-        const int row = lane < 8 * kRedValues ? lane : 0;   // rows beyond the buffer re-read row 0 (their sums are never used)
-        r0 = row * 8 + 2 * rot; r1 = row * 8 + 2 * (rot ^ 1); r2 = row * 8 + 2 * (rot ^ 2); r3 = row * 8 + 2 * (rot ^ 3);
-    }
-    __device__ __forceinline__ void put(int v, double x) const { buf[v * 64 + wofs] = x; }
-    // lane 8k+7 of the result holds the wave sum of value k (k < kRedValues); other lanes hold partial scans
-    __device__ __forceinline__ double gather() const {
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        typedef __attribute__((address_space(3))) d2 lds_d2;
-        asm volatile("" ::: "memory");   // DS operations of one wave execute in issue order: no wait, only no reordering
-        const d2 a = *(const lds_d2*)(buf + r0), b = *(const lds_d2*)(buf + r1);   // ds_read_b128 each
-        const d2 c = *(const lds_d2*)(buf + r2), d = *(const lds_d2*)(buf + r3);
-        asm volatile("" ::: "memory");
-        double s = ((a.x + a.y) + (b.x + b.y)) + ((c.x + c.y) + (d.x + d.y));
-        s += dpp_f64<0x111>(s);
-        s += dpp_f64<0x112>(s);
-        s += dpp_f64<0x114>(s);
-        return s;
-    }
-};
-__device__ __forceinline__ double red_value(double s, int k) { return readlane_f64(s, 8 * k + 7); }
+// ---- batched lane reductions through LDS ("transposed" reduction)
+template <int NS>
+__device__ __forceinline__ void red_put(const PairCtx& cx, int v, double x) {
+    ((lds_double*)cx.lds)[v * 64 + lane_id()] = x;
+}
+// lane 8k+7 of the result holds the wave sum of value k (k < kRedValues); other lanes hold partial scans
+__device__ __forceinline__ double red_gather(const PairCtx& cx) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) d2 lds_d2;
+    asm volatile("" ::: "memory");   // DS operations of one wave execute in issue order: no wait, only no reordering
+    int r0 = cx.red_lane;
+    asm volatile("" : "+v"(r0));     // keep ONE address register: the other three pieces are re-derived here, not kept live
+    lds_double* L = (lds_double*)cx.lds;
+    // the four 16-byte pieces of this lane's row in a rotated order (r0 already holds the rotation), so that a
+    // ds_read_b128 of 16 lanes covers all 64 banks (lane stride 64 B = 16 banks)
+    const d2 a = *(const lds_d2*)(L + r0), b = *(const lds_d2*)(L + (r0 ^ 2));
+    const d2 c = *(const lds_d2*)(L + (r0 ^ 4)), d = *(const lds_d2*)(L + (r0 ^ 6));
+    asm volatile("" ::: "memory");
+    double s = ((a.x + a.y) + (b.x + b.y)) + ((c.x + c.y) + (d.x + d.y));
+    s += dpp_f64<0x111>(s);
+    s += dpp_f64<0x112>(s);
+    s += dpp_f64<0x114>(s);
+    return s;
+}
+__device__ __forceinline__ int red_lane_init() {
+    const int lane = lane_id();
+    const int row = lane < 8 * kRedValues ? lane : 0;   // rows beyond the buffer re-read row 0 (their sums are never used)
+    return row * 8 + 2 * ((lane >> 2) & 3);
+}
 // any of the sums k in [k0, k0 + n) <= 0 ?
 __device__ __forceinline__ bool red_any_nonpositive(double s, int k0, int n) {
     const unsigned long long m = __ballot(s <= 0.0);
@@ -673,73 +685,95 @@ __device__ __forceinline__ bool red_any_nonpositive(double s, int k0, int n) {
     return (m & sel) != 0ull;
 }
 
-// exp on lanes (arguments <= ~700; very negative ones underflow to 0): exp_uniform_fast's algorithm with the
-// 2^(j/64) table read from LDS by every lane
-__device__ __forceinline__ double exp_lanes(double x, const double* table_lds) {
-    const double kf = rint(x * LMC_SC(92.332482616893656));            // 64 / ln 2
-    double r = __builtin_fma(-kf, LMC_SC(1.08304246932675596327e-02), x);   // ln2/64 hi
-    r = __builtin_fma(-kf, LMC_SC(2.98158582698529328128e-12), r);          // ln2/64 lo
+// exp on lanes (arguments <= ~700; very negative ones underflow to 0): exp_uniform_fast's algorithm with a 32-entry
+// 2^(j/32) table read from LDS by every lane: x = (32 e + j) ln2/32 + r, |r| <= ln2/64, degree-6 polynomial
+// (truncation r^7/5040 < 4e-18 relative). |error| < ~1 ulp.
+template <int NS>
+__device__ __forceinline__ double exp_lanes(const PairCtx& cx, double x) {
+    const double kf = rint(x * LMC_SC(46.166241308446828));            // 32 / ln 2
+    double r = __builtin_fma(-kf, LMC_SC(2.16608493865351192654e-02), x);   // ln2/32 hi
+    r = __builtin_fma(-kf, LMC_SC(5.96317165397058656256e-12), r);          // ln2/32 lo
     const int ki = static_cast<int>(kf);
-    const double t = ((const lds_double*)table_lds)[ki & 63];
-    double p = fma_sgpr_addend(r, LMC_SC(1.0 / 120.0), LMC_SC(1.0 / 24.0));
+    const double t = ((const lds_double*)cx.lds)[PairLds<NS>::kExp + (ki & 31)];
+    double p = fma_sgpr_addend(r, LMC_SC(1.0 / 720.0), LMC_SC(1.0 / 120.0));
+    p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 24.0));
     p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 6.0));
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    return ldexp(p * t, ki >> 6);
+    return ldexp(p * t, ki >> 5);
 }
 
+// ---- cold slots and subtree-stack levels: LDS offsets are immediates, the scratch row takes what does not fit
+template <int NS, int SLOT>
+__device__ __forceinline__ void cold_load(const PairCtx& cx, double (&x)[NS]) {
+    using L = PairLds<NS>;
+    if constexpr (SLOT < L::kColdLds) vload_as<NS>((lds_double*)cx.lds + (L::kCold + SLOT * L::DP), x);
+    else vload_as<NS>((glb_double*)cx.glb + (SLOT - L::kColdLds) * L::DP, x);
+}
+template <int NS, int SLOT>
+__device__ __forceinline__ void cold_store(const PairCtx& cx, const double (&x)[NS]) {
+    using L = PairLds<NS>;
+    if constexpr (SLOT < L::kColdLds) vstore_as<NS>((lds_double*)cx.lds + (L::kCold + SLOT * L::DP), x);
+    else vstore_as<NS>((glb_double*)cx.glb + (SLOT - L::kColdLds) * L::DP, x);
+}
+// level 1 (always LDS): {lp, rp, q}
 template <int NS>
-__device__ __forceinline__ void stack2_load3(const TreeStack2& stk, int j, double (&lp)[NS], double (&rp)[NS], double (&ps)[NS]) {
-    const int dp = stk.dpad;
-    if (j <= stk.nlds) {
-        lds_double* b = (lds_double*)(stk.levels) + stk.lds_off(j);
-        vload_as<NS>(b, lp); vload_as<NS>(b + dp, rp);
-        if (j > 1) vload_as<NS>(b + 2 * dp, ps);
-    } else {
-        glb_double* b = (glb_double*)(stk.glb) + stk.glb_off(j);
-        vload_as<NS>(b, lp); vload_as<NS>(b + dp, rp);
-        if (j > 1) vload_as<NS>(b + 2 * dp, ps);
-    }
-    if (j == 1) {
+__device__ __forceinline__ void level1_load(const PairCtx& cx, double (&lp)[NS], double (&rp)[NS], double (&ps)[NS]) {
+    using L = PairLds<NS>;
+    lds_double* b = (lds_double*)cx.lds + L::kL1;
+    vload_as<NS>(b, lp); vload_as<NS>(b + L::DP, rp);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) ps[s] = lp[s] + rp[s];   // the very sum the pair formed (nuts.py:386)
-    }
+    for (int s = 0; s < NS; ++s) ps[s] = lp[s] + rp[s];   // the very sum the pair formed (nuts.py:386)
 }
 template <int NS>
-__device__ __forceinline__ void stack2_load_lp(const TreeStack2& stk, int j, double (&lp)[NS]) {
-    if (j <= stk.nlds) vload_as<NS>((lds_double*)(stk.levels) + stk.lds_off(j), lp);
-    else vload_as<NS>((glb_double*)(stk.glb) + stk.glb_off(j), lp);
+__device__ __forceinline__ void level1_store(const PairCtx& cx, const double (&lp)[NS], const double (&rp)[NS], const double (&pq)[NS]) {
+    using L = PairLds<NS>;
+    lds_double* b = (lds_double*)cx.lds + L::kL1;
+    vstore_as<NS>(b, lp); vstore_as<NS>(b + L::DP, rp); vstore_as<NS>(b + 2 * L::DP, pq);
+}
+// offset (doubles) of vector v of level j > nlds in the scratch row. Opaque to the optimiser on purpose: a
+// loop-invariant level (the peeled j = 2) would otherwise get its per-lane 64-bit address precomputed outside the pair
+// loop and kept in (spilled) registers; this way the access is scalar base + uniform offset + the lane-offset register
+template <int NS>
+__device__ __forceinline__ unsigned glb_level_offset(const PairCtx& cx, int j, int v) {
+    using L = PairLds<NS>;
+    unsigned off = L::kGlbLevels + static_cast<unsigned>(j - cx.nlds - 1) * (4u * L::DP) + static_cast<unsigned>(v) * L::DP;
+    asm volatile("" : "+s"(off));
+    return off;
+}
+// levels j >= 2: {lp, rp, psum, q}; vector index v in 0..3
+template <int NS>
+__device__ __forceinline__ void levelN_load(const PairCtx& cx, int j, int v, double (&x)[NS]) {
+    using L = PairLds<NS>;
+    if (j <= cx.nlds) vload_as<NS>((lds_double*)cx.lds + (L::kL2 + (j - 2) * 4 * L::DP + v * L::DP), x);
+    else vload_as<NS>((glb_double*)cx.glb + glb_level_offset<NS>(cx, j, v), x);
 }
 template <int NS>
-__device__ __forceinline__ void stack2_load_q(const TreeStack2& stk, int j, double (&pq)[NS]) {
-    const int dp = stk.dpad;
-    const int qo = (j == 1 ? 2 : 3) * dp;
-    if (j <= stk.nlds) vload_as<NS>((lds_double*)(stk.levels) + stk.lds_off(j) + qo, pq);
-    else vload_as<NS>((glb_double*)(stk.glb) + stk.glb_off(j) + qo, pq);
+__device__ __forceinline__ void levelN_store(const PairCtx& cx, int j, int v, const double (&x)[NS]) {
+    using L = PairLds<NS>;
+    if (j <= cx.nlds) vstore_as<NS>((lds_double*)cx.lds + (L::kL2 + (j - 2) * 4 * L::DP + v * L::DP), x);
+    else vstore_as<NS>((glb_double*)cx.glb + glb_level_offset<NS>(cx, j, v), x);
+}
+// left-end momentum / proposal position of any level j >= 1
+template <int NS>
+__device__ __forceinline__ void level_load_lp(const PairCtx& cx, int j, double (&x)[NS]) {
+    if (j == 1) vload_as<NS>((lds_double*)cx.lds + PairLds<NS>::kL1, x); else levelN_load<NS>(cx, j, 0, x);
 }
 template <int NS>
-__device__ __forceinline__ void stack2_store(const TreeStack2& stk, int j, const double (&lp)[NS], const double (&rp)[NS],
-                                             const double (&ps)[NS], const double (&pq)[NS]) {
-    const int dp = stk.dpad;
-    if (j <= stk.nlds) {
-        lds_double* b = (lds_double*)(stk.levels) + stk.lds_off(j);
-        vstore_as<NS>(b, lp); vstore_as<NS>(b + dp, rp);
-        if (j == 1) { vstore_as<NS>(b + 2 * dp, pq); } else { vstore_as<NS>(b + 2 * dp, ps); vstore_as<NS>(b + 3 * dp, pq); }
-    } else {
-        glb_double* b = (glb_double*)(stk.glb) + stk.glb_off(j);
-        vstore_as<NS>(b, lp); vstore_as<NS>(b + dp, rp);
-        if (j == 1) { vstore_as<NS>(b + 2 * dp, pq); } else { vstore_as<NS>(b + 2 * dp, ps); vstore_as<NS>(b + 3 * dp, pq); }
-    }
+__device__ __forceinline__ void level_load_q(const PairCtx& cx, int j, double (&x)[NS]) {
+    if (j == 1) vload_as<NS>((lds_double*)cx.lds + (PairLds<NS>::kL1 + 2 * PairLds<NS>::DP), x); else levelN_load<NS>(cx, j, 3, x);
 }
-__device__ __forceinline__ void level_scal_put(const TreeStack2& stk, int j, double w, double a, double pe, double plogp) {
+template <int NS>
+__device__ __forceinline__ void level_scal_put(const PairCtx& cx, int j, double w, double a, double pe, double plogp) {
     if (lane_id() == 0) {
-        lds_double* s = (lds_double*)(stk.scal) + 4 * j;
+        lds_double* s = (lds_double*)cx.lds + (PairLds<NS>::kScal + 4 * j);
         s[0] = w; s[1] = a; s[2] = pe; s[3] = plogp;
     }
 }
-__device__ __forceinline__ void level_scal_get(const TreeStack2& stk, int j, double& w, double& a, double& pe, double& plogp) {
-    const lds_double* s = (const lds_double*)(stk.scal) + 4 * j;   // same address in every lane: LDS broadcast
+template <int NS>
+__device__ __forceinline__ void level_scal_get(const PairCtx& cx, int j, double& w, double& a, double& pe, double& plogp) {
+    const lds_double* s = (const lds_double*)cx.lds + (PairLds<NS>::kScal + 4 * j);   // same address in every lane: LDS broadcast
     w = s[0]; a = s[1]; pe = s[2]; plogp = s[3];
 }
 
@@ -773,26 +807,32 @@ __device__ __forceinline__ void leapfrog_partial(TeamT& tm, const Target& tgt, c
     kin_part = kin;
 }
 
-// Cold per-transition vectors (touched once per doubling, not per leaf) live in memory by design, so that the
-// register allocator has nothing to spill around the pair loop: slot order = hotness; the first stk.ncold_lds slots
-// are LDS, the others sit at the head of the chain's HBM scratch row. The proposal of the trajectory itself lives in
-// the chain's row of A.q (written when a subtree is accepted, read back once at the end of the transition).
-enum ColdSlot : int { kColdAold = 0, kColdPsum = 1, kColdOp = 2, kColdOq = 3, kColdOg = 4, kNumCold = kNumColdSlots };
+// one cascade level: node a = {alp, arp, aps} (earlier), in-flight node {tl (left end), tps, right end velocity v}
 template <int NS>
-__device__ __forceinline__ void cold_load(const TreeStack2& stk, int slot, double (&x)[NS]) {
-    if (slot < stk.ncold_lds) vload_as<NS>((lds_double*)(stk.cold) + slot * stk.dpad, x);
-    else vload_as<NS>((glb_double*)(stk.glb_cold) + (slot - stk.ncold_lds) * stk.dpad, x);
-}
-template <int NS>
-__device__ __forceinline__ void cold_store(const TreeStack2& stk, int slot, const double (&x)[NS]) {
-    if (slot < stk.ncold_lds) vstore_as<NS>((lds_double*)(stk.cold) + slot * stk.dpad, x);
-    else vstore_as<NS>((glb_double*)(stk.glb_cold) + (slot - stk.ncold_lds) * stk.dpad, x);
+__device__ __forceinline__ double cascade_dots(const PairCtx& cx, const double (&var)[NS], const double (&alp)[NS],
+                                               const double (&arp)[NS], const double (&aps)[NS], const double (&tl)[NS],
+                                               double (&tps)[NS], const double (&v)[NS]) {
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0, d4 = 0.0, d5 = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {   // nuts.py:386-396
+        const double p1 = aps[s] + tl[s];
+        const double p2 = arp[s] + tps[s];
+        const double ps = aps[s] + tps[s];
+        const double valp = var[s] * alp[s], vtlp = var[s] * tl[s], varp = var[s] * arp[s];
+        d0 = __builtin_fma(ps, valp, d0); d1 = __builtin_fma(ps, v[s], d1);
+        d2 = __builtin_fma(p1, valp, d2); d3 = __builtin_fma(p1, vtlp, d3);
+        d4 = __builtin_fma(p2, varp, d4); d5 = __builtin_fma(p2, v[s], d5);
+        tps[s] = ps;
+    }
+    red_put<NS>(cx, 0, d0); red_put<NS>(cx, 1, d1); red_put<NS>(cx, 2, d2);
+    red_put<NS>(cx, 3, d3); red_put<NS>(cx, 4, d4); red_put<NS>(cx, 5, d5);
+    return red_gather(cx);
 }
 
 // On return the chain's row of A.q (qrow) holds the proposal; q is NOT updated (the caller reloads it).
 template <int NS, class Target, class TeamT>
 __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const double (&var)[NS], RngState& rng,
-                                        const TreeStack2& stk, const RedBuf& rb, double* qrow, const double (&q)[NS],
+                                        const PairCtx& cx, double* qrow, const double (&q)[NS],
                                         const double (&p0)[NS], const double (&g0)[NS], double e0, double logp0,
                                         double step_size, double emax, int max_depth, bool momentum_f32,
                                         TransitionOut& out) {
@@ -801,8 +841,8 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
     // momentum sum and the extended end's momentum before the doubling are cold slots
     double cq[NS], cp[NS], cg[NS];
     vcopy(cq, q); vcopy(cp, p0); vcopy(cg, g0);
-    cold_store<NS>(stk, kColdOq, q); cold_store<NS>(stk, kColdOp, p0); cold_store<NS>(stk, kColdOg, g0);
-    cold_store<NS>(stk, kColdPsum, p0);
+    cold_store<NS, kColdOq>(cx, q); cold_store<NS, kColdOp>(cx, p0); cold_store<NS, kColdOg>(cx, g0);
+    cold_store<NS, kColdPsum>(cx, p0);
     bool c_right = true;                                    // which end {c*} is
     bool c_start = momentum_f32, o_start = momentum_f32;    // end still is the float32 start state
     double prop_e = e0, prop_logp = logp0;
@@ -831,8 +871,8 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
             if (x - coff > 600.0) {   // cold path: move the offset, rescale every stored weight
                 const double f = exp_uniform(coff - x);
                 const int lane = lane_id();
-                if (lane >= 1 && lane < 20) {
-                    lds_double* sc = (lds_double*)(stk.scal) + 4 * lane;
+                if (lane >= 1 && lane < kLevelScalDoubles / 4) {
+                    lds_double* sc = (lds_double*)cx.lds + (PairLds<NS>::kScal + 4 * lane);
                     sc[0] = sc[0] * f; sc[1] = sc[1] * f;
                 }
                 wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
@@ -844,7 +884,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         const double x = -de;
         const double xn = dpp_f64<0x101>(x);                   // row_shl:1: lane l <- lane l+1
         const double arg = odd_lane ? (x - coff) : ((xn - coff) + fmin(xn, 0.0));
-        ev = exp_lanes(arg, stk.exptab);
+        ev = exp_lanes<NS>(cx, arg);
         return ok;
     };
 
@@ -853,13 +893,13 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         const double eps = right ? step_size : -step_size;
         if (right != c_right) {   // the other end becomes the one that is extended
             double t[NS];
-            cold_load<NS>(stk, kColdOq, t); cold_store<NS>(stk, kColdOq, cq); vcopy(cq, t);
-            cold_load<NS>(stk, kColdOp, t); cold_store<NS>(stk, kColdOp, cp); vcopy(cp, t);
-            cold_load<NS>(stk, kColdOg, t); cold_store<NS>(stk, kColdOg, cg); vcopy(cg, t);
+            cold_load<NS, kColdOq>(cx, t); cold_store<NS, kColdOq>(cx, cq); vcopy(cq, t);
+            cold_load<NS, kColdOp>(cx, t); cold_store<NS, kColdOp>(cx, cp); vcopy(cp, t);
+            cold_load<NS, kColdOg>(cx, t); cold_store<NS, kColdOg>(cx, cg); vcopy(cg, t);
             const bool tb = c_start; c_start = o_start; o_start = tb;
             c_right = right;
         }
-        cold_store<NS>(stk, kColdAold, cp);   // momentum of the extended end before this doubling (nuts.py:332-338 operands)
+        cold_store<NS, kColdAold>(cx, cp);   // momentum of the extended end before this doubling (nuts.py:332-338 operands)
         const bool aold_start = c_start;
 
         // subtree node under construction: momentum sum tps, weights; its right-end momentum is always the current cp,
@@ -871,8 +911,8 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         if (D == 0) {
             double v[NS], kinp, lp, en, ev;
             leapfrog_partial<NS>(tm, tgt, var, eps, cq, cp, cg, v, kinp, lp);
-            rb.put(0, kinp); rb.put(1, lp);
-            const double s0 = rb.gather();
+            red_put<NS>(cx, 0, kinp); red_put<NS>(cx, 1, lp);   // (DPP butterflies for the lone leaf and the trajectory-level
+            const double s0 = red_gather(cx);                   //  test measured 1 % slower on depth-3 trees, equal on C3)
             if (leaf_scalars(s0, 1, en, ev) == 1) {
                 tw = readlane_f64(ev, 15); ta = readlane_f64(ev, 14);
                 tpe = readlane_f64(en, 15); tplogp = readlane_f64(s0, 15);
@@ -883,23 +923,17 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
             for (int k = 0; k < n_pairs; ++k) {
                 double v[NS], kinA, lpA, kinB, lpB;
                 leapfrog_partial<NS>(tm, tgt, var, eps, cq, cp, cg, v, kinA, lpA);
-                rb.put(0, kinA); rb.put(1, lpA);
+                red_put<NS>(cx, 0, kinA); red_put<NS>(cx, 1, lpA);
                 vcopy(eq, cq); vcopy(ep, cp);
                 leapfrog_partial<NS>(tm, tgt, var, eps, cq, cp, cg, v, kinB, lpB);   // speculative w.r.t. the first leaf's divergence test
-                rb.put(2, kinB); rb.put(3, lpB);
+                red_put<NS>(cx, 2, kinB); red_put<NS>(cx, 3, lpB);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) tps[s] = ep[s] + cp[s];
-                rb.put(4, pdot_v<NS>(tps, var, ep));   // var (.) ep is the first leaf's velocity, re-formed (same rounded product)
-                rb.put(5, pdot<NS>(tps, v));
-                const double s0 = rb.gather();
-                // this pair closes m right children (levels 1..m); level 1's node is requested now and arrives while
-                // the leaf scalars are evaluated
+                red_put<NS>(cx, 4, pdot_v<NS>(tps, var, ep));   // var (.) ep is the first leaf's velocity, re-formed (same rounded product)
+                red_put<NS>(cx, 5, pdot<NS>(tps, v));
+                const double s0 = red_gather(cx);
+                // this pair closes m right children (levels 1..m)
                 const int m = __builtin_ctz(~static_cast<unsigned>(k) | (1u << (D - 1)));
-                double alp[NS], arp[NS], aps[NS];
-                double aw = 0.0, aa = 0.0, ape = 0.0, aplogp = 0.0;
-#if LMC_V2_PREFETCH
-                if (m >= 1) { stack2_load3<NS>(stk, 1, alp, arp, aps); level_scal_get(stk, 1, aw, aa, ape, aplogp); }
-#endif
                 double en, ev;
                 if (leaf_scalars(s0, 2, en, ev) != 2) break;
                 // ---- level-0 merge (nuts.py:384-417 with depth 1: only the span check)
@@ -915,25 +949,13 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                     tw = wsum; ta = aA + aB;
                     if (turn) { turning = true; break; }
                 }
-                // ---- cascade level 1 (peeled: its operands were requested above; left end of the pair node = ep)
+                // ---- cascade level 1 (left end of the in-flight pair node = ep)
                 if (m >= 1) {
-#if !LMC_V2_PREFETCH
-                    stack2_load3<NS>(stk, 1, alp, arp, aps); level_scal_get(stk, 1, aw, aa, ape, aplogp);
-#endif
-                    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0, d4 = 0.0, d5 = 0.0;
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        const double p1 = aps[s] + ep[s];
-                        const double p2 = arp[s] + tps[s];
-                        const double ps = aps[s] + tps[s];
-                        const double valp = var[s] * alp[s], vtlp = var[s] * ep[s], varp = var[s] * arp[s];
-                        d0 = __builtin_fma(ps, valp, d0); d1 = __builtin_fma(ps, v[s], d1);
-                        d2 = __builtin_fma(p1, valp, d2); d3 = __builtin_fma(p1, vtlp, d3);
-                        d4 = __builtin_fma(p2, varp, d4); d5 = __builtin_fma(p2, v[s], d5);
-                        tps[s] = ps;
-                    }
-                    rb.put(0, d0); rb.put(1, d1); rb.put(2, d2); rb.put(3, d3); rb.put(4, d4); rb.put(5, d5);
-                    const double sj = rb.gather();
+                    double alp[NS], arp[NS], aps[NS];
+                    double aw, aa, ape, aplogp;
+                    level1_load<NS>(cx, alp, arp, aps);   // (requesting it before the leaf scalars measured -8 %: one more live address)
+                    level_scal_get<NS>(cx, 1, aw, aa, ape, aplogp);
+                    const double sj = cascade_dots<NS>(cx, var, alp, arp, aps, ep, tps, v);
                     const bool turn = red_any_nonpositive(sj, 0, 6);
                     const double wsum = aw + tw;
                     const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < tw);
@@ -944,24 +966,11 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                 // ---- cascade levels 2..m: node a = stack[j]; the in-flight node's left end is stack[j-1]'s
                 for (int j = 2; j <= m; ++j) {
                     double blp[NS], brp[NS], bps[NS], tl[NS];
-                    stack2_load3<NS>(stk, j, blp, brp, bps);
-                    stack2_load_lp<NS>(stk, j - 1, tl);
+                    levelN_load<NS>(cx, j, 0, blp); levelN_load<NS>(cx, j, 1, brp); levelN_load<NS>(cx, j, 2, bps);
+                    level_load_lp<NS>(cx, j - 1, tl);
                     double bw, ba, bpe, bplogp;
-                    level_scal_get(stk, j, bw, ba, bpe, bplogp);
-                    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0, d4 = 0.0, d5 = 0.0;
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        const double p1 = bps[s] + tl[s];
-                        const double p2 = brp[s] + tps[s];
-                        const double ps = bps[s] + tps[s];
-                        const double valp = var[s] * blp[s], vtlp = var[s] * tl[s], varp = var[s] * brp[s];
-                        d0 = __builtin_fma(ps, valp, d0); d1 = __builtin_fma(ps, v[s], d1);
-                        d2 = __builtin_fma(p1, valp, d2); d3 = __builtin_fma(p1, vtlp, d3);
-                        d4 = __builtin_fma(p2, varp, d4); d5 = __builtin_fma(p2, v[s], d5);
-                        tps[s] = ps;
-                    }
-                    rb.put(0, d0); rb.put(1, d1); rb.put(2, d2); rb.put(3, d3); rb.put(4, d4); rb.put(5, d5);
-                    const double sj = rb.gather();
+                    level_scal_get<NS>(cx, j, bw, ba, bpe, bplogp);
+                    const double sj = cascade_dots<NS>(cx, var, blp, brp, bps, tl, tps, v);
                     const bool turn = red_any_nonpositive(sj, 0, 6);
                     const double wsum = bw + tw;
                     const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < tw);
@@ -972,12 +981,17 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                 if (turning) break;
                 if (k + 1 < n_pairs) {   // park the node at level m + 1 (the last pair's cascade result stays in flight)
                     double tl[NS], tqv[NS];
-                    if (m == 0) vcopy(tl, ep); else stack2_load_lp<NS>(stk, m, tl);
+                    if (m == 0) vcopy(tl, ep); else level_load_lp<NS>(cx, m, tl);
                     if (qsrc == -1) vcopy(tqv, cq);
                     else if (qsrc == -2) vcopy(tqv, eq);
-                    else stack2_load_q<NS>(stk, qsrc, tqv);
-                    stack2_store<NS>(stk, m + 1, tl, cp, tps, tqv);
-                    level_scal_put(stk, m + 1, tw, ta, tpe, tplogp);
+                    else level_load_q<NS>(cx, qsrc, tqv);
+                    if (m == 0) {
+                        level1_store<NS>(cx, tl, cp, tqv);
+                    } else {
+                        levelN_store<NS>(cx, m + 1, 0, tl); levelN_store<NS>(cx, m + 1, 1, cp);
+                        levelN_store<NS>(cx, m + 1, 2, tps); levelN_store<NS>(cx, m + 1, 3, tqv);
+                    }
+                    level_scal_put<NS>(cx, m + 1, tw, ta, tpe, tplogp);
                 }
             }
         }
@@ -989,7 +1003,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
             double tqv[NS];
             if (qsrc == -1) vcopy(tqv, cq);
             else if (qsrc == -2) vcopy(tqv, eq);
-            else stack2_load_q<NS>(stk, qsrc, tqv);
+            else level_load_q<NS>(cx, qsrc, tqv);
             vstore_as<NS>((glb_double*)qrow, tqv);
             prop_e = tpe; prop_logp = tplogp;
         }
@@ -998,14 +1012,14 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         double tlp[NS], psum[NS], op[NS], aold[NS];
         if (D == 0) vcopy(tlp, cp);
         else if (D == 1) vcopy(tlp, ep);
-        else stack2_load_lp<NS>(stk, D - 1, tlp);
-        cold_load<NS>(stk, kColdPsum, psum); cold_load<NS>(stk, kColdOp, op); cold_load<NS>(stk, kColdAold, aold);
+        else level_load_lp<NS>(cx, D - 1, tlp);
+        cold_load<NS, kColdPsum>(cx, psum); cold_load<NS, kColdOp>(cx, op); cold_load<NS, kColdAold>(cx, aold);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {   // in place; float32 storage when the start momentum is float32
             const double t = psum[s] + tps[s];
             psum[s] = momentum_f32 ? static_cast<double>(static_cast<float>(t)) : t;
         }
-        cold_store<NS>(stk, kColdPsum, psum);
+        cold_store<NS, kColdPsum>(cx, psum);
         double ov[NS], av[NS];   // velocities of the untouched end and of the extended end as it was before this doubling
         end_velocity<NS>(ov, var, op, o_start);
         end_velocity<NS>(av, var, aold, aold_start);
@@ -1030,8 +1044,9 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
             }
         }
         c_start = false;
-        rb.put(0, d0); rb.put(1, d1); rb.put(2, d2); rb.put(3, d3); rb.put(4, d4); rb.put(5, d5);
-        if (red_any_nonpositive(rb.gather(), 0, 6)) { turning = true; exhausted = false; break; }
+        red_put<NS>(cx, 0, d0); red_put<NS>(cx, 1, d1); red_put<NS>(cx, 2, d2);
+        red_put<NS>(cx, 3, d3); red_put<NS>(cx, 4, d4); red_put<NS>(cx, 5, d5);
+        if (red_any_nonpositive(red_gather(cx), 0, 6)) { turning = true; exhausted = false; break; }
     }
 
     const double mean_accept = (wn > 0.0) ? first_f64(an / wn) : 0.0;
@@ -1052,7 +1067,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
 // is register resident, so wider per-thread slices trade occupancy for registers. Chains longer than
 // 128 elements are spread over W waves (dpad = 64 * NS * W) instead of growing NS further.
 #ifndef LMC_NUTS_ONE_WAVE_FORM
-#define LMC_NUTS_ONE_WAVE_FORM 0   // 1: W == 1 kernels use nuts_transition2 (pair form) and its LDS plan
+#define LMC_NUTS_ONE_WAVE_FORM 1   // 1: one-wave kernels (d <= 256) use nuts_transition2 (pair form) and its LDS plan; 0: leaf form everywhere
 #endif
 #ifndef LMC_WAVES_NS1
 #define LMC_WAVES_NS1 4
@@ -1069,7 +1084,7 @@ constexpr int run_waves_per_simd(int ns) {
 // LDS carve (doubles) behind the subtree stack: MT19937 state (624 words), team exchange area, RNG re-broadcast
 constexpr int kLdsMtDoubles = 320;
 #ifndef LMC_MT_IN_LDS_W1
-#define LMC_MT_IN_LDS_W1 0   // pair-form kernels: 1 keeps the MT19937 state in LDS for the launch, 0 uses it in place (L2)
+#define LMC_MT_IN_LDS_W1 1   // pair-form kernels: 1 keeps the MT19937 state in LDS for the launch, 0 uses it in place (L2)
 #endif
 constexpr bool run_mt_in_lds(int w) { return w > 1 || !LMC_NUTS_ONE_WAVE_FORM || LMC_MT_IN_LDS_W1; }
 constexpr int lds_tail_doubles(int w) {
@@ -1278,21 +1293,14 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     stk.glb = A.scratch + static_cast<long long>(c) * A.scratch_stride;
     stk.nlds = P.nlds;
     stk.dpad = dpad;
-    // pair form (nuts_transition2): reduction buffer, exp table, level scalars, cold slots, stack levels 1..nlds
-    TreeStack2 stk2;
-    stk2.exptab = lds + red_doubles(dpad);
-    stk2.scal = stk2.exptab + kExpTableDoubles;
-    stk2.cold = stk2.scal + kLevelScalDoubles;
-    stk2.levels = stk2.cold + P.ncold_lds * dpad;
-    stk2.glb_cold = stk.glb;
-    stk2.glb = stk.glb + kNumCold * dpad;
-    stk2.nlds = P.nlds;
-    stk2.ncold_lds = P.ncold_lds;
-    stk2.dpad = dpad;
-    RedBuf rb;
-    rb.init(lds);
-    if constexpr (W == 1 && LMC_NUTS_ONE_WAVE_FORM) {
-        if (tid < kExpTableDoubles) stk2.exptab[tid] = kExp2Table[tid];
+    // pair form (nuts_transition2): compile-time LDS plan (PairLds<NS>), the chain's scratch row for what does not fit
+    PairCtx cx;
+    cx.lds = lds;
+    cx.glb = stk.glb;
+    cx.nlds = P.nlds;
+    cx.red_lane = red_lane_init();
+    if constexpr (W == 1 && LMC_NUTS_ONE_WAVE_FORM && NS <= 4) {
+        if (tid < kExpTableDoubles) lds[PairLds<NS>::kExp + tid] = kExp2Table[2 * tid];
     }
 
     for (int it = 0; it < P.n_iters; ++it) {
@@ -1333,8 +1341,8 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         TransitionOut out;
         if (P.kind == 0) {
             const int md = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
-            if constexpr (W == 1 && LMC_NUTS_ONE_WAVE_FORM) {
-                nuts_transition2<NS>(tm, tgt, vard, rng, stk2, rb, A.q + row, q, p0, g0, e0, logp0, step_size, P.emax, md,
+            if constexpr (W == 1 && LMC_NUTS_ONE_WAVE_FORM && NS <= 4) {
+                nuts_transition2<NS>(tm, tgt, vard, rng, cx, A.q + row, q, p0, g0, e0, logp0, step_size, P.emax, md,
                                      P.momentum_f32 != 0, out);
                 vload<NS>(A.q + row, q);   // the proposal was written to the chain's row of A.q
             } else
