@@ -123,10 +123,6 @@ __device__ __forceinline__ void velocity2(const DenseMat<MatT>& mm, lds_double* 
 }
 
 // ---- momentum draws ----------------------------------------------------------------------------------------
-__device__ __forceinline__ float readlane_f32(float x, int lane) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
-}
-
 // quadpotential.py:450-453: solve_triangular(chol.T, float32(normals)) -- the column sweep of the reference
 // BLAS strsv (upper, no-trans): x_j /= U_jj, then x_i -= x_j U_ij for i < j, j descending. U_ij = L[j][i] is
 // row j of the row-major factor: contiguous over i. Rows are fetched 8 at a time one block ahead of use.

@@ -169,16 +169,32 @@ __device__ inline float sdot_openblas(const float* x, const float* y, int n, int
             const int n64 = n1 & ~63;
             float acc = 0.0f;                                  // zmm k = lane/16, element lane%16
             for (int b = 0; b < n64; b += 64) acc = __builtin_fmaf(x[b + lane], y[b + lane], acc);
-            float a = acc + __shfl_down(acc, 8, 64);           // fold 512 -> 256: valid on lanes 16k+m, m<8
+            // The cross-lane moves are VALU (DPP row shifts, gfx950 permlane swaps, v_readlane): the ds_bpermute form
+            // cost a dozen dependent LDS round trips per iteration (~2 k cycles of a depth-3 iteration's 30 k).
+            float a = acc + dpp_f32<0x108>(acc);               // row_shl:8: fold 512 -> 256, valid on lanes 16k+m, m<8
             if (n1 > n64) {                                    // one trailing 32-block on ymm accumulators
                 const int k = lane >> 4, m = lane & 15;
                 if (m < 8) a = __builtin_fmaf(x[n64 + 8 * k + m], y[n64 + 8 * k + m], a);
             }
-            float sv = a + __shfl(a, (lane & 7) + 16, 64);     // ((A0 + A1) + A2) + A3 on lanes m<8
-            sv = sv + __shfl(a, (lane & 7) + 32, 64);
-            sv = sv + __shfl(a, (lane & 7) + 48, 64);
-            const float h = sv + __shfl_down(sv, 4, 64);       // low half + high half, lanes m<4
-            const float h0 = __shfl(h, 0, 64), h1 = __shfl(h, 1, 64), h2 = __shfl(h, 2, 64), h3 = __shfl(h, 3, 64);
+            // rows of a: [A0, A1, A2, A3]; bring A1, A2, A3 to row 0: swap16(a, a) -> [A0,A0,A2,A2] / [A1,A1,A3,A3],
+            // swap32 of the second with itself -> [A1,A1,A1,A1] / [A3,A3,A3,A3]; swap32(a, a) -> [A0,A1,A0,A1] / [A2,A3,A2,A3]
+            // (written as asm: with the builtins hipcc 7.2 picked the first result of each swap where the second was
+            // asked for -- tools/ubench/swap_probe.hip shows the hardware semantics used here; "s_nop 1" covers the
+            // VALU-write -> permlane-read hazard)
+            const unsigned au = __builtin_bit_cast(unsigned, a);
+            unsigned x16 = au, y16 = au, x32 = au, y32 = au;
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x16), "+v"(y16));   // y16 rows: [A1, A1, A3, A3]
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x32), "+v"(y32));   // y32 rows: [A2, A3, A2, A3]
+            unsigned x3 = y16, y3 = y16;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x3), "+v"(y3));     // y3 rows: [A3, A3, A3, A3]
+            const float a1 = __builtin_bit_cast(float, y16);   // row 0 = A1
+            const float a2 = __builtin_bit_cast(float, y32);   // row 0 = A2
+            const float a3 = __builtin_bit_cast(float, y3);    // row 0 = A3
+            float sv = a + a1;                                 // ((A0 + A1) + A2) + A3 on lanes m<8
+            sv = sv + a2;
+            sv = sv + a3;
+            const float h = sv + dpp_f32<0x104>(sv);           // row_shl:4: low half + high half, lanes m<4
+            const float h0 = readlane_f32(h, 0), h1 = readlane_f32(h, 1), h2 = readlane_f32(h, 2), h3 = readlane_f32(h, 3);
             simd = (h0 + h1) + (h2 + h3);                      // two vhaddps
         } else {
             float acc = 0.0f;                                  // ymm k = lane/8 (lanes < 32)
@@ -1178,10 +1194,20 @@ __device__ __forceinline__ void write_outputs(const ChainArrays& A, int c, int t
 // diagonal mass adaptation (quadpotential.py:231-245, :324-340): both Welford estimators take the draw, the
 // foreground one becomes the float32 variance, the window switches every P.window samples
 struct MassScalars { double wsum_f, wsum_b; int wsel, n_samples, window; };
+// The four estimator rows of a chain (foreground / background mean and raw variance): all requested before any is used,
+// one HBM round trip per update instead of two.
+template <int NS>
+__device__ __forceinline__ void diag_mass_prefetch(const ChainArrays& A, long long row, const MassScalars& ms,
+                                                   double (&m)[NS], double (&r)[NS], double (&mb)[NS], double (&rb)[NS]) {
+    const long long plane = static_cast<long long>(A.chains) * A.dpad;
+    vload<NS>(A.wmean + ms.wsel * plane + row, m); vload<NS>(A.wraw + ms.wsel * plane + row, r);
+    vload<NS>(A.wmean + (1 - ms.wsel) * plane + row, mb); vload<NS>(A.wraw + (1 - ms.wsel) * plane + row, rb);
+}
 template <int NS>
 __device__ __forceinline__ void diag_mass_update(const ChainArrays& A, const SamplerParams& P, long long row, int tid,
                                                  const double (&q)[NS], float (&var)[NS], float (&inv_std)[NS],
-                                                 double (&vard)[NS], MassScalars& ms) {
+                                                 double (&vard)[NS], MassScalars& ms,
+                                                 double (&m)[NS], double (&r)[NS], double (&mb)[NS], double (&rb)[NS]) {
     const int d = A.d;
     const long long plane = static_cast<long long>(A.chains) * A.dpad;
     double* fm = A.wmean + ms.wsel * plane + row;
@@ -1191,9 +1217,6 @@ __device__ __forceinline__ void diag_mass_update(const ChainArrays& A, const Sam
     ms.wsum_f += 1.0;
     ms.wsum_b += 1.0;
     const double prop_f = first_f64(1.0 / ms.wsum_f), prop_b = first_f64(1.0 / ms.wsum_b);
-    // all four estimator rows are requested before any is used: one HBM round trip per update instead of two
-    double m[NS], r[NS], mb[NS], rb[NS];
-    vload<NS>(fm, m); vload<NS>(fr, r); vload<NS>(bm, mb); vload<NS>(br, rb);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const double od = q[s] - m[s];
@@ -1358,8 +1381,14 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         // ---- dual averaging (step_sizes.py:71-92)
         if (adapt_step) dual_average_update(A, P, out.accept, da);
 
-        // ---- diagonal mass adaptation (quadpotential.py:231-245, :324-340)
-        if (tune && P.adapt_mass) diag_mass_update<NS>(A, P, row, tid, q, var, inv_std, vard, ms);
+        // ---- diagonal mass adaptation (quadpotential.py:231-245, :324-340). (Requesting the estimator rows before the
+        // dual-averaging update, to take their HBM round trip off the critical path, measured -12 % at d = 128: sixteen
+        // more live registers across the update spill other state.)
+        if (tune && P.adapt_mass) {
+            double wm[NS], wr[NS], wmb[NS], wrb[NS];
+            diag_mass_prefetch<NS>(A, row, ms, wm, wr, wmb, wrb);
+            diag_mass_update<NS>(A, P, row, tid, q, var, inv_std, vard, ms, wm, wr, wmb, wrb);
+        }
 
         // ---- bookkeeping (base_hmc.py:164-190)
         if (out.diverging && !tune) ++ct_divs;

@@ -339,7 +339,9 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
             ms.wsum_f = first_f64(A.wsum[c * 2 + ms.wsel]);
             ms.wsum_b = first_f64(A.wsum[c * 2 + (1 - ms.wsel)]);
             ms.window = first_i32(A.awindow[c]);
-            diag_mass_update<NS>(A, P, row, lane, q, var, inv_std, vard, ms);
+            double wm[NS], wr[NS], wmb[NS], wrb[NS];
+            diag_mass_prefetch<NS>(A, row, ms, wm, wr, wmb, wrb);
+            diag_mass_update<NS>(A, P, row, lane, q, var, inv_std, vard, ms, wm, wr, wmb, wrb);
             if (lane == 0) {
                 A.n_samples[c] = ms.n_samples;
                 A.wsel[c] = ms.wsel;

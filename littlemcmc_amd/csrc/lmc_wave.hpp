@@ -42,6 +42,14 @@ __device__ __forceinline__ double dpp_f64(double x) {
     return __hiloint2double(hi, lo);
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float readlane_f32(float x, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+
 // Sum over the 64 lanes; result is wave-uniform (read from lane 63 into SGPRs).
 // Hillis-Steele inside each 16-lane row (row_shr 1,2,4,8), then row_bcast 15 / 31 across rows.
 __device__ __forceinline__ double wave_sum(double x) {
