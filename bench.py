@@ -312,7 +312,13 @@ def main():
         if keep_trace and not args.no_ess and n_total - n_tune >= 8:
             from littlemcmc_amd import diagnostics as dg
 
+            # one-time costs (loading the code objects of the statistics kernel and of the torch ops of the finalize
+            # step, ~0.7 s in a fresh process) are paid on a 64-chain slice first and reported separately
             torch.cuda.synchronize()
+            t_first = time.perf_counter()
+            dg.summarize(dg.trace_tensor(eng)[:64], reduce_device=red_dev)
+            torch.cuda.synchronize()
+            diag_first_s = time.perf_counter() - t_first
             t_ess = time.perf_counter()
             diag = dg.summarize(dg.trace_tensor(eng), reduce_device=red_dev)
             torch.cuda.synchronize()
@@ -320,8 +326,9 @@ def main():
             draw_s = sum(kernel_ms[s] for s in range(K) if s * ips >= trace_begin) / 1e3
             e = diag["ess"]
             ess = {"min": float(e.min()), "median": float(e.median()), "rhat_max": float(diag["rhat"].max()),
+                   "lag_passes": int(diag.get("lag_passes", 0)),
                    "draw_seconds": draw_s, "chains_total": int(diag["n_chains"] / 2), "draws": n_total - trace_begin,
-                   "diagnostics_seconds": diag_s, "definition": diag.get("definition", "")}
+                   "diagnostics_seconds": diag_s, "diagnostics_process_warmup_seconds": diag_first_s, "definition": diag.get("definition", "")}
         eng.close()
 
         wall_max, = all_reduce([wall], dist.ReduceOp.MAX)
@@ -407,7 +414,9 @@ def main():
                 "definition": "%s over all %d chains x %d post-warm-up draws; per second of post-warm-up kernel time "
                               "(slowest rank), and per second of kernel + diagnostics time" % (
                                   ess["definition"], ess["chains_total"], ess["draws"]),
-                "draw_seconds": ess["draw_seconds"], "diagnostics_seconds": ess["diagnostics_seconds"]},
+                "draw_seconds": ess["draw_seconds"], "diagnostics_seconds": ess["diagnostics_seconds"],
+                "lag_passes": ess["lag_passes"],
+                "diagnostics_process_warmup_seconds": ess["diagnostics_process_warmup_seconds"]},
             "divergences_after_tune": primary["div_after"],
             "roofline": roofline(primary),
             "source_hash": src_hash,
