@@ -102,15 +102,29 @@ def main():
                                                  " ".join("%s=%d" % kv for kv in sorted(b["count"].items()))))
     valu = sum(v for k, v in total.items() if k.startswith("v_"))
     print("blocks %d  VALU %d  %s" % (len(sel), valu, dict(sorted(total.items()))))
+    # per-loop totals (innermost loop each block belongs to), the kernel's resource metadata and the spill census
+    by_loop = collections.OrderedDict()
+    for b in blocks:
+        key = "%s depth %d" % (b["loop"] or "straight-line", b["depth"])
+        by_loop.setdefault(key, collections.Counter()).update(b["count"])
     meta = {}
-    for l in lines[end:end + 400] if end else []:
-        for key in (".vgpr_count", ".sgpr_count", ".private_segment_fixed_size", ".vgpr_spill_count", ".group_segment_fixed_size"):
-            pass
+    text = "\n".join(lines)
+    ky = text.find("amdhsa.kernels:")
+    if ky >= 0:      # one YAML list entry per kernel; take the one whose .name holds the requested substring
+        for entry in re.split(r"\n  - ", text[ky:]):
+            mname = re.search(r"\.name:\s*(\S+)", entry)
+            if mname and args.kernel in mname.group(1):
+                for m in re.finditer(r"\.(vgpr_count|agpr_count|sgpr_count|private_segment_fixed_size|vgpr_spill_count|"
+                                     r"sgpr_spill_count|group_segment_fixed_size|max_flat_workgroup_size):\s*(\d+)", entry):
+                    meta[m.group(1)] = int(m.group(2))
+                break
     if args.json:
         json.dump({"kernel": args.kernel, "loop": args.loop, "static_counts": dict(total), "valu_static": valu,
-                   "blocks": [{"label": b["label"], "depth": b["depth"], "counts": dict(b["count"])} for b in sel if b["count"]]},
+                   "metadata": meta,
+                   "by_loop": {k: dict(sorted(v.items())) for k, v in by_loop.items() if v},
+                   "blocks": [{"label": b["label"], "depth": b["depth"], "loop": b["loop"], "counts": dict(b["count"])}
+                              for b in sel if b["count"]]},
                   open(args.json, "w"), indent=1)
-
 
 if __name__ == "__main__":
     main()
