@@ -525,20 +525,21 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     if (nlds < 1) nlds = 1;
     e->nlds = nlds;
     e->lds_bytes = (2 + 4 * (nlds - 1)) * e->dpad * 8;
-    if (e->run_w == 1 && LMC_NUTS_ONE_WAVE_FORM) {
-        // pair form (nuts_transition2): compile-time plan PairLds<NS> -- reduction buffer, exp table, level scalars, cold
-        // slots, stack level 1 -- plus as many further levels as fit without lowering the occupancy; the rest of the
-        // stack goes to the chain's scratch row
+    if (run_pair_form(e->run_w) && e->run_ns <= 4) {
+        // pair form (nuts_transition2): compile-time plan PairLds<NS, W> -- reduction buffers, exp table, team combine
+        // area, level scalars, cold slots, stack level 1 -- plus as many further levels as fit without lowering the
+        // occupancy; the rest of the stack goes to the chain's scratch row
         const int waves_per_cu = 4 * run_waves_per_simd(e->run_ns);
-        const long budget = (163840L / waves_per_cu) / 1280 * 1280 - lds_tail_doubles(1) * 8L;
-        if (pair_min_doubles(e->run_ns) * 8L > budget)
+        const int blocks_per_cu = waves_per_cu / e->run_w > 0 ? waves_per_cu / e->run_w : 1;
+        const long budget = (163840L / blocks_per_cu) / 1280 * 1280 - lds_tail_doubles(e->run_w) * 8L;
+        if (pair_min_doubles(e->run_ns, e->run_w) * 8L > budget)
             return bail(fail(nullptr, LMC_ERR_INVALID, "pair form does not fit the LDS budget"));
         nlds = cfg->lds_levels > 0 ? cfg->lds_levels : 1;
         if (cfg->lds_levels <= 0)
-            while (nlds < max_levels && pair_total_doubles(e->run_ns, nlds + 1) * 8L <= budget) ++nlds;
+            while (nlds < max_levels && pair_total_doubles(e->run_ns, e->run_w, nlds + 1) * 8L <= budget) ++nlds;
         if (nlds > max_levels) nlds = max_levels;
         e->nlds = nlds;
-        e->lds_bytes = pair_total_doubles(e->run_ns, nlds) * 8;
+        e->lds_bytes = pair_total_doubles(e->run_ns, e->run_w, nlds) * 8;
     }
     if (e->lds_bytes > 160 * 1024) return bail(fail(nullptr, LMC_ERR_INVALID, "lds_levels too large"));
 

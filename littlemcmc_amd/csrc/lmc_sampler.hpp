@@ -638,13 +638,16 @@ constexpr int kLevelScalDoubles = 96;   // 4 per parked level, levels < 24 (max_
 enum ColdSlot : int { kColdAold = 0, kColdPsum = 1, kColdOp = 2, kColdOq = 3, kColdOg = 4, kNumCold = 5 };
 constexpr int kNumColdSlots = kNumCold;
 
-template <int NS>
-struct PairLds {   // offsets in doubles from the start of the block's dynamic LDS
-    static constexpr int DP = 64 * NS;
-    static constexpr int kRedSize = (2 * DP > 64 * kRedValues) ? 2 * DP : 64 * kRedValues;   // also normals / sdot staging
+template <int NS, int W = 1>
+struct PairLds {   // offsets in doubles from the start of the block's dynamic LDS; W waves share one plan
+    static constexpr int DP = 64 * NS * W;
+    static constexpr int kRedWave = 64 * kRedValues;              // one reduction buffer per wave
+    static constexpr int kRedSize = (2 * DP > W * kRedWave) ? 2 * DP : W * kRedWave;   // also normals / sdot staging
     static constexpr int kExp = kRedSize;
-    static constexpr int kScal = kExp + kExpTableDoubles;
-    static constexpr int kCold = kScal + kLevelScalDoubles;
+    static constexpr int kXsum = kExp + kExpTableDoubles;         // team combine area (W > 1): 2 buffers x 8 sums x W waves
+    static constexpr int kXsumSize = W > 1 ? 2 * 8 * W : 0;
+    static constexpr int kScal = kXsum + kXsumSize;               // per-level scalars, one copy per wave
+    static constexpr int kCold = kScal + W * kLevelScalDoubles;
     static constexpr int kColdLds = LMC_PAIR_COLD_LDS;           // cold slots in LDS; the others head the scratch row
     static constexpr int kL1 = kCold + kColdLds * DP;             // level 1: {lp, rp, q}
     static constexpr int kL2 = kL1 + 3 * DP;                      // levels 2..nlds: {lp, rp, psum, q}
@@ -652,25 +655,39 @@ struct PairLds {   // offsets in doubles from the start of the block's dynamic L
     static constexpr int kGlbLevels = (kNumCold - kColdLds) * DP; // scratch row: cold slots not in LDS, then levels > nlds
     __host__ __device__ static constexpr int total_doubles(int nlds) { return kL2 + (nlds > 1 ? (nlds - 1) * 4 * DP : 0); }
 };
-constexpr int pair_min_doubles(int ns) { return ns == 1 ? PairLds<1>::kMinDoubles : ns == 2 ? PairLds<2>::kMinDoubles : PairLds<4>::kMinDoubles; }
-constexpr int pair_total_doubles(int ns, int nlds) {
-    return ns == 1 ? PairLds<1>::total_doubles(nlds) : ns == 2 ? PairLds<2>::total_doubles(nlds) : PairLds<4>::total_doubles(nlds);
+constexpr int pair_min_doubles(int ns, int w) {
+    return w == 1 ? (ns == 1 ? PairLds<1>::kMinDoubles : ns == 2 ? PairLds<2>::kMinDoubles : PairLds<4>::kMinDoubles)
+         : w == 2 ? PairLds<4, 2>::kMinDoubles : PairLds<4, 4>::kMinDoubles;
+}
+constexpr int pair_total_doubles(int ns, int w, int nlds) {
+    return w == 1 ? (ns == 1 ? PairLds<1>::total_doubles(nlds) : ns == 2 ? PairLds<2>::total_doubles(nlds) : PairLds<4>::total_doubles(nlds))
+         : w == 2 ? PairLds<4, 2>::total_doubles(nlds) : PairLds<4, 4>::total_doubles(nlds);
 }
 
 struct PairCtx {
     double* lds;        // block's dynamic LDS
     double* glb;        // this chain's scratch row
     int nlds;           // stack levels 1..nlds live in LDS (>= 1)
-    int red_lane;       // lane * 8: this lane's 64-byte row of the reduction buffer (doubles)
+    int red_lane;       // this lane's 64-byte row of its wave's reduction buffer (doubles, rotation included)
+    int wave_red;       // this wave's reduction buffer (doubles; 0 for W = 1)
+    int wave_scal;      // this wave's copy of the level scalars (doubles; 0 for W = 1)
+    int wave;           // wave index in the team
+    int xpar;           // which team combine buffer the next reduction uses
 };
 
 // ---- batched lane reductions through LDS ("transposed" reduction)
-template <int NS>
+template <int NS, int W = 1>
 __device__ __forceinline__ void red_put(const PairCtx& cx, int v, double x) {
-    ((lds_double*)cx.lds)[v * 64 + lane_id()] = x;
+    if constexpr (W == 1) ((lds_double*)cx.lds)[v * 64 + lane_id()] = x;
+    else ((lds_double*)cx.lds)[v * 64 + lane_id() + cx.wave_red] = x;
 }
-// lane 8k+7 of the result holds the wave sum of value k (k < kRedValues); other lanes hold partial scans
-__device__ __forceinline__ double red_gather(const PairCtx& cx) {
+// lane 8k+7 of the result holds the sum of value k (k < kRedValues) over the whole team; other lanes hold partial scans
+// (W = 1) or the same totals (W > 1).
+// Team (W > 1): every wave reduces its own buffer, lanes 8k+7 drop the wave's six sums into a double-buffered combine
+// area, ONE barrier, every wave adds the W partials in wave order (the same value in every wave). A wave can reach
+// the next-but-one reduction (same buffer) only after every wave has passed the barrier in between.
+template <int NS, int W = 1>
+__device__ __forceinline__ double red_gather(PairCtx& cx) {
     typedef double d2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) d2 lds_d2;
     asm volatile("" ::: "memory");   // DS operations of one wave execute in issue order: no wait, only no reordering
@@ -686,6 +703,17 @@ __device__ __forceinline__ double red_gather(const PairCtx& cx) {
     s += dpp_f64<0x111>(s);
     s += dpp_f64<0x112>(s);
     s += dpp_f64<0x114>(s);
+    if constexpr (W > 1) {
+        const int lane = lane_id();
+        lds_double* xs = L + (PairLds<NS, W>::kXsum + cx.xpar * (8 * W)) + (lane >> 3) * W;
+        if ((lane & 7) == 7) xs[cx.wave] = s;
+        __syncthreads();
+        double t = xs[0];
+#pragma unroll
+        for (int w = 1; w < W; ++w) t += xs[w];
+        s = t;
+        cx.xpar ^= 1;
+    }
     return s;
 }
 __device__ __forceinline__ int red_lane_init() {
@@ -704,13 +732,13 @@ __device__ __forceinline__ bool red_any_nonpositive(double s, int k0, int n) {
 // exp on lanes (arguments <= ~700; very negative ones underflow to 0): exp_uniform_fast's algorithm with a 32-entry
 // 2^(j/32) table read from LDS by every lane: x = (32 e + j) ln2/32 + r, |r| <= ln2/64, degree-6 polynomial
 // (truncation r^7/5040 < 4e-18 relative). |error| < ~1 ulp.
-template <int NS>
+template <int NS, int W = 1>
 __device__ __forceinline__ double exp_lanes(const PairCtx& cx, double x) {
     const double kf = rint(x * LMC_SC(46.166241308446828));            // 32 / ln 2
     double r = __builtin_fma(-kf, LMC_SC(2.16608493865351192654e-02), x);   // ln2/32 hi
     r = __builtin_fma(-kf, LMC_SC(5.96317165397058656256e-12), r);          // ln2/32 lo
     const int ki = static_cast<int>(kf);
-    const double t = ((const lds_double*)cx.lds)[PairLds<NS>::kExp + (ki & 31)];
+    const double t = ((const lds_double*)cx.lds)[PairLds<NS, W>::kExp + (ki & 31)];
     double p = fma_sgpr_addend(r, LMC_SC(1.0 / 720.0), LMC_SC(1.0 / 120.0));
     p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 24.0));
     p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 6.0));
@@ -721,75 +749,75 @@ __device__ __forceinline__ double exp_lanes(const PairCtx& cx, double x) {
 }
 
 // ---- cold slots and subtree-stack levels: LDS offsets are immediates, the scratch row takes what does not fit
-template <int NS, int SLOT>
+template <int NS, int W, int SLOT>
 __device__ __forceinline__ void cold_load(const PairCtx& cx, double (&x)[NS]) {
-    using L = PairLds<NS>;
+    using L = PairLds<NS, W>;
     if constexpr (SLOT < L::kColdLds) vload_as<NS>((lds_double*)cx.lds + (L::kCold + SLOT * L::DP), x);
     else vload_as<NS>((glb_double*)cx.glb + (SLOT - L::kColdLds) * L::DP, x);
 }
-template <int NS, int SLOT>
+template <int NS, int W, int SLOT>
 __device__ __forceinline__ void cold_store(const PairCtx& cx, const double (&x)[NS]) {
-    using L = PairLds<NS>;
+    using L = PairLds<NS, W>;
     if constexpr (SLOT < L::kColdLds) vstore_as<NS>((lds_double*)cx.lds + (L::kCold + SLOT * L::DP), x);
     else vstore_as<NS>((glb_double*)cx.glb + (SLOT - L::kColdLds) * L::DP, x);
 }
 // level 1 (always LDS): {lp, rp, q}
-template <int NS>
+template <int NS, int W = 1>
 __device__ __forceinline__ void level1_load(const PairCtx& cx, double (&lp)[NS], double (&rp)[NS], double (&ps)[NS]) {
-    using L = PairLds<NS>;
+    using L = PairLds<NS, W>;
     lds_double* b = (lds_double*)cx.lds + L::kL1;
     vload_as<NS>(b, lp); vload_as<NS>(b + L::DP, rp);
 #pragma unroll
     for (int s = 0; s < NS; ++s) ps[s] = lp[s] + rp[s];   // the very sum the pair formed (nuts.py:386)
 }
-template <int NS>
+template <int NS, int W = 1>
 __device__ __forceinline__ void level1_store(const PairCtx& cx, const double (&lp)[NS], const double (&rp)[NS], const double (&pq)[NS]) {
-    using L = PairLds<NS>;
+    using L = PairLds<NS, W>;
     lds_double* b = (lds_double*)cx.lds + L::kL1;
     vstore_as<NS>(b, lp); vstore_as<NS>(b + L::DP, rp); vstore_as<NS>(b + 2 * L::DP, pq);
 }
 // offset (doubles) of vector v of level j > nlds in the scratch row. Opaque to the optimiser on purpose: a
 // loop-invariant level (the peeled j = 2) would otherwise get its per-lane 64-bit address precomputed outside the pair
 // loop and kept in (spilled) registers; this way the access is scalar base + uniform offset + the lane-offset register
-template <int NS>
+template <int NS, int W = 1>
 __device__ __forceinline__ unsigned glb_level_offset(const PairCtx& cx, int j, int v) {
-    using L = PairLds<NS>;
+    using L = PairLds<NS, W>;
     unsigned off = L::kGlbLevels + static_cast<unsigned>(j - cx.nlds - 1) * (4u * L::DP) + static_cast<unsigned>(v) * L::DP;
     asm volatile("" : "+s"(off));
     return off;
 }
 // levels j >= 2: {lp, rp, psum, q}; vector index v in 0..3
-template <int NS>
+template <int NS, int W = 1>
 __device__ __forceinline__ void levelN_load(const PairCtx& cx, int j, int v, double (&x)[NS]) {
-    using L = PairLds<NS>;
+    using L = PairLds<NS, W>;
     if (j <= cx.nlds) vload_as<NS>((lds_double*)cx.lds + (L::kL2 + (j - 2) * 4 * L::DP + v * L::DP), x);
-    else vload_as<NS>((glb_double*)cx.glb + glb_level_offset<NS>(cx, j, v), x);
+    else vload_as<NS>((glb_double*)cx.glb + glb_level_offset<NS, W>(cx, j, v), x);
 }
-template <int NS>
+template <int NS, int W = 1>
 __device__ __forceinline__ void levelN_store(const PairCtx& cx, int j, int v, const double (&x)[NS]) {
-    using L = PairLds<NS>;
+    using L = PairLds<NS, W>;
     if (j <= cx.nlds) vstore_as<NS>((lds_double*)cx.lds + (L::kL2 + (j - 2) * 4 * L::DP + v * L::DP), x);
-    else vstore_as<NS>((glb_double*)cx.glb + glb_level_offset<NS>(cx, j, v), x);
+    else vstore_as<NS>((glb_double*)cx.glb + glb_level_offset<NS, W>(cx, j, v), x);
 }
 // left-end momentum / proposal position of any level j >= 1
-template <int NS>
+template <int NS, int W = 1>
 __device__ __forceinline__ void level_load_lp(const PairCtx& cx, int j, double (&x)[NS]) {
-    if (j == 1) vload_as<NS>((lds_double*)cx.lds + PairLds<NS>::kL1, x); else levelN_load<NS>(cx, j, 0, x);
+    if (j == 1) vload_as<NS>((lds_double*)cx.lds + PairLds<NS, W>::kL1, x); else levelN_load<NS, W>(cx, j, 0, x);
 }
-template <int NS>
+template <int NS, int W = 1>
 __device__ __forceinline__ void level_load_q(const PairCtx& cx, int j, double (&x)[NS]) {
-    if (j == 1) vload_as<NS>((lds_double*)cx.lds + (PairLds<NS>::kL1 + 2 * PairLds<NS>::DP), x); else levelN_load<NS>(cx, j, 3, x);
+    if (j == 1) vload_as<NS>((lds_double*)cx.lds + (PairLds<NS, W>::kL1 + 2 * PairLds<NS, W>::DP), x); else levelN_load<NS, W>(cx, j, 3, x);
 }
-template <int NS>
+template <int NS, int W = 1>
 __device__ __forceinline__ void level_scal_put(const PairCtx& cx, int j, double w, double a, double pe, double plogp) {
     if (lane_id() == 0) {
-        lds_double* s = (lds_double*)cx.lds + (PairLds<NS>::kScal + 4 * j);
+        lds_double* s = (lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * j) + (W > 1 ? cx.wave_scal : 0);
         s[0] = w; s[1] = a; s[2] = pe; s[3] = plogp;
     }
 }
-template <int NS>
+template <int NS, int W = 1>
 __device__ __forceinline__ void level_scal_get(const PairCtx& cx, int j, double& w, double& a, double& pe, double& plogp) {
-    const lds_double* s = (const lds_double*)cx.lds + (PairLds<NS>::kScal + 4 * j);   // same address in every lane: LDS broadcast
+    const lds_double* s = (const lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * j) + (W > 1 ? cx.wave_scal : 0);   // same address in every lane: LDS broadcast
     w = s[0]; a = s[1]; pe = s[2]; plogp = s[3];
 }
 
@@ -811,7 +839,7 @@ __device__ __forceinline__ void leapfrog_partial(TeamT& tm, const Target& tgt, c
         lp_part = tgt.logp_grad_partial(tm, q, g);
     } else {
         const double lp = first_f64(tgt.logp_grad(tm, q, g));
-        lp_part = (lane_id() == 0) ? lp : 0.0;
+        lp_part = (tm.tid() == 0) ? lp : 0.0;
     }
     double kin = 0.0;
 #pragma unroll
@@ -824,8 +852,8 @@ __device__ __forceinline__ void leapfrog_partial(TeamT& tm, const Target& tgt, c
 }
 
 // one cascade level: node a = {alp, arp, aps} (earlier), in-flight node {tl (left end), tps, right end velocity v}
-template <int NS>
-__device__ __forceinline__ double cascade_dots(const PairCtx& cx, const double (&var)[NS], const double (&alp)[NS],
+template <int NS, int W = 1>
+__device__ __forceinline__ double cascade_dots(PairCtx& cx, const double (&var)[NS], const double (&alp)[NS],
                                                const double (&arp)[NS], const double (&aps)[NS], const double (&tl)[NS],
                                                double (&tps)[NS], const double (&v)[NS]) {
     double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0, d4 = 0.0, d5 = 0.0;
@@ -840,25 +868,25 @@ __device__ __forceinline__ double cascade_dots(const PairCtx& cx, const double (
         d4 = __builtin_fma(p2, varp, d4); d5 = __builtin_fma(p2, v[s], d5);
         tps[s] = ps;
     }
-    red_put<NS>(cx, 0, d0); red_put<NS>(cx, 1, d1); red_put<NS>(cx, 2, d2);
-    red_put<NS>(cx, 3, d3); red_put<NS>(cx, 4, d4); red_put<NS>(cx, 5, d5);
-    return red_gather(cx);
+    red_put<NS, W>(cx, 0, d0); red_put<NS, W>(cx, 1, d1); red_put<NS, W>(cx, 2, d2);
+    red_put<NS, W>(cx, 3, d3); red_put<NS, W>(cx, 4, d4); red_put<NS, W>(cx, 5, d5);
+    return red_gather<NS, W>(cx);
 }
 
 // On return the chain's row of A.q (qrow) holds the proposal; q is NOT updated (the caller reloads it).
 template <int NS, class Target, class TeamT>
 __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const double (&var)[NS], RngState& rng,
-                                        const PairCtx& cx, double* qrow, const double (&q)[NS],
+                                        PairCtx& cx, double* qrow, const double (&q)[NS],
                                         const double (&p0)[NS], const double (&g0)[NS], double e0, double logp0,
                                         double step_size, double emax, int max_depth, bool momentum_f32,
                                         TransitionOut& out) {
-    static_assert(TeamT::kWaves == 1, "one-wave form");
+    constexpr int W = TeamT::kWaves;
     // {cq, cp, cg}: the trajectory end that is being (or was last) extended (registers); the other end, the running
     // momentum sum and the extended end's momentum before the doubling are cold slots
     double cq[NS], cp[NS], cg[NS];
     vcopy(cq, q); vcopy(cp, p0); vcopy(cg, g0);
-    cold_store<NS, kColdOq>(cx, q); cold_store<NS, kColdOp>(cx, p0); cold_store<NS, kColdOg>(cx, g0);
-    cold_store<NS, kColdPsum>(cx, p0);
+    cold_store<NS, W, kColdOq>(cx, q); cold_store<NS, W, kColdOp>(cx, p0); cold_store<NS, W, kColdOg>(cx, g0);
+    cold_store<NS, W, kColdPsum>(cx, p0);
     bool c_right = true;                                    // which end {c*} is
     bool c_start = momentum_f32, o_start = momentum_f32;    // end still is the float32 start state
     double prop_e = e0, prop_logp = logp0;
@@ -888,7 +916,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                 const double f = exp_uniform(coff - x);
                 const int lane = lane_id();
                 if (lane >= 1 && lane < kLevelScalDoubles / 4) {
-                    lds_double* sc = (lds_double*)cx.lds + (PairLds<NS>::kScal + 4 * lane);
+                    lds_double* sc = (lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * lane) + (W > 1 ? cx.wave_scal : 0);
                     sc[0] = sc[0] * f; sc[1] = sc[1] * f;
                 }
                 wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
@@ -900,7 +928,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         const double x = -de;
         const double xn = dpp_f64<0x101>(x);                   // row_shl:1: lane l <- lane l+1
         const double arg = odd_lane ? (x - coff) : ((xn - coff) + fmin(xn, 0.0));
-        ev = exp_lanes<NS>(cx, arg);
+        ev = exp_lanes<NS, W>(cx, arg);
         return ok;
     };
 
@@ -909,13 +937,13 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         const double eps = right ? step_size : -step_size;
         if (right != c_right) {   // the other end becomes the one that is extended
             double t[NS];
-            cold_load<NS, kColdOq>(cx, t); cold_store<NS, kColdOq>(cx, cq); vcopy(cq, t);
-            cold_load<NS, kColdOp>(cx, t); cold_store<NS, kColdOp>(cx, cp); vcopy(cp, t);
-            cold_load<NS, kColdOg>(cx, t); cold_store<NS, kColdOg>(cx, cg); vcopy(cg, t);
+            cold_load<NS, W, kColdOq>(cx, t); cold_store<NS, W, kColdOq>(cx, cq); vcopy(cq, t);
+            cold_load<NS, W, kColdOp>(cx, t); cold_store<NS, W, kColdOp>(cx, cp); vcopy(cp, t);
+            cold_load<NS, W, kColdOg>(cx, t); cold_store<NS, W, kColdOg>(cx, cg); vcopy(cg, t);
             const bool tb = c_start; c_start = o_start; o_start = tb;
             c_right = right;
         }
-        cold_store<NS, kColdAold>(cx, cp);   // momentum of the extended end before this doubling (nuts.py:332-338 operands)
+        cold_store<NS, W, kColdAold>(cx, cp);   // momentum of the extended end before this doubling (nuts.py:332-338 operands)
         const bool aold_start = c_start;
 
         // subtree node under construction: momentum sum tps, weights; its right-end momentum is always the current cp,
@@ -927,8 +955,8 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         if (D == 0) {
             double v[NS], kinp, lp, en, ev;
             leapfrog_partial<NS>(tm, tgt, var, eps, cq, cp, cg, v, kinp, lp);
-            red_put<NS>(cx, 0, kinp); red_put<NS>(cx, 1, lp);   // (DPP butterflies for the lone leaf and the trajectory-level
-            const double s0 = red_gather(cx);                   //  test measured 1 % slower on depth-3 trees, equal on C3)
+            red_put<NS, W>(cx, 0, kinp); red_put<NS, W>(cx, 1, lp);   // (DPP butterflies for the lone leaf and the trajectory-level
+            const double s0 = red_gather<NS, W>(cx);                   //  test measured 1 % slower on depth-3 trees, equal on C3)
             if (leaf_scalars(s0, 1, en, ev) == 1) {
                 tw = readlane_f64(ev, 15); ta = readlane_f64(ev, 14);
                 tpe = readlane_f64(en, 15); tplogp = readlane_f64(s0, 15);
@@ -939,15 +967,15 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
             for (int k = 0; k < n_pairs; ++k) {
                 double v[NS], kinA, lpA, kinB, lpB;
                 leapfrog_partial<NS>(tm, tgt, var, eps, cq, cp, cg, v, kinA, lpA);
-                red_put<NS>(cx, 0, kinA); red_put<NS>(cx, 1, lpA);
+                red_put<NS, W>(cx, 0, kinA); red_put<NS, W>(cx, 1, lpA);
                 vcopy(eq, cq); vcopy(ep, cp);
                 leapfrog_partial<NS>(tm, tgt, var, eps, cq, cp, cg, v, kinB, lpB);   // speculative w.r.t. the first leaf's divergence test
-                red_put<NS>(cx, 2, kinB); red_put<NS>(cx, 3, lpB);
+                red_put<NS, W>(cx, 2, kinB); red_put<NS, W>(cx, 3, lpB);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) tps[s] = ep[s] + cp[s];
-                red_put<NS>(cx, 4, pdot_v<NS>(tps, var, ep));   // var (.) ep is the first leaf's velocity, re-formed (same rounded product)
-                red_put<NS>(cx, 5, pdot<NS>(tps, v));
-                const double s0 = red_gather(cx);
+                red_put<NS, W>(cx, 4, pdot_v<NS>(tps, var, ep));   // var (.) ep is the first leaf's velocity, re-formed (same rounded product)
+                red_put<NS, W>(cx, 5, pdot<NS>(tps, v));
+                const double s0 = red_gather<NS, W>(cx);
                 // this pair closes m right children (levels 1..m)
                 const int m = __builtin_ctz(~static_cast<unsigned>(k) | (1u << (D - 1)));
                 double en, ev;
@@ -969,9 +997,9 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                 if (m >= 1) {
                     double alp[NS], arp[NS], aps[NS];
                     double aw, aa, ape, aplogp;
-                    level1_load<NS>(cx, alp, arp, aps);   // (requesting it before the leaf scalars measured -8 %: one more live address)
-                    level_scal_get<NS>(cx, 1, aw, aa, ape, aplogp);
-                    const double sj = cascade_dots<NS>(cx, var, alp, arp, aps, ep, tps, v);
+                    level1_load<NS, W>(cx, alp, arp, aps);   // (requesting it before the leaf scalars measured -8 %: one more live address)
+                    level_scal_get<NS, W>(cx, 1, aw, aa, ape, aplogp);
+                    const double sj = cascade_dots<NS, W>(cx, var, alp, arp, aps, ep, tps, v);
                     const bool turn = red_any_nonpositive(sj, 0, 6);
                     const double wsum = aw + tw;
                     const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < tw);
@@ -982,11 +1010,11 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                 // ---- cascade levels 2..m: node a = stack[j]; the in-flight node's left end is stack[j-1]'s
                 for (int j = 2; j <= m; ++j) {
                     double blp[NS], brp[NS], bps[NS], tl[NS];
-                    levelN_load<NS>(cx, j, 0, blp); levelN_load<NS>(cx, j, 1, brp); levelN_load<NS>(cx, j, 2, bps);
-                    level_load_lp<NS>(cx, j - 1, tl);
+                    levelN_load<NS, W>(cx, j, 0, blp); levelN_load<NS, W>(cx, j, 1, brp); levelN_load<NS, W>(cx, j, 2, bps);
+                    level_load_lp<NS, W>(cx, j - 1, tl);
                     double bw, ba, bpe, bplogp;
-                    level_scal_get<NS>(cx, j, bw, ba, bpe, bplogp);
-                    const double sj = cascade_dots<NS>(cx, var, blp, brp, bps, tl, tps, v);
+                    level_scal_get<NS, W>(cx, j, bw, ba, bpe, bplogp);
+                    const double sj = cascade_dots<NS, W>(cx, var, blp, brp, bps, tl, tps, v);
                     const bool turn = red_any_nonpositive(sj, 0, 6);
                     const double wsum = bw + tw;
                     const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < tw);
@@ -997,17 +1025,17 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                 if (turning) break;
                 if (k + 1 < n_pairs) {   // park the node at level m + 1 (the last pair's cascade result stays in flight)
                     double tl[NS], tqv[NS];
-                    if (m == 0) vcopy(tl, ep); else level_load_lp<NS>(cx, m, tl);
+                    if (m == 0) vcopy(tl, ep); else level_load_lp<NS, W>(cx, m, tl);
                     if (qsrc == -1) vcopy(tqv, cq);
                     else if (qsrc == -2) vcopy(tqv, eq);
-                    else level_load_q<NS>(cx, qsrc, tqv);
+                    else level_load_q<NS, W>(cx, qsrc, tqv);
                     if (m == 0) {
-                        level1_store<NS>(cx, tl, cp, tqv);
+                        level1_store<NS, W>(cx, tl, cp, tqv);
                     } else {
-                        levelN_store<NS>(cx, m + 1, 0, tl); levelN_store<NS>(cx, m + 1, 1, cp);
-                        levelN_store<NS>(cx, m + 1, 2, tps); levelN_store<NS>(cx, m + 1, 3, tqv);
+                        levelN_store<NS, W>(cx, m + 1, 0, tl); levelN_store<NS, W>(cx, m + 1, 1, cp);
+                        levelN_store<NS, W>(cx, m + 1, 2, tps); levelN_store<NS, W>(cx, m + 1, 3, tqv);
                     }
-                    level_scal_put<NS>(cx, m + 1, tw, ta, tpe, tplogp);
+                    level_scal_put<NS, W>(cx, m + 1, tw, ta, tpe, tplogp);
                 }
             }
         }
@@ -1019,7 +1047,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
             double tqv[NS];
             if (qsrc == -1) vcopy(tqv, cq);
             else if (qsrc == -2) vcopy(tqv, eq);
-            else level_load_q<NS>(cx, qsrc, tqv);
+            else level_load_q<NS, W>(cx, qsrc, tqv);
             vstore_as<NS>((glb_double*)qrow, tqv);
             prop_e = tpe; prop_logp = tplogp;
         }
@@ -1028,14 +1056,14 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         double tlp[NS], psum[NS], op[NS], aold[NS];
         if (D == 0) vcopy(tlp, cp);
         else if (D == 1) vcopy(tlp, ep);
-        else level_load_lp<NS>(cx, D - 1, tlp);
-        cold_load<NS, kColdPsum>(cx, psum); cold_load<NS, kColdOp>(cx, op); cold_load<NS, kColdAold>(cx, aold);
+        else level_load_lp<NS, W>(cx, D - 1, tlp);
+        cold_load<NS, W, kColdPsum>(cx, psum); cold_load<NS, W, kColdOp>(cx, op); cold_load<NS, W, kColdAold>(cx, aold);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {   // in place; float32 storage when the start momentum is float32
             const double t = psum[s] + tps[s];
             psum[s] = momentum_f32 ? static_cast<double>(static_cast<float>(t)) : t;
         }
-        cold_store<NS, kColdPsum>(cx, psum);
+        cold_store<NS, W, kColdPsum>(cx, psum);
         double ov[NS], av[NS];   // velocities of the untouched end and of the extended end as it was before this doubling
         end_velocity<NS>(ov, var, op, o_start);
         end_velocity<NS>(av, var, aold, aold_start);
@@ -1060,9 +1088,9 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
             }
         }
         c_start = false;
-        red_put<NS>(cx, 0, d0); red_put<NS>(cx, 1, d1); red_put<NS>(cx, 2, d2);
-        red_put<NS>(cx, 3, d3); red_put<NS>(cx, 4, d4); red_put<NS>(cx, 5, d5);
-        if (red_any_nonpositive(red_gather(cx), 0, 6)) { turning = true; exhausted = false; break; }
+        red_put<NS, W>(cx, 0, d0); red_put<NS, W>(cx, 1, d1); red_put<NS, W>(cx, 2, d2);
+        red_put<NS, W>(cx, 3, d3); red_put<NS, W>(cx, 4, d4); red_put<NS, W>(cx, 5, d5);
+        if (red_any_nonpositive(red_gather<NS, W>(cx), 0, 6)) { turning = true; exhausted = false; break; }
     }
 
     const double mean_accept = (wn > 0.0) ? first_f64(an / wn) : 0.0;
@@ -1083,8 +1111,12 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
 // is register resident, so wider per-thread slices trade occupancy for registers. Chains longer than
 // 128 elements are spread over W waves (dpad = 64 * NS * W) instead of growing NS further.
 #ifndef LMC_NUTS_ONE_WAVE_FORM
-#define LMC_NUTS_ONE_WAVE_FORM 1   // 1: one-wave kernels (d <= 256) use nuts_transition2 (pair form) and its LDS plan; 0: leaf form everywhere
+#define LMC_NUTS_ONE_WAVE_FORM 1   // 1: one-wave kernels (d <= 256) use nuts_transition2 (pair form) and its LDS plan; 0: leaf form
 #endif
+#ifndef LMC_NUTS_TEAM_PAIR_FORM
+#define LMC_NUTS_TEAM_PAIR_FORM 1  // 1: team kernels (W = 2, 4) use the pair form too (one barrier per batched reduction); 0: leaf form
+#endif
+constexpr bool run_pair_form(int w) { return w == 1 ? LMC_NUTS_ONE_WAVE_FORM != 0 : LMC_NUTS_TEAM_PAIR_FORM != 0; }
 #ifndef LMC_WAVES_NS1
 #define LMC_WAVES_NS1 4
 #endif
@@ -1317,13 +1349,19 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     stk.nlds = P.nlds;
     stk.dpad = dpad;
     // pair form (nuts_transition2): compile-time LDS plan (PairLds<NS>), the chain's scratch row for what does not fit
+    constexpr bool kPairForm = run_pair_form(W) && NS <= 4;
     PairCtx cx;
     cx.lds = lds;
     cx.glb = stk.glb;
     cx.nlds = P.nlds;
-    cx.red_lane = red_lane_init();
-    if constexpr (W == 1 && LMC_NUTS_ONE_WAVE_FORM && NS <= 4) {
-        if (tid < kExpTableDoubles) lds[PairLds<NS>::kExp + tid] = kExp2Table[2 * tid];
+    cx.wave = tm.wave();
+    cx.wave_red = W > 1 ? cx.wave * PairLds<NS, W>::kRedWave : 0;
+    cx.wave_scal = W > 1 ? cx.wave * kLevelScalDoubles : 0;
+    cx.red_lane = red_lane_init() + cx.wave_red;
+    cx.xpar = 0;
+    if constexpr (kPairForm) {
+        if (tid < kExpTableDoubles) lds[PairLds<NS, W>::kExp + tid] = kExp2Table[2 * tid];
+        tm.sync();
     }
 
     for (int it = 0; it < P.n_iters; ++it) {
@@ -1364,7 +1402,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         TransitionOut out;
         if (P.kind == 0) {
             const int md = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
-            if constexpr (W == 1 && LMC_NUTS_ONE_WAVE_FORM && NS <= 4) {
+            if constexpr (kPairForm) {
                 nuts_transition2<NS>(tm, tgt, vard, rng, cx, A.q + row, q, p0, g0, e0, logp0, step_size, P.emax, md,
                                      P.momentum_f32 != 0, out);
                 vload<NS>(A.q + row, q);   // the proposal was written to the chain's row of A.q
