@@ -655,13 +655,19 @@ struct PairLds {   // offsets in doubles from the start of the block's dynamic L
     static constexpr int kGlbLevels = (kNumCold - kColdLds) * DP; // scratch row: cold slots not in LDS, then levels > nlds
     __host__ __device__ static constexpr int total_doubles(int nlds) { return kL2 + (nlds > 1 ? (nlds - 1) * 4 * DP : 0); }
 };
+// (ns, w) -> plan sizes for the host (every shape run_kernel is instantiated for)
+#define LMC_PAIR_SHAPES(X) X(1, 1) X(2, 1) X(4, 1) X(4, 2) X(4, 4)
 constexpr int pair_min_doubles(int ns, int w) {
-    return w == 1 ? (ns == 1 ? PairLds<1>::kMinDoubles : ns == 2 ? PairLds<2>::kMinDoubles : PairLds<4>::kMinDoubles)
-         : w == 2 ? PairLds<4, 2>::kMinDoubles : PairLds<4, 4>::kMinDoubles;
+#define X(NSV, WV) if (ns == NSV && w == WV) return PairLds<NSV, WV>::kMinDoubles;
+    LMC_PAIR_SHAPES(X)
+#undef X
+    return 1 << 30;
 }
 constexpr int pair_total_doubles(int ns, int w, int nlds) {
-    return w == 1 ? (ns == 1 ? PairLds<1>::total_doubles(nlds) : ns == 2 ? PairLds<2>::total_doubles(nlds) : PairLds<4>::total_doubles(nlds))
-         : w == 2 ? PairLds<4, 2>::total_doubles(nlds) : PairLds<4, 4>::total_doubles(nlds);
+#define X(NSV, WV) if (ns == NSV && w == WV) return PairLds<NSV, WV>::total_doubles(nlds);
+    LMC_PAIR_SHAPES(X)
+#undef X
+    return 1 << 30;
 }
 
 struct PairCtx {

@@ -327,12 +327,8 @@ struct UserTarget {
 """
 
 
-def test_user_target_is_compiled_and_sampled():
-    import shutil
-
-    if shutil.which("hipcc") is None and not __import__("os").path.exists("/opt/rocm/bin/hipcc"):
-        pytest.skip("hipcc not available on this box")
-    d = 70
+@pytest.mark.parametrize("d", [70, 1000])   # one wavefront per chain / a team of four (72 KB of dynamic LDS)
+def test_user_target_is_compiled_and_sampled(d):
     mu = np.linspace(-2.0, 3.0, d)
     tgt = lmc.targets.UserTarget(d, USER_SRC, params=mu)
     q = np.random.RandomState(0).randn(d)
