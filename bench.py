@@ -279,23 +279,34 @@ def main():
             if n_total - n_tune > fit:
                 trace_begin = n_total - max(fit, 1)
         eng = new_job(n_total, trace_begin, keep_trace=keep_trace)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        # HIP events on the streams the kernel is launched on: the engine launches its chains as sub-blocks (two halves on
+        # two internal streams, lmc_engine_run_streams), so a step is `len(run_streams)` concurrent dispatches
+        run_streams = [torch.cuda.ExternalStream(h, device=torch.device("cuda", local_rank)) for h in eng.run_streams()]
+        nst = len(run_streams)
+        ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nst)] for _ in range(K)]
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for s in range(K):
-            ev[s][0].record(stream)
+            for b in range(nst):
+                ev[s][b][0].record(run_streams[b])
             eng.run(n_tune, s * ips, ips)
-            ev[s][1].record(stream)
+            for b in range(nst):
+                ev[s][b][1].record(run_streams[b])
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
 
-        kernel_ms = [a.elapsed_time(b) for a, b in ev]
+        dispatch_ms = [[a.elapsed_time(b) for a, b in ev[s]] for s in range(K)]          # per dispatch, what rocprofv3 lists
+
+        def span_ms(s0):   # kernel-busy time from the start of step s0 to the end of the last step
+            return max(ev[s0][b0][0].elapsed_time(ev[K - 1][b1][1]) for b0 in range(nst) for b1 in range(nst))
+
+        kernel_ms = [span_ms(0) / K] * K                                                  # per step, all sub-blocks
         ct = eng.counters()
         leap_local = float(ct[:, _abi.CT_LEAPFROGS].sum())
         status = eng.status()
@@ -323,7 +334,8 @@ def main():
             diag = dg.summarize(dg.trace_tensor(eng), reduce_device=red_dev)
             torch.cuda.synchronize()
             diag_s = time.perf_counter() - t_ess
-            draw_s = sum(kernel_ms[s] for s in range(K) if s * ips >= trace_begin) / 1e3
+            s_draw = min(K - 1, -(-trace_begin // ips))
+            draw_s = span_ms(s_draw) / 1e3      # kernel-busy time of the steps that produced the kept draws
             e = diag["ess"]
             ess = {"min": float(e.min()), "median": float(e.median()), "rhat_max": float(diag["rhat"].max()),
                    "lag_passes": int(diag.get("lag_passes", 0)),
@@ -344,6 +356,7 @@ def main():
             "workload": "%s: %d chains x dim %d %s, %s, %s, tune %d + draws %d in %d launches of %d iterations; %s" % (
                 label, chains_total, dim, target_desc, method, mass_desc, n_tune, n_total - n_tune, K, ips, part),
             "wall": wall_max, "leap_all": leap_all, "leap_local": leap_local, "kernel_ms": kernel_ms,
+            "dispatch_ms_avg": float(np.mean(dispatch_ms)), "dispatches_per_step": nst,
             "depth_mean": depth_mean, "div_after": int(div_all), "ess": ess,
         }
 
@@ -360,6 +373,10 @@ def main():
         r = {
             "kernel": ("lmc::run_kernel<NS=%d>" if args.mass == "diag" else "lmc::run_dense_kernel<NS=%d>") % max(1, (dim + 63) // 64),
             "kernel_ms_avg": sum(job["kernel_ms"]) / K, "leapfrogs_per_launch": job["leap_local"] / K,
+            "dispatches_per_step": job["dispatches_per_step"], "dispatch_ms_avg": job["dispatch_ms_avg"],
+            "launch_note": "a step (launch) is %d concurrent dispatches of the kernel, one per sub-block of chains on its own "
+                           "stream; kernel_ms_avg = HIP-event span of the timed region / steps, dispatch_ms_avg = mean event "
+                           "time of one dispatch (what rocprofv3 --kernel-trace lists per row)" % job["dispatches_per_step"],
             "flop_per_leapfrog": flop, "flop_model": "26*d FP64 flop per leapfrog incl. amortised U-turn dots (SURVEY.md 8d)",
             "hbm_contract_60d": {"bytes_per_leapfrog": 60 * dim + extra, "GB_per_s": rate_local * (60 * dim + extra) / 1e9,
                                  "frac_of_8TBps": rate_local * (60 * dim + extra) / HBM_PEAK},

@@ -190,9 +190,16 @@ int lmc_engine_set_dual_average(lmc_engine* e, double log_step, double log_bar, 
  *        >= trace_begin (0 = all, tune = discard_tuned_samples, < 0 = keep no trace: statistics only).
  * run(): iterations [iter_begin, iter_begin + n_iters) of every chain; iterations with global index
  *        < n_tune are tuning iterations (stop_tuning happens at index n_tune, sampling.py:510-511).
- *        Asynchronous on the engine's stream. */
+ *        Asynchronous. Chains are independent (sampling.py:131-136: one process per chain in the reference), so
+ *        the engine launches them as two contiguous sub-blocks on two internal streams: consecutive run() calls chain
+ *        up per sub-block, and the tail of one sub-block's launch is covered by the other's next launch. Every other
+ *        entry point (and lmc_engine_synchronize) is ordered after all launched sub-blocks; work on the engine's
+ *        stream that precedes a run() is ordered before it.
+ * run_streams(): the streams run() launches its kernels on (returns their number, at most `capacity` written) -- for
+ *        callers that bracket launches with their own timing events. */
 int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int64_t trace_begin);
 int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters);
+int lmc_engine_run_streams(lmc_engine* e, void** streams, int32_t capacity);
 
 /* ---- results (synchronise the stream). dst shapes: trace [chains][n_iters][dim]; stats [chains][n_iters] */
 int lmc_engine_get_trace(lmc_engine* e, double* dst, int64_t iter_begin, int64_t n_iters);

@@ -98,6 +98,7 @@ struct SamplerParams {
     int nlds;             // subtree levels kept in LDS (>= 1)
     int lds_doubles;      // LDS doubles used by the subtree stack; the MT19937 state (624 words) follows
     int sdot_mode;        // SdotMode for the float32 start-state kinetic energy
+    int chain_begin;      // run_kernel: first chain of this launch (the engine launches its chains as sub-blocks)
 };
 
 // ---- vector <-> memory (blocked layout, 8*NS contiguous bytes per thread of the team) -----------------
@@ -1296,7 +1297,7 @@ __device__ __forceinline__ void diag_mass_update(const ChainArrays& A, const Sam
 template <int NS, int W, template <int> class TargetT>
 __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(ChainArrays A, SamplerParams P, const double* tparams) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x + P.chain_begin;
     const int d = A.d, dpad = A.dpad;
     const long long row = static_cast<long long>(c) * dpad;
     Team<W> tm;

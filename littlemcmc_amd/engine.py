@@ -158,6 +158,14 @@ class Engine:
             return self._run_ticks(int(n_tune), int(iter_begin), int(n_iters))
         self._check(self._lib.lmc_engine_run(self._h, int(n_tune), int(iter_begin), int(n_iters)))
 
+    def run_streams(self):
+        """Raw HIP stream handles run() launches its kernels on (one per sub-block of chains)."""
+        arr = (C.c_void_p * 4)()
+        n = self._lib.lmc_engine_run_streams(self._h, arr, 4)
+        if n < 0:
+            self._check(n)
+        return [int(arr[i] or 0) for i in range(n)]
+
     # ---- externally evaluated density (targets.TorchTarget): the tick protocol of include/lmc_hip.h ---------
     def tick_begin(self, n_tune, iter_begin, n_iters):
         self._check(self._lib.lmc_engine_tick_begin(self._h, int(n_tune), int(iter_begin), int(n_iters)))

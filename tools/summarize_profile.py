@@ -46,7 +46,7 @@ out = {"command": "rocprofv3 --kernel-trace --stats / --pmc <one group per pass>
                   "--no-secondary ... (see bench_line_under_profiler.config)",
        "bench_line_under_profiler": {k: b[k] for k in ("value", "leapfrogs", "wall_s", "ms_per_step", "steps", "warmup")},
        "source_hash": b.get("source_hash"), "workload": b["config"]["workload"], "counters": {},
-       "kernel_trace": {"dispatches": len(keep), "avg_ms": sum(dur_ns) / len(dur_ns) / 1e6, "vgpr": vgpr,
+       "kernel_trace": {"dispatches": len(keep), "dispatches_per_step": int((b.get("roofline") or {}).get("dispatches_per_step", 1)), "avg_ms": sum(dur_ns) / len(dur_ns) / 1e6, "vgpr": vgpr,
                         "scratch_bytes_per_lane": int(keep[0]["Scratch_Size"]), "lds_bytes_per_block": int(keep[0]["LDS_Block_Size"]),
                         "waves_per_simd_by_vgpr": waves_per_simd}}
 n_disp = None
@@ -61,7 +61,8 @@ for f in ["pmc_sq", "pmc_fetch", "pmc_write", "pmc_mem"]:
     n_disp = len(disp)
     out["counters"].update(agg)
 out["dispatches"] = n_disp
-leap_total = b["leapfrogs"] * n_disp / b["steps"]          # warm-up launches are the same size as timed ones
+dps = int((b.get("roofline") or {}).get("dispatches_per_step", 1))   # the engine launches a step as dps concurrent sub-block dispatches
+leap_total = b["leapfrogs"] * n_disp / (b["steps"] * dps)    # warm-up launches are the same size as timed ones
 c = out["counters"]
 out["per_leapfrog"] = {k: v / leap_total for k, v in c.items()}
 fetch_b, write_b = c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
@@ -71,7 +72,7 @@ out["hbm"] = {
             "(guides/MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated, taken as is; separate --pmc passes",
     "read_bytes_per_leapfrog_corrected": 2 * fetch_b / leap_total, "write_bytes_per_leapfrog": write_b / leap_total,
     "hbm_bytes_per_leapfrog": (2 * fetch_b + write_b) / leap_total, "algorithmic_bytes_per_leapfrog": 60 * dim,
-    "hbm_bytes_per_launch": (2 * fetch_b + write_b) / n_disp}
+    "hbm_bytes_per_launch": (2 * fetch_b + write_b) / n_disp * dps}
 wc = c["SQ_WAVE_CYCLES"]
 out["wave_time_split"] = {"valu_active": c["SQ_ACTIVE_INST_VALU"] / wc, "wait_inst_any": c["SQ_WAIT_INST_ANY"] / wc,
                           "wait_any": c["SQ_WAIT_ANY"] / wc}
