@@ -158,6 +158,22 @@ class Engine:
             return self._run_ticks(int(n_tune), int(iter_begin), int(n_iters))
         self._check(self._lib.lmc_engine_run(self._h, int(n_tune), int(iter_begin), int(n_iters)))
 
+    def resident_chains(self):
+        """How many chains the sampling kernel keeps resident on the GPU at once (wave slots / waves per chain);
+        None for engines without a fused sampling kernel."""
+        if self.target.family == _abi.TARGET_EXTERNAL:
+            return None
+        import torch
+
+        ns, rns, rw = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._lib.lmc_engine_kernel_shape(self._h, C.byref(ns), C.byref(rns), C.byref(rw)))
+        run_ns, run_w = int(rns.value), int(rw.value)
+        if self.potential not in ("diag", "diag_adapt"):
+            return None
+        cus = torch.cuda.get_device_properties(int(self.cfg.device)).multi_processor_count
+        waves_per_simd = {1: 4, 2: 3, 4: 2}.get(run_ns, 1)      # lmc_sampler.hpp: run_waves_per_simd
+        return cus * 4 * waves_per_simd // run_w
+
     def run_streams(self):
         """Raw HIP stream handles run() launches its kernels on (one per sub-block of chains)."""
         arr = (C.c_void_p * 4)()
