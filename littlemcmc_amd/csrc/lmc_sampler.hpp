@@ -1371,9 +1371,17 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         tm.sync();
     }
 
+#ifdef LMC_PHASE_TIMING   // diagnostic build (tools/phase_timing.py): s_memtime ticks per phase replace three counters
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ph_t = clock64();
+#define LMC_PHASE(i) { const unsigned long long now_ = clock64(); ph[i] += now_ - ph_t; ph_t = now_; }
+#else
+#define LMC_PHASE(i)
+#endif
     for (int it = 0; it < P.n_iters; ++it) {
         const long long git = P.iter_begin + it;
         const bool tune = git < P.n_tune;
+        LMC_PHASE(5)
 
         // ---- momentum draw (quadpotential.py:221-224 / :374-376)
         team_normals(tm, rng, d, lds, lds + dpad, rng_bcast);   // level-0 LDS region (2*dpad doubles) = normals + staging
@@ -1386,6 +1394,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
                                    : z * static_cast<double>(inv_std[s]);
         }
         tm.sync();
+        LMC_PHASE(0)
 
         // ---- start state (integration.py:52-66)
         double g0[NS];
@@ -1406,6 +1415,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         const bool adapt_step = tune && P.adapt_step_size;
         const double step_size = adapt_step ? da.step_now : da.step_bar_now;   // exp(log_step) / exp(log_bar)
 
+        LMC_PHASE(1)
         TransitionOut out;
         if (P.kind == 0) {
             const int md = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
@@ -1422,9 +1432,11 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
                                P.max_steps, out);
         }
         ct_leap += out.n_leapfrog;
+        LMC_PHASE(2)
 
         // ---- dual averaging (step_sizes.py:71-92)
         if (adapt_step) dual_average_update(A, P, out.accept, da);
+        LMC_PHASE(3)
 
         // ---- diagonal mass adaptation (quadpotential.py:231-245, :324-340). (Requesting the estimator rows before the
         // dual-averaging update, to take their HBM round trip off the critical path, measured -12 % at d = 128: sixteen
@@ -1435,6 +1447,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
             diag_mass_update<NS>(A, P, row, tid, q, var, inv_std, vard, ms, wm, wr, wmb, wrb);
         }
 
+        LMC_PHASE(4)
         // ---- bookkeeping (base_hmc.py:164-190)
         if (out.diverging && !tune) ++ct_divs;
         ++iter_count;
@@ -1474,6 +1487,12 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         A.counters[c * kNumCounters + kCtDivsSample] += ct_divs;
         A.counters[c * kNumCounters + kCtSamplesAfterTune] += ct_after;
         A.counters[c * kNumCounters + kCtLeapfrogs] += ct_leap;
+#ifdef LMC_PHASE_TIMING
+        LMC_PHASE(5)
+        A.counters[c * kNumCounters + 0] += static_cast<long long>(((ph[0] & 0xffffffffull) << 32) | (ph[1] & 0xffffffffull)) - ct_maxdepth;
+        A.counters[c * kNumCounters + 1] += static_cast<long long>(((ph[2] & 0xffffffffull) << 32) | (ph[3] & 0xffffffffull)) - ct_divs;
+        A.counters[c * kNumCounters + 2] += static_cast<long long>(((ph[4] & 0xffffffffull) << 32) | (ph[5] & 0xffffffffull)) - ct_after;
+#endif
     }
 }
 

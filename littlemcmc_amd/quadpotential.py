@@ -49,6 +49,10 @@ def partial_check_positive_definite(C):
 
 def quad_potential(C, is_cov):
     """quadpotential.py:33-65: build a potential from a scaling vector (diagonal) or matrix."""
+    if hasattr(C, "toarray") and hasattr(C, "nnz"):   # scipy.sparse (quadpotential.py:49-53; the reference's own sparse
+        if not is_cov:                                #  class does not exist -- a sparse covariance is densified here)
+            raise ValueError("Sparse precision matrices are not supported")
+        C = C.toarray()
     C = np.asarray(C)
     partial_check_positive_definite(C)
     if C.ndim == 1:
@@ -56,6 +60,11 @@ def quad_potential(C, is_cov):
     if is_cov:
         return QuadPotentialFull(C)
     return QuadPotentialFullInv(C)
+
+
+def isquadpotential(value):
+    """quadpotential.py:143-145."""
+    return isinstance(value, QuadPotential)
 
 
 class QuadPotential:

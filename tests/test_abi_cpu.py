@@ -137,6 +137,13 @@ def test_reference_argument_errors():
     with pytest.raises(TypeError):                    # sampling.py:138
         from littlemcmc_amd.sampling import _derive_seeds
         _derive_seeds(1.5, 2)
+    import scipy.sparse as sp
+    from littlemcmc_amd.quadpotential import isquadpotential
+
+    with pytest.raises(ValueError, match="Sparse precision"):   # quadpotential.py:49-53
+        lmc.quad_potential(sp.identity(3, format="csr"), False)
+    pot = lmc.quad_potential(sp.identity(3, format="csr") * 2.0, True)   # a sparse covariance is densified
+    assert isinstance(pot, lmc.QuadPotentialFull) and isquadpotential(pot) and not isquadpotential(np.ones(3))
 
 
 def test_seed_derivation_and_start_match_golden(golden_dir):

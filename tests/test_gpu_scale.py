@@ -57,6 +57,40 @@ def test_chain_block_prefix_stability_and_launch_slicing():
         np.testing.assert_array_equal(spart[k], sfull[k][lo:hi])
 
 
+def test_sub_block_streams_do_not_change_a_bit(monkeypatch):
+    """lmc_engine_run launches the chains as two halves on two internal streams (tails of one half's launch are
+    covered by the other's next launch). Same job, launched as ONE block: identical draws, statistics and adaptation
+    state -- with reads, position pushes and other entry points interleaved between the launches."""
+    d, tune, draws, chains = 48, 70, 30, 513
+    tgt = T.AR1(d, 0.9)
+    seeds = lmc.distributed.global_seeds(11, chains)
+
+    def job(sub_blocks):
+        if sub_blocks is None:
+            monkeypatch.delenv("LMC_SUB_BLOCKS", raising=False)
+        else:
+            monkeypatch.setenv("LMC_SUB_BLOCKS", str(sub_blocks))
+        start, step = lmc.init_nuts(tgt, d, random_seed=seeds)
+        eng = step._make_engine(chains)
+        assert len(eng.run_streams()) == (1 if sub_blocks == 1 else 2)
+        eng.seed(seeds); eng.set_position(start); eng.reset_tuning()
+        eng.reserve(tune + draws, keep_trace=True, trace_begin=0)
+        eng.run(tune, 0, 13)
+        eng.run(tune, 13, 40)                 # back to back: chained per sub-block, no host sync
+        mid = eng.trace(20, 10)               # a read between launches is ordered after both halves
+        eng.run(tune, 53, 17)
+        eng.run(tune, 70, 30)
+        out = (eng.trace(0, tune + draws), eng.stat_i32(_abi.STAT_DEPTH, 0, tune + draws), eng.counters(),
+               eng.stat_f64(_abi.STAT_STEP_SIZE, 0, tune + draws), mid)
+        eng.close()
+        return out
+
+    a, b = job(None), job(1)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a[4], a[0][:, 20:30])
+
+
 def test_checkpoint_resume_is_bit_identical():
     d, chains = 32, 64
     tgt = T.StdNormal(d)
