@@ -546,37 +546,25 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         if (se != hipSuccess) return bail(fail(nullptr, LMC_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(se)));
     }
 
-    // subtree-stack levels in LDS: as many as fit in ~10 KiB per wave (16 waves/CU), at least one
     const int max_levels = (cfg->max_treedepth > cfg->early_max_treedepth ? cfg->max_treedepth
                                                                           : cfg->early_max_treedepth);
-    // LDS per block: subtree-stack levels + tail (RNG state, team exchange). Keep as many stack levels in LDS
-    // as fit WITHOUT lowering the occupancy the register budget allows (160 KiB per CU; allocation granule
-    // taken as 1280 B -- measured: 12 800 B per wave keeps 12 waves/CU, 12 960 B does not).
-    int nlds = cfg->lds_levels;
-    if (nlds <= 0) {
-        const int waves_per_cu = 4 * run_waves_per_simd(e->run_ns);
-        const int blocks_per_cu = waves_per_cu / e->run_w > 0 ? waves_per_cu / e->run_w : 1;
-        const long budget = (163840L / blocks_per_cu) / 1280 * 1280 - lds_tail_doubles(e->run_w) * 8L;
-        nlds = 1;
-        while (nlds < max_levels && (2L + 4 * nlds) * e->dpad * 8 <= budget) ++nlds;
-    }
-    if (nlds > max_levels) nlds = max_levels;
-    if (nlds < 1) nlds = 1;
-    e->nlds = nlds;
-    e->lds_bytes = (2 + 4 * (nlds - 1)) * e->dpad * 8;
-    if (run_pair_form(e->run_w) && e->run_ns <= 4) {
-        // pair form (nuts_transition2): compile-time plan PairLds<NS, W> -- reduction buffers, exp table, team combine
-        // area, level scalars, cold slots, stack level 1 -- plus as many further levels as fit without lowering the
-        // occupancy; the rest of the stack goes to the chain's scratch row
+    // LDS per block: the compile-time plan PairLds<NS, W> -- reduction buffers (which double as the normals / float32-dot
+    // staging area), exp table, team combine area, level scalars, cold slots, stack level 1 -- plus as many further
+    // stack levels as fit WITHOUT lowering the occupancy the register budget allows (160 KiB per CU; allocation
+    // granule taken as 1280 B -- measured: 12 800 B per wave keeps 12 waves/CU, 12 960 B does not); behind it the tail
+    // (MT19937 state, team exchange). The rest of the stack goes to the chain's scratch row.
+    int nlds = 1;
+    {
         const int waves_per_cu = 4 * run_waves_per_simd(e->run_ns);
         const int blocks_per_cu = waves_per_cu / e->run_w > 0 ? waves_per_cu / e->run_w : 1;
         const long budget = (163840L / blocks_per_cu) / 1280 * 1280 - lds_tail_doubles(e->run_w) * 8L;
         if (pair_min_doubles(e->run_ns, e->run_w) * 8L > budget)
-            return bail(fail(nullptr, LMC_ERR_INVALID, "pair form does not fit the LDS budget"));
+            return bail(fail(nullptr, LMC_ERR_INVALID, "the sampling kernel's LDS plan does not fit the budget"));
         nlds = cfg->lds_levels > 0 ? cfg->lds_levels : 1;
         if (cfg->lds_levels <= 0)
             while (nlds < max_levels && pair_total_doubles(e->run_ns, e->run_w, nlds + 1) * 8L <= budget) ++nlds;
         if (nlds > max_levels) nlds = max_levels;
+        if (nlds < 1) nlds = 1;
         e->nlds = nlds;
         e->lds_bytes = pair_total_doubles(e->run_ns, e->run_w, nlds) * 8;
     }

@@ -327,18 +327,7 @@ __device__ __forceinline__ void leapfrog(TeamT& tm, const Target& tgt, const dou
     }
 }
 
-// ---- subtree stack -----------------------------------------------------------------------------------
-// Level j < nlds lives in LDS, deeper levels in the chain's HBM scratch row. Level 0 holds {p, q},
-// level j > 0 holds {lp, rp, psum, prop q}; per-level scalars live in registers (lane j).
-struct TreeStack {
-    double* lds;        // this team's LDS region
-    double* glb;        // this chain's scratch row (levels >= nlds)
-    int nlds;
-    int dpad;
-    __device__ __forceinline__ int lds_offset(int j) const { return (j == 0 ? 0 : (2 + 4 * (j - 1)) * dpad); }
-    __device__ __forceinline__ long long glb_offset(int j) const { return static_cast<long long>(j - nlds) * 4 * dpad; }
-};
-
+// ---- vector slots in LDS / the scratch row --------------------------------------------------------------
 // Stack traffic with explicit address spaces: ds_read/ds_write_b128 for the LDS levels, global_load/store for
 // the spilled ones (a generic pointer would make every access a flat_* instruction that checks the aperture
 // and ties up both the LDS and the vector-memory counters).
@@ -356,41 +345,6 @@ __device__ __forceinline__ void vstore_as(PTR base, const double (&x)[NS]) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) p[s] = x[s];
 }
-// level 0 holds {p, q}; level j > 0 holds {lp, rp, psum, prop q}
-template <int NS>
-__device__ __forceinline__ void stack_load(const TreeStack& stk, int j, double (&lp)[NS], double (&rp)[NS],
-                                           double (&ps)[NS], double (&pq)[NS]) {
-    const int dp = stk.dpad;
-    if (j < stk.nlds) {
-        lds_double* b = (lds_double*)(stk.lds) + stk.lds_offset(j);
-        if (j == 0) {
-            vload_as<NS>(b, lp); vload_as<NS>(b + dp, pq);
-        } else {
-            vload_as<NS>(b, lp); vload_as<NS>(b + dp, rp); vload_as<NS>(b + 2 * dp, ps); vload_as<NS>(b + 3 * dp, pq);
-        }
-    } else {
-        glb_double* b = (glb_double*)(stk.glb) + stk.glb_offset(j);
-        vload_as<NS>(b, lp); vload_as<NS>(b + dp, rp); vload_as<NS>(b + 2 * dp, ps); vload_as<NS>(b + 3 * dp, pq);
-    }
-    if (j == 0) { vcopy(rp, lp); vcopy(ps, lp); }
-}
-template <int NS>
-__device__ __forceinline__ void stack_store(const TreeStack& stk, int j, const double (&lp)[NS], const double (&rp)[NS],
-                                            const double (&ps)[NS], const double (&pq)[NS]) {
-    const int dp = stk.dpad;
-    if (j < stk.nlds) {
-        lds_double* b = (lds_double*)(stk.lds) + stk.lds_offset(j);
-        if (j == 0) {
-            vstore_as<NS>(b, ps); vstore_as<NS>(b + dp, pq);
-        } else {
-            vstore_as<NS>(b, lp); vstore_as<NS>(b + dp, rp); vstore_as<NS>(b + 2 * dp, ps); vstore_as<NS>(b + 3 * dp, pq);
-        }
-    } else {
-        glb_double* b = (glb_double*)(stk.glb) + stk.glb_offset(j);
-        vstore_as<NS>(b, lp); vstore_as<NS>(b + dp, rp); vstore_as<NS>(b + 2 * dp, ps); vstore_as<NS>(b + 3 * dp, pq);
-    }
-}
-
 // Tree weights are kept in the LINEAR domain: w = exp(-dE - c) with one offset c per transition.
 // The reference carries log-weights and pays logaddexp (exp + log1p) twice plus log(U) per merge
 // (nuts.py:322-328, :399-404); in the linear domain a merge is two additions and the multinomial
@@ -417,156 +371,6 @@ struct TransitionOut {
     int exhausted;         // NUTS: loop ran to max_treedepth without turning/diverging
     int accepted;          // HMC
 };
-
-// ---- NUTS transition -----------------------------------------------------------------------------------
-// q0/p0/g0: start state (p0 float32-valued when momentum_f32). On return q holds the proposal.
-template <int NS, class Target, class TeamT>
-__device__ inline void nuts_transition(TeamT& tm, const Target& tgt, const double (&var)[NS], RngState& rng,
-                                       const TreeStack& stk, double (&q)[NS], const double (&p0)[NS],
-                                       const double (&g0)[NS], double e0, double logp0, double step_size,
-                                       double emax, int max_depth, bool momentum_f32, TransitionOut& out) {
-    // trajectory ends + running totals (registers)
-    double Lq[NS], Lp[NS], Lg[NS], Rq[NS], Rp[NS], Rg[NS], psum[NS], propq[NS];
-    vcopy(Lq, q); vcopy(Lp, p0); vcopy(Lg, g0);
-    vcopy(Rq, q); vcopy(Rp, p0); vcopy(Rg, g0);
-    vcopy(psum, p0); vcopy(propq, q);
-    bool l_start = momentum_f32, r_start = momentum_f32;   // end still is the float32 start state
-    double prop_e = e0, prop_logp = logp0;
-    double coff = 0.0;          // weight offset c
-    double w_start = 1.0;       // exp(0 - c): the start state's weight
-    double wn = 0.0, an = 0.0;  // accepted subtrees: sum of weights, sum of weight * min(1, e^{-dE})
-    double max_de = 0.0;
-    int depth = 0, n_leap = 0;
-    bool diverging = false, turning = false, exhausted = true;
-    LevelScalars lsc = {0.0, 0.0, 0.0, 0.0};
-    UniformWindow win;
-    window_reset(win);
-
-    for (int dd = 0; dd < max_depth; ++dd) {
-        const bool right = team_uniform(tm, rng, win) < 0.5;   // log(U) < log(.5), nuts.py:213
-        const double eps = right ? step_size : -step_size;
-        double cq[NS], cp[NS], cg[NS];
-        if (right) { vcopy(cq, Rq); vcopy(cp, Rp); vcopy(cg, Rg); }
-        else       { vcopy(cq, Lq); vcopy(cp, Lp); vcopy(cg, Lg); }
-
-        // in-flight node t (registers)
-        double tlp[NS], trp[NS], tps[NS], tq[NS];
-        double tw = 0.0, ta = 0.0, tpe = 0.0, tplogp = 0.0;
-        const int n_leaves = 1 << depth;
-        for (int i = 0; i < n_leaves; ++i) {
-            double energy, logp;
-            leapfrog<NS>(tm, tgt, var, eps, cq, cp, cg, energy, logp);
-            ++n_leap;
-            double de = first_f64(energy - e0);
-            if (isnan(de)) de = __builtin_inf();
-            if (fabs(de) > fabs(max_de)) max_de = de;
-            if (!(fabs(de) < emax)) { diverging = true; break; }   // nuts.py:358,370-375
-            const double x = -de;
-            if (x - coff > 600.0) {   // cold path: move the offset, rescale every stored weight
-                const double f = exp_uniform(coff - x);
-                lsc.w *= f; lsc.a *= f;
-                wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
-                coff = x;
-            }
-            tw = exp_uniform_fast(x - coff);                               // e^{log_size}; x - coff <= 600
-            const double sat = (coff == 0.0) ? fmin(1.0, tw) : ((x >= 0.0) ? 1.0 : exp_uniform(x));
-            ta = tw * sat;                                                 // e^{log_p_accept_weighted}
-            vcopy(tlp, cp); vcopy(trp, cp); vcopy(tps, cp); vcopy(tq, cq);
-            tpe = energy; tplogp = logp;
-            int j = 0;
-            while ((i >> j) & 1) {   // t closes a right child: merge stack[j] (a, earlier) with t (b)
-                double alp[NS], arp[NS], aps[NS], aq[NS];
-                double aw, aa, ape, aplogp;
-                stack_load<NS>(stk, j, alp, arp, aps, aq);
-                lsc.get(j, aw, aa, ape, aplogp);
-                double ps[NS];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) ps[s] = aps[s] + tps[s];
-                bool turn;
-                if (j > 0) {   // nuts.py:389-396
-                    double p1[NS], p2[NS];
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) { p1[s] = aps[s] + tlp[s]; p2[s] = arp[s] + tps[s]; }
-                    double dots[6] = {pdot_v<NS>(ps, var, alp), pdot_v<NS>(ps, var, trp),
-                                      pdot_v<NS>(p1, var, alp), pdot_v<NS>(p1, var, tlp),
-                                      pdot_v<NS>(p2, var, arp), pdot_v<NS>(p2, var, trp)};
-                    turn = tm.any_nonpositive6(dots);
-                } else {
-                    turn = tm.any_nonpositive2(pdot_v<NS>(ps, var, alp), pdot_v<NS>(ps, var, trp));
-                }
-                const double wsum = aw + tw;
-                const double asum = aa + ta;
-                const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < tw);   // nuts.py:404 (drawn even if turning)
-                // merged node: left end from a, right end from b(t)
-                vcopy(tlp, alp); vcopy(tps, ps);
-                if (!take_b) { vcopy(tq, aq); tpe = ape; tplogp = aplogp; }
-                tw = wsum; ta = asum;
-                ++j;
-                if (turn) { turning = true; break; }
-            }
-            if (turning) break;
-            if (i + 1 < n_leaves) {   // park t at level j (the last leaf's cascade result stays in registers)
-                stack_store<NS>(stk, j, tlp, trp, tps, tq);
-                lsc.put(j, tw, ta, tpe, tplogp);
-                // no fence: every lane reads back exactly the slice it wrote (same-thread program order)
-            }
-        }
-        ++depth;   // nuts.py:315
-        if (diverging || turning) { exhausted = false; break; }
-
-        // ---- accepted subtree t: merge into the trajectory (nuts.py:321-340)
-        if (uniform_true(team_uniform(tm, rng, win) * (w_start + wn) < tw)) {   // biased progressive: U < w_sub / w_tree
-            vcopy(propq, tq); prop_e = tpe; prop_logp = tplogp;
-        }
-        wn = first_f64(wn + tw);
-        an = first_f64(an + ta);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {   // in place; float32 storage when the start momentum is float32
-            const double t = psum[s] + tps[s];
-            psum[s] = momentum_f32 ? static_cast<double>(static_cast<float>(t)) : t;
-        }
-        // velocities of the four momenta involved, each computed once: the two trajectory ends as they were BEFORE
-        // this doubling (float32 product while an end still is the float32 start state) and the subtree's two ends
-        double oLv[NS], oRv[NS], vtl[NS], vtr[NS];
-        end_velocity<NS>(oLv, var, Lp, l_start);
-        end_velocity<NS>(oRv, var, Rp, r_start);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) { vtl[s] = var[s] * tlp[s]; vtr[s] = var[s] * trp[s]; }
-        double dots[6];
-        if (right) {   // new right end = far end of the subtree (trp == cp); left end unchanged
-            double p1[NS], p2[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) { p1[s] = psum[s] + tlp[s]; p2[s] = Rp[s] + tps[s]; }
-            dots[0] = pdot<NS>(psum, oLv); dots[1] = pdot<NS>(psum, vtr);
-            dots[2] = pdot<NS>(p1, oLv);   dots[3] = pdot<NS>(p1, vtl);
-            dots[4] = pdot<NS>(p2, oRv);   dots[5] = pdot<NS>(p2, vtr);
-            vcopy(Rq, cq); vcopy(Rp, cp); vcopy(Rg, cg); r_start = false;
-        } else {       // new left end = far end of the subtree; right end unchanged
-            double p1[NS], p2[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) { p1[s] = tps[s] + Lp[s]; p2[s] = tlp[s] + psum[s]; }
-            dots[0] = pdot<NS>(psum, vtr); dots[1] = pdot<NS>(psum, oRv);
-            dots[2] = pdot<NS>(p1, vtr);   dots[3] = pdot<NS>(p1, oLv);
-            dots[4] = pdot<NS>(p2, vtl);   dots[5] = pdot<NS>(p2, oRv);
-            vcopy(Lq, cq); vcopy(Lp, cp); vcopy(Lg, cg); l_start = false;
-        }
-        if (tm.any_nonpositive6(dots)) { turning = true; exhausted = false; break; }
-    }
-
-    // nuts.py:421-425: exp(lwas - log(e^{log_size} - 1)) == sum(w min(1,w)) / sum(w) over accepted leaves
-    const double mean_accept = (wn > 0.0) ? first_f64(an / wn) : 0.0;
-    vcopy(q, propq);
-    out.accept = mean_accept;
-    out.energy = prop_e;
-    out.energy_error = first_f64(prop_e - e0);
-    out.max_energy_error = max_de;
-    out.model_logp = prop_logp;
-    out.depth = depth;
-    out.n_leapfrog = n_leap;
-    out.diverging = diverging;
-    out.exhausted = exhausted;
-    out.accepted = 0;
-}
 
 // ---- HMC transition (hmc.py:140-182) -------------------------------------------------------------------
 template <int NS, class Target, class TeamT>
@@ -606,12 +410,12 @@ __device__ inline void hmc_transition(TeamT& tm, const Target& tgt, const double
     out.accepted = accepted;
 }
 
-// ---- NUTS transition, pair form (one-wave kernels): batched LDS-transposed reductions, leaf pairs ---------------
-// Same algorithm and decisions as nuts_transition() above (the leaf form; it stays the team form for W > 1 and the
-// form for shallow trees); what changes is where the issue slots go. Measured on gfx950 (tools/ubench/valu_cost.hip):
-// a wave issues at most one instruction of ANY kind every ~10 cycles, a DPP move costs as much VALU time as a float64
-// operation, a permlane swap ~1.9x, a v_readlane with an SGPR index ~1.8x -- at 3 waves per SIMD every instruction of
-// the per-leaf path counts.
+// ---- NUTS transition (nuts.py:204-224, _Tree :251-435; iterative post-order), pair form ----------------
+// Batched LDS-transposed reductions, leaf pairs. The straightforward statement of the same algorithm -- one leaf at a
+// time, a DPP/permlane reduction per dot product group, level scalars in VGPR lanes -- is what lmc_dense.hpp and
+// lmc_tick.hpp still use; here it was replaced because of where the issue slots go. Measured on gfx950
+// (tools/ubench/valu_cost.hip): a DPP move costs as much VALU time as a float64 operation, a permlane swap ~1.9x, a
+// v_readlane with an SGPR index ~1.8x, and at 2-3 waves per SIMD every instruction of the per-leaf path counts.
 //   * leaves are processed in PAIRS (2k, 2k+1): the even leaf's {p, q} stays in registers, so subtree-stack
 //     level 0 is never written to or read from LDS;
 //   * every length-d reduction of a pair -- two kinetic energies, two log-densities, the two level-0 U-turn dots --
@@ -1117,13 +921,6 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
 // Occupancy target per vector width (waves per SIMD; the VGPR budget is 512 / waves): the per-chain state
 // is register resident, so wider per-thread slices trade occupancy for registers. Chains longer than
 // 128 elements are spread over W waves (dpad = 64 * NS * W) instead of growing NS further.
-#ifndef LMC_NUTS_ONE_WAVE_FORM
-#define LMC_NUTS_ONE_WAVE_FORM 1   // 1: one-wave kernels (d <= 256) use nuts_transition2 (pair form) and its LDS plan; 0: leaf form
-#endif
-#ifndef LMC_NUTS_TEAM_PAIR_FORM
-#define LMC_NUTS_TEAM_PAIR_FORM 1  // 1: team kernels (W = 2, 4) use the pair form too (one barrier per batched reduction); 0: leaf form
-#endif
-constexpr bool run_pair_form(int w) { return w == 1 ? LMC_NUTS_ONE_WAVE_FORM != 0 : LMC_NUTS_TEAM_PAIR_FORM != 0; }
 #ifndef LMC_WAVES_NS1
 #define LMC_WAVES_NS1 4
 #endif
@@ -1139,9 +936,9 @@ constexpr int run_waves_per_simd(int ns) {
 // LDS carve (doubles) behind the subtree stack: MT19937 state (624 words), team exchange area, RNG re-broadcast
 constexpr int kLdsMtDoubles = 320;
 #ifndef LMC_MT_IN_LDS_W1
-#define LMC_MT_IN_LDS_W1 1   // pair-form kernels: 1 keeps the MT19937 state in LDS for the launch, 0 uses it in place (L2)
+#define LMC_MT_IN_LDS_W1 1   // one-wave kernels: 1 keeps the MT19937 state in LDS for the launch, 0 uses it in place (L2)
 #endif
-constexpr bool run_mt_in_lds(int w) { return w > 1 || !LMC_NUTS_ONE_WAVE_FORM || LMC_MT_IN_LDS_W1; }
+constexpr bool run_mt_in_lds(int w) { return w > 1 || LMC_MT_IN_LDS_W1; }
 constexpr int lds_tail_doubles(int w) {
     return w == 1 ? (run_mt_in_lds(1) ? kLdsMtDoubles : 0) : kLdsMtDoubles + 2 * w * kTeamSlots + 4;
 }
@@ -1350,26 +1147,19 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     long long ct_maxdepth = 0, ct_divs = 0, ct_after = 0, ct_leap = 0;
     int status = 0;
 
-    TreeStack stk;
-    stk.lds = lds;
-    stk.glb = A.scratch + static_cast<long long>(c) * A.scratch_stride;
-    stk.nlds = P.nlds;
-    stk.dpad = dpad;
-    // pair form (nuts_transition2): compile-time LDS plan (PairLds<NS>), the chain's scratch row for what does not fit
-    constexpr bool kPairForm = run_pair_form(W) && NS <= 4;
+    // compile-time LDS plan (PairLds<NS, W>), the chain's scratch row for what does not fit
+    static_assert(NS <= 4, "sampling kernels hold at most four elements per lane");
     PairCtx cx;
     cx.lds = lds;
-    cx.glb = stk.glb;
+    cx.glb = A.scratch + static_cast<long long>(c) * A.scratch_stride;
     cx.nlds = P.nlds;
     cx.wave = tm.wave();
     cx.wave_red = W > 1 ? cx.wave * PairLds<NS, W>::kRedWave : 0;
     cx.wave_scal = W > 1 ? cx.wave * kLevelScalDoubles : 0;
     cx.red_lane = red_lane_init() + cx.wave_red;
     cx.xpar = 0;
-    if constexpr (kPairForm) {
-        if (tid < kExpTableDoubles) lds[PairLds<NS, W>::kExp + tid] = kExp2Table[2 * tid];
-        tm.sync();
-    }
+    if (tid < kExpTableDoubles) lds[PairLds<NS, W>::kExp + tid] = kExp2Table[2 * tid];
+    tm.sync();
 
 #ifdef LMC_PHASE_TIMING   // diagnostic build (tools/phase_timing.py): s_memtime ticks per phase replace three counters
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
@@ -1419,13 +1209,10 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         TransitionOut out;
         if (P.kind == 0) {
             const int md = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
-            if constexpr (kPairForm) {
-                nuts_transition2<NS>(tm, tgt, vard, rng, cx, A.q + row, q, p0, g0, e0, logp0, step_size, P.emax, md,
-                                     P.momentum_f32 != 0, out);
-                vload<NS>(A.q + row, q);   // the proposal was written to the chain's row of A.q
-            } else
-                nuts_transition<NS>(tm, tgt, vard, rng, stk, q, p0, g0, e0, logp0, step_size, P.emax, md,
-                                    P.momentum_f32 != 0, out);
+            nuts_transition2<NS>(tm, tgt, vard, rng, cx, A.q + row, q, p0, g0, e0, logp0, step_size, P.emax, md,
+                                 P.momentum_f32 != 0, out);
+            vload<NS>(A.q + row, q);   // the proposal was written to the chain's row of A.q
+            // (handing it over in registers when the last doubling accepted it measured -4 % on depth-3 trees)
             if (out.exhausted && !tune) ++ct_maxdepth;
         } else {
             hmc_transition<NS>(tm, tgt, vard, rng, q, p0, g0, e0, logp0, step_size, P.emax, P.path_length,
