@@ -209,13 +209,13 @@ __device__ inline void rng_normals(RngState& r, int d, double* out, double* stag
             const double r2 = x1 * x1 + x2 * x2;
             acc = (r2 > 0.0) && (r2 < 1.0);
         }
-        unsigned long long mask = __ballot(acc);
+        unsigned long long mask = ballot64(acc);
         const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         const int rank = __popcll(mask & below);
         int consumed = n_att;
         const int want = need_pairs - have;
         if (__popcll(mask) >= want) {             // the want-th accepted attempt ends the call
-            const unsigned long long lastm = __ballot(acc && rank == want - 1);
+            const unsigned long long lastm = ballot64(acc && rank == want - 1);
             const int last = __ffsll(static_cast<long long>(lastm)) - 1;
             consumed = last + 1;
             mask &= (last == 63) ? ~0ull : ((1ull << (last + 1)) - 1ull);

@@ -534,7 +534,7 @@ __device__ __forceinline__ int red_lane_init() {
 }
 // any of the sums k in [k0, k0 + n) <= 0 ?
 __device__ __forceinline__ bool red_any_nonpositive(double s, int k0, int n) {
-    const unsigned long long m = __ballot(s <= 0.0);
+    const unsigned long long m = ballot64(s <= 0.0);
     unsigned long long sel = 0ull;
     for (int k = k0; k < k0 + n; ++k) sel |= 1ull << (8 * k + 7);
     return (m & sel) != 0ull;
@@ -701,7 +701,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
     bool c_right = true;                                    // which end {c*} is
     bool c_start = momentum_f32, o_start = momentum_f32;    // end still is the float32 start state
     double prop_e = e0, prop_logp = logp0;
-    double coff = 0.0, w_start = 1.0, wn = 0.0, an = 0.0, max_de = 0.0;
+    double coff = 0.0, w_start = 1.0, wn = 0.0, an = 0.0;
     int depth = 0, n_leap = 0;
     bool diverging = false, turning = false, exhausted = true;
     const bool odd_lane = (lane_id() & 1) != 0;
@@ -712,28 +712,49 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
     // 23 / 31 (second) of s (nuts.py:344-375): energy errors, divergence, linear-domain weights. On return lanes
     // 15 / 31 of en hold the energies, of ev the weights w = e^{-dE - c}, lanes 14 / 30 of ev w * min(1, e^{-dE}).
     // Returns the number of leaves accepted into the subtree (a diverging leaf stops the count).
+    // The running signed max |dE| (nuts.py:356-357) is kept on lanes: lane 15 follows the first leaves of the pairs,
+    // lane 31 the second ones; the two are combined when the transition ends (and whenever the slow path runs).
+    double mde = 0.0;
+    const bool lane15 = lane_id() == 15, lane31 = lane_id() == 31;
+    auto mde_combined = [&]() -> double {
+        const double a = readlane_f64(mde, 15), b = readlane_f64(mde, 31);
+        return (fabs(b) > fabs(a)) ? b : a;
+    };
     auto leaf_scalars = [&](double s, int n, double& en, double& ev) -> int {
         en = 0.5 * dpp_f64<0x118>(s) - s;                      // row_shr:8 brings the kinetic sum next to the log-density
         double de = en - e0;
         int ok = 0;
-        for (int i = 0; i < n; ++i) {
-            double dei = readlane_f64(de, 15 + 16 * i);
-            ++n_leap;
-            if (isnan(dei)) dei = __builtin_inf();
-            if (fabs(dei) > fabs(max_de)) max_de = dei;
-            if (!(fabs(dei) < emax)) { diverging = true; break; }   // nuts.py:358,370-375
-            const double x = -dei;
-            if (x - coff > 600.0) {   // cold path: move the offset, rescale every stored weight
-                const double f = exp_uniform(coff - x);
-                const int lane = lane_id();
-                if (lane >= 1 && lane < kLevelScalDoubles / 4) {
-                    lds_double* sc = (lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * lane) + (W > 1 ? cx.wave_scal : 0);
-                    sc[0] = sc[0] * f; sc[1] = sc[1] * f;
+        // Both leaves at once on their lanes: neither diverges (or is NaN) and no weight offset has to move -- the
+        // usual case -- costs three compares and one ballot; anything else takes the sequential path below.
+        const bool leaf_lane = lane15 | (lane31 & (n == 2));
+        const bool rare = (!(fabs(de) < emax)) | ((-de) - coff > 600.0);
+        if ((ballot64(rare & leaf_lane)) == 0ull) {
+            n_leap += n;
+            ok = n;
+            const bool upd = (fabs(de) > fabs(mde)) & leaf_lane;
+            mde = upd ? de : mde;
+        } else {
+            double cur_max = mde_combined();
+            for (int i = 0; i < n; ++i) {
+                double dei = readlane_f64(de, 15 + 16 * i);
+                ++n_leap;
+                if (isnan(dei)) dei = __builtin_inf();
+                if (fabs(dei) > fabs(cur_max)) cur_max = dei;
+                if (!(fabs(dei) < emax)) { diverging = true; break; }   // nuts.py:358,370-375
+                const double x = -dei;
+                if (x - coff > 600.0) {   // cold path: move the offset, rescale every stored weight
+                    const double f = exp_uniform(coff - x);
+                    const int lane = lane_id();
+                    if (lane >= 1 && lane < kLevelScalDoubles / 4) {
+                        lds_double* sc = (lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * lane) + (W > 1 ? cx.wave_scal : 0);
+                        sc[0] = sc[0] * f; sc[1] = sc[1] * f;
+                    }
+                    wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
+                    coff = x;
                 }
-                wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
-                coff = x;
+                ++ok;
             }
-            ++ok;
+            mde = cur_max;   // every lane: later lane-wise updates compete against the overall maximum
         }
         // lanes 15 / 31: x - c; lanes 14 / 30: (x - c) + min(x, 0), i.e. log of w * min(1, e^{-dE})
         const double x = -de;
@@ -908,7 +929,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
     out.accept = mean_accept;
     out.energy = prop_e;
     out.energy_error = first_f64(prop_e - e0);
-    out.max_energy_error = max_de;
+    out.max_energy_error = mde_combined();
     out.model_logp = prop_logp;
     out.depth = depth;
     out.n_leapfrog = n_leap;

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
 __global__ __launch_bounds__(256) void tick_count_kernel(TickArrays K, int chains) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const bool active = c < chains && K.phase[c] != kTickDone;
-    const unsigned long long m = __ballot(active);
+    const unsigned long long m = ballot64(active);
     __shared__ int part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = __popcll(m);
     __syncthreads();

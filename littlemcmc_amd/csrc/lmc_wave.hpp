@@ -14,6 +14,9 @@ namespace lmc {
 constexpr int kWave = 64;
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & 63; }
+// lane predicate -> 64-bit mask. The builtin takes the i1 as it is (a v_cmp result already IS the mask in an SGPR pair);
+// HIP's __ballot() widens it to an int first, which costs a v_cndmask + v_cmp_ne per call.
+__device__ __forceinline__ unsigned long long ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 
 // ---- uniform <-> per-lane moves -------------------------------------------------------------
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
@@ -108,7 +111,7 @@ __device__ __forceinline__ bool any_sum_nonpositive2(double d0, double d1) {
     double x = swap32_add(d0, d1);
     x = row_scan(x);
     x += dpp_f64<0x142>(x);
-    const unsigned long long m = __ballot(x <= 0.0);
+    const unsigned long long m = ballot64(x <= 0.0);
     return (m & ((1ull << 31) | (1ull << 63))) != 0ull;
 }
 __device__ __forceinline__ bool any_sum_nonpositive6(const double (&d)[6]) {
@@ -119,8 +122,8 @@ __device__ __forceinline__ bool any_sum_nonpositive6(const double (&d)[6]) {
     double z = swap16_add(x45, 0.0);       // rows: d4, 0, d5, 0
     y = row_scan(y);
     z = row_scan(z);
-    const unsigned long long my = __ballot(y <= 0.0);
-    const unsigned long long mz = __ballot(z <= 0.0);
+    const unsigned long long my = ballot64(y <= 0.0);
+    const unsigned long long mz = ballot64(z <= 0.0);
     const unsigned long long rows = (1ull << 15) | (1ull << 31) | (1ull << 47) | (1ull << 63);
     return ((my & rows) | (mz & ((1ull << 15) | (1ull << 47)))) != 0ull;
 }
@@ -209,7 +212,7 @@ __device__ __forceinline__ double exp_uniform_fast(double x) {
 
 // Uniform predicate from a comparison whose operands are wave-uniform but VGPR-resident: all lanes agree, so
 // the ballot is either 0 or exec. One v_cmp + scalar test; tells the compiler the branch is uniform.
-__device__ __forceinline__ bool uniform_true(bool lane_pred) { return __ballot(lane_pred) != 0ull; }
+__device__ __forceinline__ bool uniform_true(bool lane_pred) { return ballot64(lane_pred) != 0ull; }
 
 // Neighbour exchange for banded targets: value held by lane-1 / lane+1 (0 at the wave edge).
 // DPP wave_shr:1 / wave_shl:1 (GFX9 whole-wave shifts, 0x138 / 0x130) with bound_ctrl: two VALU moves per
