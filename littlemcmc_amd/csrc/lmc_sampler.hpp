@@ -434,6 +434,9 @@ __device__ inline void hmc_transition(TeamT& tm, const Target& tgt, const double
 //     trajectory proposal in the chain's row of A.q, so nothing but the hot set occupies registers in the pair loop;
 //   * the whole LDS plan is compile-time (dpad = 64 * NS): every LDS access is one lane-offset register plus an
 //     immediate, no per-slot address registers.
+#ifndef LMC_EXP_LANES_SLOAD
+#define LMC_EXP_LANES_SLOAD 2
+#endif
 constexpr int kRedValues = 6;
 constexpr int kExpTableDoubles = 32;    // 2^(j/32): the even entries of kExp2Table
 constexpr int kLevelScalDoubles = 96;   // 4 per parked level, levels < 24 (max_treedepth <= 20)
@@ -543,16 +546,42 @@ __device__ __forceinline__ bool red_any_nonpositive(double s, int k0, int n) {
 // exp on lanes (arguments <= ~700; very negative ones underflow to 0): exp_uniform_fast's algorithm with a 32-entry
 // 2^(j/32) table read from LDS by every lane: x = (32 e + j) ln2/32 + r, |r| <= ln2/64, degree-6 polynomial
 // (truncation r^7/5040 < 4e-18 relative). |error| < ~1 ulp.
+// The reduction and polynomial constants come from constant memory in ONE scalar load (s_load_dwordx16, scalar cache):
+// as s_mov literals they cost two SALU issue slots each plus a wait state, 22 slots per call on a wave that can issue
+// one instruction of any kind at a time.
+__constant__ double kExpLanesConst[8] = {46.166241308446828,            // 32 / ln 2
+                                         2.16608493865351192654e-02,    // ln2/32 hi
+                                         5.96317165397058656256e-12,    // ln2/32 lo
+                                         1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.0};
+struct ExpLanesConst { double inv, hi, lo, c6, c5, c4, c3; };
+__device__ __forceinline__ ExpLanesConst exp_lanes_const() {
+    ExpLanesConst c;
+#if LMC_EXP_LANES_SLOAD == 2
+    // re-loaded where it is used (the address is made opaque, so the load is not hoisted and the seven values do not
+    // occupy fourteen SGPRs for the whole kernel)
+    typedef const __attribute__((address_space(4))) double cst_double;
+    cst_double* p = (cst_double*)kExpLanesConst;
+    asm volatile("" : "+s"(p));
+    c.inv = p[0]; c.hi = p[1]; c.lo = p[2]; c.c6 = p[3]; c.c5 = p[4]; c.c4 = p[5]; c.c3 = p[6];
+#elif LMC_EXP_LANES_SLOAD == 1
+    c.inv = kExpLanesConst[0]; c.hi = kExpLanesConst[1]; c.lo = kExpLanesConst[2];
+    c.c6 = kExpLanesConst[3]; c.c5 = kExpLanesConst[4]; c.c4 = kExpLanesConst[5]; c.c3 = kExpLanesConst[6];
+#else
+    c.inv = LMC_SC(46.166241308446828); c.hi = LMC_SC(2.16608493865351192654e-02); c.lo = LMC_SC(5.96317165397058656256e-12);
+    c.c6 = LMC_SC(1.0 / 720.0); c.c5 = LMC_SC(1.0 / 120.0); c.c4 = LMC_SC(1.0 / 24.0); c.c3 = LMC_SC(1.0 / 6.0);
+#endif
+    return c;
+}
 template <int NS, int W = 1>
-__device__ __forceinline__ double exp_lanes(const PairCtx& cx, double x) {
-    const double kf = rint(x * LMC_SC(46.166241308446828));            // 32 / ln 2
-    double r = __builtin_fma(-kf, LMC_SC(2.16608493865351192654e-02), x);   // ln2/32 hi
-    r = __builtin_fma(-kf, LMC_SC(5.96317165397058656256e-12), r);          // ln2/32 lo
+__device__ __forceinline__ double exp_lanes(const PairCtx& cx, const ExpLanesConst& c, double x) {
+    const double kf = rint(x * c.inv);
+    double r = __builtin_fma(-kf, c.hi, x);
+    r = __builtin_fma(-kf, c.lo, r);
     const int ki = static_cast<int>(kf);
     const double t = ((const lds_double*)cx.lds)[PairLds<NS, W>::kExp + (ki & 31)];
-    double p = fma_sgpr_addend(r, LMC_SC(1.0 / 720.0), LMC_SC(1.0 / 120.0));
-    p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 24.0));
-    p = fma_sgpr_addend(p, r, LMC_SC(1.0 / 6.0));
+    double p = fma_sgpr_addend(r, c.c6, c.c5);
+    p = fma_sgpr_addend(p, r, c.c4);
+    p = fma_sgpr_addend(p, r, c.c3);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
@@ -701,7 +730,13 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
     bool c_right = true;                                    // which end {c*} is
     bool c_start = momentum_f32, o_start = momentum_f32;    // end still is the float32 start state
     double prop_e = e0, prop_logp = logp0;
-    double coff = 0.0, w_start = 1.0, wn = 0.0, an = 0.0;
+    double coff = 0.0;
+    // Sum of accepted subtree weights wn, of weight * min(1, e^{-dE}) an, and the start state's weight w_start are touched
+    // once per doubling but would otherwise be loop-carried through the pair loop (and re-copied there every pair, because
+    // the rare rescale path writes them): they live in slot 0 of this wave's level scalars {wn, an, w_start}, where
+    // that path's rescale of the level scalars reaches them too.
+    lds_double* tot = (lds_double*)cx.lds + PairLds<NS, W>::kScal + (W > 1 ? cx.wave_scal : 0);
+    if (lane_id() == 0) { tot[0] = 0.0; tot[1] = 0.0; tot[2] = 1.0; }
     int depth = 0, n_leap = 0;
     bool diverging = false, turning = false, exhausted = true;
     const bool odd_lane = (lane_id() & 1) != 0;
@@ -721,6 +756,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         return (fabs(b) > fabs(a)) ? b : a;
     };
     auto leaf_scalars = [&](double s, int n, double& en, double& ev) -> int {
+        const ExpLanesConst ec = exp_lanes_const();            // requested first: the scalar load runs under the checks below
         en = 0.5 * dpp_f64<0x118>(s) - s;                      // row_shr:8 brings the kinetic sum next to the log-density
         double de = en - e0;
         int ok = 0;
@@ -728,39 +764,43 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         // usual case -- costs three compares and one ballot; anything else takes the sequential path below.
         const bool leaf_lane = lane15 | (lane31 & (n == 2));
         const bool rare = (!(fabs(de) < emax)) | ((-de) - coff > 600.0);
+        bool examined = leaf_lane;   // lanes whose leaf counts for the running max |dE|
+        double de_x = de;            // ... and its energy error (NaN -> inf on the sequential path)
         if ((ballot64(rare & leaf_lane)) == 0ull) {
             n_leap += n;
             ok = n;
-            const bool upd = (fabs(de) > fabs(mde)) & leaf_lane;
-            mde = upd ? de : mde;
         } else {
-            double cur_max = mde_combined();
+            int seen = 0;
             for (int i = 0; i < n; ++i) {
                 double dei = readlane_f64(de, 15 + 16 * i);
-                ++n_leap;
+                ++n_leap; ++seen;
                 if (isnan(dei)) dei = __builtin_inf();
-                if (fabs(dei) > fabs(cur_max)) cur_max = dei;
                 if (!(fabs(dei) < emax)) { diverging = true; break; }   // nuts.py:358,370-375
                 const double x = -dei;
                 if (x - coff > 600.0) {   // cold path: move the offset, rescale every stored weight
                     const double f = exp_uniform(coff - x);
                     const int lane = lane_id();
-                    if (lane >= 1 && lane < kLevelScalDoubles / 4) {
+                    if (lane < kLevelScalDoubles / 4) {   // slot 0 = {wn, an, w_start}, slots >= 1 = levels {w, a, ..}
                         lds_double* sc = (lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * lane) + (W > 1 ? cx.wave_scal : 0);
                         sc[0] = sc[0] * f; sc[1] = sc[1] * f;
+                        if (lane == 0) sc[2] = sc[2] * f;
                     }
-                    wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
                     coff = x;
                 }
                 ++ok;
             }
-            mde = cur_max;   // every lane: later lane-wise updates compete against the overall maximum
+            de_x = isnan(de) ? __builtin_inf() : de;
+            examined = lane15 | (lane31 & (seen == 2));
         }
+        // running signed max |dE| (nuts.py:356-357), one definition for both paths (a second one would make it a
+        // two-register loop-carried value that is copied back and forth every pair)
+        const bool upd = (fabs(de_x) > fabs(mde)) & examined;
+        mde = upd ? de_x : mde;
         // lanes 15 / 31: x - c; lanes 14 / 30: (x - c) + min(x, 0), i.e. log of w * min(1, e^{-dE})
         const double x = -de;
         const double xn = dpp_f64<0x101>(x);                   // row_shl:1: lane l <- lane l+1
         const double arg = odd_lane ? (x - coff) : ((xn - coff) + fmin(xn, 0.0));
-        ev = exp_lanes<NS, W>(cx, arg);
+        ev = exp_lanes<NS, W>(cx, ec, arg);
         return ok;
     };
 
@@ -875,6 +915,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         if (diverging || turning) { exhausted = false; break; }
 
         // ---- accepted subtree: merge into the trajectory (nuts.py:321-340)
+        const double wn = tot[0], an = tot[1], w_start = tot[2];   // same address in every lane: LDS broadcast
         if (uniform_true(team_uniform(tm, rng, win) * (w_start + wn) < tw)) {   // biased progressive
             double tqv[NS];
             if (qsrc == -1) vcopy(tqv, cq);
@@ -883,8 +924,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
             vstore_as<NS>((glb_double*)qrow, tqv);
             prop_e = tpe; prop_logp = tplogp;
         }
-        wn = first_f64(wn + tw);
-        an = first_f64(an + ta);
+        if (lane_id() == 0) { tot[0] = wn + tw; tot[1] = an + ta; }
         double tlp[NS], psum[NS], op[NS], aold[NS];
         if (D == 0) vcopy(tlp, cp);
         else if (D == 1) vcopy(tlp, ep);
@@ -925,7 +965,8 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         if (red_any_nonpositive(red_gather<NS, W>(cx), 0, 6)) { turning = true; exhausted = false; break; }
     }
 
-    const double mean_accept = (wn > 0.0) ? first_f64(an / wn) : 0.0;
+    const double wn_end = first_f64(tot[0]), an_end = first_f64(tot[1]);
+    const double mean_accept = (wn_end > 0.0) ? first_f64(an_end / wn_end) : 0.0;
     out.accept = mean_accept;
     out.energy = prop_e;
     out.energy_error = first_f64(prop_e - e0);
