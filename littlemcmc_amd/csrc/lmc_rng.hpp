@@ -147,24 +147,30 @@ struct UniformWindow {
 __device__ __forceinline__ void window_reset(UniformWindow& w) { w.val = 0.0; w.n = 0; w.idx = 0; }
 
 __device__ inline double window_next(RngState& r, UniformWindow& w) {
-    if (w.idx == w.n) {   // (re)fill from the current stream position
-        if (r.pos >= kMtN) mt_regen(r);
-        int n = (kMtN - r.pos) >> 1;
-        if (n == 0) {          // one word left (odd position inherited from the host): this double straddles the twist
-            w.n = 0; w.idx = 0;
-            return rng_uniform(r);
-        }
-        n = n > 64 ? 64 : n;
-        const int lane = lane_id();
+    // every quantity that steers this function is wave-uniform and kept scalar on purpose (first_i32): the window test,
+    // the index and the stream position are then SALU work and scalar branches instead of VALU compares under exec masks
+    int idx = first_i32(w.idx);
+    if (idx == first_i32(w.n)) {   // (re)fill from the current stream position
+        if (first_i32(r.pos) >= kMtN) mt_regen(r);
+        const int pos = first_i32(r.pos);
+        int n = (kMtN - pos) >> 1;
         double v = 0.0;
-        if (lane < n) v = mt_words_to_double(r.mt[r.pos + 2 * lane], r.mt[r.pos + 2 * lane + 1]);
+        if (n == 0) {          // one word left (odd position inherited from the host): this double straddles the twist;
+            v = rng_uniform(r);   // it becomes a window of one (the position advance below is taken back here)
+            r.pos = first_i32(r.pos) - 2;
+            n = 1;
+        } else {
+            n = n > 64 ? 64 : n;
+            const int lane = lane_id();
+            if (lane < n) v = mt_words_to_double(r.mt[pos + 2 * lane], r.mt[pos + 2 * lane + 1]);
+        }
         w.val = v;
         w.n = n;
-        w.idx = 0;
+        idx = 0;
     }
-    const double u = readlane_f64(w.val, w.idx);
-    ++w.idx;
-    r.pos += 2;
+    const double u = readlane_f64(w.val, idx);
+    w.idx = idx + 1;
+    r.pos = first_i32(r.pos) + 2;
     return u;
 }
 
@@ -224,8 +230,8 @@ __device__ inline void rng_normals(RngState& r, int d, double* out, double* stag
             stage[2 * (have + rank)] = x1;
             stage[2 * (have + rank) + 1] = x2;
         }
-        have += __popcll(mask);
-        r.pos += 4 * consumed;
+        have = first_i32(have + __popcll(mask));
+        r.pos = first_i32(r.pos + 4 * consumed);   // stream position and counts stay scalar (SGPR) values
     }
     wave_sync();
     for (int base = 0; base < need_pairs; base += 64) {

@@ -482,7 +482,7 @@ struct PairCtx {
     double* lds;        // block's dynamic LDS
     double* glb;        // this chain's scratch row
     int nlds;           // stack levels 1..nlds live in LDS (>= 1)
-    int red_lane;       // this lane's 64-byte row of its wave's reduction buffer (doubles, rotation included)
+    int red_lane;       // LDS address (bytes) of this lane's 64-byte row of its wave's reduction buffer, rotation included
     int wave_red;       // this wave's reduction buffer (doubles; 0 for W = 1)
     int wave_scal;      // this wave's copy of the level scalars (doubles; 0 for W = 1)
     int wave;           // wave index in the team
@@ -505,13 +505,15 @@ __device__ __forceinline__ double red_gather(PairCtx& cx) {
     typedef double d2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) d2 lds_d2;
     asm volatile("" ::: "memory");   // DS operations of one wave execute in issue order: no wait, only no reordering
-    int r0 = cx.red_lane;
+    unsigned r0 = static_cast<unsigned>(cx.red_lane);   // LDS address of this lane's row (rotation included)
     asm volatile("" : "+v"(r0));     // keep ONE address register: the other three pieces are re-derived here, not kept live
     lds_double* L = (lds_double*)cx.lds;
     // the four 16-byte pieces of this lane's row in a rotated order (r0 already holds the rotation), so that a
-    // ds_read_b128 of 16 lanes covers all 64 banks (lane stride 64 B = 16 banks)
-    const d2 a = *(const lds_d2*)(L + r0), b = *(const lds_d2*)(L + (r0 ^ 2));
-    const d2 c = *(const lds_d2*)(L + (r0 ^ 4)), d = *(const lds_d2*)(L + (r0 ^ 6));
+    // ds_read_b128 of 16 lanes covers all 64 banks (lane stride 64 B = 16 banks); plain LDS addresses, so that a piece's
+    // address is one v_xor away from r0 (an element index would cost a shift-add per piece on top; the row is 64-byte
+    // aligned, so the xor stays inside it)
+    const d2 a = *(const lds_d2*)(r0), b = *(const lds_d2*)(r0 ^ 16u);
+    const d2 c = *(const lds_d2*)(r0 ^ 32u), d = *(const lds_d2*)(r0 ^ 48u);
     asm volatile("" ::: "memory");
     double s = ((a.x + a.y) + (b.x + b.y)) + ((c.x + c.y) + (d.x + d.y));
     s += dpp_f64<0x111>(s);
@@ -1218,7 +1220,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     cx.wave = tm.wave();
     cx.wave_red = W > 1 ? cx.wave * PairLds<NS, W>::kRedWave : 0;
     cx.wave_scal = W > 1 ? cx.wave * kLevelScalDoubles : 0;
-    cx.red_lane = red_lane_init() + cx.wave_red;
+    cx.red_lane = static_cast<int>(reinterpret_cast<size_t>((lds_double*)lds + (red_lane_init() + cx.wave_red)));
     cx.xpar = 0;
     if (tid < kExpTableDoubles) lds[PairLds<NS, W>::kExp + tid] = kExp2Table[2 * tid];
     tm.sync();
