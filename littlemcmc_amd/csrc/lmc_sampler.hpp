@@ -765,10 +765,13 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         // Both leaves at once on their lanes: neither diverges (or is NaN) and no weight offset has to move -- the
         // usual case -- costs three compares and one ballot; anything else takes the sequential path below.
         const bool leaf_lane = lane15 | (lane31 & (n == 2));
-        const bool rare = (!(fabs(de) < emax)) | ((-de) - coff > 600.0);
+        const unsigned long long leaf_bits = (n == 2) ? ((1ull << 15) | (1ull << 31)) : (1ull << 15);
+        // (one ballot per compare: the mask of a compare IS its SGPR result, a ballot of an AND/OR of lane predicates is
+        //  materialised as 0/1 in a VGPR and compared again)
+        const unsigned long long rare = ballot64(!(fabs(de) < emax)) | ballot64((-de) - coff > 600.0);
         bool examined = leaf_lane;   // lanes whose leaf counts for the running max |dE|
         double de_x = de;            // ... and its energy error (NaN -> inf on the sequential path)
-        if ((ballot64(rare & leaf_lane)) == 0ull) {
+        if ((rare & leaf_bits) == 0ull) {
             n_leap += n;
             ok = n;
         } else {
