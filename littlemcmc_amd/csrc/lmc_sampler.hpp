@@ -657,6 +657,28 @@ __device__ __forceinline__ void level_scal_put(const PairCtx& cx, int j, double 
         s[0] = w; s[1] = a; s[2] = pe; s[3] = plogp;
     }
 }
+// weights of level j only (the proposal's energy / log-density stay where they are until a node is parked or accepted)
+template <int NS, int W = 1>
+__device__ __forceinline__ void level_scal_get_wa(const PairCtx& cx, int j, double& w, double& a) {
+    const lds_double* s = (const lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * j) + (W > 1 ? cx.wave_scal : 0);
+    w = s[0]; a = s[1];
+}
+// scalars of a node parked at level j: weights from the caller; the proposal's {energy, log-density} from their source --
+// lane `elane` of (en, lp) when the proposal is a leaf of the current pair (src < 0: that lane stores them itself, no
+// cross-lane read), else copied from level src
+template <int NS, int W = 1>
+__device__ __forceinline__ void level_scal_park(const PairCtx& cx, int j, double w, double a, int src, int elane, double en, double lp) {
+    lds_double* s = (lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * j) + (W > 1 ? cx.wave_scal : 0);
+    const int lane = lane_id();
+    if (src < 0) {
+        if (lane == elane) { s[2] = en; s[3] = lp; }
+    } else {
+        const lds_double* f = (const lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * src) + (W > 1 ? cx.wave_scal : 0);
+        const double pe = f[2], pl = f[3];
+        if (lane == 0) { s[2] = pe; s[3] = pl; }
+    }
+    if (lane == 0) { s[0] = w; s[1] = a; }
+}
 template <int NS, int W = 1>
 __device__ __forceinline__ void level_scal_get(const PairCtx& cx, int j, double& w, double& a, double& pe, double& plogp) {
     const lds_double* s = (const lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * j) + (W > 1 ? cx.wave_scal : 0);   // same address in every lane: LDS broadcast
@@ -826,8 +848,14 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         // subtree node under construction: momentum sum tps, weights; its right-end momentum is always the current cp,
         // its left-end momentum and proposal position are identified by their sources
         double tps[NS], eq[NS], ep[NS];
-        double tw = 0.0, ta = 0.0, tpe = 0.0, tplogp = 0.0;
+        double tw = 0.0, ta = 0.0;
         int qsrc = -1;   // proposal position: -2 first leaf of the last pair (eq), -1 the current state (cq), j >= 1 stack level j
+        // The proposal's energy and log-density are not carried through the merges: for qsrc < 0 they sit on lane `elane`
+        // of the last pair's (en_last, lp_last), for qsrc >= 1 in that level's scalars; they are fetched when the node is
+        // parked or accepted. (The sum of w * min(1, e^{-dE}) could leave the merges the same way -- accumulated on lanes
+        // 14 / 30 -- but the extra loop-carried register measured -1.6 % on depth-3 trees, 0 on C3.)
+        int elane = 15;
+        double en_last = 0.0, lp_last = 0.0;
         const int D = depth;
         if (D == 0) {
             double v[NS], kinp, lp, en, ev;
@@ -836,7 +864,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
             const double s0 = red_gather<NS, W>(cx);                   //  test measured 1 % slower on depth-3 trees, equal on C3)
             if (leaf_scalars(s0, 1, en, ev) == 1) {
                 tw = readlane_f64(ev, 15); ta = readlane_f64(ev, 14);
-                tpe = readlane_f64(en, 15); tplogp = readlane_f64(s0, 15);
+                en_last = en; lp_last = s0;
                 vcopy(tps, cp);
             }
         } else {
@@ -865,22 +893,22 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                     const double wsum = wA + wB;
                     const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < wB);   // drawn even if turning
                     qsrc = take_b ? -1 : -2;
-                    const int pl = take_b ? 31 : 15;
-                    tpe = readlane_f64(en, pl); tplogp = readlane_f64(s0, pl);
+                    elane = take_b ? 31 : 15;
+                    en_last = en; lp_last = s0;
                     tw = wsum; ta = aA + aB;
                     if (turn) { turning = true; break; }
                 }
                 // ---- cascade level 1 (left end of the in-flight pair node = ep)
                 if (m >= 1) {
                     double alp[NS], arp[NS], aps[NS];
-                    double aw, aa, ape, aplogp;
+                    double aw, aa;
                     level1_load<NS, W>(cx, alp, arp, aps);   // (requesting it before the leaf scalars measured -8 %: one more live address)
-                    level_scal_get<NS, W>(cx, 1, aw, aa, ape, aplogp);
+                    level_scal_get_wa<NS, W>(cx, 1, aw, aa);
                     const double sj = cascade_dots<NS, W>(cx, var, alp, arp, aps, ep, tps, v);
                     const bool turn = red_any_nonpositive(sj, 0, 6);
                     const double wsum = aw + tw;
                     const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < tw);
-                    if (!take_b) { qsrc = 1; tpe = ape; tplogp = aplogp; }
+                    if (!take_b) qsrc = 1;
                     tw = wsum; ta = aa + ta;
                     if (turn) { turning = true; break; }
                 }
@@ -889,13 +917,13 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                     double blp[NS], brp[NS], bps[NS], tl[NS];
                     levelN_load<NS, W>(cx, j, 0, blp); levelN_load<NS, W>(cx, j, 1, brp); levelN_load<NS, W>(cx, j, 2, bps);
                     level_load_lp<NS, W>(cx, j - 1, tl);
-                    double bw, ba, bpe, bplogp;
-                    level_scal_get<NS, W>(cx, j, bw, ba, bpe, bplogp);
+                    double bw, ba;
+                    level_scal_get_wa<NS, W>(cx, j, bw, ba);
                     const double sj = cascade_dots<NS, W>(cx, var, blp, brp, bps, tl, tps, v);
                     const bool turn = red_any_nonpositive(sj, 0, 6);
                     const double wsum = bw + tw;
                     const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < tw);
-                    if (!take_b) { qsrc = j; tpe = bpe; tplogp = bplogp; }
+                    if (!take_b) qsrc = j;
                     tw = wsum; ta = ba + ta;
                     if (turn) { turning = true; break; }
                 }
@@ -912,7 +940,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                         levelN_store<NS, W>(cx, m + 1, 0, tl); levelN_store<NS, W>(cx, m + 1, 1, cp);
                         levelN_store<NS, W>(cx, m + 1, 2, tps); levelN_store<NS, W>(cx, m + 1, 3, tqv);
                     }
-                    level_scal_put<NS, W>(cx, m + 1, tw, ta, tpe, tplogp);
+                    level_scal_park<NS, W>(cx, m + 1, tw, ta, qsrc, elane, en_last, lp_last);
                 }
             }
         }
@@ -927,7 +955,13 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
             else if (qsrc == -2) vcopy(tqv, eq);
             else level_load_q<NS, W>(cx, qsrc, tqv);
             vstore_as<NS>((glb_double*)qrow, tqv);
-            prop_e = tpe; prop_logp = tplogp;
+            if (qsrc < 0) {
+                prop_e = readlane_f64(en_last, elane); prop_logp = readlane_f64(lp_last, elane);
+            } else {
+                double w_, a_;
+                level_scal_get<NS, W>(cx, qsrc, w_, a_, prop_e, prop_logp);
+                prop_e = first_f64(prop_e); prop_logp = first_f64(prop_logp);
+            }
         }
         if (lane_id() == 0) { tot[0] = wn + tw; tot[1] = an + ta; }
         double tlp[NS], psum[NS], op[NS], aold[NS];
