@@ -289,6 +289,7 @@ __device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, con
     bool l_start = true, r_start = true;   // the end still is the start state: its stored velocity is v0s
     double prop_e = e0, prop_logp = logp0;
     double coff = 0.0, w_start = 1.0, wn = 0.0, an = 0.0, max_de = 0.0;   // linear-domain weights, see lmc_sampler.hpp
+    double c_tot = 0.0;   // offset the accepted totals {w_start, wn, an} are expressed in (see nuts_transition2)
     int depth = 0, n_leap = 0;
     bool diverging = false, turning = false, exhausted = true;
     LevelScalars lsc = {0.0, 0.0, 0.0, 0.0};
@@ -318,7 +319,6 @@ __device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, con
             if (x - coff > 600.0) {
                 const double f = exp_uniform(coff - x);
                 lsc.w *= f; lsc.a *= f;
-                wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
                 coff = x;
             }
             tw = exp_uniform_fast(x - coff);
@@ -369,6 +369,11 @@ __device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, con
         if (diverging || turning) { exhausted = false; break; }
 
         // ---- accepted subtree: merge into the trajectory (nuts.py:321-340)
+        if (c_tot != coff) {   // the offset moved inside this subtree: bring the accepted totals to it (rare)
+            const double f = exp_uniform(c_tot - coff);
+            wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
+            c_tot = coff;
+        }
         if (uniform_true(window_next(rng, win) * (w_start + wn) < tw)) {
             vcopy(propq, tq); prop_e = tpe; prop_logp = tplogp;
         }

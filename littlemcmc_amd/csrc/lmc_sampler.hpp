@@ -512,8 +512,8 @@ __device__ __forceinline__ double red_gather(PairCtx& cx) {
     // ds_read_b128 of 16 lanes covers all 64 banks (lane stride 64 B = 16 banks); plain LDS addresses, so that a piece's
     // address is one v_xor away from r0 (an element index would cost a shift-add per piece on top; the row is 64-byte
     // aligned, so the xor stays inside it)
-    const d2 a = *(const lds_d2*)(r0), b = *(const lds_d2*)(r0 ^ 16u);
-    const d2 c = *(const lds_d2*)(r0 ^ 32u), d = *(const lds_d2*)(r0 ^ 48u);
+    const d2 a = *(const lds_d2*)(size_t)(r0), b = *(const lds_d2*)(size_t)(r0 ^ 16u);
+    const d2 c = *(const lds_d2*)(size_t)(r0 ^ 32u), d = *(const lds_d2*)(size_t)(r0 ^ 48u);
     asm volatile("" ::: "memory");
     double s = ((a.x + a.y) + (b.x + b.y)) + ((c.x + c.y) + (d.x + d.y));
     s += dpp_f64<0x111>(s);
@@ -757,10 +757,13 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
     double coff = 0.0;
     // Sum of accepted subtree weights wn, of weight * min(1, e^{-dE}) an, and the start state's weight w_start are touched
     // once per doubling but would otherwise be loop-carried through the pair loop (and re-copied there every pair, because
-    // the rare rescale path writes them): they live in slot 0 of this wave's level scalars {wn, an, w_start}, where
-    // that path's rescale of the level scalars reaches them too.
+    // the rare rescale path would write them): they live in slot 0 of this wave's level scalars {wn, an, w_start,
+    // c_tot}. They are expressed in the weight offset
+    // c_tot of the moment they were last merged and are brought to the current one only when a subtree is ACCEPTED: a
+    // rejected subtree whose leaf moved the offset by more than ~745 would otherwise flush them to zero and the
+    // acceptance statistic with them (0/0).
     lds_double* tot = (lds_double*)cx.lds + PairLds<NS, W>::kScal + (W > 1 ? cx.wave_scal : 0);
-    if (lane_id() == 0) { tot[0] = 0.0; tot[1] = 0.0; tot[2] = 1.0; }
+    if (lane_id() == 0) { tot[0] = 0.0; tot[1] = 0.0; tot[2] = 1.0; tot[3] = 0.0; }
     int depth = 0, n_leap = 0;
     bool diverging = false, turning = false, exhausted = true;
     const bool odd_lane = (lane_id() & 1) != 0;
@@ -807,10 +810,9 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                 if (x - coff > 600.0) {   // cold path: move the offset, rescale every stored weight
                     const double f = exp_uniform(coff - x);
                     const int lane = lane_id();
-                    if (lane < kLevelScalDoubles / 4) {   // slot 0 = {wn, an, w_start}, slots >= 1 = levels {w, a, ..}
+                    if (lane >= 1 && lane < kLevelScalDoubles / 4) {   // the parked levels {w, a, ..}; slot 0 (totals) keeps its own offset
                         lds_double* sc = (lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * lane) + (W > 1 ? cx.wave_scal : 0);
                         sc[0] = sc[0] * f; sc[1] = sc[1] * f;
-                        if (lane == 0) sc[2] = sc[2] * f;
                     }
                     coff = x;
                 }
@@ -948,7 +950,13 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         if (diverging || turning) { exhausted = false; break; }
 
         // ---- accepted subtree: merge into the trajectory (nuts.py:321-340)
-        const double wn = tot[0], an = tot[1], w_start = tot[2];   // same address in every lane: LDS broadcast
+        double wn = tot[0], an = tot[1], w_start = tot[2];   // same address in every lane: LDS broadcast
+        const double c_tot = tot[3];
+        if (uniform_true(c_tot != coff)) {   // the offset moved inside this subtree: bring the accepted totals to it (rare)
+            const double f = exp_uniform(first_f64(c_tot) - coff);
+            wn = wn * f; an = an * f; w_start = w_start * f;
+            if (lane_id() == 0) { tot[2] = w_start; tot[3] = coff; }
+        }
         if (uniform_true(team_uniform(tm, rng, win) * (w_start + wn) < tw)) {   // biased progressive
             double tqv[NS];
             if (qsrc == -1) vcopy(tqv, cq);

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
     double logp0 = first_f64(td[kTdLogp0]), prop_e = first_f64(td[kTdPropE]), prop_logp = first_f64(td[kTdPropLogp]);
     double coff = first_f64(td[kTdCoff]), w_start = first_f64(td[kTdWStart]), wn = first_f64(td[kTdWn]);
     double an = first_f64(td[kTdAn]), max_de = first_f64(td[kTdMaxDe]), plen = first_f64(td[kTdPlen]);
+    double c_tot = first_f64(td[kTdCtot]);   // offset the accepted totals {w_start, wn, an} are expressed in
     LevelScalars lsc = {0.0, 0.0, 0.0, 0.0};
     double* lvl = K.lvl + static_cast<long long>(c) * 4 * kTickLevels;
     if (lane < kTickLevels) {
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
             vstore_as<NS>(slot(6), p0); vstore_as<NS>(slot(7), q);
             l_start = momentum_f32; r_start = momentum_f32;
             prop_e = e0; prop_logp = logp0;
-            coff = 0.0; w_start = 1.0; wn = 0.0; an = 0.0; max_de = 0.0;
+            coff = 0.0; c_tot = 0.0; w_start = 1.0; wn = 0.0; an = 0.0; max_de = 0.0;
             depth = 0;
             lsc = {0.0, 0.0, 0.0, 0.0};
             begin_doubling = true;
@@ -163,7 +164,6 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
                 if (x - coff > 600.0) {
                     const double f = exp_uniform(coff - x);
                     lsc.w *= f; lsc.a *= f;
-                    wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
                     coff = x;
                 }
                 tw = exp_uniform_fast(x - coff);
@@ -219,6 +219,11 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
                 ++depth;
                 double psum[NS], propq[NS];
                 vload_as<NS>(slot(6), psum); vload_as<NS>(slot(7), propq);
+                if (c_tot != coff) {   // the offset moved inside this subtree: bring the accepted totals to it (rare)
+                    const double f = exp_uniform(c_tot - coff);
+                    wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
+                    c_tot = coff;
+                }
                 if (uniform_true(window_next(rng, win) * (w_start + wn) < tw)) {
                     vcopy(propq, tq); prop_e = tpe; prop_logp = tplogp;
                     vstore_as<NS>(slot(7), propq);
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(64, tick_waves_per_simd(NS)) void tick_kernel(Chain
         ti[kTiLStart] = l_start ? 1 : 0; ti[kTiRStart] = r_start ? 1 : 0; ti[kTiMaxDepth] = max_depth; ti[kTiSteps] = n_steps;
         td[kTdEps] = eps; td[kTdStep] = step_size; td[kTdE0] = e0; td[kTdLogp0] = logp0; td[kTdPropE] = prop_e;
         td[kTdPropLogp] = prop_logp; td[kTdCoff] = coff; td[kTdWStart] = w_start; td[kTdWn] = wn; td[kTdAn] = an;
-        td[kTdMaxDe] = max_de; td[kTdPlen] = plen;
+        td[kTdMaxDe] = max_de; td[kTdPlen] = plen; td[kTdCtot] = c_tot;
         A.rng_pos[c] = rng.pos;
         A.rng_has_gauss[c] = rng.has_gauss;
         A.rng_gauss[c] = rng.gauss;

@@ -10,7 +10,7 @@ namespace lmc {
 enum TickPhase : int { kTickStart = 0, kTickLeap = 1, kTickDone = 2 };
 enum TickInt : int { kTiDepth = 0, kTiLeaf, kTiRight, kTiNLeap, kTiLStart, kTiRStart, kTiMaxDepth, kTiSteps, kNumTickInt };
 enum TickDbl : int { kTdEps = 0, kTdStep, kTdE0, kTdLogp0, kTdPropE, kTdPropLogp, kTdCoff, kTdWStart, kTdWn, kTdAn,
-                     kTdMaxDe, kTdPlen, kNumTickDbl };
+                     kTdMaxDe, kTdPlen, kTdCtot, kNumTickDbl };
 constexpr int kTickLevels = 24;   // per-level subtree scalars kept per chain (max_treedepth <= 20)
 
 struct TickArrays {

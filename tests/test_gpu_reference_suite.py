@@ -403,3 +403,46 @@ def test_separable_user_target_student_t():
     # Var of t_5 = nu/(nu-2) = 5/3; heavy tails: pooled estimate within 8 %
     assert abs(trace.var() / (nu / (nu - 2)) - 1) < 0.08 and abs(trace.mean()) < 0.02
     assert stats["diverging"].mean() < 0.01
+
+
+@pytest.mark.parametrize("path", ["fused", "dense", "ticks"])
+def test_weight_offset_moves_when_the_energy_drops_by_more_than_600(path):
+    """Tree weights are kept in the linear domain as e^{-dE - c} with ONE offset c per transition; a leaf whose -dE
+    exceeds c by more than 600 moves the offset and rescales the stored weights. That path is rare by construction:
+    force it with a unit Gaussian entered far out with a step size close to the stability limit (leapfrog's modified
+    energy makes H drop by 700-860 on the way in) and compare with the oracle, which carries log-weights and has no
+    such path. In four of the six chains the drop exceeds 745 inside a subtree that is then REJECTED (it turns): the
+    accepted totals must survive that (they once underflowed to 0/0 and the acceptance statistic read 0)."""
+    from oracle import lmc_oracle as orc
+    from oracle import targets as OT
+
+    d = 3
+    f = OT.make("std_normal", d)
+    sc = 1.85 * d ** 0.25
+    starts = [np.full(d, v) for v in (24.0, 24.5, 25.0, 25.5, 26.0, 23.5)]
+    seeds = [5, 6, 7, 8, 9, 10]
+    if path == "dense":
+        opot, pot = orc.FullPotential(np.eye(d)), lmc.QuadPotentialFull(np.eye(d))
+    else:
+        opot, pot = None, None
+    if path == "ticks":
+        import torch
+
+        tgt = lmc.targets.TorchTarget(d, lambda q: (-0.5 * (q * q).sum(dim=1), -q))
+    else:
+        tgt = lmc.targets.StdNormal(d)
+    okw = dict(potential=opot) if opot is not None else {}
+    kw = dict(potential=pot) if pot is not None else {}
+    ostep = orc.Step(f, d, kind="nuts", adapt_step_size=False, step_scale=sc, **okw)
+    ot, ost = orc.sample(f, d, draws=6, tune=0, step=ostep, chains=len(seeds), start=starts, random_seed=seeds,
+                         discard_tuned_samples=False)
+    step = lmc.NUTS(tgt, d, adapt_step_size=False, step_scale=sc, **kw)
+    gt, gst = lmc.sample(tgt, d, draws=6, tune=0, step=step, chains=len(seeds), start=starts, random_seed=seeds,
+                         discard_tuned_samples=False)
+    assert (ost["max_energy_error"].min(axis=(1, 2)) < -745.0).sum() >= 3 and not ost["diverging"].any()   # the rare case
+    npt.assert_array_equal(gst["depth"], ost["depth"])
+    npt.assert_array_equal(gst["tree_size"], ost["tree_size"])
+    npt.assert_array_equal(gst["diverging"], ost["diverging"])
+    npt.assert_allclose(gst["max_energy_error"], ost["max_energy_error"], rtol=1e-9)
+    npt.assert_allclose(gst["mean_tree_accept"], ost["mean_tree_accept"], rtol=1e-8, atol=1e-300)
+    npt.assert_allclose(gt, ot, rtol=1e-9, atol=1e-10)
