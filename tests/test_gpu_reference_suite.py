@@ -446,3 +446,19 @@ def test_weight_offset_moves_when_the_energy_drops_by_more_than_600(path):
     npt.assert_allclose(gst["max_energy_error"], ost["max_energy_error"], rtol=1e-9)
     npt.assert_allclose(gst["mean_tree_accept"], ost["mean_tree_accept"], rtol=1e-8, atol=1e-300)
     npt.assert_allclose(gt, ot, rtol=1e-9, atol=1e-10)
+
+
+def test_rare_paths_differential_fuzz():
+    """tools/fuzz_rare.py: chains entered far out in the tails with step sizes up to the stability limit (weight-offset
+    moves in shallow and deep trees, divergences in either leaf of a pair, depth-capped trees, one-wave and team
+    kernels), every sampler statistic of the first iterations against the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_rare.py"), "80", "11"], capture_output=True,
+                         text=True, timeout=900, cwd=root)
+    tail = "\n".join(res.stdout.strip().split("\n")[-6:])
+    assert res.returncode == 0, tail + "\n" + res.stderr[-2000:]
+    assert "failures: 0" in tail
