@@ -197,6 +197,10 @@ int lmc_engine_set_dual_average(lmc_engine* e, double log_step, double log_bar, 
  *        stream that precedes a run() is ordered before it.
  * run_streams(): the streams run() launches its kernels on (returns their number, at most `capacity` written) -- for
  *        callers that bracket launches with their own timing events. */
+/* step_rand (base_hmc.py:46,123,154-155) in the one form that keeps same-seed parity on the device:
+ * step_rand = lambda s: s * np.random.uniform(lo, hi) -- one double of the chain's own stream per iteration, drawn
+ * between the start state and the trajectory. enable = 0 switches it off (the default). */
+int lmc_engine_set_step_jitter(lmc_engine* e, int32_t enable, double lo, double hi);
 int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int64_t trace_begin);
 int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters);
 int lmc_engine_run_streams(lmc_engine* e, void** streams, int32_t capacity);

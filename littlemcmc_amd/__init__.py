@@ -7,6 +7,7 @@ importing the package needs no GPU, using it does -- there is no CPU fallback.""
 __version__ = "0.1.0"
 
 from . import diagnostics, distributed, quadpotential as _qp, targets
+from .base_hmc import StepRandUniform
 from .engine import Engine
 from .hmc import HamiltonianMC
 from .nuts import NUTS
@@ -19,5 +20,5 @@ QuadPotentialFull, QuadPotentialFullInv, QuadPotentialFullAdapt = (
     _qp.QuadPotentialFull, _qp.QuadPotentialFullInv, _qp.QuadPotentialFullAdapt)
 
 __all__ = ["sample", "init_nuts", "HamiltonianMC", "NUTS", "quad_potential", "QuadPotentialDiag", "QuadPotentialFull",
-           "QuadPotentialFullInv", "QuadPotentialDiagAdapt", "QuadPotentialFullAdapt", "Engine", "targets",
+           "QuadPotentialFullInv", "QuadPotentialDiagAdapt", "QuadPotentialFullAdapt", "Engine", "StepRandUniform", "targets",
            "diagnostics", "distributed"]

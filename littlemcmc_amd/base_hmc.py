@@ -43,6 +43,25 @@ class _StepIntegrator(HipLeapfrogIntegrator):
         return self._step._engine()
 
 
+class StepRandUniform:
+    """``step_rand`` (base_hmc.py:46,123,154-155) in the form the device can honour with same-seed parity:
+    ``StepRandUniform(lo, hi)`` is ``lambda s: s * np.random.uniform(lo, hi)`` -- one double of the chain's own legacy stream
+    per iteration, drawn where the reference calls the function (after the momentum draw and the start state, before the
+    trajectory). Calling the object does exactly that on the host, so it can be handed to the reference too; an arbitrary
+    Python callable cannot run inside the sampling kernel and is refused."""
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi = float(lo), float(hi)
+        if not (np.isfinite(self.lo) and np.isfinite(self.hi)):
+            raise ValueError("step_rand bounds must be finite")
+
+    def __call__(self, step_size):
+        return step_size * np.random.uniform(self.lo, self.hi)
+
+    def __repr__(self):
+        return "StepRandUniform(%r, %r)" % (self.lo, self.hi)
+
+
 class BaseHMC:
     """Superclass of the Hamiltonian samplers (base_hmc.py:29)."""
 
@@ -52,8 +71,10 @@ class BaseHMC:
     def __init__(self, logp_dlogp_func, model_ndim, scaling, is_cov, potential, target_accept, Emax,
                  adapt_step_size, step_scale, gamma, k, t0, step_rand):
         self._logp_dlogp_func = require_device_target(logp_dlogp_func, model_ndim)
-        if step_rand is not None:
-            raise NotImplementedError("step_rand is a per-iteration host callback; not available on the device path")
+        if step_rand is not None and not isinstance(step_rand, StepRandUniform):
+            raise NotImplementedError(
+                "an arbitrary step_rand callable cannot run inside the sampling kernel; the device form is "
+                "littlemcmc_amd.StepRandUniform(lo, hi) == lambda s: s * np.random.uniform(lo, hi)")
         self.adapt_step_size = adapt_step_size
         self.Emax = Emax
         self.iter_count = 0
@@ -75,7 +96,7 @@ class BaseHMC:
             self.potential = quad_potential(np.asarray(scaling), is_cov)
         self._eng1 = None
         self.integrator = _StepIntegrator(self)
-        self._step_rand = None
+        self._step_rand = step_rand
         self._warnings = []
         self._samples_after_tune = 0
         self._num_divs_sample = 0
@@ -96,6 +117,8 @@ class BaseHMC:
 
         eng = Engine(self._logp_dlogp_func, chains=chains, device=device, **self._engine_kwargs())
         self.potential._push_initial(eng)
+        if self._step_rand is not None:
+            eng.set_step_jitter(self._step_rand.lo, self._step_rand.hi)
         return eng
 
     def _engine(self):

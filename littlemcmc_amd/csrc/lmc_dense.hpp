@@ -533,7 +533,7 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel
             break;
         }
         const bool adapt_step = tune && P.adapt_step_size;
-        const double step_size = adapt_step ? da.step_now : da.step_bar_now;
+        const double step_size = jitter_step_size(tm, rng, P, adapt_step ? da.step_now : da.step_bar_now);
 
         TransitionOut out;
         if (P.kind == 0) {

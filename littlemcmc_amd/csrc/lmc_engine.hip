@@ -191,6 +191,8 @@ struct lmc_engine {
     hipStream_t sub_stream[kMaxSub] = {nullptr, nullptr};
     hipEvent_t sub_done[kMaxSub] = {nullptr, nullptr};
     hipEvent_t main_done = nullptr;
+    int step_jitter = 0;        // step_rand as step * uniform(lo, hi) (lmc_engine_set_step_jitter)
+    double jitter_lo = 1.0, jitter_hi = 1.0;
     bool sub_pending = false;   // sub-block kernels in flight that the main stream has not been ordered after
     bool main_dirty = true;     // work enqueued on the main stream that the sub-streams have not been ordered after
     ChainArrays A;
@@ -753,6 +755,15 @@ static int user_launch(lmc_engine* e, hipFunction_t f, hipStream_t st, unsigned 
     return LMC_OK;
 }
 
+int lmc_engine_set_step_jitter(lmc_engine* e, int32_t enable, double lo, double hi) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    if (enable && !(std::isfinite(lo) && std::isfinite(hi))) return fail(e, LMC_ERR_INVALID, "step jitter bounds must be finite");
+    e->step_jitter = enable ? 1 : 0;
+    e->jitter_lo = lo;
+    e->jitter_hi = hi;
+    return LMC_OK;
+}
+
 int lmc_engine_set_stream(lmc_engine* e, void* hip_stream) {
     if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
     HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
@@ -1218,6 +1229,9 @@ static SamplerParams make_params(const lmc_engine* e, int64_t n_tune, int64_t it
     P.nlds = e->nlds;
     P.lds_doubles = e->lds_bytes / 8;
     P.sdot_mode = e->cfg.start_energy_sdot;
+    P.step_jitter = e->step_jitter;
+    P.jitter_lo = e->jitter_lo;
+    P.jitter_hi = e->jitter_hi;
     return P;
 }
 

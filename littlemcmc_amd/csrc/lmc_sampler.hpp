@@ -99,6 +99,8 @@ struct SamplerParams {
     int lds_doubles;      // LDS doubles used by the subtree stack; the MT19937 state (624 words) follows
     int sdot_mode;        // SdotMode for the float32 start-state kinetic energy
     int chain_begin;      // run_kernel: first chain of this launch (the engine launches its chains as sub-blocks)
+    int step_jitter;      // step_rand (base_hmc.py:154-155) in its one device form: step * uniform(jitter_lo, jitter_hi)
+    double jitter_lo, jitter_hi;
 };
 
 // ---- vector <-> memory (blocked layout, 8*NS contiguous bytes per thread of the team) -----------------
@@ -266,6 +268,17 @@ __device__ inline double team_uniform(TeamT& tm, RngState& r, UniformWindow& w) 
         }
         return window_next(r, w);
     }
+}
+// step_rand (base_hmc.py:46,123,154-155) for  lambda s: s * np.random.uniform(lo, hi): ONE double of the chain's own
+// stream, drawn where the reference calls it -- after the momentum draw and the start state, before the trajectory
+// (np.random.uniform(lo, hi) = lo + (hi - lo) * random_sample())
+template <class TeamT>
+__device__ __forceinline__ double jitter_step_size(TeamT& tm, RngState& rng, const SamplerParams& P, double step_size) {
+    if (!P.step_jitter) return step_size;
+    UniformWindow jw;
+    window_reset(jw);
+    const double u = team_uniform(tm, rng, jw);
+    return first_f64(step_size * (P.jitter_lo + (P.jitter_hi - P.jitter_lo) * u));
 }
 template <class TeamT>
 __device__ inline void team_normals(TeamT& tm, RngState& r, int d, double* out, double* stage, double* bcast) {
@@ -1312,7 +1325,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
 
         // ---- step size for this iteration (base_hmc.py:151-153)
         const bool adapt_step = tune && P.adapt_step_size;
-        const double step_size = adapt_step ? da.step_now : da.step_bar_now;   // exp(log_step) / exp(log_bar)
+        const double step_size = jitter_step_size(tm, rng, P, adapt_step ? da.step_now : da.step_bar_now);   // exp(log_step) / exp(log_bar)
 
         LMC_PHASE(1)
         TransitionOut out;

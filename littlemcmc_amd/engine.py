@@ -158,6 +158,10 @@ class Engine:
             return self._run_ticks(int(n_tune), int(iter_begin), int(n_iters))
         self._check(self._lib.lmc_engine_run(self._h, int(n_tune), int(iter_begin), int(n_iters)))
 
+    def set_step_jitter(self, lo, hi, enable=True):
+        """step_rand as step * uniform(lo, hi) drawn from each chain's own stream (include/lmc_hip.h)."""
+        self._check(self._lib.lmc_engine_set_step_jitter(self._h, int(bool(enable)), float(lo), float(hi)))
+
     def resident_chains(self):
         """How many chains the sampling kernel keeps resident on the GPU at once (wave slots / waves per chain);
         None for engines without a fused sampling kernel."""

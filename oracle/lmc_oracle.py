@@ -568,8 +568,12 @@ class Step:
     def __init__(self, f, d, kind="nuts", scaling=None, is_cov=False, potential=None,
                  target_accept=0.8, Emax=1000, adapt_step_size=True, step_scale=0.25, gamma=0.05,
                  k=0.75, t0=10, path_length=2.0, max_treedepth=10, early_max_treedepth=8,
-                 max_steps=1024):
+                 max_steps=1024, step_rand=None):
         self.f, self.d, self.kind = f, d, kind
+        # base_hmc.py:46,123,154-155: step_rand(step_size) -> step_size, any callable in the reference. Restated for the
+        # one form that can keep same-seed parity: (lo, hi) stands for  lambda s: s * np.random.uniform(lo, hi)  -- ONE
+        # uniform from the chain's stream, drawn where the reference calls it (after the momentum draw, before the tree)
+        self.step_rand = step_rand
         self.Emax = Emax
         self.adapt_step_size = adapt_step_size
         self.step_size = step_scale / (d ** 0.25)  # base_hmc.py:102
@@ -605,6 +609,9 @@ class Step:
         adapt_step = self.tune and self.adapt_step_size
         step_size = self.adapt.current(adapt_step)
         self.step_size = step_size
+        if self.step_rand is not None:   # base_hmc.py:154-155
+            lo, hi = self.step_rand
+            step_size = step_size * rng.uniform(lo, hi)
         if self.kind == "nuts":
             md = self.early_max_treedepth if (self.tune and self.iter_count < 200) else self.max_treedepth
             end, stats, diverging, exhausted, m = nuts_transition(

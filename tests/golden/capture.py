@@ -486,10 +486,38 @@ def capture_diag_window_multiplier():
     save("diag_window_multiplier", **out)
 
 
+# ---------------------------------------------------------------------------------------
+# step_rand (base_hmc.py:46,123,154-155): the per-iteration step-size jitter, in the one form that consumes the
+# chain's own stream in a fixed way -- lambda s: s * np.random.uniform(lo, hi)
+# ---------------------------------------------------------------------------------------
+def capture_step_rand():
+    lo, hi = 0.8, 1.25
+    jitter = lambda s: s * np.random.uniform(lo, hi)   # noqa: E731
+    out = {"lo": np.array(lo), "hi": np.array(hi), "random_seed": np.array(SEED)}
+    # NUTS through the plain API (kwargs reach the NUTS constructor, sampling.py:149-155)
+    f = targets.make("ar1", 12)
+    trace, stats = ref.sample(f, 12, draws=15, tune=60, chains=2, cores=1, progressbar=False, random_seed=SEED,
+                              discard_tuned_samples=False, step_rand=jitter)
+    out.update(nuts_family=np.array("ar1"), nuts_d=np.array(12), nuts_chains=np.array(2), nuts_tune=np.array(60),
+               nuts_draws=np.array(15), nuts_trace=trace)
+    for k, v in stats.items():
+        out["nuts_stat_" + k] = v
+    # HMC with an explicit step object
+    f = targets.make("std_normal", 6)
+    step = ref.HamiltonianMC(f, 6, path_length=1.5, step_rand=jitter)
+    trace, stats = ref.sample(f, 6, draws=15, tune=60, step=step, chains=2, cores=1, progressbar=False,
+                              random_seed=SEED, discard_tuned_samples=False)
+    out.update(hmc_family=np.array("std_normal"), hmc_d=np.array(6), hmc_chains=np.array(2), hmc_tune=np.array(60),
+               hmc_draws=np.array(15), hmc_path_length=np.array(1.5), hmc_trace=trace)
+    for k, v in stats.items():
+        out["hmc_stat_" + k] = v
+    save("e2e_step_rand", **out)
+
+
 CAPTURES = {"leapfrog": capture_leapfrog, "transitions": capture_transitions, "adapt": capture_adapt,
             "e2e": capture_e2e, "seeds": capture_seeds, "dense_units": capture_dense_units,
             "dense_adapt": capture_dense_adapt, "dense_e2e": capture_dense_e2e,
-            "diag_window_multiplier": capture_diag_window_multiplier}
+            "diag_window_multiplier": capture_diag_window_multiplier, "step_rand": capture_step_rand}
 
 if __name__ == "__main__":
     # capture.py [group | e2e:<name>[,<name>...]] ...   (no argument: everything)

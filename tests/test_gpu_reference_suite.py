@@ -462,3 +462,55 @@ def test_rare_paths_differential_fuzz():
     tail = "\n".join(res.stdout.strip().split("\n")[-6:])
     assert res.returncode == 0, tail + "\n" + res.stderr[-2000:]
     assert "failures: 0" in tail
+
+
+@pytest.mark.parametrize("kind", ["nuts", "hmc", "nuts_dense", "nuts_ticks"])
+def test_step_rand_uniform_draws_from_the_chain_stream(golden_dir, kind):
+    """step_rand (base_hmc.py:154-155) as StepRandUniform(lo, hi) == lambda s: s * np.random.uniform(lo, hi): the jitter
+    uniform comes out of each chain's own stream between the start state and the trajectory, in the fused, dense and
+    tick kernels alike. The NUTS / HMC cases reproduce chains captured from the imported reference running that very
+    lambda (tests/golden/e2e_step_rand.npz); the dense / tick cases are checked against the oracle."""
+    import os
+
+    from oracle import lmc_oracle as orc
+    from oracle import targets as OT
+
+    g = np.load(os.path.join(golden_dir, "e2e_step_rand.npz"))
+    lo, hi, seed = float(g["lo"]), float(g["hi"]), int(g["random_seed"])
+    sr = lmc.StepRandUniform(lo, hi)
+    n = 12   # iterations compared: dual averaging amplifies 1-ulp differences beyond that (DESIGN section 5)
+    if kind == "hmc":
+        d, chains, tune, draws = int(g["hmc_d"]), int(g["hmc_chains"]), int(g["hmc_tune"]), int(g["hmc_draws"])
+        tgt = lmc.targets.StdNormal(d)
+        step = lmc.HamiltonianMC(tgt, d, path_length=float(g["hmc_path_length"]), step_rand=sr)
+        gt, gst = lmc.sample(tgt, d, draws=draws, tune=tune, step=step, chains=chains, random_seed=seed,
+                             discard_tuned_samples=False)
+        want_t, want_n = g["hmc_trace"], g["hmc_stat_n_steps"]
+        npt.assert_array_equal(gst["n_steps"][:, :n], want_n[:, :n])
+        npt.assert_allclose(gst["step_size"][:, :n], g["hmc_stat_step_size"][:, :n], rtol=1e-9)
+        npt.assert_allclose(gt[:, :n], want_t[:, :n], rtol=1e-7, atol=1e-9)
+        return
+    d, chains, tune, draws = int(g["nuts_d"]), int(g["nuts_chains"]), int(g["nuts_tune"]), int(g["nuts_draws"])
+    f = OT.make("ar1", d)
+    if kind == "nuts":
+        tgt = lmc.targets.AR1(d)
+        gt, gst = lmc.sample(tgt, d, draws=draws, tune=tune, chains=chains, random_seed=seed, discard_tuned_samples=False,
+                             step_rand=sr)
+        want_t, want_ts = g["nuts_trace"], g["nuts_stat_tree_size"]
+    else:
+        if kind == "nuts_dense":
+            tgt, init = lmc.targets.AR1(d), "adapt_full"
+        else:
+            import torch
+
+            prec = torch.as_tensor(np.linalg.inv(0.9 ** np.abs(np.subtract.outer(np.arange(d), np.arange(d)))), device="cuda")
+            tgt, init = lmc.targets.TorchTarget(d, lambda q: (-0.5 * ((q @ prec) * q).sum(dim=1), -(q @ prec))), "auto"
+        gt, gst = lmc.sample(tgt, d, draws=draws, tune=tune, chains=chains, random_seed=seed, discard_tuned_samples=False,
+                             step_rand=sr, init=init)
+        want_t, ost = orc.sample(f, d, draws=draws, tune=tune, chains=chains, random_seed=seed, discard_tuned_samples=False,
+                                 step_rand=(lo, hi), init=init)
+        want_ts = ost["tree_size"]
+        n = 6 if kind == "nuts_dense" else 10
+    npt.assert_array_equal(gst["tree_size"][:, :n], want_ts[:, :n])
+    tol = 5e-4 if kind == "nuts_dense" else 1e-6
+    npt.assert_allclose(gt[:, :n], want_t[:, :n], rtol=tol, atol=tol)

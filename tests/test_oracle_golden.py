@@ -172,3 +172,28 @@ def test_diag_adapt_growing_window_golden(golden_dir):
     np.testing.assert_array_equal(stats["tree_size"], g["e2e_stat_tree_size"])
     assert pot2.window == int(g["e2e_final_window"])
     np.testing.assert_array_equal(np.asarray(pot2.var, dtype="d"), g["e2e_final_var"])
+
+
+@pytest.mark.parametrize("kind", ["nuts", "hmc"])
+def test_step_rand_golden(golden_dir, kind):
+    """base_hmc.py:154-155 with step_rand = lambda s: s * np.random.uniform(lo, hi): one uniform of the chain's own stream
+    per iteration, between the momentum draw and the trajectory (captured from the imported reference)."""
+    g = _load(golden_dir, "e2e_step_rand")
+    lo, hi = float(g["lo"]), float(g["hi"])
+    d, chains = int(g[kind + "_d"]), int(g[kind + "_chains"])
+    tune, draws = int(g[kind + "_tune"]), int(g[kind + "_draws"])
+    f = targets.make(str(g[kind + "_family"]), d)
+    if kind == "hmc":
+        step = orc.Step(f, d, kind="hmc", path_length=float(g["hmc_path_length"]), step_rand=(lo, hi))
+        trace, stats = orc.sample(f, d, draws=draws, tune=tune, step=step, chains=chains,
+                                  random_seed=int(g["random_seed"]), discard_tuned_samples=False)
+    else:
+        trace, stats = orc.sample(f, d, draws=draws, tune=tune, chains=chains, random_seed=int(g["random_seed"]),
+                                  discard_tuned_samples=False, step_rand=(lo, hi))
+    for name_ in stats:
+        want = g[kind + "_stat_" + name_]
+        if name_ in INT_STATS:
+            np.testing.assert_array_equal(stats[name_], want, err_msg=name_)
+        else:
+            np.testing.assert_allclose(stats[name_], want, rtol=RTOL, atol=1e-12, err_msg=name_)
+    np.testing.assert_allclose(trace, g[kind + "_trace"], rtol=RTOL, atol=1e-300)
