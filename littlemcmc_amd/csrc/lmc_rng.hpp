@@ -191,48 +191,54 @@ __device__ inline void rng_normals(RngState& r, int d, double* out, double* stag
         r.gauss = 0.0;
         produced = 1;
     }
-    const int need_pairs = (d - produced + 1) >> 1;
+    const int need_pairs = first_i32((d - produced + 1) >> 1);
+    // Loop control is wave-uniform and kept scalar on purpose (first_i32, no `continue`): counts and the stream position
+    // then live in SGPRs and the loop is a scalar branch -- otherwise the compiler runs it as an exec-masked loop with
+    // VGPR counters.
     int have = 0;
+    int pos = first_i32(r.pos);
     while (have < need_pairs) {
-        const int avail = (kMtN - r.pos) >> 2;   // whole attempts left in this generation
-        if (avail == 0) {                         // fewer than 4 words left: one attempt across the twist
+        const int avail = (kMtN - pos) >> 2;   // whole attempts left in this generation
+        if (avail == 0) {                       // fewer than 4 words left: one attempt across the twist
+            r.pos = pos;
             const double x1 = 2.0 * rng_uniform(r) - 1.0;
             const double x2 = 2.0 * rng_uniform(r) - 1.0;
+            pos = first_i32(r.pos);
             const double r2 = x1 * x1 + x2 * x2;
-            if (r2 > 0.0 && r2 < 1.0) {
+            if (ballot64(r2 > 0.0) & ballot64(r2 < 1.0) & 1ull) {
                 if (lane == 0) { stage[2 * have] = x1; stage[2 * have + 1] = x2; }
                 ++have;
             }
-            continue;
-        }
-        const int n_att = avail < 64 ? avail : 64;
-        bool acc = false;
-        double x1 = 0.0, x2 = 0.0;
-        if (lane < n_att) {
-            const uint32_t* w = r.mt + r.pos + 4 * lane;
-            x1 = 2.0 * mt_words_to_double(w[0], w[1]) - 1.0;
-            x2 = 2.0 * mt_words_to_double(w[2], w[3]) - 1.0;
+        } else {
+            const int n_att = avail < 64 ? avail : 64;
+            // every lane forms an attempt (a lane beyond n_att re-reads the last whole one and is masked out below)
+            const int at = lane < n_att ? lane : n_att - 1;
+            const uint32_t* w = r.mt + pos + 4 * at;
+            const double x1 = 2.0 * mt_words_to_double(w[0], w[1]) - 1.0;
+            const double x2 = 2.0 * mt_words_to_double(w[2], w[3]) - 1.0;
             const double r2 = x1 * x1 + x2 * x2;
-            acc = (r2 > 0.0) && (r2 < 1.0);
+            const bool acc = (r2 > 0.0) & (r2 < 1.0) & (lane < n_att);
+            // (one ballot per compare: a ballot of a compound predicate is materialised in a VGPR first)
+            const unsigned long long lanes = n_att == 64 ? ~0ull : ((1ull << n_att) - 1ull);
+            const unsigned long long mask = ballot64(r2 > 0.0) & ballot64(r2 < 1.0) & lanes;
+            const int rank = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                              __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u)));
+            const int want = need_pairs - have;
+            int consumed = n_att, taken = __popcll(mask);
+            if (taken >= want) {                  // the want-th accepted attempt ends the call
+                const unsigned long long lastm = mask & ballot64(rank == want - 1);
+                consumed = __ffsll(static_cast<long long>(lastm));
+                taken = want;
+            }
+            if (acc & (rank < want)) {
+                stage[2 * (have + rank)] = x1;
+                stage[2 * (have + rank) + 1] = x2;
+            }
+            have += taken;
+            pos += 4 * consumed;
         }
-        unsigned long long mask = ballot64(acc);
-        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const int rank = __popcll(mask & below);
-        int consumed = n_att;
-        const int want = need_pairs - have;
-        if (__popcll(mask) >= want) {             // the want-th accepted attempt ends the call
-            const unsigned long long lastm = ballot64(acc && rank == want - 1);
-            const int last = __ffsll(static_cast<long long>(lastm)) - 1;
-            consumed = last + 1;
-            mask &= (last == 63) ? ~0ull : ((1ull << (last + 1)) - 1ull);
-        }
-        if (acc && ((mask >> lane) & 1ull)) {
-            stage[2 * (have + rank)] = x1;
-            stage[2 * (have + rank) + 1] = x2;
-        }
-        have = first_i32(have + __popcll(mask));
-        r.pos = first_i32(r.pos + 4 * consumed);   // stream position and counts stay scalar (SGPR) values
     }
+    r.pos = pos;
     wave_sync();
     for (int base = 0; base < need_pairs; base += 64) {
         const int pi = base + lane;
