@@ -57,8 +57,8 @@ namespace lmc {
     }
 
 int dense_launch_run(int family, int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
-                     const SamplerParams& P, const double* tparams) {
-    const dim3 grid(A.chains), block(64);
+                     const SamplerParams& P, const double* tparams, int n_chains) {
+    const dim3 grid(n_chains > 0 ? n_chains : A.chains), block(64);
     const int lds = dense_lds_doubles(A.dpad) * 8 + D.cache_rows * A.dpad * (mat_f64 ? 8 : 4) + D.lds_slots * A.dpad * 8;
     (void)hipGetLastError();
 #define RUN_CALL(T) \
@@ -105,15 +105,16 @@ int dense_launch_momentum(int ns, hipStream_t stream, const ChainArrays& A, cons
 }
 
 int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, double multiplier,
-                       int update_window, int* mask) {
+                       int update_window, int* mask, int chain_begin, int n_chains) {
     const int lds = dense_adapt_lds_bytes(A.d, A.dpad);
+    const dim3 grid(n_chains > 0 ? n_chains : A.chains);
     (void)hipGetLastError();
     if (dense_adapt_grid(A.d) == 8)
-        hipLaunchKernelGGL(dense_adapt_kernel<8>, dim3(A.chains), dim3(64), lds, stream, A, D, multiplier, update_window, mask);
+        hipLaunchKernelGGL(dense_adapt_kernel<8>, grid, dim3(64), lds, stream, A, D, multiplier, update_window, mask, chain_begin);
     else if (dense_adapt_grid(A.d) == 16)
-        hipLaunchKernelGGL(dense_adapt_kernel<16>, dim3(A.chains), dim3(256), lds, stream, A, D, multiplier, update_window, mask);
+        hipLaunchKernelGGL(dense_adapt_kernel<16>, grid, dim3(256), lds, stream, A, D, multiplier, update_window, mask, chain_begin);
     else
-        hipLaunchKernelGGL(dense_adapt_kernel<32>, dim3(A.chains), dim3(1024), lds, stream, A, D, multiplier, update_window, mask);
+        hipLaunchKernelGGL(dense_adapt_kernel<32>, grid, dim3(1024), lds, stream, A, D, multiplier, update_window, mask, chain_begin);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -471,7 +471,7 @@ __device__ inline void dense_hmc_transition(Team<1>& tm, const Target& tgt, cons
 template <int NS, class MatT, template <int> class TargetT>
 __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel(ChainArrays A, DenseArrays D, SamplerParams P, const double* tparams) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x + P.chain_begin;   // the engine launches its chains as sub-blocks (lmc_engine_run)
     const int d = A.d, dpad = A.dpad;
     const long long row = static_cast<long long>(c) * dpad;
     Team<1> tm{nullptr, 0};
@@ -754,10 +754,10 @@ __device__ inline bool cholesky_registers(const float* covT, float* fac, int d, 
 
 template <int T>
 __global__ __launch_bounds__(T * T) void dense_adapt_kernel(ChainArrays A, DenseArrays D, double multiplier,
-                                                            int update_window, int* mask) {
+                                                            int update_window, int* mask, int chain_begin) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int kThreads = T * T;
-    const int c = blockIdx.x, tid = threadIdx.x;
+    const int c = blockIdx.x + chain_begin, tid = threadIdx.x;
     // mask != nullptr (tick path): only the chains that finished a tuning iteration in the last tick take part
     if (mask != nullptr && mask[c] == 0) return;
     const int d = A.d, dpad = A.dpad;

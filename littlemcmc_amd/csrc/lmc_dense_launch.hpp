@@ -9,15 +9,16 @@ namespace lmc {
 
 constexpr int kDenseUnsupported = -1;
 
+// run / adapt: chains [P.chain_begin, P.chain_begin + n_chains) resp. [chain_begin, chain_begin + n_chains); n_chains <= 0 = all
 int dense_launch_run(int family, int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
-                     const SamplerParams& P, const double* tparams);
+                     const SamplerParams& P, const double* tparams, int n_chains = 0);
 int dense_launch_trajectory(int family, int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A,
                             const DenseArrays& D, const double* tparams, const double* q0, const double* p0,
                             int p0_is_f32, int sdot_mode, double eps, int n_fwd, int n_back, double* oq, double* op,
                             double* ov, double* og, double* oe, double* ol);
 int dense_launch_momentum(int ns, hipStream_t stream, const ChainArrays& A, const DenseArrays& D, double* out);
 int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, double multiplier,
-                       int update_window, int* mask = nullptr);
+                       int update_window, int* mask = nullptr, int chain_begin = 0, int n_chains = 0);
 // the tick kernel with a dense mass matrix (lmc_tick_dense.hpp)
 struct TickArrays;
 int tick_dense_launch(int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,

@@ -389,21 +389,36 @@ static int dense_run(lmc_engine* e, SamplerParams P) {
         if (slots > dense_scratch_vectors(max_levels)) slots = dense_scratch_vectors(max_levels);
         e->D.lds_slots = static_cast<int>(slots < 0 ? 0 : slots);
     }
+    // the chains go out as sub-blocks on their own streams, like the diagonal kernels (lmc_engine_run): each sub-block is a
+    // chain of launches of its own -- with FullAdapt two per tuning iteration -- and the tail of one is covered by the other
+    const int n_sub = e->n_sub;
+    if (n_sub > 1 && e->main_dirty) {
+        HIP_TRY(e, hipEventRecord(e->main_done, e->stream_));
+        for (int b = 0; b < n_sub; ++b) HIP_TRY(e, hipStreamWaitEvent(e->sub_stream[b], e->main_done, 0));
+        e->main_dirty = false;
+    }
     const long long end = P.iter_begin + P.n_iters;
+    if (n_sub > 1) e->sub_pending = true;
     long long it = P.iter_begin;
     while (it < end) {
         // while tuning, FullAdapt refreshes covariance and factor after EVERY iteration (quadpotential.py:528-552):
         // one iteration per launch, the update kernel in between; everything else runs whole blocks of iterations
         const bool adapt = e->cfg.potential == LMC_POT_FULL_ADAPT && it < P.n_tune;
         const long long n = adapt ? 1 : end - it;
-        SamplerParams Q = P;
-        Q.iter_begin = it;
-        Q.n_iters = static_cast<int>(n);
-        int rc = dense_launch_run(e->cfg.target_family, e->ns, mat_f64, main_stream(e), e->A, e->D, Q, e->tparams);
-        if (rc != 0) return dense_fail(e, rc, "run");
-        if (adapt) {
-            rc = dense_launch_adapt(main_stream(e), e->A, e->D, e->dense_multiplier, e->dense_update_window);
-            if (rc != 0) return dense_fail(e, rc, "dense update");
+        for (int b = 0; b < n_sub; ++b) {   // (launches of the sub-blocks interleaved, so that neither stream waits for the host)
+            const long long lo = static_cast<long long>(e->cfg.chains) * b / n_sub, hi = static_cast<long long>(e->cfg.chains) * (b + 1) / n_sub;
+            hipStream_t st = n_sub > 1 ? e->sub_stream[b] : main_stream(e);
+            SamplerParams Q = P;
+            Q.iter_begin = it;
+            Q.n_iters = static_cast<int>(n);
+            Q.chain_begin = static_cast<int>(lo);
+            int rc = dense_launch_run(e->cfg.target_family, e->ns, mat_f64, st, e->A, e->D, Q, e->tparams, static_cast<int>(hi - lo));
+            if (rc != 0) return dense_fail(e, rc, "run");
+            if (adapt) {
+                rc = dense_launch_adapt(st, e->A, e->D, e->dense_multiplier, e->dense_update_window, nullptr,
+                                        static_cast<int>(lo), static_cast<int>(hi - lo));
+                if (rc != 0) return dense_fail(e, rc, "dense update");
+            }
         }
         it += n;
     }

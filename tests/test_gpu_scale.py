@@ -91,6 +91,26 @@ def test_sub_block_streams_do_not_change_a_bit(monkeypatch):
     np.testing.assert_array_equal(a[4], a[0][:, 20:30])
 
 
+def test_sub_block_streams_dense_mass(monkeypatch):
+    """The dense-mass kernels go out as sub-blocks too (with FullAdapt: run kernel + covariance refresh per tuning
+    iteration, chained per sub-block): same draws and statistics as launched in one block."""
+    d, tune, draws, chains = 10, 40, 12, 300
+    tgt = T.AR1(d, 0.9)
+
+    def job(sub_blocks):
+        if sub_blocks is None:
+            monkeypatch.delenv("LMC_SUB_BLOCKS", raising=False)
+        else:
+            monkeypatch.setenv("LMC_SUB_BLOCKS", str(sub_blocks))
+        return lmc.sample(tgt, d, draws=draws, tune=tune, chains=chains, init="jitter+adapt_full", random_seed=3,
+                          discard_tuned_samples=False)
+
+    (ta, sa), (tb, sb) = job(None), job(1)
+    np.testing.assert_array_equal(ta, tb)
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k])
+
+
 def test_checkpoint_resume_is_bit_identical():
     d, chains = 32, 64
     tgt = T.StdNormal(d)
