@@ -391,11 +391,22 @@ def main():
                       "note": "the leapfrog State lives in registers/LDS, HBM carries draws and adaptation state only, so "
                               "the HBM contract figures are not a bound (they may exceed the 8 TB/s peak); the kernel is "
                               "limited by per-wave instruction issue at 3-4 waves per SIMD (DESIGN.md section 6)"})
+        elif args.mass == "full_adapt":
+            # one float32 matrix PER CHAIN: the kernel's own algorithmic traffic is ONE d x d float32 sweep per leapfrog
+            # (4 d^2 B; the reference does two, which is what the contract figure above counts) plus the State
+            kb = 60 * dim + 4 * dim * dim
+            r.update({"bound": "hbm", "achieved": rate_local * kb / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                      "frac": rate_local * kb / HBM_PEAK, "bytes_per_leapfrog": kb,
+                      "note": "per-chain matrices stream from HBM / Infinity Cache: 60 d + 4 d^2 bytes per leapfrog "
+                              "(DESIGN.md section 9); hbm_contract_60d above is the reference's two-sweep figure"})
         else:
-            r.update({"bound": "hbm", "achieved": rate_local * (60 * dim + extra) / 1e9, "peak": HBM_PEAK / 1e9,
-                      "unit": "GB/s", "frac": rate_local * (60 * dim + extra) / HBM_PEAK,
-                      "note": "one float32 d x d matrix sweep per leapfrog (4 d^2 B; the reference does two): per-chain "
-                              "matrices stream from HBM / Infinity Cache, a shared matrix from L2 (DESIGN.md section 9)"})
+            # ONE matrix shared by all chains is L2 resident: the sweep is vector work, 2 d^2 flop on top of the leapfrog's
+            mv = 2 * dim * dim + flop
+            r.update({"bound": "fp64_valu", "achieved": rate_local * mv / 1e12, "peak": FP64_VALU_PEAK / 1e12,
+                      "unit": "TFLOP/s", "frac": rate_local * mv / FP64_VALU_PEAK, "flop_per_leapfrog": mv,
+                      "flop_model": "2 d^2 (matrix sweep, float32 operands accumulated in float64) + 26 d",
+                      "note": "a matrix shared by all chains is read from L2; the kernel is vector-issue bound "
+                              "(DESIGN.md section 9); the HBM contract figures above are not a bound here"})
         if prof:   # measured on this very build (source hash match)
             r["traffic"] = prof["hbm_bytes_per_leapfrog"] * job["leap_local"] / K
             r["valu_inst_per_leapfrog"] = prof.get("valu_inst_per_leapfrog")
