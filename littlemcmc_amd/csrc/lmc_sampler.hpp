@@ -645,13 +645,17 @@ __device__ __forceinline__ unsigned glb_level_offset(const PairCtx& cx, int j, i
 template <int NS, int W = 1>
 __device__ __forceinline__ void levelN_load(const PairCtx& cx, int j, int v, double (&x)[NS]) {
     using L = PairLds<NS, W>;
-    if (j <= cx.nlds) vload_as<NS>((lds_double*)cx.lds + (L::kL2 + (j - 2) * 4 * L::DP + v * L::DP), x);
+    int nl = cx.nlds;
+    asm volatile("" : "+s"(nl));   // compared afresh (one s_cmp): hoisted, the loop-invariant test lives in a spilled lane mask
+    if (j <= nl) vload_as<NS>((lds_double*)cx.lds + (L::kL2 + (j - 2) * 4 * L::DP + v * L::DP), x);
     else vload_as<NS>((glb_double*)cx.glb + glb_level_offset<NS, W>(cx, j, v), x);
 }
 template <int NS, int W = 1>
 __device__ __forceinline__ void levelN_store(const PairCtx& cx, int j, int v, const double (&x)[NS]) {
     using L = PairLds<NS, W>;
-    if (j <= cx.nlds) vstore_as<NS>((lds_double*)cx.lds + (L::kL2 + (j - 2) * 4 * L::DP + v * L::DP), x);
+    int nl = cx.nlds;
+    asm volatile("" : "+s"(nl));
+    if (j <= nl) vstore_as<NS>((lds_double*)cx.lds + (L::kL2 + (j - 2) * 4 * L::DP + v * L::DP), x);
     else vstore_as<NS>((glb_double*)cx.glb + glb_level_offset<NS, W>(cx, j, v), x);
 }
 // left-end momentum / proposal position of any level j >= 1
