@@ -141,6 +141,13 @@ def cpu_baseline(name, dim, seeds, start, budget_iters, mass="diag"):
     }
 
 
+class _DevView:
+    """__cuda_array_interface__ shim: engine-owned HBM as a torch tensor, no copy."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
 def pmc_profile(key, source_hash):
     """Counter-derived figures of this workload, if profiles/pmc_counters.json holds a profile of THIS build."""
     try:
@@ -150,6 +157,23 @@ def pmc_profile(key, source_hash):
     if not entry or entry.get("source_hash") != source_hash:
         return None
     return entry
+
+
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: re-run this very command line as N ranks (one per GPU) under
+    ``torch.distributed.run`` on 127.0.0.1 with a free port; rank 0 prints the one JSON line, which passes through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -175,9 +199,13 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the standard-normal d=128 secondary workload")
     ap.add_argument("--cpu-iters", type=int, default=2000, help="iterations per oracle chain in the CPU baseline")
     ap.add_argument("--lds-levels", type=int, default=0)
+    ap.add_argument("--no-rccl-check", action="store_true", help="N = 1: do not bring up the one-rank RCCL group")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (nccl = RCCL; gloo only to exercise the multi-rank path on one GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -186,19 +214,46 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (start bench.py without WORLD_SIZE to let it launch its own "
+                         "ranks, or under torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
     if args.backend == "gloo":          # test mode: several ranks may share one GPU
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    rccl_error = None
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif args.backend == "nccl" and not args.no_rccl_check:
+        # N = 1: the job needs no collective, but the line still says whether RCCL works on this box (a one-rank group;
+        # a failure is recorded, it cannot cost the measurement)
+        try:
+            if "MASTER_PORT" not in os.environ:
+                import socket
+
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        except Exception as err:
+            rccl_error = "%s: %s" % (type(err).__name__, str(err)[:200])
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
+    group_up = dist.is_available() and dist.is_initialized()
+    rccl_ranks = None
+    if group_up and args.backend == "nccl":
+        try:   # an all-reduce of ones on the GPUs: how many ranks RCCL actually connected
+            one = torch.ones(1, device="cuda")
+            dist.all_reduce(one)
+            torch.cuda.synchronize()
+            rccl_ranks = int(one.item())
+        except Exception as err:
+            if world > 1:
+                raise
+            rccl_error = "%s: %s" % (type(err).__name__, str(err)[:200])
 
     import littlemcmc_amd as lmc
     from littlemcmc_amd import _abi, _build
@@ -215,7 +270,6 @@ def main():
     chains = hi - lo
     if chains < 1:
         raise SystemExit("rank %d owns no chain (%d chains over %d ranks)" % (rank, chains_total, world))
-    stream = torch.cuda.Stream()        # a real (non-null) HIP stream: the engine launches on it, the events time it
 
     # seeds: sample()'s own derivation over the GLOBAL chain index space (prefix stable), block per rank
     np.random.seed(SEED)
@@ -227,6 +281,15 @@ def main():
         if world > 1:
             dist.all_reduce(t, op=op)
         return [float(v) for v in t]
+
+    def all_gather(vals):
+        """[world][len(vals)] -- per-rank figures for the line (imbalance must be visible in the record itself)"""
+        t = torch.tensor(vals, dtype=torch.float64, device=red_dev)
+        if world == 1:
+            return [[float(v) for v in t]]
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [[float(v) for v in o] for o in out]
 
     def run_job(target_name, dim, with_ess):
         """The timed job on this rank's chain block -> dict of measurements (wall / leapfrogs reduced over ranks)."""
@@ -255,12 +318,58 @@ def main():
         def new_job(capacity, trace_from, keep_trace):
             eng = lmc.Engine(target, chains=chains, device=local_rank, **kw)
             step.potential._push_initial(eng)
-            eng.set_stream(stream.cuda_stream)
             eng.seed(seeds)
             eng.set_position(start)
             eng.reset_tuning()
             eng.reserve(capacity, keep_trace=keep_trace, trace_begin=trace_from)
             return eng
+
+        def tail_block(eng, ct, kernel_s, nst, target, step, kw, start):
+            """Why the job cannot be faster than its busiest chain (ragged trees): per launch every sub-block waits for its
+            slowest chain, and a chain is one wavefront (or team) whose leapfrogs run back to back."""
+            resident, wpc, hz = eng.occupancy()
+            leap_chain = ct[:, _abi.CT_LEAPFROGS]
+            # tree_size of every iteration, where it lives: [chains][capacity] int32 in HBM -> leapfrogs per chain per launch
+            ts = torch.as_tensor(_DevView(eng.stat_i32_device_ptr() + 4 * _abi.STAT_TREE_SIZE * chains * n_total,
+                                          (chains, n_total), "<i4"), device="cuda:%d" % local_rank)
+            per_launch = ts.reshape(chains, K, ips).sum(dim=2, dtype=torch.int64)                 # [chains, K]
+            bounds = [chains * b // nst for b in range(nst + 1)]
+            crit = max(int(per_launch[bounds[b]:bounds[b + 1]].max(dim=0).values.sum()) for b in range(nst))
+            ratio = float((per_launch.max(dim=0).values.double() / per_launch.double().mean(dim=0).clamp(min=1.0)).mean())
+            # a lone chain on an otherwise idle GPU: the issue latency of one wavefront (team) of this kernel
+            lone = lmc.Engine(target, chains=1, device=local_rank, **kw)
+            step.potential._push_initial(lone)
+            lone.seed(seeds[:1])
+            lone.set_position(start)
+            lone.reset_tuning()
+            n_l = 2 * ips
+            lone.reserve(n_l, keep_trace=False)
+            lone.run(n_l // 2, 0, n_l // 2)
+            lone.synchronize()
+            l0 = int(lone.counters()[0, _abi.CT_LEAPFROGS])
+            t_l = time.perf_counter()
+            lone.run(n_l // 2, n_l // 2, n_l - n_l // 2)
+            lone.synchronize()
+            t_l = time.perf_counter() - t_l
+            l1 = int(lone.counters()[0, _abi.CT_LEAPFROGS]) - l0
+            lone.close()
+            lone_us = 1e6 * t_l / max(l1, 1)
+            slots = resident * wpc
+            return {
+                "busiest_chain_leapfrogs": int(leap_chain.max()), "mean_chain_leapfrogs": float(leap_chain.mean()),
+                "launch_max_over_mean": ratio,
+                "critical_path_leapfrogs": crit,
+                "lone_wave_us_per_leapfrog": lone_us,
+                "implied_wall_lower_bound_s": crit * lone_us * 1e-6,
+                "kernel_s": kernel_s,
+                "resident_chains": resident, "waves_per_chain": wpc,
+                "mean_wave_slot_occupancy": (float(ct[:, _abi.CT_WAVE_TICKS].sum()) / hz / (slots * kernel_s)) if slots else None,
+                "note": "per launch each sub-block of chains ends with its busiest chain; critical_path_leapfrogs = max over "
+                        "sub-blocks of the sum over launches of that chain's leapfrogs; x the leapfrog latency of a lone "
+                        "wavefront (measured on a 1-chain engine of the same kernel, %d post-tuning iterations) = a lower "
+                        "bound on the wall time whatever the number of GPUs; occupancy = resident wave time (device "
+                        "counter) / (wave slots x kernel time)" % (n_l - n_l // 2),
+            }
 
         if W > 0:   # warm-up: W launches of a throw-away copy of the job
             warm = new_job(W * ips, (W * ips) // 2, keep_trace=False)
@@ -309,6 +418,7 @@ def main():
         kernel_ms = [span_ms(0) / K] * K                                                  # per step, all sub-blocks
         ct = eng.counters()
         leap_local = float(ct[:, _abi.CT_LEAPFROGS].sum())
+        tail = tail_block(eng, ct, span_ms(0) / 1e3, nst, target, step, kw, start)
         status = eng.status()
         if status.any():
             raise SystemExit("chains reported failure status bits: %s" % np.unique(status))
@@ -343,6 +453,7 @@ def main():
                    "diagnostics_seconds": diag_s, "diagnostics_process_warmup_seconds": diag_first_s, "definition": diag.get("definition", "")}
         eng.close()
 
+        per_rank = all_gather([leap_local, span_ms(0) / 1e3, wall, float(chains)])
         wall_max, = all_reduce([wall], dist.ReduceOp.MAX)
         leap_all, div_all = all_reduce([leap_local, float(div_after)], dist.ReduceOp.SUM)
         if ess is not None:   # post-warm-up time of the slowest rank
@@ -357,7 +468,9 @@ def main():
                 label, chains_total, dim, target_desc, method, mass_desc, n_tune, n_total - n_tune, K, ips, part),
             "wall": wall_max, "leap_all": leap_all, "leap_local": leap_local, "kernel_ms": kernel_ms,
             "dispatch_ms_avg": float(np.mean(dispatch_ms)), "dispatches_per_step": nst,
-            "depth_mean": depth_mean, "div_after": int(div_all), "ess": ess,
+            "depth_mean": depth_mean, "div_after": int(div_all), "ess": ess, "tail": tail,
+            "per_rank": [{"rank": r, "chains": int(v[3]), "leapfrogs": v[0], "kernel_s": v[1], "wall_s": v[2]}
+                         for r, v in enumerate(per_rank)],
         }
 
     src_hash = _build.source_hash()
@@ -447,6 +560,9 @@ def main():
                 "diagnostics_process_warmup_seconds": ess["diagnostics_process_warmup_seconds"]},
             "divergences_after_tune": primary["div_after"],
             "roofline": roofline(primary),
+            "tail": primary["tail"],
+            "per_rank": primary["per_rank"],
+            "rccl_ranks": rccl_ranks, "rccl_error": rccl_error, "backend": args.backend,
             "source_hash": src_hash,
         }
         if secondary is not None:
@@ -454,12 +570,14 @@ def main():
                 "workload": secondary["workload"], "value": secondary["leap_all"] / secondary["wall"],
                 "unit": "leapfrog-steps/s", "ms_per_step": secondary["wall"] * 1e3 / K, "leapfrogs": secondary["leap_all"],
                 "wall_s": secondary["wall"], "mean_depth_draws": secondary["depth_mean"],
-                "divergences_after_tune": secondary["div_after"], "roofline": roofline(secondary)}]
+                "divergences_after_tune": secondary["div_after"], "roofline": roofline(secondary),
+                "tail": secondary["tail"], "per_rank": secondary["per_rank"]}]
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.target, args.dim, seeds_all[:64], primary["start"], args.cpu_iters, args.mass)
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
+    if group_up:
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

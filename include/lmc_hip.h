@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LMC_ABI_VERSION 3
+#define LMC_ABI_VERSION 4
 
 /* status codes */
 #define LMC_OK 0
@@ -98,7 +98,11 @@ extern "C" {
 #define LMC_CT_DIVS_AFTER_TUNE 1         /* base_hmc.py:171 */
 #define LMC_CT_SAMPLES_AFTER_TUNE 2      /* base_hmc.py:183 */
 #define LMC_CT_LEAPFROGS 3               /* sum of tree_size / n_steps: the bench metric's numerator */
-#define LMC_NUM_COUNTERS 4
+#define LMC_CT_WAVE_TICKS 4              /* wall-clock ticks (lmc_engine_occupancy: wall_clock_hz) the chain's wavefronts were
+                                          * resident in lmc_engine_run() launches: sum over chains / (resident slots x launch
+                                          * time) = mean wave-slot occupancy; the reference's analogue is a chain's process
+                                          * time (parallel_sampling.py:377-496). Fused diagonal-mass kernels only. */
+#define LMC_NUM_COUNTERS 5
 
 typedef struct lmc_engine lmc_engine;
 
@@ -141,7 +145,10 @@ int32_t lmc_has_target(int32_t family);
 /* ---- lifecycle: NUTS(...) / HamiltonianMC(...) construction ------------------------------------ */
 int lmc_engine_create(const lmc_config* cfg, lmc_engine** out);
 void lmc_engine_destroy(lmc_engine* e);
-/* Launch on an externally owned hipStream_t (e.g. torch's current stream). NULL = engine's own. */
+/* Launch on an externally owned hipStream_t (e.g. torch's current stream). NULL = engine's own. On an external stream
+ * every lmc_engine_run() is ordered after whatever the caller enqueued on that stream before the call, and the stream is
+ * ordered after the run's kernels on return (event waits on the device): the caller's own work on the stream needs no
+ * lmc_engine_synchronize(). (With the engine's own stream consecutive runs overlap per sub-block instead.) */
 int lmc_engine_set_stream(lmc_engine* e, void* hip_stream);
 int lmc_engine_synchronize(lmc_engine* e);
 
@@ -202,6 +209,12 @@ int lmc_engine_set_dual_average(lmc_engine* e, double log_step, double log_bar, 
  * between the start state and the trajectory. enable = 0 switches it off (the default). */
 int lmc_engine_set_step_jitter(lmc_engine* e, int32_t enable, double lo, double hi);
 int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int64_t trace_begin);
+/* KeyboardInterrupt (sampling.py:324-328, :470-471: the reference keeps what has been drawn so far). stop = 1: every
+ * chain leaves the launch it is in at its next iteration boundary and launches still queued return at once -- the
+ * request overtakes the kernels in flight; chains end at different iterations (lmc_chain_state.iter_count says where,
+ * draws and statistics below the smallest one are complete for every chain). stop = 0 re-arms the engine, ordered
+ * after everything launched so far. Fused kernels (diagonal and dense mass); a tick-driven job stops by not ticking. */
+int lmc_engine_request_stop(lmc_engine* e, int32_t stop);
 int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters);
 int lmc_engine_run_streams(lmc_engine* e, void** streams, int32_t capacity);
 
@@ -315,6 +328,12 @@ int lmc_engine_draw_momentum(lmc_engine* e, double* out);
  * 40,62,115) becomes a device function linked into the leapfrog kernel without hipcc on the machine. Diagonal mass
  * matrices only; littlemcmc_amd.targets.UserTarget drives it. */
 int lmc_engine_kernel_shape(lmc_engine* e, int32_t* unit_ns, int32_t* run_ns, int32_t* run_w);
+/* How the sampling kernel of this engine occupies the GPU (asked of the HIP runtime for the very kernel, block size and
+ * dynamic LDS lmc_engine_run() launches with): resident_chains = chains that run concurrently (compute units x
+ * workgroups per unit; 0 for engines without a fused sampling kernel), waves_per_chain, and the rate of the constant
+ * wall clock LMC_CT_WAVE_TICKS counts in. The host uses it to size launches (the reference's analogue is `cores`,
+ * sampling.py:117-129). Any pointer may be NULL. */
+int lmc_engine_occupancy(lmc_engine* e, int32_t* resident_chains, int32_t* waves_per_chain, double* wall_clock_hz);
 int lmc_engine_load_user_kernels(lmc_engine* e, const void* code_object, const char* run_name, const char* trajectory_name,
                                  const char* logp_name);
 

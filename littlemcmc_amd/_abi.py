@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LMC_HIP_LIB") or os.path.join(_HERE, "liblmc_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK = 0
 
 KIND_NUTS, KIND_HMC = 0, 1
@@ -23,8 +23,8 @@ SDOT_NATIVE, SDOT_OPENBLAS_SKYLAKEX, SDOT_OPENBLAS_HASWELL = 0, 1, 2
  STAT_MODEL_LOGP) = range(7)
 STAT_DEPTH, STAT_TREE_SIZE = 0, 1
 STAT_DIVERGING, STAT_TUNE, STAT_ACCEPTED = 0, 1, 2
-CT_REACHED_MAX_TREEDEPTH, CT_DIVS_AFTER_TUNE, CT_SAMPLES_AFTER_TUNE, CT_LEAPFROGS = range(4)
-NUM_COUNTERS = 4
+CT_REACHED_MAX_TREEDEPTH, CT_DIVS_AFTER_TUNE, CT_SAMPLES_AFTER_TUNE, CT_LEAPFROGS, CT_WAVE_TICKS = range(5)
+NUM_COUNTERS = 5
 
 
 class Config(C.Structure):
@@ -121,6 +121,8 @@ _SIGNATURES = {
     "lmc_engine_rng_draw": (C.c_int, [_P, _P, C.c_int32, _P]),
     "lmc_engine_draw_momentum": (C.c_int, [_P, _P]),
     "lmc_engine_kernel_shape": (C.c_int, [_P, _P, _P, _P]),
+    "lmc_engine_occupancy": (C.c_int, [_P, _P, _P, _P]),
+    "lmc_engine_request_stop": (C.c_int, [_P, C.c_int32]),
     "lmc_engine_load_user_kernels": (C.c_int, [_P, _P, C.c_char_p, C.c_char_p, C.c_char_p]),
     "lmc_diag_lags_per_pass": (C.c_int, []),
     "lmc_diag_chain_stats": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _P, _P]),

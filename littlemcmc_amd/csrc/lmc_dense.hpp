@@ -515,6 +515,7 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel
     for (int it = 0; it < P.n_iters; ++it) {
         const long long git = P.iter_begin + it;
         const bool tune = git < P.n_tune;
+        if (first_i32(__hip_atomic_load(A.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0) break;
 
         // ---- momentum draw
         rng_normals(rng, d, lds, lds + dpad);

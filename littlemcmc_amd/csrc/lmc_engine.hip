@@ -191,6 +191,8 @@ struct lmc_engine {
     hipStream_t sub_stream[kMaxSub] = {nullptr, nullptr};
     hipEvent_t sub_done[kMaxSub] = {nullptr, nullptr};
     hipEvent_t main_done = nullptr;
+    int* stop_flag = nullptr;   // device word the sampling kernels poll once per iteration (lmc_engine_request_stop)
+    hipStream_t ctl_stream = nullptr;   // carries the stop request past the kernels in flight
     int step_jitter = 0;        // step_rand as step * uniform(lo, hi) (lmc_engine_set_step_jitter)
     double jitter_lo = 1.0, jitter_hi = 1.0;
     bool sub_pending = false;   // sub-block kernels in flight that the main stream has not been ordered after
@@ -237,6 +239,31 @@ static hipStream_t main_stream(lmc_engine* e) {
     }
     e->main_dirty = true;
     return e->stream_;
+}
+
+// run(): the sub-block streams are ordered after whatever the main stream holds. With the engine's own stream only the
+// engine's entry points can have put work there (main_dirty); on a caller's stream anything may have been enqueued
+// between two run() calls, so the order is established every time.
+static hipError_t order_sub_blocks_after_main(lmc_engine* e) {
+    if (e->n_sub <= 1) return hipSuccess;
+    const bool external = e->stream_ != e->own_stream;
+    if (!e->main_dirty && !external) return hipSuccess;
+    hipError_t err = hipEventRecord(e->main_done, e->stream_);
+    for (int b = 0; b < e->n_sub && err == hipSuccess; ++b) err = hipStreamWaitEvent(e->sub_stream[b], e->main_done, 0);
+    if (err == hipSuccess) e->main_dirty = false;
+    return err;
+}
+// ... and a caller's stream is ordered after the kernels run() just launched, so that what the caller enqueues next
+// (a torch op on the trace pointer, say) sees their results -- the contract run() had when it launched on that stream.
+static hipError_t order_external_stream_after_sub_blocks(lmc_engine* e) {
+    if (e->n_sub <= 1 || e->stream_ == e->own_stream || !e->sub_pending) return hipSuccess;
+    hipError_t err = hipSuccess;
+    for (int b = 0; b < e->n_sub && err == hipSuccess; ++b) {
+        err = hipEventRecord(e->sub_done[b], e->sub_stream[b]);
+        if (err == hipSuccess) err = hipStreamWaitEvent(e->stream_, e->sub_done[b], 0);
+    }
+    if (err == hipSuccess) e->sub_pending = false;
+    return err;
 }
 
 static int fail(lmc_engine* e, int code, const char* fmt, ...) {
@@ -392,11 +419,7 @@ static int dense_run(lmc_engine* e, SamplerParams P) {
     // the chains go out as sub-blocks on their own streams, like the diagonal kernels (lmc_engine_run): each sub-block is a
     // chain of launches of its own -- with FullAdapt two per tuning iteration -- and the tail of one is covered by the other
     const int n_sub = e->n_sub;
-    if (n_sub > 1 && e->main_dirty) {
-        HIP_TRY(e, hipEventRecord(e->main_done, e->stream_));
-        for (int b = 0; b < n_sub; ++b) HIP_TRY(e, hipStreamWaitEvent(e->sub_stream[b], e->main_done, 0));
-        e->main_dirty = false;
-    }
+    HIP_TRY(e, order_sub_blocks_after_main(e));
     const long long end = P.iter_begin + P.n_iters;
     if (n_sub > 1) e->sub_pending = true;
     long long it = P.iter_begin;
@@ -422,6 +445,7 @@ static int dense_run(lmc_engine* e, SamplerParams P) {
         }
         it += n;
     }
+    HIP_TRY(e, order_external_stream_after_sub_blocks(e));
     return LMC_OK;
 }
 
@@ -613,6 +637,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     TRY_ALLOC(dev_alloc(e, &A.rng_gauss, C));
     TRY_ALLOC(dev_alloc(e, &A.status, C));
     TRY_ALLOC(dev_alloc(e, &A.counters, C * kNumCounters));
+    TRY_ALLOC(dev_alloc(e, &e->stop_flag, 1));
+    A.stop = e->stop_flag;
     A.scratch_stride = static_cast<long long>(max_levels - nlds + 1) * 4 * dp + static_cast<long long>(kNumColdSlots) * dp;
     const bool dense = cfg->potential >= LMC_POT_FULL;
     if (dense) A.scratch_stride = static_cast<long long>(dense_scratch_vectors(max_levels)) * dp;
@@ -719,6 +745,7 @@ void lmc_engine_destroy(lmc_engine* e) {
         if (e->sub_done[b]) (void)hipEventDestroy(e->sub_done[b]);
     }
     if (e->main_done) (void)hipEventDestroy(e->main_done);
+    if (e->ctl_stream) (void)hipStreamDestroy(e->ctl_stream);
     for (void* p : e->allocs)
         if (p) (void)hipFree(p);
     if (e->user_module) (void)hipModuleUnload(e->user_module);
@@ -738,6 +765,54 @@ int lmc_engine_kernel_shape(lmc_engine* e, int32_t* unit_ns, int32_t* run_ns, in
     if (unit_ns) *unit_ns = e->ns;
     if (run_ns) *run_ns = e->run_ns;
     if (run_w) *run_w = e->run_w;
+    return LMC_OK;
+}
+
+int lmc_engine_occupancy(lmc_engine* e, int32_t* resident_chains, int32_t* waves_per_chain, double* wall_clock_hz) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (waves_per_chain) *waves_per_chain = e->run_w;
+    if (wall_clock_hz) {
+        int khz = 0;
+        HIP_TRY(e, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device));
+        *wall_clock_hz = 1e3 * khz;
+    }
+    if (!resident_chains) return LMC_OK;
+    *resident_chains = 0;
+    if (e->cfg.target_family == LMC_TARGET_EXTERNAL || e->cfg.potential >= LMC_POT_FULL) return LMC_OK;
+    int cus = 0;
+    HIP_TRY(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device));
+    const int run_lds = e->lds_bytes + lds_tail_doubles(e->run_w) * 8;
+    const int block = 64 * e->run_w;
+    int per_cu = 0;
+    if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledIn) {
+        if (!e->user_run) return fail(e, LMC_ERR_STATE, "the user density's kernels are not loaded");
+        HIP_TRY(e, hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, e->user_run, block, static_cast<size_t>(run_lds)));
+        *resident_chains = per_cu * cus;
+        return LMC_OK;
+    }
+#define OCC_ONE(NSV, WV, T)                                                                                    \
+    {                                                                                                          \
+        if (run_lds > 64 * 1024)                                                                               \
+            HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NSV, WV, T>),             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));              \
+        HIP_TRY(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, run_kernel<NSV, WV, T>, block,        \
+                                                                static_cast<size_t>(run_lds)));                \
+    }
+#define OCC_CALL(T)                                                                                            \
+    {                                                                                                          \
+        const int shape = e->run_ns * 10 + e->run_w;                                                           \
+        if (shape == 11) OCC_ONE(1, 1, T)                                                                      \
+        else if (shape == 21) OCC_ONE(2, 1, T)                                                                 \
+        else if (shape == 41) OCC_ONE(4, 1, T)                                                                 \
+        else if (shape == 42) OCC_ONE(4, 2, T)                                                                 \
+        else if (shape == 44) OCC_ONE(4, 4, T)                                                                 \
+        else return fail(e, LMC_ERR_INVALID, "unsupported kernel shape ns=%d w=%d", e->run_ns, e->run_w);      \
+    }
+    LMC_FAMILY_SWITCH(e, e->cfg.target_family, OCC_CALL)
+#undef OCC_CALL
+#undef OCC_ONE
+    *resident_chains = per_cu * cus;
     return LMC_OK;
 }
 
@@ -776,6 +851,24 @@ int lmc_engine_set_step_jitter(lmc_engine* e, int32_t enable, double lo, double 
     e->step_jitter = enable ? 1 : 0;
     e->jitter_lo = lo;
     e->jitter_hi = hi;
+    return LMC_OK;
+}
+
+// Ctrl-C: every chain leaves its launch at the next iteration boundary; launches still queued return at once.
+int lmc_engine_request_stop(lmc_engine* e, int32_t stop) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    static const int kOne = 1, kZero = 0;
+    if (stop) {   // overtakes the kernels in flight: its own stream, not ordered after anything
+        if (!e->ctl_stream) HIP_TRY(e, hipStreamCreateWithFlags(&e->ctl_stream, hipStreamNonBlocking));
+        HIP_TRY(e, hipMemcpyAsync(e->stop_flag, &kOne, sizeof(int), hipMemcpyHostToDevice, e->ctl_stream));
+        HIP_TRY(e, hipStreamSynchronize(e->ctl_stream));
+    } else {      // cleared in order: after everything that was launched under the request has drained
+        if (e->ctl_stream) HIP_TRY(e, hipStreamSynchronize(e->ctl_stream));
+        hipStream_t st = main_stream(e);
+        HIP_TRY(e, hipMemcpyAsync(e->stop_flag, &kZero, sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(e, hipStreamSynchronize(st));
+    }
     return LMC_OK;
 }
 
@@ -1265,11 +1358,7 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
     const int run_lds = e->lds_bytes + lds_tail_doubles(e->run_w) * 8;   // subtree stack + MT19937 + team exchange
     const dim3 block(64 * e->run_w);
     const int n_sub = e->n_sub;
-    if (n_sub > 1 && e->main_dirty) {   // whatever was enqueued on the main stream since the last run() comes first
-        HIP_TRY(e, hipEventRecord(e->main_done, e->stream_));
-        for (int b = 0; b < n_sub; ++b) HIP_TRY(e, hipStreamWaitEvent(e->sub_stream[b], e->main_done, 0));
-        e->main_dirty = false;
-    }
+    HIP_TRY(e, order_sub_blocks_after_main(e));
 #define RUN_ONE(NSV, WV, T)                                                                                    \
     {                                                                                                          \
         if (run_lds > 64 * 1024)                                                                               \
@@ -1304,6 +1393,7 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
 #undef RUN_CALL
 #undef RUN_ONE
     HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, order_external_stream_after_sub_blocks(e));
     return LMC_OK;
 }
 

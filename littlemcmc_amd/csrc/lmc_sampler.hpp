@@ -41,7 +41,7 @@ enum StatF64 : int {
 };
 enum StatI32 : int { kSiDepth = 0 /* HMC: n_steps */, kSiTreeSize = 1 /* leapfrogs */, kNumStatI32 = 2 };
 enum StatU8 : int { kSbDiverging = 0, kSbTune = 1, kSbAccepted = 2, kNumStatU8 = 3 };
-enum Counter : int { kCtMaxTreedepth = 0, kCtDivsSample = 1, kCtSamplesAfterTune = 2, kCtLeapfrogs = 3, kNumCounters = 4 };
+enum Counter : int { kCtMaxTreedepth = 0, kCtDivsSample = 1, kCtSamplesAfterTune = 2, kCtLeapfrogs = 3, kCtWaveTicks = 4, kNumCounters = 5 };
 
 struct ChainArrays {
     int chains, d, dpad;
@@ -67,6 +67,7 @@ struct ChainArrays {
     double* rng_gauss;    // [C]
     int* status;          // [C]
     long long* counters;  // [C][kNumCounters]
+    const int* stop;      // [1] != 0: every chain leaves its launch at the next iteration boundary (lmc_engine_request_stop)
     double* mom_mean;     // [C][dpad] running mean of the post-warm-up draws (nullptr = not kept)
     double* mom_m2;       // [C][dpad] running sum of squared deviations (Welford)
     int* mom_n;           // [C] number of draws accumulated
@@ -1070,6 +1071,20 @@ constexpr int lds_tail_doubles(int w) {
 }
 
 // ---- pieces of the iteration body shared by the diagonal and the dense-mass kernels ---------------------------
+// lmc_engine_request_stop(): the host's Ctrl-C (sampling.py:324-328, :470-471 in the reference: keep what has been drawn).
+// One uncached dword per iteration; a team agrees on ONE value (wave 0's) so that no wave leaves a barrier behind.
+template <class TeamT>
+__device__ __forceinline__ bool stop_requested(const ChainArrays& A, TeamT& tm, double* bcast) {
+    if constexpr (TeamT::kWaves == 1) {
+        return first_i32(__hip_atomic_load(A.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0;
+    } else {
+        tm.sync();
+        if (tm.tid() == 0) bcast[3] = static_cast<double>(__hip_atomic_load(A.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        tm.sync();
+        return first_f64(bcast[3]) != 0.0;
+    }
+}
+
 struct DualAverage {   // step_sizes.py:49-99, wave-uniform
     double log_step, log_bar, hbar, mu;
     int count;
@@ -1220,6 +1235,7 @@ __device__ __forceinline__ void diag_mass_update(const ChainArrays& A, const Sam
 template <int NS, int W, template <int> class TargetT>
 __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(ChainArrays A, SamplerParams P, const double* tparams) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    const long long t_resident = wall_clock64();   // constant-rate clock: the chain's residence time (kCtWaveTicks)
     const int c = blockIdx.x + P.chain_begin;
     const int d = A.d, dpad = A.dpad;
     const long long row = static_cast<long long>(c) * dpad;
@@ -1298,6 +1314,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         const long long git = P.iter_begin + it;
         const bool tune = git < P.n_tune;
         LMC_PHASE(5)
+        if (stop_requested(A, tm, rng_bcast)) break;
 
         // ---- momentum draw (quadpotential.py:221-224 / :374-376)
         team_normals(tm, rng, d, lds, lds + dpad, rng_bcast);   // level-0 LDS region (2*dpad doubles) = normals + staging
@@ -1400,6 +1417,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         A.counters[c * kNumCounters + kCtDivsSample] += ct_divs;
         A.counters[c * kNumCounters + kCtSamplesAfterTune] += ct_after;
         A.counters[c * kNumCounters + kCtLeapfrogs] += ct_leap;
+        A.counters[c * kNumCounters + kCtWaveTicks] += static_cast<long long>(W) * (wall_clock64() - t_resident);
 #ifdef LMC_PHASE_TIMING
         LMC_PHASE(5)
         A.counters[c * kNumCounters + 0] += static_cast<long long>(((ph[0] & 0xffffffffull) << 32) | (ph[1] & 0xffffffffull)) - ct_maxdepth;

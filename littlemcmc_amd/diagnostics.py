@@ -13,8 +13,10 @@ Everything reduces to per-dimension *sufficient statistics that add over chains*
 For draws in HBM (``Engine.trace_device_ptr()`` through ``trace_tensor``) they come from the HIP kernel
 ``lmc_diag_chain_stats`` (csrc/lmc_diag.hip), 16 lags per pass over the trace; passes continue until Geyer's initial
 positive sequence has ended in every dimension (one pass for well-mixing NUTS chains), each pass followed by ONE
-small all-reduce (RCCL on GPUs) of its (3 + 16) x d block. CPU tensors (the gloo tests of the reduction logic) take
-the same statistics from an FFT in torch tensor code."""
+small all-reduce (RCCL on GPUs) of its (3 + 16) x d block. There is one backend: the HIP kernel. The reduction /
+finalisation logic above it is backend-agnostic tensor code, and the CPU tests of that logic (gloo, world_size 2) inject
+the test oracle's restatement of the kernel's block (oracle/diagnostics_oracle.py: torch_chain_stats) through the
+``stats_fn`` argument; nothing in this package computes the statistics on the host."""
 import ctypes
 import math
 
@@ -47,39 +49,22 @@ def _hip_chain_stats(x, t0, n, lag0):
     return out
 
 
-def _torch_chain_stats(x, t0, n, lag0):
-    """Host mirror of the kernel's statistics for CPU tensors: FFT autocovariances of the lags [lag0, lag0 + 16)."""
-    blk = x[:, t0:t0 + n].to(torch.float64)
-    d = blk.shape[2]
-    out = torch.zeros((3 + LAGS_PER_PASS, d), dtype=torch.float64, device=x.device)
-    if blk.shape[0] == 0:
-        return out
-    mean = blk.mean(dim=1)
-    cen = blk - mean[:, None, :]
-    nfft = 1 << (2 * n - 1).bit_length()
-    f = torch.fft.rfft(cen, n=nfft, dim=1)
-    acov = torch.fft.irfft(f.real ** 2 + f.imag ** 2, n=nfft, dim=1)[:, :n] / n       # [c, n, d], biased
-    out[0] = mean.sum(dim=0)
-    out[1] = (mean ** 2).sum(dim=0)
-    if lag0 == 0:
-        out[2] = acov[:, 0].sum(dim=0) * (n / (n - 1.0))
-    hi = min(lag0 + LAGS_PER_PASS, n)
-    if hi > lag0:
-        out[3:3 + hi - lag0] = acov[:, lag0:hi].sum(dim=0)
-    return out
-
-
-def chain_stats_pass(x, ranges, lag0):
+def chain_stats_pass(x, ranges, lag0, stats_fn=None):
     """Statistics block [3 + 16, d] of one pass, summed over the sub-series ``ranges`` = [(t0, n), ...] of every
-    chain of x (the two halves for split diagnostics)."""
+    chain of x (the two halves for split diagnostics). ``stats_fn(x, t0, n, lag0)`` replaces the HIP kernel (tests of
+    the reduction logic only)."""
     if x.shape[0] == 0:
         return torch.zeros((3 + LAGS_PER_PASS, x.shape[2]), dtype=torch.float64, device=x.device)
-    if x.is_cuda:
+    fn = stats_fn
+    if fn is None:
+        if not x.is_cuda:
+            from ._abi import HipLibraryError
+
+            raise HipLibraryError("diagnostics run on draws in HBM (a ROCm tensor, e.g. diagnostics.trace_tensor(engine)); "
+                                  "got a CPU tensor and there is no host implementation")
         if x.dtype != torch.float64 or not x.is_contiguous():
             x = x.to(torch.float64).contiguous()
         fn = _hip_chain_stats
-    else:
-        fn = _torch_chain_stats
     tot = None
     for t0, n in ranges:
         blk = fn(x, t0, n, lag0)
@@ -87,14 +72,22 @@ def chain_stats_pass(x, ranges, lag0):
     return tot
 
 
-def _all_reduce(t, group=None, reduce_device=None):
+def _group_active(group=None):
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    return dist.is_available() and dist.is_initialized()
+
+
+def _all_reduce(t, group=None, reduce_device=None, op="sum"):
+    """All-reduce over the ranks of ``group`` (a no-op without a process group). The collective runs even in a group
+    of one rank: a single-GPU job under RCCL executes the very calls the 8-GPU job does."""
+    import torch.distributed as dist
+
+    if not _group_active(group):
         return t
     home = t.device
     r = t.clone() if reduce_device is None else t.to(reduce_device)
-    dist.all_reduce(r, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(r, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op], group=group)
     return r.to(home)
 
 
@@ -113,9 +106,22 @@ def _geyer_ended(stats):
     return bool(((pairs <= 0).any(dim=0) | ~torch.isfinite(pairs).all(dim=0)).all())
 
 
-def sufficient_stats(x, split=True, max_lag=None, group=None, reduce_device=None):
-    """Reduced (over chains, halves and ranks) sufficient statistics of x[chains, draws, d] (this rank's block)."""
+def sufficient_stats(x, split=True, max_lag=None, group=None, reduce_device=None, stats_fn=None):
+    """Reduced (over chains, halves and ranks) sufficient statistics of x[chains, draws, d] (this rank's block).
+    Every quantity that steers the pass loop -- the draw count, the lag limit, "Geyer's sequence has ended" -- is a
+    REDUCED one, so all ranks issue the same collectives whatever their blocks hold (a rank may own no chain at all)."""
     c, n_all, d = x.shape
+    dev = x.device
+    # the draw count is agreed first: ranks that own chains must have the same, ranks that own none adopt it
+    big = float(2 ** 52)
+    mine = torch.tensor([float(n_all), -float(n_all)] if c > 0 else [0.0, -big], dtype=torch.float64, device=dev)
+    agreed = _all_reduce(mine, group, reduce_device, op="max")
+    n_max, n_min = int(agreed[0]), int(-agreed[1])
+    if n_max == 0 and n_min >= int(big):
+        raise ValueError("no rank holds any chain")
+    if n_max != n_min:
+        raise ValueError("ranks hold different numbers of draws per chain (%d .. %d)" % (n_min, n_max))
+    n_all = n_max
     if split:
         h = n_all // 2
         ranges, n, halves = [(0, h), (n_all - h, h)], h, 2
@@ -124,19 +130,23 @@ def sufficient_stats(x, split=True, max_lag=None, group=None, reduce_device=None
     if n < 4:
         raise ValueError("need at least %d draws per chain" % (4 * halves))
     limit = n if max_lag is None else min(int(max_lag), n)
-    dev = x.device
     nch = _all_reduce(torch.tensor([float(c * halves)], dtype=torch.float64, device=dev), group, reduce_device)
     stats = {"n_chains": nch[0], "n_draws": torch.tensor(float(n), dtype=torch.float64, device=dev)}
     acov_blocks = []
     lag0 = 0
     while True:
-        blk = _all_reduce(chain_stats_pass(x, ranges, lag0), group, reduce_device)   # the pass's one collective
+        blk = _all_reduce(chain_stats_pass(x, ranges, lag0, stats_fn), group, reduce_device)   # the pass's one collective
         if lag0 == 0:
             stats["sum_mean"], stats["sum_mean_sq"], stats["sum_var"] = blk[0], blk[1], blk[2]
         acov_blocks.append(blk[3:])
         lag0 += LAGS_PER_PASS
         stats["sum_acov"] = torch.cat(acov_blocks, dim=0)[:limit]
-        if lag0 >= limit or _geyer_ended(stats):
+        if lag0 >= limit:
+            break
+        ended = torch.tensor([1.0 if _geyer_ended(stats) else 0.0], dtype=torch.float64, device=dev)
+        if _group_active(group):   # the verdict is a function of reduced data, but ranks must not differ by a rounding
+            ended = _all_reduce(ended, group, reduce_device, op="min")
+        if float(ended[0]) > 0.5:
             break
     stats["lag_passes"] = len(acov_blocks)
     return stats
@@ -172,30 +182,66 @@ def finalize(stats):
             "lag_passes": stats.get("lag_passes", 0)}
 
 
-def rank_normalize(x, chunk_dims=8):
-    """z-scores of the pooled ranks of every dimension (Vehtari et al. 2021, eq. 14; average ranks for ties are not
-    needed for continuous draws): z = Phi^-1((rank - 3/8) / (S + 1/4)), S = chains x draws. The ranks pool the chains
-    of the calling rank (a multi-GPU job normalises each rank's block on its own and pools the z-scores)."""
+def rank_normalize(x, chunk_dims=8, group=None, reduce_device=None):
+    """z-scores of the pooled ranks of every dimension (Vehtari et al. 2021, eq. 14): z = Phi^-1((r - 3/8) / (S + 1/4)),
+    S = ALL chains x draws of ALL ranks, r = the average rank of the draw among them (ties -- a rejected HMC proposal, a
+    NUTS tree that returns its start point -- share the mean of their positions, scipy's rankdata(method="average")).
+
+    Multi-GPU: the ranks are global. Every rank sorts its own pooled draws of a block of dimensions, the sorted blocks
+    are all-gathered (padded to the largest block with +inf), and a draw's global rank is the sum over ranks of its
+    insertion points: r = #less + (#equal + 1) / 2. Normalising each rank's block on its own would map every block to
+    N(0, 1) separately and erase exactly the between-rank differences R-hat is there to detect."""
+    import torch.distributed as dist
+
     c, n, d = x.shape
-    S = c * n
+    S_local = c * n
+    active = _group_active(group)
+    S = S_local
+    sizes = None
+    if active:
+        world = dist.get_world_size(group)
+        cnt = torch.zeros((world,), dtype=torch.float64, device=x.device)
+        cnt[dist.get_rank(group)] = float(S_local)
+        sizes = [int(v) for v in _all_reduce(cnt, group, reduce_device)]
+        S = sum(sizes)
     out = torch.empty((c, n, d), dtype=torch.float64, device=x.device)
     for lo in range(0, d, chunk_dims):
-        blk = x[:, :, lo:lo + chunk_dims].reshape(S, -1).to(torch.float64)
-        order = torch.argsort(blk, dim=0)
-        ranks = torch.empty_like(order)
-        ar = torch.arange(1, S + 1, device=x.device, dtype=order.dtype)[:, None].expand_as(order)
-        ranks.scatter_(0, order, ar)
-        p = (ranks.to(torch.float64) - 0.375) / (S + 0.25)
-        out[:, :, lo:lo + chunk_dims] = (math.sqrt(2.0) * torch.erfinv(2.0 * p - 1.0)).reshape(c, n, -1)
+        hi = min(lo + chunk_dims, d)
+        blk = x[:, :, lo:hi].reshape(S_local, hi - lo).to(torch.float64).t().contiguous()      # [k, S_local]
+        srt = torch.sort(blk, dim=1).values
+        if active:
+            pad = max(sizes)
+            mine = torch.full((hi - lo, pad), float("inf"), dtype=torch.float64, device=x.device)
+            mine[:, :S_local] = srt
+            send = mine if reduce_device is None else mine.to(reduce_device)
+            gathered = [torch.empty_like(send) for _ in sizes]
+            dist.all_gather(gathered, send, group=group)
+            pools = [g.to(x.device)[:, :sz] for g, sz in zip(gathered, sizes)]
+        else:
+            pools = [srt]
+        less = torch.zeros_like(blk)
+        leq = torch.zeros_like(blk)
+        for pool in pools:
+            if pool.shape[1] == 0:
+                continue
+            less += torch.searchsorted(pool, blk, right=False).to(torch.float64)
+            leq += torch.searchsorted(pool, blk, right=True).to(torch.float64)
+        ranks = less + 0.5 * (leq - less + 1.0)
+        p = (ranks - 0.375) / (S + 0.25)
+        z = math.sqrt(2.0) * torch.erfinv(2.0 * p - 1.0)
+        out[:, :, lo:hi] = z.t().reshape(c, n, hi - lo)
     return out
 
 
-def summarize(x, split=True, max_lag=None, group=None, reduce_device=None, rank_normalized=False, chunk=None):
+def summarize(x, split=True, max_lag=None, group=None, reduce_device=None, rank_normalized=False, chunk=None,
+              stats_fn=None):
     """x[chains, draws, d] (this rank's chain block) -> dict(rhat[d], ess[d], mean[d], var[d]) over ALL ranks.
-    ``rank_normalized=True``: the rank-normalised split-R-hat / bulk ESS (diagnostics of the z-scores)."""
-    if rank_normalized and x.shape[0] > 0:
-        x = rank_normalize(x)
-    out = finalize(sufficient_stats(x, split=split, max_lag=max_lag, group=group, reduce_device=reduce_device))
+    ``rank_normalized=True``: the rank-normalised split-R-hat / bulk ESS (diagnostics of the z-scores of the GLOBAL
+    ranks). ``stats_fn`` replaces the HIP kernel (tests of the reduction logic only)."""
+    if rank_normalized:
+        x = rank_normalize(x, group=group, reduce_device=reduce_device)
+    out = finalize(sufficient_stats(x, split=split, max_lag=max_lag, group=group, reduce_device=reduce_device,
+                                    stats_fn=stats_fn))
     out["definition"] = ("rank-normalised " if rank_normalized else "") + (
         "split-R-hat / Geyer initial-monotone-sequence ESS" if split else "R-hat / Geyer initial-monotone-sequence ESS")
     return out

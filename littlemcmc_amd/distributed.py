@@ -29,17 +29,21 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def _reduce_device(group):
-    """Where the diagnostics all-reduce runs: on the GPUs for RCCL ("nccl"), on the host for gloo."""
+def _reduce_device(group, device_index):
+    """Where the diagnostics collectives run: on this rank's GPU for RCCL ("nccl" -- it has no host path, every tensor
+    handed to it must live on the device), on the host for gloo."""
+    import torch
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and str(dist.get_backend(group)) == "gloo":
-        return "cpu"
+    if dist.is_available() and dist.is_initialized():
+        if str(dist.get_backend(group)) == "gloo":
+            return torch.device("cpu")
+        return torch.device("cuda", int(device_index))
     return None
 
 
 def sample_distributed(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, chains=None, random_seed=None,
-                       start=None, group=None, diagnostics=True, **kwargs):   # diagnostics: True | False | "moments"
+                       start=None, group=None, diagnostics=True, **kwargs):   # diagnostics: True | False | "moments" | "rank_normalized"
     """``sample()`` for a job of ``chains`` chains spread over the ranks of the current process group.
 
     Returns (trace, stats, diag): this rank's block of the trace/stats (same layouts as ``sample``) and, if
@@ -73,39 +77,36 @@ def sample_distributed(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, 
         step_kw = {}
     sample_kw.setdefault("device", local_rank)
     eng = None
+    n_keep = int(draws) if sample_kw.get("discard_tuned_samples", True) else int(draws) + int(tune)
     if hi > lo:
         trace, stats, eng = sample(logp_dlogp_func, model_ndim, draws=draws, tune=tune, chains=hi - lo,
                                    random_seed=seeds[lo:hi], start=start, return_engine=True,
                                    keep_moments=(diagnostics == "moments"), **sample_kw, **step_kw)
     else:   # more ranks than chains: this rank owns nothing but still joins the diagnostics reduction
-        d = int(model_ndim)
-        n_keep = draws if sample_kw.get("discard_tuned_samples", True) else draws + tune
-        trace, stats = np.zeros((0, n_keep, d)), {}
+        trace, stats = np.zeros((0, n_keep, int(model_ndim))), {}
     diag = None
+    import torch
+
+    dev = torch.device("cuda", int(sample_kw["device"]))
+    red = _reduce_device(group, sample_kw["device"])
     if diagnostics == "moments":
         # trace-free cross-chain R-hat: the kernel kept (mean, M2, n) per chain; ranks exchange
         # 3 x d doubles
         from . import diagnostics as dg
 
         if eng is not None:
-            mean, m2, n = eng.moments()
+            mean, m2, n = (torch.as_tensor(a).to(dev) for a in eng.moments())
         else:
-            import torch
-
-            mean = m2 = torch.zeros((0, int(model_ndim)), dtype=torch.float64)
-            n = torch.zeros((0,), dtype=torch.int32)
-        rhat = dg.rhat_from_moments(mean, m2, n, group=group, reduce_device=_reduce_device(group))
+            mean = m2 = torch.zeros((0, int(model_ndim)), dtype=torch.float64, device=dev)
+            n = torch.zeros((0,), dtype=torch.int32, device=dev)
+        rhat = dg.rhat_from_moments(mean, m2, n, group=group, reduce_device=red)
         diag = {"rhat": rhat.cpu().numpy(), "n_chains": float(chains)}
     elif diagnostics:
         from . import diagnostics as dg
 
-        if eng is not None:
-            x = dg.trace_tensor(eng)
-        else:
-            import torch
-
-            x = torch.zeros((0, draws, int(model_ndim)), dtype=torch.float64)
-        diag = dg.summarize(x, group=group, reduce_device=_reduce_device(group))
+        # a rank without chains joins every collective with an empty block of the SAME draw count as the others
+        x = dg.trace_tensor(eng) if eng is not None else torch.zeros((0, n_keep, int(model_ndim)), dtype=torch.float64, device=dev)
+        diag = dg.summarize(x, group=group, reduce_device=red, rank_normalized=(diagnostics == "rank_normalized"))
         diag = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in diag.items()}
     if eng is not None:
         eng.close()

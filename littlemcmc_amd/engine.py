@@ -162,21 +162,27 @@ class Engine:
         """step_rand as step * uniform(lo, hi) drawn from each chain's own stream (include/lmc_hip.h)."""
         self._check(self._lib.lmc_engine_set_step_jitter(self._h, int(bool(enable)), float(lo), float(hi)))
 
+    def request_stop(self, stop=True):
+        """Ctrl-C for the device: every chain leaves its launch at its next iteration boundary (include/lmc_hip.h)."""
+        self._check(self._lib.lmc_engine_request_stop(self._h, int(bool(stop))))
+
+    def completed_iterations(self):
+        """Iterations EVERY chain has completed since reset_tuning() (the smallest per-chain iteration count)."""
+        return int(self.get_chain_state(fields=("iter_count",))["iter_count"].min())
+
+    def occupancy(self):
+        """(resident_chains, waves_per_chain, wall_clock_hz) of this engine's sampling kernel, asked of the HIP runtime
+        for the very kernel / block size / dynamic LDS run() launches with (lmc_engine_occupancy)."""
+        rc, wpc, hz = C.c_int32(), C.c_int32(), C.c_double()
+        self._check(self._lib.lmc_engine_occupancy(self._h, C.byref(rc), C.byref(wpc), C.byref(hz)))
+        return int(rc.value), int(wpc.value), float(hz.value)
+
     def resident_chains(self):
-        """How many chains the sampling kernel keeps resident on the GPU at once (wave slots / waves per chain);
-        None for engines without a fused sampling kernel."""
+        """How many chains the sampling kernel keeps resident on the GPU at once; None for engines without a fused
+        diagonal-mass sampling kernel."""
         if self.target.family == _abi.TARGET_EXTERNAL:
             return None
-        import torch
-
-        ns, rns, rw = C.c_int32(), C.c_int32(), C.c_int32()
-        self._check(self._lib.lmc_engine_kernel_shape(self._h, C.byref(ns), C.byref(rns), C.byref(rw)))
-        run_ns, run_w = int(rns.value), int(rw.value)
-        if self.potential not in ("diag", "diag_adapt"):
-            return None
-        cus = torch.cuda.get_device_properties(int(self.cfg.device)).multi_processor_count
-        waves_per_simd = {1: 4, 2: 3, 4: 2}.get(run_ns, 1)      # lmc_sampler.hpp: run_waves_per_simd
-        return cus * 4 * waves_per_simd // run_w
+        return self.occupancy()[0] or None
 
     def run_streams(self):
         """Raw HIP stream handles run() launches its kernels on (one per sub-block of chains)."""

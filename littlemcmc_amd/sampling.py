@@ -69,6 +69,64 @@ def init_nuts(logp_dlogp_func, model_ndim=None, init="auto", random_seed=None, s
     return start, step
 
 
+def _run_job(eng, tune, n_total, per_launch, progressbar):
+    """Enqueue the job's launches, then wait for them in a way Ctrl-C can reach (sampling.py:324-328, :470-471 in the
+    reference: a KeyboardInterrupt ends sampling and what has been drawn so far is returned).
+
+    The launches are asynchronous and back to back (the engine's sub-block streams keep the chip full across launch
+    boundaries), so the host does not step in between them: it polls the completion events of the launches it queued,
+    logs progress as they complete (``progressbar=True``; the reference's per-draw bar, sampling.py:455-459, at launch
+    granularity) and, on Ctrl-C, asks the device to stop -- every chain leaves its launch at its next iteration
+    boundary (lmc_engine_request_stop). Returns (iterations completed by EVERY chain, interrupted)."""
+    import time
+
+    marks = []   # (iterations enqueued so far, [event per run stream]) per launch
+    events_ok = eng.target.family != _abi.TARGET_EXTERNAL
+    torch = None
+    if events_ok:
+        try:
+            import torch
+            streams = [torch.cuda.ExternalStream(h, device=torch.device("cuda", int(eng.cfg.device))) for h in eng.run_streams()]
+        except Exception:   # no torch: plain blocking wait (no progress lines, Ctrl-C acts when the job ends)
+            torch = None
+    t0 = time.perf_counter()
+    try:
+        it = 0
+        while it < n_total:
+            n = min(per_launch, n_total - it)
+            eng.run(tune, it, n)
+            it += n
+            if torch is not None:
+                evs = [torch.cuda.Event() for _ in streams]
+                for e_, s_ in zip(evs, streams):
+                    e_.record(s_)
+                marks.append((it, evs))
+        if torch is None:
+            eng.synchronize()
+        else:
+            reported = 0
+            while marks:
+                if all(e_.query() for e_ in marks[0][1]):
+                    done = marks.pop(0)[0]
+                    if progressbar and done != reported:
+                        reported = done
+                        _log.info("Sampling %d chains: %d/%d iterations (%s), %.1f s" % (
+                            eng.chains, done, n_total, "tuning" if done <= tune else "drawing", time.perf_counter() - t0))
+                    continue
+                time.sleep(0.002)
+            eng.synchronize()
+        return n_total, False
+    except KeyboardInterrupt:
+        if eng.target.family != _abi.TARGET_EXTERNAL:
+            eng.request_stop(True)
+        eng.synchronize()
+        n_done = min(eng.completed_iterations(), n_total)
+        if eng.target.family != _abi.TARGET_EXTERNAL:
+            eng.request_stop(False)     # re-armed for whoever keeps the engine (return_engine=True)
+        _log.warning("Sampling interrupted after %d of %d iterations; returning the draws so far." % (n_done, n_total))
+        return n_done, True
+
+
 def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, init="auto", chains=None,
            cores=None, start=None, progressbar=True, random_seed=None, discard_tuned_samples=True,
            chain_idx=0, callback=None, mp_ctx=None, pickle_backend="pickle", size=None, device=0,
@@ -134,15 +192,10 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
                 per_launch = min(per_launch, 100)
         if target.family == _abi.TARGET_EXTERNAL and not launch_iters:
             per_launch = max(n_total, 1)   # ticks: chains never wait for each other inside one request
-        it = 0
-        while it < n_total:
-            n = min(per_launch, n_total - it)
-            eng.run(tune, it, n)
-            it += n
-        eng.synchronize()
+        n_done, interrupted = _run_job(eng, int(tune), n_total, per_launch, progressbar)
         raise_for_status(eng.status())
 
-        n_out = n_total - lo
+        n_out = max(n_done - lo, 0)
         if n_out > 0:
             trace = eng.trace(lo, n_out)
             raw = step._stats_from_engine(eng, lo, n_out)
@@ -152,8 +205,11 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
             stats = {name: np.zeros((chains, 0, 1), dtype=dtype) for name, dtype in step.stats_dtypes[0].items()}
 
         # leave the step object as the reference's sequential driver leaves it: state of the LAST chain
-        step.tune = False if n_total > 0 else step.tune
-        step.iter_count = n_total
+        if not interrupted:
+            step.tune = False if n_total > 0 else step.tune
+        elif n_done > 0:
+            step.tune = n_done <= int(tune)          # stop_tuning() happens at iteration index `tune` (sampling.py:510-511)
+        step.iter_count = n_done
         step.step_adapt._pull(eng, chains - 1)
         step.potential._pull(eng, chains - 1)
         ct = eng.counters()
@@ -161,10 +217,10 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
         step._num_divs_sample += int(ct[:, _abi.CT_DIVS_AFTER_TUNE].sum())
         if hasattr(step, "_reached_max_treedepth"):
             step._reached_max_treedepth += int(ct[:, _abi.CT_REACHED_MAX_TREEDEPTH].sum())
-        if draws > 0:
-            tail = eng.stat_f64(_abi.STAT_ACCEPT, int(tune), int(draws))
+        if n_done > int(tune):
+            tail = eng.stat_f64(_abi.STAT_ACCEPT, int(tune), n_done - int(tune))
             step.step_adapt._tuned_stats = list(tail[chains - 1])
-    except Exception:
+    except BaseException:   # KeyboardInterrupt / SystemExit included: never leak the engine (its HBM, its streams)
         eng.close()
         raise
     if return_engine:

@@ -61,3 +61,33 @@ def rhat_ess(x, do_split=True, rank_normalized=False):
         tau = max(tau, 1.0 / np.log10(max(m * n, 10.0)))
         ess[j] = m * n / tau
     return rhat, ess
+
+
+def torch_chain_stats(x, t0, n, lag0, lags_per_pass=16):
+    """Restatement of ONE pass of the device kernel ``lmc_diag_chain_stats`` (littlemcmc_amd/csrc/lmc_diag.hip) for CPU
+    tensors, by FFT: out[0] = sum of chain means, out[1] = sum of squared chain means, out[2] = sum of unbiased
+    within-chain variances (lag0 == 0 only), out[3 + k] = sum of biased autocovariances at lag lag0 + k of the
+    sub-series [t0, t0 + n) of every chain of x[chains, draws, d].
+
+    TEST INFRASTRUCTURE ONLY: the CPU tests of the multi-rank reduction logic (gloo, world_size 2) inject it through
+    ``diagnostics.summarize(..., stats_fn=torch_chain_stats)``; the -m gpu tests compare the HIP kernel with it."""
+    import torch
+
+    blk = x[:, t0:t0 + n].to(torch.float64)
+    d = blk.shape[2]
+    out = torch.zeros((3 + lags_per_pass, d), dtype=torch.float64, device=x.device)
+    if blk.shape[0] == 0:
+        return out
+    mean = blk.mean(dim=1)
+    cen = blk - mean[:, None, :]
+    nfft = 1 << (2 * n - 1).bit_length()
+    f = torch.fft.rfft(cen, n=nfft, dim=1)
+    acov = torch.fft.irfft(f.real ** 2 + f.imag ** 2, n=nfft, dim=1)[:, :n] / n       # [c, n, d], biased
+    out[0] = mean.sum(dim=0)
+    out[1] = (mean ** 2).sum(dim=0)
+    if lag0 == 0:
+        out[2] = acov[:, 0].sum(dim=0) * (n / (n - 1.0))
+    hi = min(lag0 + lags_per_pass, n)
+    if hi > lag0:
+        out[3:3 + hi - lag0] = acov[:, lag0:hi].sum(dim=0)
+    return out

@@ -174,3 +174,29 @@ def replay_iterations_on_device(step, snaps, outs, label=""):
         finally:
             eng.close()
     return checked, fragile
+
+
+# ---------------------------------------------------------------------------------------------------
+# oracle chains inside a full-size job: the seeds are prefix stable over the GLOBAL chain index space, so chain i of
+# a 65 536-chain device job is the oracle's one-chain run with seeds[i]
+# ---------------------------------------------------------------------------------------------------
+def assert_selected_chains_match_oracle(family, d, seeds, start, sel, n_it, trace, stats, okw=None, label=""):
+    """trace[chains, >= n_it, d] / stats[name][chains, >= n_it, 1] of a device job (iterations from 0, tuning included);
+    chains ``sel`` are compared with oracle chains on the same global seeds over the first n_it iterations: integer
+    statistics exact, positions to RTOL_Q. Returns the iterations verified per chain."""
+    from oracle import lmc_oracle as orc
+    from oracle import targets as OT
+
+    f = OT.make(family, d)
+    okw = dict(okw or {})
+    _s, ostep = orc.init_nuts(f, d, seeds=seeds, **okw)
+    np.testing.assert_array_equal(_s, start)
+    ot, os_, margins = orc.sample(f, d, draws=0, tune=n_it, step=ostep, chains=len(sel), start=start,
+                                  random_seed=[seeds[i] for i in sel], discard_tuned_samples=False, record_margins=True)
+    out = []
+    for k, c in enumerate(sel):
+        got = {n_: np.asarray(stats[n_])[c, :n_it].reshape(n_it) for n_ in stats}
+        want = {n_: os_[n_][k, :, 0] for n_ in os_ if n_ in stats}
+        out.append(assert_chain_matches(np.asarray(trace)[c, :n_it], got, ot[k], want, margins[k, :, 0],
+                                        label="%s chain %d" % (label, c)))
+    return out

@@ -27,7 +27,7 @@ def ar1_chains(chains, n, d, rho, seed):
 @pytest.mark.parametrize("rho", [0.0, 0.6, -0.4])
 def test_rhat_ess_match_numpy_restatement(rho):
     x = ar1_chains(6, 80, 3, rho, 1)
-    got = dg.summarize(torch.from_numpy(x))
+    got = dg.summarize(torch.from_numpy(x), stats_fn=odg.torch_chain_stats)
     rhat, ess = odg.rhat_ess(x)
     np.testing.assert_allclose(got["rhat"].numpy(), rhat, rtol=1e-10)
     np.testing.assert_allclose(got["ess"].numpy(), ess, rtol=1e-8)
@@ -36,7 +36,7 @@ def test_rhat_ess_match_numpy_restatement(rho):
 def test_ess_recovers_known_autocorrelation_time():
     rho = 0.5
     x = ar1_chains(256, 400, 2, rho, 3)
-    got = dg.summarize(torch.from_numpy(x))
+    got = dg.summarize(torch.from_numpy(x), stats_fn=odg.torch_chain_stats)
     want = 256 * 400 * (1 - rho) / (1 + rho)
     assert np.all(np.abs(got["ess"].numpy() / want - 1) < 0.1)
     assert np.all(np.abs(got["rhat"].numpy() - 1) < 0.01)
@@ -44,24 +44,24 @@ def test_ess_recovers_known_autocorrelation_time():
 
 def test_lag_passes_follow_the_autocorrelation_length():
     """16 lags per pass; passes stop once Geyer's initial positive sequence has ended in every dimension."""
-    fast = dg.summarize(torch.from_numpy(ar1_chains(10, 400, 4, 0.3, 5)))
-    slow = dg.summarize(torch.from_numpy(ar1_chains(10, 400, 4, 0.95, 5)))
+    fast = dg.summarize(torch.from_numpy(ar1_chains(10, 400, 4, 0.3, 5)), stats_fn=odg.torch_chain_stats)
+    slow = dg.summarize(torch.from_numpy(ar1_chains(10, 400, 4, 0.95, 5)), stats_fn=odg.torch_chain_stats)
     assert fast["lag_passes"] == 1 and slow["lag_passes"] >= 3
     x = ar1_chains(10, 400, 4, 0.95, 5)
     rhat, ess = odg.rhat_ess(x)
     np.testing.assert_allclose(slow["ess"].numpy(), ess, rtol=1e-8)
-    capped = dg.summarize(torch.from_numpy(x), max_lag=16)
+    capped = dg.summarize(torch.from_numpy(x), max_lag=16, stats_fn=odg.torch_chain_stats)
     assert capped["lag_passes"] == 1 and np.all(capped["ess"].numpy() >= slow["ess"].numpy())
 
 
 @pytest.mark.parametrize("rho", [0.0, 0.7])
 def test_rank_normalised_variant_matches_numpy_restatement(rho):
     x = np.exp(ar1_chains(5, 90, 3, rho, 11))          # heavy right tail: rank normalisation matters
-    got = dg.summarize(torch.from_numpy(x), rank_normalized=True)
+    got = dg.summarize(torch.from_numpy(x), rank_normalized=True, stats_fn=odg.torch_chain_stats)
     rhat, ess = odg.rhat_ess(x, rank_normalized=True)
     np.testing.assert_allclose(got["rhat"].numpy(), rhat, rtol=1e-9)
     np.testing.assert_allclose(got["ess"].numpy(), ess, rtol=1e-7)
-    plain = dg.summarize(torch.from_numpy(x))
+    plain = dg.summarize(torch.from_numpy(x), stats_fn=odg.torch_chain_stats)
     assert not np.allclose(plain["ess"].numpy(), got["ess"].numpy(), rtol=1e-3)
 
 
@@ -80,16 +80,47 @@ sys.path.insert(0, {root!r})
 import numpy as np, torch, torch.distributed as dist
 from littlemcmc_amd import diagnostics as dg
 from littlemcmc_amd.distributed import chain_block, global_seeds
+from oracle import diagnostics_oracle as odg
 from tests.test_diagnostics_cpu import ar1_chains
 dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
 rank, world = dist.get_rank(), dist.get_world_size()
+solo = [dist.new_group([r]) for r in range(world)][rank]       # a one-rank group per rank (created collectively)
+fft = odg.torch_chain_stats                                    # the oracle's restatement of the kernel's block
 x = ar1_chains(12, 90, 3, 0.5, 7)                    # the WHOLE job, identical on both ranks
 lo, hi = chain_block(12, rank, world)
-got = dg.summarize(torch.from_numpy(x[lo:hi]))       # each rank only sees its block
-ref = dg.summarize(torch.from_numpy(x), group=dist.new_group([rank]))   # single-rank reduction of everything
+got = dg.summarize(torch.from_numpy(x[lo:hi]), stats_fn=fft)       # each rank only sees its block
+ref = dg.summarize(torch.from_numpy(x), group=solo, stats_fn=fft)  # single-rank reduction of everything
 np.testing.assert_allclose(got["ess"].numpy(), ref["ess"].numpy(), rtol=1e-10)
 np.testing.assert_allclose(got["rhat"].numpy(), ref["rhat"].numpy(), rtol=1e-12)
 assert got["n_chains"] == 24.0
+# several lag passes: every rank must issue the same number of collectives
+xs = ar1_chains(12, 400, 3, 0.95, 9)
+gs = dg.summarize(torch.from_numpy(xs[lo:hi]), stats_fn=fft)
+rs = dg.summarize(torch.from_numpy(xs), group=solo, stats_fn=fft)
+assert gs["lag_passes"] == rs["lag_passes"] >= 3
+np.testing.assert_allclose(gs["ess"].numpy(), rs["ess"].numpy(), rtol=1e-10)
+# rank-normalised: GLOBAL ranks (the blocks differ in location: per-rank normalisation would erase it), ties averaged
+xt = np.round(np.exp(ar1_chains(12, 90, 3, 0.5, 11)), 1)           # rounding makes exact ties
+xt[6:] += 2.0                                                     # the second rank's chains sit somewhere else
+gr = dg.summarize(torch.from_numpy(xt[lo:hi]), rank_normalized=True, stats_fn=fft)
+want_rhat, want_ess = odg.rhat_ess(xt, rank_normalized=True)       # scipy rankdata(method="average") over everything
+np.testing.assert_allclose(gr["rhat"].numpy(), want_rhat, rtol=1e-9)
+np.testing.assert_allclose(gr["ess"].numpy(), want_ess, rtol=1e-7)
+assert want_rhat.max() > 1.05                                      # the shift is visible, i.e. was not normalised away
+# a rank that owns NO chain (more ranks than chains) joins every collective with an empty block of any draw count
+one = ar1_chains(1, 400, 3, 0.95, 13)
+l1, h1 = chain_block(1, rank, world)
+blk = torch.from_numpy(one[l1:h1]) if h1 > l1 else torch.zeros((0, 7, 3), dtype=torch.float64)
+g1 = dg.summarize(blk, stats_fn=fft)
+r1 = dg.summarize(torch.from_numpy(one), group=solo, stats_fn=fft)
+np.testing.assert_allclose(g1["ess"].numpy(), r1["ess"].numpy(), rtol=1e-10)
+assert g1["lag_passes"] == r1["lag_passes"] and g1["n_chains"] == 2.0
+# ranks that disagree on the draw count fail TOGETHER (no rank is left waiting in a collective)
+try:
+    dg.summarize(torch.from_numpy(x[lo:hi, : 90 - 2 * rank]), stats_fn=fft)
+    raise SystemExit("draw-count mismatch went unnoticed")
+except ValueError as err:
+    assert "different numbers of draws" in str(err)
 seeds = global_seeds(20260928, 12)
 assert seeds[:4] == global_seeds(20260928, 4)          # prefix stable: blocks do not depend on the job size
 out = [None] * world
@@ -100,12 +131,27 @@ blk = x[lo:hi]
 mean = blk.mean(axis=1)
 m2 = ((blk - mean[:, None, :]) ** 2).sum(axis=1)
 rh = dg.rhat_from_moments(mean, m2, np.full(hi - lo, blk.shape[1])).numpy()
-from oracle import diagnostics_oracle as odg
 want, _ = odg.rhat_ess(x, do_split=False)
 np.testing.assert_allclose(rh, want, rtol=1e-10)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
+
+
+def test_the_package_has_no_host_implementation_of_the_statistics():
+    """CPU tensors are refused: the HIP kernel is the only backend (the FFT restatement lives in oracle/)."""
+    from littlemcmc_amd._abi import HipLibraryError
+
+    with pytest.raises(HipLibraryError):
+        dg.summarize(torch.zeros((4, 40, 2), dtype=torch.float64))
+    assert not hasattr(dg, "_torch_chain_stats")
+
+
+def test_rank_normalisation_averages_ties():
+    rs = np.random.RandomState(3)
+    x = np.round(rs.randn(4, 50, 2), 1)                  # many exact ties
+    z = dg.rank_normalize(torch.from_numpy(x)).numpy()
+    np.testing.assert_allclose(z, odg.rank_normalize(x), rtol=1e-12, atol=1e-14)
 
 
 def test_two_rank_gloo_reduction_equals_single_process(tmp_path):

@@ -42,7 +42,7 @@ def test_hip_chain_statistics_kernel_against_numpy(chains, n, d, rho):
         rhat, ess = odg.rhat_ess(x, do_split=split)
         np.testing.assert_allclose(got["rhat"].cpu().numpy(), rhat, rtol=1e-9)
         np.testing.assert_allclose(got["ess"].cpu().numpy(), ess, rtol=1e-7)
-        host = dg.summarize(torch.from_numpy(x), split=split)        # the FFT mirror used by the gloo tests
+        host = dg.summarize(torch.from_numpy(x), split=split, stats_fn=odg.torch_chain_stats)   # the oracle's FFT restatement the gloo tests inject
         assert host["lag_passes"] == got["lag_passes"]
         np.testing.assert_allclose(got["ess"].cpu().numpy(), host["ess"].numpy(), rtol=1e-9)
     if rho > 0.9:
@@ -154,8 +154,16 @@ tgt = lmc.targets.AR1(d, 0.9)
 tr, st, diag = lmc.distributed.sample_distributed(tgt, d, draws=60, tune=80, chains=chains, random_seed=20260928, device=0)
 tr2, st2, diag2 = lmc.distributed.sample_distributed(tgt, d, draws=60, tune=80, chains=chains, random_seed=20260928,
                                                      device=0, diagnostics="moments", discard_tuned_samples=False)
+tr3, st3, diag3 = lmc.distributed.sample_distributed(tgt, d, draws=60, tune=80, chains=chains, random_seed=20260928, device=0,
+                                                     diagnostics="rank_normalized")
+# more ranks than chains: rank 1 owns nothing and still joins every collective (discard_tuned_samples=False: its
+# placeholder must carry draws + tune rows like the other rank's trace)
+tr4, st4, diag4 = lmc.distributed.sample_distributed(tgt, d, draws=40, tune=40, chains=1, random_seed=5, device=0,
+                                                     discard_tuned_samples=False)
+assert tr4.shape == ((1, 80, d) if rank == 0 else (0, 80, d)) and diag4["n_chains"] == 2.0
 np.savez({out!r} + "/rank%d.npz" % rank, trace=tr, tree_size=st["tree_size"], depth=st["depth"], rhat=diag["rhat"],
-         ess=diag["ess"], n_chains=diag["n_chains"], rhat_m=diag2["rhat"], trace_all=tr2)
+         ess=diag["ess"], n_chains=diag["n_chains"], rhat_m=diag2["rhat"], trace_all=tr2, rhat_z=diag3["rhat"],
+         ess_z=diag3["ess"], ess_one=diag4["ess"])
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
@@ -197,6 +205,64 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_run(tmp_path):
             np.testing.assert_allclose(p["ess"], want["ess"].cpu().numpy(), rtol=1e-10)
         rhat_m, _ = odg.rhat_ess(trace, do_split=False)
         np.testing.assert_allclose(parts[0]["rhat_m"], rhat_m, rtol=1e-9)
+        rhat_z, ess_z = odg.rhat_ess(trace, rank_normalized=True)      # GLOBAL ranks over both blocks
+        for p in parts:
+            np.testing.assert_allclose(p["rhat_z"], rhat_z, rtol=1e-8)
+            np.testing.assert_allclose(p["ess_z"], ess_z, rtol=1e-6)
+        np.testing.assert_array_equal(parts[0]["ess_one"], parts[1]["ess_one"])
         assert parts[0]["trace_all"].shape == (6, 140, d)          # sample()'s own keywords reach sample()
     finally:
         eng.close()
+
+
+RCCL_WORKER = """
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+import littlemcmc_amd as lmc
+from littlemcmc_amd import diagnostics as dg
+from oracle import diagnostics_oracle as odg
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))     # "nccl" IS RCCL on ROCm
+ones = torch.ones(4, device="cuda")
+dist.all_reduce(ones)                                                                        # RCCL has executed
+torch.cuda.synchronize()
+assert ones.tolist() == [1.0] * 4
+d = 9
+tgt = lmc.targets.AR1(d, 0.6)
+tr, st, eng = lmc.sample(tgt, d, draws=120, tune=100, chains=10, random_seed=4, return_engine=True)
+got = dg.summarize(dg.trace_tensor(eng), reduce_device="cuda")           # every pass: one RCCL all-reduce on the GPU
+rhat, ess = odg.rhat_ess(tr)
+np.testing.assert_allclose(got["rhat"].cpu().numpy(), rhat, rtol=1e-9)
+np.testing.assert_allclose(got["ess"].cpu().numpy(), ess, rtol=1e-7)
+z = dg.summarize(dg.trace_tensor(eng), reduce_device="cuda", rank_normalized=True)       # all_gather over RCCL
+rz, ez = odg.rhat_ess(tr, rank_normalized=True)
+np.testing.assert_allclose(z["rhat"].cpu().numpy(), rz, rtol=1e-8)
+eng.close()
+for mode in ("moments", True):
+    tr2, st2, diag = lmc.distributed.sample_distributed(tgt, d, draws=120, tune=100, chains=10, random_seed=4, diagnostics=mode)
+    np.testing.assert_array_equal(tr2, tr)
+    want, _ = odg.rhat_ess(tr, do_split=(mode is True))
+    np.testing.assert_allclose(diag["rhat"], want, rtol=1e-9)
+dist.barrier(); dist.destroy_process_group()
+print("rccl ok")
+"""
+
+
+def test_rccl_backend_single_rank(tmp_path):
+    """The "nccl" (= RCCL) process group, world_size 1, on this GPU: an all-reduce of ones, diagnostics.summarize with the
+    reduction on the device, the rank-normalised variant (all_gather), and sample_distributed with both diagnostics modes
+    -- the very collectives the 8-GPU job issues have executed once on this box. Runs in a subprocess so that a RCCL
+    failure cannot take the test session with it."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER.format(root=root))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "rccl ok" in res.stdout

@@ -79,6 +79,7 @@ def test_transitions_golden(golden_dir):
             total += iters
         finally:
             eng.close()
+    print("transitions golden: %d of %d transitions verified bit-exactly" % (verified, total))
     assert verified >= 0.9 * total, "only %d of %d golden transitions verified bit-exactly" % (verified, total)
 
 
@@ -122,6 +123,7 @@ def test_e2e_golden_through_sample_api(golden_dir, name):
     # whole tuned chains are chaotic (see test_every_iteration_of_the_golden_runs, which checks EVERY iteration from
     # the oracle's own state): require a solid prefix. Deep trees at d = 128 amplify the float32 start-energy
     # rounding faster (60+ leapfrogs per iteration feeding dual averaging), so their prefix is shorter.
+    print("%s: %d of %d iterations verified as one chain" % (name, verified, chains * (tune + draws)))
     need = 10 if name == "e2e_nuts_ar1_128" else 15
     assert verified >= chains * min(need, tune + draws), "%s: only %d iterations verified" % (name, verified)
 
@@ -163,11 +165,14 @@ def test_every_iteration_of_the_golden_runs(golden_dir, name):
         if same:
             np.testing.assert_array_equal(np.array([o["stats"]["diverging"] for o in outs]),
                                           g["stat_diverging"][c, :, 0])
+    print("%s: replay checked %d of %d iterations, %d fragile" % (name, total_checked, chains * (tune + draws), total_fragile))
     assert total_checked >= 0.99 * (chains * (tune + draws)), (total_checked, total_fragile)
 
 
 @pytest.mark.parametrize("family,d,kw", [("ar1", 200, {}), ("ar1", 300, {}), ("funnel", 600, {"max_treedepth": 9}),
-                                           ("diag_gaussian", 1000, {}), ("std_normal", 129, {})])
+                                           ("diag_gaussian", 1000, {}), ("std_normal", 129, {}),
+                                           ("funnel", 256, {"max_treedepth": 12}),      # C5's instantiation: run_kernel<4, 1, FunnelTarget>
+                                           ("std_normal", 64, {})])                     # C2's: run_kernel<1, 1, StdNormalTarget>
 def test_every_iteration_replay_on_wide_and_multi_wave_shapes(family, d, kw):
     """The kernel shapes beyond one-wave NS<=2 -- NS=4 (d<=256) and teams of 2 / 4 wavefronts per chain
     (d<=512 / d<=1024, LDS exchange + barrier per reduction) -- replayed iteration by iteration against the
