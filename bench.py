@@ -206,6 +206,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
+    # stdout carries ONE line, the JSON record: whatever the libraries print (RCCL's version banner, c10d warnings) goes
+    # to stderr -- at the file-descriptor level, C stdio included -- and the record is written to the real stdout last
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -574,7 +579,8 @@ def main():
                 "tail": secondary["tail"], "per_rank": secondary["per_rank"]}]
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.target, args.dim, seeds_all[:64], primary["start"], args.cpu_iters, args.mass)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if group_up:
         if world > 1:
             dist.barrier()

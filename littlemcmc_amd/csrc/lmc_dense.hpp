@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel
     for (int it = 0; it < P.n_iters; ++it) {
         const long long git = P.iter_begin + it;
         const bool tune = git < P.n_tune;
-        if (first_i32(__hip_atomic_load(A.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0) break;
+        const int stop_word = stop_request_load(A);   // looked at when the iteration ends (lmc_sampler.hpp)
 
         // ---- momentum draw
         rng_normals(rng, d, lds, lds + dpad);
@@ -554,6 +554,7 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel
         if (!tune) ++ct_after;
         if (A.mom_mean != nullptr && !tune) moments_update<NS>(A, tm, c, row, q);
         write_outputs<NS>(A, c, tid, git, q, out, da.step_now, da.step_bar_now, tune);
+        if (first_i32(stop_word) != 0) break;
     }
 
     tm.sync();

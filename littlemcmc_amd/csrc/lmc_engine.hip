@@ -860,8 +860,14 @@ int lmc_engine_request_stop(lmc_engine* e, int32_t stop) {
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     static const int kOne = 1, kZero = 0;
     if (stop) {   // overtakes the kernels in flight: its own stream, not ordered after anything
+        // A stream memory operation (executed by the command processor: needs no compute unit and no DMA engine). With
+        // every wave slot held by sampling kernels it lands in ~0.1 s; hipMemcpyAsync / hipMemsetAsync (a blit kernel that
+        // has to win a wave slot) took 2-30 s in the same situation (tools/ubench/stop_probe.hip).
         if (!e->ctl_stream) HIP_TRY(e, hipStreamCreateWithFlags(&e->ctl_stream, hipStreamNonBlocking));
-        HIP_TRY(e, hipMemcpyAsync(e->stop_flag, &kOne, sizeof(int), hipMemcpyHostToDevice, e->ctl_stream));
+        if (hipStreamWriteValue32(e->ctl_stream, e->stop_flag, 1u, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(e, hipMemcpyAsync(e->stop_flag, &kOne, sizeof(int), hipMemcpyHostToDevice, e->ctl_stream));
+        }
         HIP_TRY(e, hipStreamSynchronize(e->ctl_stream));
     } else {      // cleared in order: after everything that was launched under the request has drained
         if (e->ctl_stream) HIP_TRY(e, hipStreamSynchronize(e->ctl_stream));

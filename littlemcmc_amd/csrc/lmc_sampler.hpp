@@ -1072,19 +1072,23 @@ constexpr int lds_tail_doubles(int w) {
 
 // ---- pieces of the iteration body shared by the diagonal and the dense-mass kernels ---------------------------
 // lmc_engine_request_stop(): the host's Ctrl-C (sampling.py:324-328, :470-471 in the reference: keep what has been drawn).
-// One uncached dword per iteration; a team agrees on ONE value (wave 0's) so that no wave leaves a barrier behind.
+// One uncached dword per iteration, REQUESTED when the iteration starts and LOOKED AT when it ends (its latency hides
+// behind the whole iteration; looked at where it is requested it cost a full memory round trip per iteration). A team
+// agrees on ONE value (thread 0's) so that no wave leaves a barrier behind.
+__device__ __forceinline__ int stop_request_load(const ChainArrays& A) {
+    return __hip_atomic_load(A.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 template <class TeamT>
-__device__ __forceinline__ bool stop_requested(const ChainArrays& A, TeamT& tm, double* bcast) {
+__device__ __forceinline__ bool stop_requested(TeamT& tm, int loaded, double* bcast) {
     if constexpr (TeamT::kWaves == 1) {
-        return first_i32(__hip_atomic_load(A.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0;
+        return first_i32(loaded) != 0;
     } else {
         tm.sync();
-        if (tm.tid() == 0) bcast[3] = static_cast<double>(__hip_atomic_load(A.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (tm.tid() == 0) bcast[3] = static_cast<double>(loaded);
         tm.sync();
         return first_f64(bcast[3]) != 0.0;
     }
 }
-
 struct DualAverage {   // step_sizes.py:49-99, wave-uniform
     double log_step, log_bar, hbar, mu;
     int count;
@@ -1314,7 +1318,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         const long long git = P.iter_begin + it;
         const bool tune = git < P.n_tune;
         LMC_PHASE(5)
-        if (stop_requested(A, tm, rng_bcast)) break;
+        const int stop_word = stop_request_load(A);
 
         // ---- momentum draw (quadpotential.py:221-224 / :374-376)
         team_normals(tm, rng, d, lds, lds + dpad, rng_bcast);   // level-0 LDS region (2*dpad doubles) = normals + staging
@@ -1385,6 +1389,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
 
         if (A.mom_mean != nullptr && !tune) moments_update<NS>(A, tm, c, row, q);
         write_outputs<NS>(A, c, tid, git, q, out, da.step_now, da.step_bar_now, tune);
+        if (stop_requested(tm, stop_word, rng_bcast)) break;
     }
 
     // ---- store persistent chain state
