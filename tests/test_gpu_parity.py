@@ -80,7 +80,8 @@ def test_transitions_golden(golden_dir):
         finally:
             eng.close()
     print("transitions golden: %d of %d transitions verified bit-exactly" % (verified, total))
-    assert verified >= 0.9 * total, "only %d of %d golden transitions verified bit-exactly" % (verified, total)
+    # measured on MI355X (round 3): 1950 of 1950; the slack is for a host BLAS whose float32 dot rounds differently
+    assert verified >= total - 20, "only %d of %d golden transitions verified bit-exactly" % (verified, total)
 
 
 E2E = ["e2e_hmc_c1", "e2e_nuts_std64", "e2e_nuts_std128", "e2e_nuts_ar1_16", "e2e_nuts_funnel8",
@@ -124,8 +125,11 @@ def test_e2e_golden_through_sample_api(golden_dir, name):
     # the oracle's own state): require a solid prefix. Deep trees at d = 128 amplify the float32 start-energy
     # rounding faster (60+ leapfrogs per iteration feeding dual averaging), so their prefix is shorter.
     print("%s: %d of %d iterations verified as one chain" % (name, verified, chains * (tune + draws)))
-    need = 10 if name == "e2e_nuts_ar1_128" else 15
-    assert verified >= chains * min(need, tune + draws), "%s: only %d iterations verified" % (name, verified)
+    # Floors = what this build measures on MI355X (round 3: 1637, 71, 39, 149, 159, 105, 400, 32 iterations summed over the
+    # captured chains) minus ~20 % for hosts whose float32 BLAS dot rounds differently from the capture host's.
+    floors = {"e2e_hmc_c1": 1300, "e2e_nuts_std64": 56, "e2e_nuts_std128": 30, "e2e_nuts_ar1_16": 120,
+              "e2e_nuts_funnel8": 125, "e2e_nuts_diag50": 84, "e2e_nuts_normal1d": 400, "e2e_nuts_ar1_128": 25}
+    assert verified >= min(floors[name], chains * (tune + draws)), "%s: only %d iterations verified" % (name, verified)
 
 
 @pytest.mark.parametrize("name", E2E)
@@ -166,7 +170,8 @@ def test_every_iteration_of_the_golden_runs(golden_dir, name):
             np.testing.assert_array_equal(np.array([o["stats"]["diverging"] for o in outs]),
                                           g["stat_diverging"][c, :, 0])
     print("%s: replay checked %d of %d iterations, %d fragile" % (name, total_checked, chains * (tune + draws), total_fragile))
-    assert total_checked >= 0.99 * (chains * (tune + draws)), (total_checked, total_fragile)
+    # measured on MI355X (round 3): every iteration of every golden checked, none fragile
+    assert total_checked >= chains * (tune + draws) - 2, (total_checked, total_fragile)
 
 
 @pytest.mark.parametrize("family,d,kw", [("ar1", 200, {}), ("ar1", 300, {}), ("funnel", 600, {"max_treedepth": 9}),

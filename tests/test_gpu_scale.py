@@ -100,6 +100,8 @@ def test_sub_block_streams_do_not_change_a_bit(monkeypatch):
 
     a, b = job(None), job(1)
     for x, y in zip(a, b):
+        if x.ndim == 2 and x.shape[1] == _abi.NUM_COUNTERS:     # the residency clock (CT_WAVE_TICKS) is a timing, not a result
+            x, y = x[:, :_abi.CT_WAVE_TICKS], y[:, :_abi.CT_WAVE_TICKS]
         np.testing.assert_array_equal(x, y)
     np.testing.assert_array_equal(a[4], a[0][:, 20:30])
 
