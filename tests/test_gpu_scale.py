@@ -374,7 +374,7 @@ def test_c3_full_size_65536_chains_dim128_ar1(golden_dir):
         fstats = {k: v[:, :, None] for k, v in step._stats_from_engine(eng, 0, n_it).items()}
         done = assert_selected_chains_match_oracle("ar1", d, seeds, start, sel, n_it, first, fstats, label="C3")
         print("C3 full size: oracle-identical iterations of chains %s: %s" % (sel, done))
-        assert min(done) >= 8 and sum(done) >= n_it * len(sel) - 8, done     # deep trees at d = 128: see test_e2e_golden...
+        assert min(done) >= 11 and sum(done) >= n_it * len(sel) - 2, done    # measured (round 3): 12 of 12 for all six chains
         del first
         mean, m2, n = eng.moments()
         assert (np.asarray(n) == draws).all()
