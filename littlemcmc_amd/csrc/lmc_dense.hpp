@@ -39,12 +39,23 @@ template <int N, class P> __device__ __forceinline__ auto pack_get(const P& p, i
 // while a launch runs; FullAdapt refreshes it between launches): that share of every sweep costs no HBM / L2
 // traffic, and the loads of the remaining rows are already in flight while the cached rows are consumed. Each
 // lane copies and later reads only its own columns, so the copy needs no barrier.
+// A matrix shared by all chains, met by eight chains at a time (run_dense_coop_kernel below): the whole transposed
+// matrix sits in the workgroup's LDS, the chains' operand vectors and the products travel through two LDS panels.
+struct DenseCoop {
+    __attribute__((address_space(3))) const float* ct;    // [k_rows][ct_stride] transposed matrix, float32 (row k over i)
+    lds_double* x;                                        // [16][xs]: column 2w = first operand of wave w's chain, 2w+1 = second
+    lds_double* dout;                                     // [16][xs]: the products, same columns
+    __attribute__((address_space(3))) int* n_active;      // chains of this workgroup still sampling
+    int ct_stride, xs, k_rows, dpad, wave, n_waves;
+};
+
 template <class MatT>
 struct DenseMat {
     const MatT* glb;                                            // [sweep_rows(d)][dpad]
     __attribute__((address_space(3))) const MatT* cache;        // [cache_rows][dpad] in LDS
     int cache_rows;                                             // multiple of kSweepBatch, <= sweep_rows(d) - 2 * kSweepBatch or == sweep_rows(d)
     int d, dpad;
+    const DenseCoop* coop;                                      // != nullptr only in the coop kernel (LMC_DENSE_COOP builds)
 };
 
 // ---- one sweep over the transposed matrix: acc[v][s] = sum_j M[j][lane*NS+s] * x[j][v] --------------------------
@@ -111,10 +122,63 @@ __device__ __forceinline__ void stage2(lds_double* x, const double (&a)[NS], con
     wave_sync();
 }
 
+#ifdef LMC_DENSE_COOP
+// C [p g] for the EIGHT chains of a workgroup at once, on the matrix cores (quadpotential.py:446-464 for every chain of
+// the group). Every chain needs exactly one such product per leapfrog (and one for its start state) wherever it is in its
+// tree, so the chains' wavefronts meet here: each drops its two vectors into columns of the operand panel, one barrier,
+// wave w forms rows [16 t, 16 t + 16) (t = w, w + 8, ...) of  C (dpad x k_rows) x X (k_rows x 16)  with
+// v_mfma_f64_16x16x4_f64 -- the float32 entries promoted on the way in, float64 accumulation, as numpy's dgemv on the
+// promoted matrix -- writes them to the product panel, one more barrier, each wave picks its two columns up.
+// Operand / result layout of the instruction (guides/cdna_hip_programming.md): A[i][k] on lane i + 16 k, B[k][j] on lane
+// j + 16 k, D[row = (lane >> 4) + 4 r][col = lane & 15] in result register r. Row stride of the matrix dpad + 16 floats and
+// column stride of the panels dpad + 2 doubles keep the four k-groups of a wave on different LDS banks.
+// Returns the number of chains of the workgroup still sampling (read between the two barriers: the same in every wave).
+template <int NS>
+__device__ __forceinline__ int coop_product(const DenseCoop& cc, const double (&p)[NS], const double (&g)[NS],
+                                            double (&v)[NS], double (&w)[NS]) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int lane = lane_id();
+    lds_double* xp = cc.x + (2 * cc.wave) * cc.xs + lane * NS;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { xp[s] = p[s]; xp[cc.xs + s] = g[s]; }
+    __syncthreads();
+    const int active = first_i32(*cc.n_active);
+    const int kk = lane >> 4, jj = lane & 15;
+    for (int t = cc.wave; t < cc.dpad / 16; t += cc.n_waves) {
+        v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};   // two accumulators: back-to-back issues do not wait on each other
+        __attribute__((address_space(3))) const float* a = cc.ct + kk * cc.ct_stride + 16 * t + jj;
+        const lds_double* b = cc.x + jj * cc.xs + kk;
+        const int nkb = cc.k_rows / 4;   // a multiple of 4: k_rows is a multiple of 16
+        for (int kb = 0; kb < nkb; kb += 4) {   // the four tiles' operands are requested before the first product is issued
+            float af[4];
+            double bf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { af[u] = a[(4 * (kb + u)) * cc.ct_stride]; bf[u] = b[4 * (kb + u)]; }
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(static_cast<double>(af[0]), bf[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(static_cast<double>(af[1]), bf[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(static_cast<double>(af[2]), bf[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(static_cast<double>(af[3]), bf[3], acc1, 0, 0, 0);
+        }
+        lds_double* o = cc.dout + jj * cc.xs + 16 * t + kk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[4 * r] = acc0[r] + acc1[r];
+    }
+    __syncthreads();
+    const lds_double* dp = cc.dout + (2 * cc.wave) * cc.xs + lane * NS;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { v[s] = dp[s]; w[s] = dp[cc.xs + s]; }
+    return active;
+}
+#endif
+
 // v = C p and w = C g in one sweep
 template <int NS, class MatT>
 __device__ __forceinline__ void velocity2(const DenseMat<MatT>& mm, lds_double* xop, const double (&p)[NS],
                                           const double (&g)[NS], double (&v)[NS], double (&w)[NS]) {
+#ifdef LMC_DENSE_COOP
+    coop_product<NS>(*mm.coop, p, g, v, w);
+    return;
+#endif
     stage2<NS>(xop, p, g);
     double acc[2][NS];
     dense_sweep<NS, 2, MatT>(mm, xop, acc);
@@ -185,6 +249,35 @@ __device__ inline void dense_momentum_inv(const double* __restrict__ LT, int d, 
     DenseMat<double> mm{LT, nullptr, 0, d, dpad};
     dense_sweep<NS, 1, double>(mm, z, acc);
     vcopy(p0, acc[0]);
+}
+
+// quadpotential.py:450-453 once more, for the kernel in which eight chains meet at every product (run_dense_coop_kernel):
+// there the column sweep above -- 128 steps, each waiting for the one before (a division, two cross-lane reads) -- would
+// hold seven other chains at the barrier for ~20 k cycles per iteration. With L^-1 formed once on the host in extended
+// precision,  solve_triangular(chol.T, z) = L^-T z = sum_k z_k (row k of L^-1)  is a sweep of independent multiply-adds
+// like every other matrix product here. z is the float32 cast of the normals and the result is rounded to float32, as the
+// reference's (float32 BLAS strsv); the value is the correctly rounded solution instead of strsv's, i.e. it differs from
+// the reference by strsv's own float32 rounding error -- the size of difference the dense parity tests already allow for
+// the float32-born momentum (tests/test_gpu_dense.py).
+template <int NS>
+__device__ inline void dense_momentum_solved(const double* __restrict__ Linv, int d, int dpad, lds_double* z, double (&p0)[NS]) {
+    const int lane = lane_id();
+    double zf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = lane * NS + s;
+        zf[s] = (e < d) ? static_cast<double>(static_cast<float>(z[e])) : 0.0;
+    }
+    wave_sync();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) z[lane * NS + s] = zf[s];      // (also zero beyond d: the sweep runs over sweep_rows(d) rows)
+    for (int e = 64 * NS + lane; e < sweep_rows(d); e += 64) z[e] = 0.0;
+    wave_sync();
+    double acc[1][NS];
+    DenseMat<double> mm{Linv, nullptr, 0, d, dpad, nullptr};
+    dense_sweep<NS, 1, double>(mm, z, acc);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) p0[s] = static_cast<double>(static_cast<float>(acc[0][s]));
 }
 
 // ---- start state (integration.py:52-66) -----------------------------------------------------------------------
@@ -468,27 +561,19 @@ __device__ inline void dense_hmc_transition(Team<1>& tm, const Target& tgt, cons
 // LDS: [0, 2*dpad) doubles = sweep operands / normal(size=d) + its staging / float32 sdot staging; then the chain's
 // MT19937 state for the duration of the launch.
 
+// All iterations of one chain (one wavefront): the body of the dense-mass kernels. `lds` = this wavefront's private LDS
+// (sweep operands / normals + staging, then the MT19937 state); the tree's leading slots in LDS start at `slot_base`.
 template <int NS, class MatT, template <int> class TargetT>
-__global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel(ChainArrays A, DenseArrays D, SamplerParams P, const double* tparams) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int c = blockIdx.x + P.chain_begin;   // the engine launches its chains as sub-blocks (lmc_engine_run)
+__device__ __forceinline__ void dense_run_chain(const ChainArrays& A, const DenseArrays& D, const SamplerParams& P,
+                                                const double* tparams, int c, double* lds, const DenseMat<MatT>& mm,
+                                                lds_double* slot_base, int n_lds_slots) {
     const int d = A.d, dpad = A.dpad;
     const long long row = static_cast<long long>(c) * dpad;
     Team<1> tm{nullptr, 0};
     const int tid = tm.tid();
-    if (A.status[c] & kStatusBadInitialEnergy) return;
-
     TargetT<NS> tgt;
     tgt.init(tm, tparams, d);
-    const MatT* M = static_cast<const MatT*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
     lds_double* xop = (lds_double*)lds;
-    MatT* mcache = reinterpret_cast<MatT*>(lds + dense_lds_doubles(dpad));
-    for (int j = 0; j < D.cache_rows; ++j) {   // every lane copies (and later reads) its own columns only
-#pragma unroll
-        for (int s = 0; s < NS; ++s) mcache[j * dpad + tid * NS + s] = M[static_cast<long long>(j) * dpad + tid * NS + s];
-    }
-    DenseMat<MatT> mm{M, (__attribute__((address_space(3))) const MatT*)mcache, D.cache_rows, d, dpad};
-
     double q[NS];
     vload<NS>(A.q + row, q);
     RngState rng;
@@ -507,8 +592,8 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel
     int status = 0;
     DenseScratch scr;
     scr.base = (glb_double*)(A.scratch + static_cast<long long>(c) * A.scratch_stride);
-    scr.lbase = (lds_double*)(lds + dense_lds_doubles(dpad)) + (static_cast<long long>(D.cache_rows) * dpad * sizeof(MatT)) / 8;
-    scr.nlds = D.lds_slots;
+    scr.lbase = slot_base;
+    scr.nlds = n_lds_slots;
     scr.dpad = dpad;
     const bool momentum_f32 = P.momentum_f32 != 0;
 
@@ -522,6 +607,10 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel
         double p0[NS];
         if (D.kind == kDenseFullInv)
             dense_momentum_inv<NS>(static_cast<const double*>(D.fac), d, dpad, xop, p0);
+#ifdef LMC_DENSE_COOP
+        else if (D.fac_inv != nullptr)   // the meeting point must not wait for a 128-step dependent chain: see dense_momentum_solved
+            dense_momentum_solved<NS>(D.fac_inv, d, dpad, xop, p0);
+#endif
         else
             dense_momentum_full<NS>(static_cast<const float*>(D.fac) + static_cast<long long>(c) * D.fac_stride, d, dpad, xop, p0);
 
@@ -576,6 +665,80 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel
         A.counters[c * kNumCounters + kCtLeapfrogs] += ct_leap;
     }
 }
+
+template <int NS, class MatT, template <int> class TargetT>
+__global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel(ChainArrays A, DenseArrays D, SamplerParams P, const double* tparams) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int c = blockIdx.x + P.chain_begin;   // the engine launches its chains as sub-blocks (lmc_engine_run)
+    const int dpad = A.dpad;
+    const int tid = LMC_CHAIN_THREAD;
+    if (A.status[c] & kStatusBadInitialEnergy) return;
+    const MatT* M = static_cast<const MatT*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
+    MatT* mcache = reinterpret_cast<MatT*>(lds + dense_lds_doubles(dpad));
+    for (int j = 0; j < D.cache_rows; ++j) {   // every lane copies (and later reads) its own columns only
+#pragma unroll
+        for (int s = 0; s < NS; ++s) mcache[j * dpad + tid * NS + s] = M[static_cast<long long>(j) * dpad + tid * NS + s];
+    }
+    DenseMat<MatT> mm{M, (__attribute__((address_space(3))) const MatT*)mcache, D.cache_rows, A.d, dpad, nullptr};
+    lds_double* slots = (lds_double*)(lds + dense_lds_doubles(dpad)) + (static_cast<long long>(D.cache_rows) * dpad * sizeof(MatT)) / 8;
+    dense_run_chain<NS, MatT, TargetT>(A, D, P, tparams, c, lds, mm, slots, D.lds_slots);
+}
+
+#ifdef LMC_DENSE_COOP
+// ---- a matrix shared by all chains (QuadPotentialFull): eight chains per workgroup, one MFMA product per leapfrog ----
+// LDS of the workgroup: the transposed float32 matrix [k_rows][dpad + 16], the operand and product panels
+// [16][dpad + 2] doubles each, the count of chains still sampling, then eight private regions of dense_lds_doubles(dpad)
+// doubles. The chains run their own control flow (ragged trees) and only meet in coop_product(); a chain that is done
+// keeps answering the barriers with zero operands until the whole group is done.
+constexpr int kCoopWaves = 8;
+__host__ __device__ constexpr int coop_ct_stride(int dpad) { return dpad + 16; }
+__host__ __device__ constexpr int coop_xs(int dpad) { return dpad + 2; }
+__host__ __device__ constexpr int coop_lds_bytes(int d, int dpad) {
+    return sweep_rows(d) * coop_ct_stride(dpad) * 4 + 2 * 16 * coop_xs(dpad) * 8 + 16 + kCoopWaves * dense_lds_doubles(dpad) * 8;
+}
+template <int NS, template <int> class TargetT>
+__global__ __launch_bounds__(64 * kCoopWaves, 2) void run_dense_coop_kernel(ChainArrays A, DenseArrays D, SamplerParams P,
+                                                                             const double* tparams, int n_chains) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int d = A.d, dpad = A.dpad;
+    const int wave = first_i32(static_cast<int>(threadIdx.x) >> 6);
+    const int k_rows = sweep_rows(d), cts = coop_ct_stride(dpad), xs = coop_xs(dpad);
+    float* ct = reinterpret_cast<float*>(lds);
+    double* x = lds + (k_rows * cts * 4) / 8;
+    double* dout = x + 16 * xs;
+    int* n_active = reinterpret_cast<int*>(dout + 16 * xs);
+    double* priv = dout + 16 * xs + 2 + wave * dense_lds_doubles(dpad);
+    // the matrix: all 512 threads, rows of the stored transposed matrix are contiguous (coalesced)
+    const float* M = static_cast<const float*>(D.covT);
+    for (int idx = threadIdx.x; idx < k_rows * dpad; idx += 64 * kCoopWaves) {
+        const int k = idx / dpad, i = idx - k * dpad;
+        ct[k * cts + i] = M[idx];
+    }
+    for (int idx = threadIdx.x; idx < 2 * 16 * xs; idx += 64 * kCoopWaves) x[idx] = 0.0;   // both panels
+    const int c = P.chain_begin + static_cast<int>(blockIdx.x) * kCoopWaves + wave;
+    const bool mine = (blockIdx.x * kCoopWaves + wave < n_chains) && !(A.status[c < A.chains ? c : 0] & kStatusBadInitialEnergy);
+    if (threadIdx.x == 0) *n_active = 0;
+    __syncthreads();
+    if (mine && lane_id() == 0) atomicAdd(n_active, 1);
+    __syncthreads();
+    DenseCoop cc;
+    cc.ct = (__attribute__((address_space(3))) const float*)ct;
+    cc.x = (lds_double*)x;
+    cc.dout = (lds_double*)dout;
+    cc.n_active = (__attribute__((address_space(3))) int*)n_active;
+    cc.ct_stride = cts; cc.xs = xs; cc.k_rows = k_rows; cc.dpad = dpad; cc.wave = wave; cc.n_waves = kCoopWaves;
+    if (mine) {
+        DenseMat<float> mm{M, nullptr, 0, d, dpad, &cc};
+        dense_run_chain<NS, float, TargetT>(A, D, P, tparams, c, priv, mm, nullptr, 0);
+        if (lane_id() == 0) atomicSub(n_active, 1);
+    }
+    // drain: answer the group's barriers until every chain is done
+    double z[NS], v[NS], w[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) z[s] = 0.0;
+    while (coop_product<NS>(cc, z, z, v, w) > 0) {}
+}
+#endif
 
 // ---- unit kernels (test entries behind lmc_engine_trajectory / lmc_engine_draw_momentum) -----------------------
 template <int NS, class MatT, template <int> class TargetT>
@@ -847,7 +1010,7 @@ __global__ __launch_bounds__(T * T) void dense_adapt_kernel(ChainArrays A, Dense
 
 // QuadPotentialFullAdapt.__init__ for every chain (quadpotential.py:474-519): replicate the initial covariance,
 // its factor and the foreground estimator (mean, raw = weight * cov, n = weight); empty background.
-__global__ __launch_bounds__(256) void dense_reset_kernel(ChainArrays A, DenseArrays D, const float* cov1T,
+static __global__ __launch_bounds__(256) void dense_reset_kernel(ChainArrays A, DenseArrays D, const float* cov1T,
                                                           const float* fac1, const double* raw1T, const double* mean1,
                                                           double weight, int window, int d8) {
     const int c = blockIdx.x;

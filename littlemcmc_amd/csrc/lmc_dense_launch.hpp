@@ -12,6 +12,11 @@ constexpr int kDenseUnsupported = -1;
 // run / adapt: chains [P.chain_begin, P.chain_begin + n_chains) resp. [chain_begin, chain_begin + n_chains); n_chains <= 0 = all
 int dense_launch_run(int family, int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
                      const SamplerParams& P, const double* tparams, int n_chains = 0);
+// QuadPotentialFull with a matrix shared by all chains, dim <= 128: eight chains per workgroup, the per-leapfrog product on
+// the matrix cores (lmc_dense_coop.hip). dense_coop_supported() says whether that kernel exists for the shape.
+int dense_coop_supported(int family, int ns, int d, int dpad);
+int dense_launch_run_coop(int family, int ns, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
+                          const SamplerParams& P, const double* tparams, int n_chains = 0);
 int dense_launch_trajectory(int family, int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A,
                             const DenseArrays& D, const double* tparams, const double* q0, const double* p0,
                             int p0_is_f32, int sdot_mode, double eps, int n_fwd, int n_back, double* oq, double* op,

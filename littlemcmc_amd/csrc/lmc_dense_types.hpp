@@ -12,6 +12,9 @@ struct DenseArrays {
     void* covT;             // MatT [P][sweep_rows(d)][dpad]: transposed inverse mass matrix (P = chains for FullAdapt, else 1)
     void* fac;              // Full*: float Cholesky factor L of cov, row-major lower [P][d8][dpad] (rows >= d identity);
                             // FullInv: double LT[j][i] = L[i][j] of the mass matrix A = L L^T, [d][dpad]
+    const double* fac_inv;  // Full with a shared matrix only (else nullptr): L^-1 of the float32 factor, float64 [sweep_rows(d)][dpad],
+                            // formed once on the host in extended precision: solve_triangular(chol.T, z) = rows of L^-1 swept
+                            // with z (the coop kernel's momentum draw: no 128-step dependent chain at the meeting point)
     long long mat_stride;   // elements between two chains' matrices (0 = shared)
     long long fac_stride;
     int cache_rows;         // leading rows of covT every wave keeps in LDS during a launch (host-chosen, lmc_engine.hip)

@@ -384,6 +384,11 @@ static int dense_reset(lmc_engine* e) {   // FULL_ADAPT: constructor state for e
     return LMC_OK;
 }
 
+#ifdef LMC_USER_TARGET_HEADER
+static const bool kUserCompiledInDense = true;   // a private library around a user density: its dense kernels are the per-wave ones
+#else
+static const bool kUserCompiledInDense = false;
+#endif
 static int dense_run(lmc_engine* e, SamplerParams P) {
     P.momentum_f32 = e->cfg.potential != LMC_POT_FULL_INV;   // quadpotential.py:452 (float32) vs :413 (float64)
     P.adapt_mass = 0;
@@ -420,6 +425,9 @@ static int dense_run(lmc_engine* e, SamplerParams P) {
     // chain of launches of its own -- with FullAdapt two per tuning iteration -- and the tail of one is covered by the other
     const int n_sub = e->n_sub;
     HIP_TRY(e, order_sub_blocks_after_main(e));
+    bool coop = e->cfg.potential == LMC_POT_FULL && !kUserCompiledInDense &&
+                dense_coop_supported(e->cfg.target_family, e->ns, e->cfg.dim, e->dpad) != 0;
+    if (const char* env = std::getenv("LMC_DENSE_COOP")) coop = coop && std::atoi(env) != 0;
     const long long end = P.iter_begin + P.n_iters;
     if (n_sub > 1) e->sub_pending = true;
     long long it = P.iter_begin;
@@ -435,7 +443,11 @@ static int dense_run(lmc_engine* e, SamplerParams P) {
             Q.iter_begin = it;
             Q.n_iters = static_cast<int>(n);
             Q.chain_begin = static_cast<int>(lo);
-            int rc = dense_launch_run(e->cfg.target_family, e->ns, mat_f64, st, e->A, e->D, Q, e->tparams, static_cast<int>(hi - lo));
+            int rc;
+            if (coop)   // one matrix for all chains: eight chains per workgroup, the product on the matrix cores
+                rc = dense_launch_run_coop(e->cfg.target_family, e->ns, st, e->A, e->D, Q, e->tparams, static_cast<int>(hi - lo));
+            else
+                rc = dense_launch_run(e->cfg.target_family, e->ns, mat_f64, st, e->A, e->D, Q, e->tparams, static_cast<int>(hi - lo));
             if (rc != 0) return dense_fail(e, rc, "run");
             if (adapt) {
                 rc = dense_launch_adapt(st, e->A, e->D, e->dense_multiplier, e->dense_update_window, nullptr,
@@ -696,6 +708,11 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
             if ((rc = dev_alloc(e, &m, P * drows * dp)) != LMC_OK) return bail(rc);
             if ((rc = dev_alloc(e, &f, P * e->d8 * dp)) != LMC_OK) return bail(rc);
             D.covT = m; D.fac = f;
+            if (!per_chain) {
+                double* fi = nullptr;
+                if ((rc = dev_alloc(e, &fi, drows * dp)) != LMC_OK) return bail(rc);
+                D.fac_inv = fi;
+            }
         }
         if (per_chain) {
             if ((rc = dev_alloc(e, &D.rawT, 2 * C * d * dp)) != LMC_OK) return bail(rc);
@@ -1004,6 +1021,18 @@ int lmc_engine_set_dense_potential(lmc_engine* e, const double* matrix, const do
     if (e->cfg.potential == LMC_POT_FULL) {
         HIP_TRY(e, hipMemcpy(e->D.covT, covT.data(), covT.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(e, hipMemcpy(e->D.fac, fac.data(), fac.size() * sizeof(float), hipMemcpyHostToDevice));
+        // L^-1 of the float32 factor, extended precision, for the coop kernel's momentum draw (lmc_dense_types.hpp)
+        std::vector<long double> Li(dd, 0.0L);
+        for (int c = 0; c < d; ++c)
+            for (int i = c; i < d; ++i) {
+                long double acc = (i == c) ? 1.0L : 0.0L;
+                for (int k = c; k < i; ++k) acc -= static_cast<long double>(L[static_cast<size_t>(i) * d + k]) * Li[static_cast<size_t>(k) * d + c];
+                Li[static_cast<size_t>(i) * d + c] = acc / static_cast<long double>(L[static_cast<size_t>(i) * d + i]);
+            }
+        std::vector<double> finv(static_cast<size_t>(sweep_rows(d)) * dp, 0.0);
+        for (int k = 0; k < d; ++k)
+            for (int i = 0; i <= k; ++i) finv[static_cast<size_t>(k) * dp + i] = static_cast<double>(Li[static_cast<size_t>(k) * d + i]);
+        HIP_TRY(e, hipMemcpy(const_cast<double*>(e->D.fac_inv), finv.data(), finv.size() * sizeof(double), hipMemcpyHostToDevice));
         return LMC_OK;
     }
     if (adaptation_window < 1 || update_window < 1 || !(adaptation_window_multiplier > 0.0) || initial_weight < 0.0)

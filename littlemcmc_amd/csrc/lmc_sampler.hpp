@@ -104,16 +104,43 @@ struct SamplerParams {
     double jitter_lo, jitter_hi;
 };
 
+// ---- kernel arguments, re-read where they are used ---------------------------------------------------------------
+// ChainArrays + SamplerParams are ~100 SGPRs of loop-invariant values. Taken by value they are all loaded at kernel entry
+// and stay live across the tree build; the register allocator then parks them in lanes of VGPRs and every use outside the
+// tree costs a v_readlane -- a VALU issue slot (~1.8 of them, tools/ubench/valu_cost.hip): ~200 per iteration of the
+// sampling kernel, 12 % of a depth-3 iteration. The sampling kernel therefore reads them from the kernarg segment itself
+// (constant address space: s_load through the scalar cache, no VALU slot) through a pointer that is made opaque once per
+// REGION of the iteration body, so the loads are issued where the values are used -- adjacent fields in one
+// s_load_dwordx4/x8 -- and nothing but the two segment pointers lives across the transition.
+typedef const __attribute__((address_space(4))) ChainArrays KChainArrays;
+typedef const __attribute__((address_space(4))) SamplerParams KSamplerParams;
+struct KernArgs {   // run_kernel(ChainArrays, SamplerParams, const double*): the by-value structs as they lie in the kernarg segment
+    KChainArrays* a;
+    KSamplerParams* p;
+    __device__ __forceinline__ static KernArgs get() {
+        typedef const __attribute__((address_space(4))) char kchar;
+        static_assert(alignof(ChainArrays) == 8 && alignof(SamplerParams) == 8 && sizeof(ChainArrays) % 8 == 0, "kernarg layout");
+        kchar* base = (kchar*)__builtin_amdgcn_kernarg_segment_ptr();
+        KernArgs k;
+        k.a = (KChainArrays*)base;
+        k.p = (KSamplerParams*)(base + sizeof(ChainArrays));
+        return k;
+    }
+    // a fresh opaque copy of the pointer: loads through the returned reference are issued after this point
+    __device__ __forceinline__ KChainArrays& A() const { KChainArrays* q = a; asm volatile("" : "+s"(q)); return *q; }
+    __device__ __forceinline__ KSamplerParams& P() const { KSamplerParams* q = p; asm volatile("" : "+s"(q)); return *q; }
+};
+
 // ---- vector <-> memory (blocked layout, 8*NS contiguous bytes per thread of the team) -----------------
 template <int NS>
 __device__ __forceinline__ void vload(const double* base, double (&x)[NS]) {
-    const double* p = base + static_cast<int>(threadIdx.x) * NS;
+    const double* p = base + LMC_CHAIN_THREAD * NS;
 #pragma unroll
     for (int s = 0; s < NS; ++s) x[s] = p[s];
 }
 template <int NS>
 __device__ __forceinline__ void vstore(double* base, const double (&x)[NS]) {
-    double* p = base + static_cast<int>(threadIdx.x) * NS;
+    double* p = base + LMC_CHAIN_THREAD * NS;
 #pragma unroll
     for (int s = 0; s < NS; ++s) p[s] = x[s];
 }
@@ -273,8 +300,8 @@ __device__ inline double team_uniform(TeamT& tm, RngState& r, UniformWindow& w) 
 // step_rand (base_hmc.py:46,123,154-155) for  lambda s: s * np.random.uniform(lo, hi): ONE double of the chain's own
 // stream, drawn where the reference calls it -- after the momentum draw and the start state, before the trajectory
 // (np.random.uniform(lo, hi) = lo + (hi - lo) * random_sample())
-template <class TeamT>
-__device__ __forceinline__ double jitter_step_size(TeamT& tm, RngState& rng, const SamplerParams& P, double step_size) {
+template <class TeamT, class PT>
+__device__ __forceinline__ double jitter_step_size(TeamT& tm, RngState& rng, const PT& P, double step_size) {
     if (!P.step_jitter) return step_size;
     UniformWindow jw;
     window_reset(jw);
@@ -349,13 +376,13 @@ typedef __attribute__((address_space(3))) double lds_double;
 typedef __attribute__((address_space(1))) double glb_double;
 template <int NS, class PTR>
 __device__ __forceinline__ void vload_as(PTR base, double (&x)[NS]) {
-    PTR p = base + static_cast<int>(threadIdx.x) * NS;
+    PTR p = base + LMC_CHAIN_THREAD * NS;
 #pragma unroll
     for (int s = 0; s < NS; ++s) x[s] = p[s];
 }
 template <int NS, class PTR>
 __device__ __forceinline__ void vstore_as(PTR base, const double (&x)[NS]) {
-    PTR p = base + static_cast<int>(threadIdx.x) * NS;
+    PTR p = base + LMC_CHAIN_THREAD * NS;
 #pragma unroll
     for (int s = 0; s < NS; ++s) p[s] = x[s];
 }
@@ -1075,7 +1102,8 @@ constexpr int lds_tail_doubles(int w) {
 // One uncached dword per iteration, REQUESTED when the iteration starts and LOOKED AT when it ends (its latency hides
 // behind the whole iteration; looked at where it is requested it cost a full memory round trip per iteration). A team
 // agrees on ONE value (thread 0's) so that no wave leaves a barrier behind.
-__device__ __forceinline__ int stop_request_load(const ChainArrays& A) {
+template <class CA>
+__device__ __forceinline__ int stop_request_load(const CA& A) {
     return __hip_atomic_load(A.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 template <class TeamT>
@@ -1094,7 +1122,8 @@ struct DualAverage {   // step_sizes.py:49-99, wave-uniform
     int count;
     double step_now, step_bar_now;   // exp(log_step), exp(log_bar)
 };
-__device__ __forceinline__ void dual_average_load(const ChainArrays& A, int c, DualAverage& da) {
+template <class CA>
+__device__ __forceinline__ void dual_average_load(const CA& A, int c, DualAverage& da) {
     da.log_step = first_f64(A.da[c * 4 + 0]);
     da.log_bar = first_f64(A.da[c * 4 + 1]);
     da.hbar = first_f64(A.da[c * 4 + 2]);
@@ -1103,7 +1132,8 @@ __device__ __forceinline__ void dual_average_load(const ChainArrays& A, int c, D
     da.step_now = exp_uniform(da.log_step);
     da.step_bar_now = exp_uniform(da.log_bar);
 }
-__device__ __forceinline__ void dual_average_update(const ChainArrays& A, const SamplerParams& P, double accept, DualAverage& da) {
+template <class CA, class PT>
+__device__ __forceinline__ void dual_average_update(const CA& A, const PT& P, double accept, DualAverage& da) {
     const double w = 1.0 / (static_cast<double>(da.count) + P.t0);
     da.hbar = first_f64((1.0 - w) * da.hbar + w * (P.target_accept - accept));
     // sqrt(count) and count ** -k come from host-built tables (glibc sqrt/pow: the very values the
@@ -1124,8 +1154,8 @@ __device__ __forceinline__ void dual_average_update(const ChainArrays& A, const 
 }
 
 // running per-chain moments of the post-warm-up draws (optional): enough for R-hat without a trace
-template <int NS, class TeamT>
-__device__ __forceinline__ void moments_update(const ChainArrays& A, TeamT& tm, int c, long long row, const double (&q)[NS]) {
+template <int NS, class TeamT, class CA>
+__device__ __forceinline__ void moments_update(const CA& A, TeamT& tm, int c, long long row, const double (&q)[NS]) {
     const int n_new = first_i32(A.mom_n[c]) + 1;
     const double inv_n = 1.0 / static_cast<double>(n_new);
     double mm[NS], m2[NS];
@@ -1142,8 +1172,8 @@ __device__ __forceinline__ void moments_update(const ChainArrays& A, TeamT& tm, 
 }
 
 // draw row + per-draw statistics of iteration `git`
-template <int NS>
-__device__ __forceinline__ void write_outputs(const ChainArrays& A, int c, int tid, long long git, const double (&q)[NS],
+template <int NS, class CA>
+__device__ __forceinline__ void write_outputs(const CA& A, int c, int tid, long long git, const double (&q)[NS],
                                               const TransitionOut& out, double step_now, double step_bar_now, bool tune) {
     const int d = A.d;
     const long long orow = static_cast<long long>(c) * A.cap + git;
@@ -1177,15 +1207,15 @@ __device__ __forceinline__ void write_outputs(const ChainArrays& A, int c, int t
 struct MassScalars { double wsum_f, wsum_b; int wsel, n_samples, window; };
 // The four estimator rows of a chain (foreground / background mean and raw variance): all requested before any is used,
 // one HBM round trip per update instead of two.
-template <int NS>
-__device__ __forceinline__ void diag_mass_prefetch(const ChainArrays& A, long long row, const MassScalars& ms,
+template <int NS, class CA>
+__device__ __forceinline__ void diag_mass_prefetch(const CA& A, long long row, const MassScalars& ms,
                                                    double (&m)[NS], double (&r)[NS], double (&mb)[NS], double (&rb)[NS]) {
     const long long plane = static_cast<long long>(A.chains) * A.dpad;
     vload<NS>(A.wmean + ms.wsel * plane + row, m); vload<NS>(A.wraw + ms.wsel * plane + row, r);
     vload<NS>(A.wmean + (1 - ms.wsel) * plane + row, mb); vload<NS>(A.wraw + (1 - ms.wsel) * plane + row, rb);
 }
-template <int NS>
-__device__ __forceinline__ void diag_mass_update(const ChainArrays& A, const SamplerParams& P, long long row, int tid,
+template <int NS, class CA, class PT>
+__device__ __forceinline__ void diag_mass_update(const CA& A, const PT& P, long long row, int tid,
                                                  const double (&q)[NS], float (&var)[NS], float (&inv_std)[NS],
                                                  double (&vard)[NS], MassScalars& ms,
                                                  double (&m)[NS], double (&r)[NS], double (&mb)[NS], double (&rb)[NS]) {
@@ -1237,19 +1267,24 @@ __device__ __forceinline__ void diag_mass_update(const ChainArrays& A, const Sam
 }
 
 template <int NS, int W, template <int> class TargetT>
-__global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(ChainArrays A, SamplerParams P, const double* tparams) {
+__global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(ChainArrays, SamplerParams, const double* tparams) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const long long t_resident = wall_clock64();   // constant-rate clock: the chain's residence time (kCtWaveTicks)
-    const int c = blockIdx.x + P.chain_begin;
-    const int d = A.d, dpad = A.dpad;
+    // the two argument structs are read from the kernarg segment region by region (KernArgs above), never held by value
+    const KernArgs ka = KernArgs::get();
+    KChainArrays& A0 = ka.A();
+    KSamplerParams& P0 = ka.P();
+    const int c = blockIdx.x + P0.chain_begin;
+    const int d = A0.d, dpad = A0.dpad;
     const long long row = static_cast<long long>(c) * dpad;
+    const int lds_doubles = P0.lds_doubles;
     Team<W> tm;
-    tm.xbuf = lds + P.lds_doubles + kLdsMtDoubles;
+    tm.xbuf = lds + lds_doubles + kLdsMtDoubles;
     tm.parity = 0;
     double* rng_bcast = tm.xbuf + 2 * W * kTeamSlots;
     const int tid = tm.tid();
 
-    if (A.status[c] & kStatusBadInitialEnergy) return;   // chain already aborted (ValueError on host)
+    if (A0.status[c] & kStatusBadInitialEnergy) return;   // chain already aborted (ValueError on host)
 
     TargetT<NS> tgt;
     tgt.init(tm, tparams, d);
@@ -1258,18 +1293,19 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     double q[NS];
     float var[NS], inv_std[NS];
     double vard[NS];   // the float32 mass promoted once (every use is a float64 product)
-    vload<NS>(A.q + row, q);
+    double* const qrow = A0.q + row;
+    vload<NS>(qrow, q);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        var[s] = A.var[row + tid * NS + s];
-        inv_std[s] = A.inv_std[row + tid * NS + s];
+        var[s] = A0.var[row + tid * NS + s];
+        inv_std[s] = A0.inv_std[row + tid * NS + s];
         vard[s] = static_cast<double>(var[s]);
     }
     // The MT19937 state lives in LDS for the whole launch (2.5 KB per wave, behind the subtree stack): the
     // momentum draw, the uniform window and the twist then cost LDS latency instead of HBM/L2 round trips.
     RngState rng;
-    uint32_t* mt_glb = A.mt + static_cast<long long>(c) * kMtN;
-    uint32_t* mt_lds = reinterpret_cast<uint32_t*>(lds + P.lds_doubles);
+    uint32_t* mt_glb = A0.mt + static_cast<long long>(c) * kMtN;
+    uint32_t* mt_lds = reinterpret_cast<uint32_t*>(lds + lds_doubles);
     constexpr bool kMtInLds = run_mt_in_lds(W);
     if constexpr (kMtInLds) {
         for (int i = tid; i < kMtN; i += 64 * W) mt_lds[i] = mt_glb[i];
@@ -1278,18 +1314,18 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     } else {
         rng.mt = mt_glb;   // used in place (L2): the LDS it would take holds subtree-stack data instead
     }
-    rng.pos = first_i32(A.rng_pos[c]);
-    rng.has_gauss = first_i32(A.rng_has_gauss[c]);
-    rng.gauss = first_f64(A.rng_gauss[c]);
+    rng.pos = first_i32(A0.rng_pos[c]);
+    rng.has_gauss = first_i32(A0.rng_has_gauss[c]);
+    rng.gauss = first_f64(A0.rng_gauss[c]);
     DualAverage da;
-    dual_average_load(A, c, da);
-    int iter_count = first_i32(A.iter_count[c]);
+    dual_average_load(A0, c, da);
+    int iter_count = first_i32(A0.iter_count[c]);
     MassScalars ms;
-    ms.n_samples = first_i32(A.n_samples[c]);
-    ms.wsel = first_i32(A.wsel[c]);
-    ms.wsum_f = first_f64(A.wsum[c * 2 + ms.wsel]);
-    ms.wsum_b = first_f64(A.wsum[c * 2 + (1 - ms.wsel)]);
-    ms.window = first_i32(A.awindow[c]);
+    ms.n_samples = first_i32(A0.n_samples[c]);
+    ms.wsel = first_i32(A0.wsel[c]);
+    ms.wsum_f = first_f64(A0.wsum[c * 2 + ms.wsel]);
+    ms.wsum_b = first_f64(A0.wsum[c * 2 + (1 - ms.wsel)]);
+    ms.window = first_i32(A0.awindow[c]);
     long long ct_maxdepth = 0, ct_divs = 0, ct_after = 0, ct_leap = 0;
     int status = 0;
 
@@ -1297,8 +1333,8 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     static_assert(NS <= 4, "sampling kernels hold at most four elements per lane");
     PairCtx cx;
     cx.lds = lds;
-    cx.glb = A.scratch + static_cast<long long>(c) * A.scratch_stride;
-    cx.nlds = P.nlds;
+    cx.glb = A0.scratch + static_cast<long long>(c) * A0.scratch_stride;
+    cx.nlds = P0.nlds;
     cx.wave = tm.wave();
     cx.wave_red = W > 1 ? cx.wave * PairLds<NS, W>::kRedWave : 0;
     cx.wave_scal = W > 1 ? cx.wave * kLevelScalDoubles : 0;
@@ -1314,11 +1350,15 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
 #else
 #define LMC_PHASE(i)
 #endif
-    for (int it = 0; it < P.n_iters; ++it) {
+    const int n_iters = P0.n_iters;
+    for (int it = 0; it < n_iters; ++it) {
+        // ---- region 1 of the arguments: iteration head (momentum draw, start state, step size, transition inputs)
+        KSamplerParams& P = ka.P();
         const long long git = P.iter_begin + it;
         const bool tune = git < P.n_tune;
+        const bool momentum_f32 = P.momentum_f32 != 0;
         LMC_PHASE(5)
-        const int stop_word = stop_request_load(A);
+        const int stop_word = stop_request_load(ka.A());
 
         // ---- momentum draw (quadpotential.py:221-224 / :374-376)
         team_normals(tm, rng, d, lds, lds + dpad, rng_bcast);   // level-0 LDS region (2*dpad doubles) = normals + staging
@@ -1327,8 +1367,8 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         for (int s = 0; s < NS; ++s) {
             const int e = tid * NS + s;
             const double z = (e < d) ? lds[e] : 0.0;
-            p0[s] = P.momentum_f32 ? static_cast<double>(inv_std[s] * static_cast<float>(z))
-                                   : z * static_cast<double>(inv_std[s]);
+            p0[s] = momentum_f32 ? static_cast<double>(inv_std[s] * static_cast<float>(z))
+                                 : z * static_cast<double>(inv_std[s]);
         }
         tm.sync();
         LMC_PHASE(0)
@@ -1337,7 +1377,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         double g0[NS];
         const double logp0 = first_f64(tgt.logp_grad(tm, q, g0));
         double e0;
-        if (P.momentum_f32) {   // float32 velocity, float32 kinetic energy (BLAS-order faithful)
+        if (momentum_f32) {   // float32 velocity, float32 kinetic energy (BLAS-order faithful)
             const float kin = start_kinetic_f32<NS>(tm, p0, var, d, P.sdot_mode, reinterpret_cast<float*>(lds), dpad);
             e0 = first_f64(static_cast<double>(kin) - logp0);
         } else {
@@ -1356,9 +1396,9 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         TransitionOut out;
         if (P.kind == 0) {
             const int md = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
-            nuts_transition2<NS>(tm, tgt, vard, rng, cx, A.q + row, q, p0, g0, e0, logp0, step_size, P.emax, md,
-                                 P.momentum_f32 != 0, out);
-            vload<NS>(A.q + row, q);   // the proposal was written to the chain's row of A.q
+            nuts_transition2<NS>(tm, tgt, vard, rng, cx, qrow, q, p0, g0, e0, logp0, step_size, P.emax, md,
+                                 momentum_f32, out);
+            vload<NS>(qrow, q);   // the proposal was written to the chain's row of A.q
             // (handing it over in registers when the last doubling accepted it measured -4 % on depth-3 trees)
             if (out.exhausted && !tune) ++ct_maxdepth;
         } else {
@@ -1368,17 +1408,20 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         ct_leap += out.n_leapfrog;
         LMC_PHASE(2)
 
+        // ---- region 2 of the arguments: everything after the transition
+        KChainArrays& A = ka.A();
+        KSamplerParams& P2 = ka.P();
         // ---- dual averaging (step_sizes.py:71-92)
-        if (adapt_step) dual_average_update(A, P, out.accept, da);
+        if (adapt_step) dual_average_update(A, P2, out.accept, da);
         LMC_PHASE(3)
 
         // ---- diagonal mass adaptation (quadpotential.py:231-245, :324-340). (Requesting the estimator rows before the
         // dual-averaging update, to take their HBM round trip off the critical path, measured -12 % at d = 128: sixteen
         // more live registers across the update spill other state.)
-        if (tune && P.adapt_mass) {
+        if (tune && P2.adapt_mass) {
             double wm[NS], wr[NS], wmb[NS], wrb[NS];
             diag_mass_prefetch<NS>(A, row, ms, wm, wr, wmb, wrb);
-            diag_mass_update<NS>(A, P, row, tid, q, var, inv_std, vard, ms, wm, wr, wmb, wrb);
+            diag_mass_update<NS>(A, P2, row, tid, q, var, inv_std, vard, ms, wm, wr, wmb, wrb);
         }
 
         LMC_PHASE(4)
@@ -1392,12 +1435,13 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         if (stop_requested(tm, stop_word, rng_bcast)) break;
     }
 
-    // ---- store persistent chain state
+    // ---- store persistent chain state (region 3 of the arguments)
+    KChainArrays& A = ka.A();
     tm.sync();
     if constexpr (kMtInLds) {
         for (int i = tid; i < kMtN; i += 64 * W) mt_glb[i] = mt_lds[i];
     }
-    vstore<NS>(A.q + row, q);
+    vstore<NS>(qrow, q);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         A.var[row + tid * NS + s] = var[s];

@@ -123,6 +123,12 @@ struct AR1Target {
 };
 
 // Neal's funnel: v = q_0, x = q_{1..d-1}
+// Everything that depends on v alone -- e^{-v}, -v^2/18, -v/9 -- is wave-uniform scalar work on the critical path of every
+// leapfrog (a chain in the funnel's neck builds 4095-leapfrog trees alone on its SIMD, where each dependent instruction
+// costs a full pipeline latency: DESIGN.md section 6, C5). It is therefore kept short: the exponential is the table-driven
+// uniform form (lmc_wave.hpp: ~15 VALU, < 1 ulp, instead of ~40 for the generic exp) and is issued BEFORE the reduction of
+// sum x^2 so that the two overlap; the divisions by the constants 18 and 9 are multiplications by their reciprocals
+// (~2 VALU instead of ~12 each; the result differs from numpy's quotient by at most one ulp, like the exponential's).
 template <int NS>
 struct FunnelTarget {
     static constexpr bool kLanePartial = false;
@@ -133,21 +139,23 @@ struct FunnelTarget {
     __device__ double logp_grad(Team& tm, const double (&q)[NS], double (&g)[NS]) const {
         const int t = tm.tid();
         const double v = tm.bcast0(q[0]);
+        const double ev = exp_uniform_fast(fmax(-v, -700.0));   // (q_0 beyond 700 has diverged long before)
         double part = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int e = t * NS + s;
             if (e > 0) part = __builtin_fma(q[s], q[s], part);
         }
-        const double ssum = tm.sum(part);
-        const double ev = exp(-v);
-        const double hes = 0.5 * ev * ssum;
         const double dm1 = static_cast<double>(d - 1);
-        const double logp = -(v * v) / 18.0 - 0.5 * dm1 * v - hes;
+        const double lin = -(v * v) * (1.0 / 18.0) - 0.5 * dm1 * v;      // the part of logp that needs no reduction
+        const double g0_lin = -v * (1.0 / 9.0) - 0.5 * dm1;
+        const double ssum = tm.sum(part);
+        const double hes = 0.5 * ev * ssum;
+        const double logp = lin - hes;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int e = t * NS + s;
-            g[s] = (e == 0) ? (-v / 9.0 - 0.5 * dm1 + hes) : ((e < d) ? -(ev * q[s]) : 0.0);
+            g[s] = (e == 0) ? (g0_lin + hes) : ((e < d) ? -(ev * q[s]) : 0.0);
         }
         return logp;
     }

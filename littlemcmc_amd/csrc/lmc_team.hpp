@@ -34,7 +34,7 @@ struct Team {
     double* xbuf;   // LDS exchange area, 2 * W * kTeamSlots doubles (unused for W == 1)
     int parity;
 
-    __device__ __forceinline__ int tid() const { return static_cast<int>(threadIdx.x); }
+    __device__ __forceinline__ int tid() const { return LMC_CHAIN_THREAD; }
     __device__ __forceinline__ int wave() const { return first_i32(static_cast<int>(threadIdx.x) >> 6); }
     __device__ __forceinline__ void sync() const {
         if constexpr (W == 1) wave_sync(); else __syncthreads();

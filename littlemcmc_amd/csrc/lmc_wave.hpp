@@ -14,6 +14,12 @@ namespace lmc {
 constexpr int kWave = 64;
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & 63; }
+// Index of a thread within the team that owns its chain: the thread index of the block when a block IS one chain
+// (every kernel but one); a translation unit whose blocks hold several one-wave chains side by side (lmc_dense_coop.hip:
+// eight chains meet per leapfrog for one MFMA product) defines it as the lane.
+#ifndef LMC_CHAIN_THREAD
+#define LMC_CHAIN_THREAD static_cast<int>(threadIdx.x)
+#endif
 // lane predicate -> 64-bit mask. The builtin takes the i1 as it is (a v_cmp result already IS the mask in an SGPR pair);
 // HIP's __ballot() widens it to an int first, which costs a v_cndmask + v_cmp_ne per call.
 __device__ __forceinline__ unsigned long long ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }

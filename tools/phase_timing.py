@@ -28,7 +28,7 @@ eng.seed(seeds); eng.set_position(start); eng.reset_tuning()
 eng.reserve(tune + draws, keep_trace=True, trace_begin=tune)
 names = ["momentum draw", "start state (logp, float32 energy)", "NUTS transition", "dual averaging", "mass adaptation",
          "bookkeeping + outputs + loop"]
-prev = np.zeros((chains, 4), dtype=np.int64)
+prev = np.zeros((chains, _abi.NUM_COUNTERS), dtype=np.int64)
 for label, lo, n in (("tuning", 0, tune), ("draws", tune, draws)):
     eng.run(tune, lo, n)
     eng.synchronize()
