@@ -693,8 +693,9 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel
 constexpr int kCoopWaves = 8;
 __host__ __device__ constexpr int coop_ct_stride(int dpad) { return dpad + 16; }
 __host__ __device__ constexpr int coop_xs(int dpad) { return dpad + 2; }
-__host__ __device__ constexpr int coop_lds_bytes(int d, int dpad) {
-    return sweep_rows(d) * coop_ct_stride(dpad) * 4 + 2 * 16 * coop_xs(dpad) * 8 + 16 + kCoopWaves * dense_lds_doubles(dpad) * 8;
+__host__ __device__ constexpr int coop_matrix_bytes(int d, int dpad) { return sweep_rows(d) * coop_ct_stride(dpad) * 4; }
+__host__ __device__ constexpr int coop_lds_bytes(int d, int dpad, int slots) {
+    return coop_matrix_bytes(d, dpad) + 2 * 16 * coop_xs(dpad) * 8 + 16 + kCoopWaves * (dense_lds_doubles(dpad) + slots * dpad) * 8;
 }
 template <int NS, template <int> class TargetT>
 __global__ __launch_bounds__(64 * kCoopWaves, 2) void run_dense_coop_kernel(ChainArrays A, DenseArrays D, SamplerParams P,
@@ -704,12 +705,14 @@ __global__ __launch_bounds__(64 * kCoopWaves, 2) void run_dense_coop_kernel(Chai
     const int wave = first_i32(static_cast<int>(threadIdx.x) >> 6);
     const int k_rows = sweep_rows(d), cts = coop_ct_stride(dpad), xs = coop_xs(dpad);
     float* ct = reinterpret_cast<float*>(lds);
-    double* x = lds + (k_rows * cts * 4) / 8;
+    double* x = lds + coop_matrix_bytes(d, dpad) / 8;
     double* dout = x + 16 * xs;
     int* n_active = reinterpret_cast<int*>(dout + 16 * xs);
-    double* priv = dout + 16 * xs + 2 + wave * dense_lds_doubles(dpad);
-    // the matrix: all 512 threads, rows of the stored transposed matrix are contiguous (coalesced)
+    const int slots = D.lds_slots;
+    double* priv = dout + 16 * xs + 2 + wave * (dense_lds_doubles(dpad) + slots * dpad);
     const float* M = static_cast<const float*>(D.covT);
+    DenseCoop cc;
+    // the matrix: all 512 threads, rows of the stored transposed matrix are contiguous (coalesced)
     for (int idx = threadIdx.x; idx < k_rows * dpad; idx += 64 * kCoopWaves) {
         const int k = idx / dpad, i = idx - k * dpad;
         ct[k * cts + i] = M[idx];
@@ -721,7 +724,6 @@ __global__ __launch_bounds__(64 * kCoopWaves, 2) void run_dense_coop_kernel(Chai
     __syncthreads();
     if (mine && lane_id() == 0) atomicAdd(n_active, 1);
     __syncthreads();
-    DenseCoop cc;
     cc.ct = (__attribute__((address_space(3))) const float*)ct;
     cc.x = (lds_double*)x;
     cc.dout = (lds_double*)dout;
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(64 * kCoopWaves, 2) void run_dense_coop_kernel(Chai
     cc.ct_stride = cts; cc.xs = xs; cc.k_rows = k_rows; cc.dpad = dpad; cc.wave = wave; cc.n_waves = kCoopWaves;
     if (mine) {
         DenseMat<float> mm{M, nullptr, 0, d, dpad, &cc};
-        dense_run_chain<NS, float, TargetT>(A, D, P, tparams, c, priv, mm, nullptr, 0);
+        dense_run_chain<NS, float, TargetT>(A, D, P, tparams, c, priv, mm, (lds_double*)(priv + dense_lds_doubles(dpad)), slots);
         if (lane_id() == 0) atomicSub(n_active, 1);
     }
     // drain: answer the group's barriers until every chain is done

@@ -13,9 +13,15 @@
 
 namespace lmc {
 
+int dense_coop_lds_slots(int d, int dpad, int max_slots) {   // tree slots per chain that fit next to the panels (one workgroup per CU)
+    long slots = (160L * 1024 - coop_lds_bytes(d, dpad, 0)) / (static_cast<long>(kCoopWaves) * dpad * 8);
+    if (slots > max_slots) slots = max_slots;
+    return static_cast<int>(slots < 0 ? 0 : slots);
+}
+
 int dense_coop_supported(int family, int ns, int d, int dpad) {
     if (ns != 1 && ns != 2) return 0;                       // dpad <= 128: the float32 matrix fits one CU's LDS next to the panels
-    if (coop_lds_bytes(d, dpad) > 160 * 1024) return 0;
+    if (coop_lds_bytes(d, dpad, 0) > 160 * 1024) return 0;
     switch (family) {
         case LMC_TARGET_STD_NORMAL: case LMC_TARGET_DIAG_GAUSSIAN: case LMC_TARGET_AR1: case LMC_TARGET_FUNNEL: return 1;
         default: return 0;
@@ -26,7 +32,7 @@ int dense_launch_run_coop(int family, int ns, hipStream_t stream, const ChainArr
                           const SamplerParams& P, const double* tparams, int n_chains) {
     const int n = n_chains > 0 ? n_chains : A.chains;
     const dim3 grid((n + kCoopWaves - 1) / kCoopWaves), block(64 * kCoopWaves);
-    const int lds = coop_lds_bytes(A.d, A.dpad);
+    const int lds = coop_lds_bytes(A.d, A.dpad, D.lds_slots);
     (void)hipGetLastError();
 #define COOP_ONE(NSV, T)                                                                                             \
     {                                                                                                                \

@@ -15,6 +15,7 @@ int dense_launch_run(int family, int ns, bool mat_f64, hipStream_t stream, const
 // QuadPotentialFull with a matrix shared by all chains, dim <= 128: eight chains per workgroup, the per-leapfrog product on
 // the matrix cores (lmc_dense_coop.hip). dense_coop_supported() says whether that kernel exists for the shape.
 int dense_coop_supported(int family, int ns, int d, int dpad);
+int dense_coop_lds_slots(int d, int dpad, int max_slots);
 int dense_launch_run_coop(int family, int ns, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
                           const SamplerParams& P, const double* tparams, int n_chains = 0);
 int dense_launch_trajectory(int family, int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A,

@@ -428,6 +428,13 @@ static int dense_run(lmc_engine* e, SamplerParams P) {
     bool coop = e->cfg.potential == LMC_POT_FULL && !kUserCompiledInDense &&
                 dense_coop_supported(e->cfg.target_family, e->ns, e->cfg.dim, e->dpad) != 0;
     if (const char* env = std::getenv("LMC_DENSE_COOP")) coop = coop && std::atoi(env) != 0;
+    if (coop) {   // the LDS the panels and private regions leave holds the leading tree slots of the eight chains
+        const int max_levels = e->cfg.max_treedepth > e->cfg.early_max_treedepth ? e->cfg.max_treedepth : e->cfg.early_max_treedepth;
+        int slots = dense_coop_lds_slots(e->cfg.dim, e->dpad, dense_scratch_vectors(max_levels));
+        if (const char* env = std::getenv("LMC_DENSE_LDS_SLOTS")) slots = std::atoi(env) < slots ? std::atoi(env) : slots;
+        e->D.cache_rows = 0;
+        e->D.lds_slots = slots < 0 ? 0 : slots;
+    }
     const long long end = P.iter_begin + P.n_iters;
     if (n_sub > 1) e->sub_pending = true;
     long long it = P.iter_begin;
