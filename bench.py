@@ -199,6 +199,12 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the standard-normal d=128 secondary workload")
     ap.add_argument("--cpu-iters", type=int, default=2000, help="iterations per oracle chain in the CPU baseline")
     ap.add_argument("--lds-levels", type=int, default=0)
+    ap.add_argument("--rng", default="numpy", choices=["numpy", "philox"],
+                    help="momentum stream of the PRIMARY workload: numpy = the reference's (same-seed parity; the headline), "
+                         "philox = counter-based throughput mode (include/lmc_hip.h: LMC_RNG_PHILOX)")
+    ap.add_argument("--no-philox-line", action="store_true", help="skip the separately labelled counter-based-RNG line of the north_star shape")
+    ap.add_argument("--no-tail", action="store_true", help="skip the lone-chain latency measurement of the tail block (profiling "
+                                                           "runs: keeps every run_kernel dispatch the same size)")
     ap.add_argument("--no-rccl-check", action="store_true", help="N = 1: do not bring up the one-rank RCCL group")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (nccl = RCCL; gloo only to exercise the multi-rank path on one GPU)")
@@ -296,7 +302,10 @@ def main():
         dist.all_gather(out, t)
         return [[float(v) for v in o] for o in out]
 
-    def run_job(target_name, dim, with_ess):
+    RNG_LABEL = {"numpy": "MT19937 (numpy legacy stream, same-seed parity mode)",
+                 "philox": "Philox4x32-10 momentum stream (throughput mode: NOT the reference's draws), tree uniforms MT19937"}
+
+    def run_job(target_name, dim, with_ess, rng="numpy"):
         """The timed job on this rank's chain block -> dict of measurements (wall / leapfrogs reduced over ranks)."""
         target, target_desc = make_target(lmc, target_name, dim)
         np.random.seed(int(seeds_all[0]))
@@ -319,6 +328,7 @@ def main():
             step = lmc.HamiltonianMC(target, dim, potential=pot, path_length=2.0)
         kw = step._engine_kwargs()
         kw["lds_levels"] = args.lds_levels
+        kw["rng"] = rng
 
         def new_job(capacity, trace_from, keep_trace):
             eng = lmc.Engine(target, chains=chains, device=local_rank, **kw)
@@ -341,6 +351,12 @@ def main():
             bounds = [chains * b // nst for b in range(nst + 1)]
             crit = max(int(per_launch[bounds[b]:bounds[b + 1]].max(dim=0).values.sum()) for b in range(nst))
             ratio = float((per_launch.max(dim=0).values.double() / per_launch.double().mean(dim=0).clamp(min=1.0)).mean())
+            lds_bytes = eng.run_lds_bytes()
+            if args.no_tail:
+                return {"busiest_chain_leapfrogs": int(leap_chain.max()), "mean_chain_leapfrogs": float(leap_chain.mean()),
+                        "launch_max_over_mean": ratio, "critical_path_leapfrogs": crit, "kernel_s": kernel_s,
+                        "resident_chains": resident, "waves_per_chain": wpc, "lds_bytes_per_workgroup": lds_bytes,
+                        "mean_wave_slot_occupancy": (float(ct[:, _abi.CT_WAVE_TICKS].sum()) / hz / (resident * wpc * kernel_s)) if resident else None}
             # a lone chain on an otherwise idle GPU: the issue latency of one wavefront (team) of this kernel
             lone = lmc.Engine(target, chains=1, device=local_rank, **kw)
             step.potential._push_initial(lone)
@@ -367,7 +383,7 @@ def main():
                 "lone_wave_us_per_leapfrog": lone_us,
                 "implied_wall_lower_bound_s": crit * lone_us * 1e-6,
                 "kernel_s": kernel_s,
-                "resident_chains": resident, "waves_per_chain": wpc,
+                "resident_chains": resident, "waves_per_chain": wpc, "lds_bytes_per_workgroup": lds_bytes,
                 "mean_wave_slot_occupancy": (float(ct[:, _abi.CT_WAVE_TICKS].sum()) / hz / (slots * kernel_s)) if slots else None,
                 "note": "per launch each sub-block of chains ends with its busiest chain; critical_path_leapfrogs = max over "
                         "sub-blocks of the sum over launches of that chain's leapfrogs; x the leapfrog latency of a lone "
@@ -468,7 +484,7 @@ def main():
         label = config_label(target_name, dim, chains_total, args.max_treedepth, args.kind, args.mass)
         part = ("%d chains on this GPU" % chains) if world == 1 else ("%d chains in blocks of ~%d per GPU" % (chains_total, chains))
         return {
-            "label": label, "target": target_name, "dim": dim, "start": start, "mass_desc": mass_desc,
+            "label": label, "target": target_name, "dim": dim, "start": start, "mass_desc": mass_desc, "rng": RNG_LABEL[rng], "rng_mode": rng,
             "workload": "%s: %d chains x dim %d %s, %s, %s, tune %d + draws %d in %d launches of %d iterations; %s" % (
                 label, chains_total, dim, target_desc, method, mass_desc, n_tune, n_total - n_tune, K, ips, part),
             "wall": wall_max, "leap_all": leap_all, "leap_local": leap_local, "kernel_ms": kernel_ms,
@@ -486,7 +502,7 @@ def main():
         rate_local = job["leap_local"] / kern_s                  # this GPU's kernel: leapfrogs per second of kernel time
         flop = FLOP_PER_LEAPFROG_PER_DIM * dim
         extra = 0 if args.mass == "diag" else 8 * dim * dim      # dense: the reference's two float32 d x d sweeps
-        key = ("%s:%d" % (job["target"], dim)) + ("" if args.mass == "diag" else ":" + args.mass)
+        key = ("%s:%d" % (job["target"], dim)) + ("" if args.mass == "diag" else ":" + args.mass) + ("" if job["rng_mode"] == "numpy" else ":" + job["rng_mode"])
         prof = pmc_profile(key, src_hash)
         r = {
             "kernel": ("lmc::run_kernel<NS=%d>" if args.mass == "diag" else "lmc::run_dense_kernel<NS=%d>") % max(1, (dim + 63) // 64),
@@ -532,10 +548,13 @@ def main():
             r["pmc_source"] = prof.get("source")
         return r
 
-    primary = run_job(args.target, args.dim, with_ess=True)
+    primary = run_job(args.target, args.dim, with_ess=True, rng=args.rng)
     secondary = None
+    philox_line = None
     if not args.no_secondary and args.mass == "diag" and args.kind == "nuts" and (args.target, args.dim) != ("std_normal", 128):
         secondary = run_job("std_normal", 128, with_ess=False)
+        if not args.no_philox_line and args.rng == "numpy":
+            philox_line = run_job("std_normal", 128, with_ess=False, rng="philox")
 
     if rank == 0:
         value = primary["leap_all"] / primary["wall"]
@@ -548,7 +567,7 @@ def main():
             "config": {
                 "workload": primary["workload"], "chains_total": chains_total, "chains_this_gpu": chains,
                 "dim": args.dim, "target": args.target, "tune": n_tune, "draws": n_total - n_tune,
-                "rng": "MT19937 (numpy legacy stream, same-seed parity mode)",
+                "rng": primary["rng"],
                 "trace_in_hbm": not args.no_trace, "parallelism": "chain-block x%d (%s scaling)" % (world, args.scaling),
             },
             "leapfrogs": primary["leap_all"], "wall_s": primary["wall"], "mean_depth_draws": primary["depth_mean"],
@@ -576,7 +595,14 @@ def main():
                 "unit": "leapfrog-steps/s", "ms_per_step": secondary["wall"] * 1e3 / K, "leapfrogs": secondary["leap_all"],
                 "wall_s": secondary["wall"], "mean_depth_draws": secondary["depth_mean"],
                 "divergences_after_tune": secondary["div_after"], "roofline": roofline(secondary),
-                "tail": secondary["tail"], "per_rank": secondary["per_rank"]}]
+                "tail": secondary["tail"], "per_rank": secondary["per_rank"], "rng": secondary["rng"]}]
+        if philox_line is not None:   # separately labelled, never the headline: not the reference's random stream
+            out["secondary"].append({
+                "workload": philox_line["workload"] + "; COUNTER-BASED MOMENTUM STREAM", "rng": philox_line["rng"],
+                "value": philox_line["leap_all"] / philox_line["wall"], "unit": "leapfrog-steps/s",
+                "ms_per_step": philox_line["wall"] * 1e3 / K, "leapfrogs": philox_line["leap_all"], "wall_s": philox_line["wall"],
+                "mean_depth_draws": philox_line["depth_mean"], "divergences_after_tune": philox_line["div_after"],
+                "roofline": roofline(philox_line), "tail": philox_line["tail"], "per_rank": philox_line["per_rank"]})
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.target, args.dim, seeds_all[:64], primary["start"], args.cpu_iters, args.mass)
         sys.stdout.flush()

@@ -68,6 +68,15 @@ extern "C" {
 #define LMC_SDOT_OPENBLAS_SKYLAKEX 1   /* OpenBLAS 0.3.29 sdot_k_SKYLAKEX (AVX-512 hosts); default */
 #define LMC_SDOT_OPENBLAS_HASWELL 2    /* OpenBLAS 0.3.29 sdot_k_HASWELL (AVX2 hosts) */
 
+/* Where the momentum draw's normals come from (potential.random(), quadpotential.py:221-224 / :374-376).
+ * NUMPY: the reference's own stream -- per-chain legacy MT19937 + polar method in numpy's consumption order (same-seed
+ * parity; the default). PHILOX: a counter-based stream, Philox4x32-10 keyed by the chain's seed and counted by
+ * (iteration, element), float32 Box-Muller: the throughput mode for callers that do not need the reference's draws
+ * (the momentum draw is ~20 % of a depth-3 iteration on the parity stream). Tree uniforms stay on MT19937 in both.
+ * Fused diagonal-mass kernels with one wavefront per chain (dim <= 256) and the built-in densities. */
+#define LMC_RNG_NUMPY 0
+#define LMC_RNG_PHILOX 1
+
 /* per-chain status bits (lmc_engine_get_status) */
 #define LMC_STATUS_BAD_INITIAL_ENERGY 1   /* base_hmc.py:145-148 (ValueError in the reference) */
 /* (No bit for math.py:23-24's FloatingPointError: logbern() only sees log-weights of leaves that passed the divergence
@@ -131,6 +140,8 @@ typedef struct lmc_config {
     int32_t lds_levels;           /* subtree-stack levels kept in LDS; 0 = choose automatically */
     int32_t start_energy_sdot;    /* LMC_SDOT_*: summation order of the float32 start-state kinetic energy */
     double adaptation_window_multiplier; /* 1.0: QuadPotentialDiagAdapt's window grows by this factor at every switch (quadpotential.py:243) */
+    int32_t rng_mode;             /* LMC_RNG_*; 0 = the reference's stream */
+    int32_t reserved0;
 } lmc_config;
 
 /* Fill *cfg with the reference's defaults for the given shape. */
@@ -334,6 +345,9 @@ int lmc_engine_kernel_shape(lmc_engine* e, int32_t* unit_ns, int32_t* run_ns, in
  * wall clock LMC_CT_WAVE_TICKS counts in. The host uses it to size launches (the reference's analogue is `cores`,
  * sampling.py:117-129). Any pointer may be NULL. */
 int lmc_engine_occupancy(lmc_engine* e, int32_t* resident_chains, int32_t* waves_per_chain, double* wall_clock_hz);
+/* Dynamic LDS bytes per workgroup (= per chain) of the sampling kernel lmc_engine_run() launches; rocprofv3's kernel trace
+ * lists only the static part (0). Negative: no fused diagonal-mass kernel. */
+int32_t lmc_engine_run_lds_bytes(lmc_engine* e);
 int lmc_engine_load_user_kernels(lmc_engine* e, const void* code_object, const char* run_name, const char* trajectory_name,
                                  const char* logp_name);
 

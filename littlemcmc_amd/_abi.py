@@ -19,6 +19,7 @@ POT_DIAG_ADAPT, POT_DIAG, POT_FULL, POT_FULL_INV, POT_FULL_ADAPT = range(5)
 TARGET_STD_NORMAL, TARGET_DIAG_GAUSSIAN, TARGET_AR1, TARGET_FUNNEL, TARGET_NORMAL1D, TARGET_USER, TARGET_EXTERNAL = range(7)
 STATUS_BAD_INITIAL_ENERGY = 1
 SDOT_NATIVE, SDOT_OPENBLAS_SKYLAKEX, SDOT_OPENBLAS_HASWELL = 0, 1, 2
+RNG_NUMPY, RNG_PHILOX = 0, 1
 (STAT_STEP_SIZE, STAT_STEP_SIZE_BAR, STAT_ACCEPT, STAT_ENERGY_ERROR, STAT_ENERGY, STAT_MAX_ENERGY_ERROR,
  STAT_MODEL_LOGP) = range(7)
 STAT_DEPTH, STAT_TREE_SIZE = 0, 1
@@ -39,6 +40,7 @@ class Config(C.Structure):
         ("max_treedepth", C.c_int32), ("early_max_treedepth", C.c_int32),
         ("path_length", C.c_double), ("max_steps", C.c_int32), ("adaptation_window", C.c_int32),
         ("lds_levels", C.c_int32), ("start_energy_sdot", C.c_int32), ("adaptation_window_multiplier", C.c_double),
+        ("rng_mode", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -123,6 +125,7 @@ _SIGNATURES = {
     "lmc_engine_kernel_shape": (C.c_int, [_P, _P, _P, _P]),
     "lmc_engine_occupancy": (C.c_int, [_P, _P, _P, _P]),
     "lmc_engine_request_stop": (C.c_int, [_P, C.c_int32]),
+    "lmc_engine_run_lds_bytes": (C.c_int32, [_P]),
     "lmc_engine_load_user_kernels": (C.c_int, [_P, _P, C.c_char_p, C.c_char_p, C.c_char_p]),
     "lmc_diag_lags_per_pass": (C.c_int, []),
     "lmc_diag_chain_stats": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _P, _P]),

@@ -109,6 +109,7 @@ class BaseHMC:
             gamma=self._gamma, k=self._k, t0=self._t0,
             adaptation_window=getattr(self.potential, "_initial_adaptation_window", 101),
             adaptation_window_multiplier=getattr(self.potential, "adaptation_window_multiplier", 1.0),
+            rng=getattr(self, "_momentum_rng", "numpy"),
         )
 
     def _make_engine(self, chains, device=0):

@@ -191,6 +191,7 @@ struct lmc_engine {
     hipStream_t sub_stream[kMaxSub] = {nullptr, nullptr};
     hipEvent_t sub_done[kMaxSub] = {nullptr, nullptr};
     hipEvent_t main_done = nullptr;
+    uint32_t* seeds = nullptr;  // [C] the seeds of lmc_engine_seed (key of LMC_RNG_PHILOX's momentum stream)
     int* stop_flag = nullptr;   // device word the sampling kernels poll once per iteration (lmc_engine_request_stop)
     hipStream_t ctl_stream = nullptr;   // carries the stop request past the kernels in flight
     int step_jitter = 0;        // step_rand as step * uniform(lo, hi) (lmc_engine_set_step_jitter)
@@ -515,6 +516,8 @@ void lmc_config_defaults(lmc_config* cfg, int32_t chains, int32_t dim) {
     cfg->max_steps = 1024;
     cfg->adaptation_window = 101;
     cfg->adaptation_window_multiplier = 1.0;
+    cfg->rng_mode = LMC_RNG_NUMPY;
+    cfg->reserved0 = 0;
     cfg->lds_levels = 0;
     cfg->start_energy_sdot = LMC_SDOT_OPENBLAS_SKYLAKEX;
 }
@@ -554,6 +557,11 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         return fail(nullptr, LMC_ERR_INVALID, "unknown start_energy_sdot mode %d", cfg->start_energy_sdot);
     if (cfg->adaptation_window < 1 || !(cfg->adaptation_window_multiplier > 0.0))
         return fail(nullptr, LMC_ERR_INVALID, "adaptation_window must be >= 1 and its multiplier > 0");
+    if (cfg->rng_mode != LMC_RNG_NUMPY && cfg->rng_mode != LMC_RNG_PHILOX)
+        return fail(nullptr, LMC_ERR_INVALID, "unknown rng_mode %d", cfg->rng_mode);
+    if (cfg->rng_mode == LMC_RNG_PHILOX && (cfg->dim > 256 || cfg->potential >= LMC_POT_FULL ||
+                                            cfg->target_family == LMC_TARGET_USER || cfg->target_family == LMC_TARGET_EXTERNAL))
+        return fail(nullptr, LMC_ERR_INVALID, "LMC_RNG_PHILOX runs in the fused diagonal-mass kernels with the built-in densities, dim <= 256");
     if (cfg->max_treedepth < 1 || cfg->max_treedepth > 20 || cfg->early_max_treedepth < 1 ||
         cfg->early_max_treedepth > 20)
         return fail(nullptr, LMC_ERR_INVALID, "max_treedepth must be in [1, 20]");
@@ -658,6 +666,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     TRY_ALLOC(dev_alloc(e, &A.counters, C * kNumCounters));
     TRY_ALLOC(dev_alloc(e, &e->stop_flag, 1));
     A.stop = e->stop_flag;
+    TRY_ALLOC(dev_alloc(e, &e->seeds, C));
+    A.seed = e->seeds;
     A.scratch_stride = static_cast<long long>(max_levels - nlds + 1) * 4 * dp + static_cast<long long>(kNumColdSlots) * dp;
     const bool dense = cfg->potential >= LMC_POT_FULL;
     if (dense) A.scratch_stride = static_cast<long long>(dense_scratch_vectors(max_levels)) * dp;
@@ -838,6 +848,11 @@ int lmc_engine_occupancy(lmc_engine* e, int32_t* resident_chains, int32_t* waves
 #undef OCC_ONE
     *resident_chains = per_cu * cus;
     return LMC_OK;
+}
+
+int32_t lmc_engine_run_lds_bytes(lmc_engine* e) {
+    if (!e || e->cfg.target_family == LMC_TARGET_EXTERNAL || e->cfg.potential >= LMC_POT_FULL) return -1;
+    return e->lds_bytes + lds_tail_doubles(e->run_w) * 8;
 }
 
 int lmc_engine_load_user_kernels(lmc_engine* e, const void* code_object, const char* run_name, const char* trajectory_name,
@@ -1244,6 +1259,8 @@ int lmc_engine_seed(lmc_engine* e, const uint32_t* seeds) {
     if (err == hipSuccess) {
         LMC_LAUNCH(seed_kernel, dim3(e->cfg.chains), dim3(64), 0, main_stream(e), e->A, dseeds);
         err = hipGetLastError();
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(e->seeds, dseeds, e->cfg.chains * sizeof(uint32_t), hipMemcpyDeviceToDevice, main_stream(e));
     }
     if (err == hipSuccess) err = hipStreamSynchronize(main_stream(e));
     (void)hipFree(dseeds);
@@ -1379,6 +1396,7 @@ static SamplerParams make_params(const lmc_engine* e, int64_t n_tune, int64_t it
     P.nlds = e->nlds;
     P.lds_doubles = e->lds_bytes / 8;
     P.sdot_mode = e->cfg.start_energy_sdot;
+    P.rng_mode = e->cfg.rng_mode;
     P.step_jitter = e->step_jitter;
     P.jitter_lo = e->jitter_lo;
     P.jitter_hi = e->jitter_hi;
@@ -1408,9 +1426,16 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
                                            hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));              \
         LMC_LAUNCH((run_kernel<NSV, WV, T>), grid, block, run_lds, st, e->A, P, e->tparams);                   \
     }
+#define RUN_PHILOX(NSV, T) LMC_LAUNCH((run_kernel<NSV, 1, T, 1>), grid, block, run_lds, st, e->A, P, e->tparams);
 #define RUN_CALL(T)                                                                                            \
     {                                                                                                          \
         const int shape = e->run_ns * 10 + e->run_w;                                                           \
+        if (e->cfg.rng_mode == LMC_RNG_PHILOX) {                                                               \
+            if (shape == 11) RUN_PHILOX(1, T)                                                                  \
+            else if (shape == 21) RUN_PHILOX(2, T)                                                             \
+            else if (shape == 41) RUN_PHILOX(4, T)                                                             \
+            else return fail(e, LMC_ERR_INVALID, "LMC_RNG_PHILOX: unsupported kernel shape ns=%d w=%d", e->run_ns, e->run_w); \
+        } else                                                                                                 \
         if (shape == 11) RUN_ONE(1, 1, T)                                                                      \
         else if (shape == 21) RUN_ONE(2, 1, T)                                                                 \
         else if (shape == 41) RUN_ONE(4, 1, T)                                                                 \
@@ -1434,6 +1459,7 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
     }
 #undef RUN_CALL
 #undef RUN_ONE
+#undef RUN_PHILOX
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, order_external_stream_after_sub_blocks(e));
     return LMC_OK;

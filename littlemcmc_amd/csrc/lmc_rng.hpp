@@ -303,4 +303,46 @@ __device__ inline void rng_normals(RngState& r, int d, double* out, double* stag
     wave_sync();
 }
 
+// ---- counter-based momentum draw (LMC_RNG_PHILOX: the throughput mode, NOT the reference's stream) -----------------
+// With the numpy-legacy stream the momentum draw is ~20 % of a depth-3 iteration: the polar method's rejection loop, the
+// compaction of accepted pairs through LDS, the MT19937 twist. When same-seed parity with the reference is not needed,
+// normal(size=d) can instead be a pure function of (chain seed, iteration, element): Philox4x32-10 (Salmon et al., SC11;
+// key = the chain's seed, counter = iteration and lane) and a float32 Box-Muller -- the momentum of QuadPotentialDiagAdapt
+// is float32 in the reference too (quadpotential.py:221-224) -- with the hardware's single-instruction log2 / sin / cos.
+// No LDS, no cross-lane traffic, no barrier; every thread of a team draws its own elements. Results are independent of
+// launch slicing and of the chain-block partition, like the parity stream's. Tree uniforms stay on the chain's MT19937.
+struct Philox4 { uint32_t c[4]; };
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    Philox4 o;
+    o.c[0] = c0; o.c[1] = c1; o.c[2] = c2; o.c[3] = c3;
+    return o;
+}
+// two standard normals (float32 precision) from two 32-bit words
+__device__ __forceinline__ void box_muller_f32(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float u1 = static_cast<float>(a >> 8) * 5.9604645e-08f + 2.9802322e-08f;   // (0, 1): (k + 1/2) 2^-24
+    const float u2 = static_cast<float>(b >> 8) * 5.9604645e-08f;                    // [0, 1) of a revolution
+    const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), v_log_f32 is log2
+    z0 = r * __builtin_amdgcn_cosf(u2);   // v_cos_f32 / v_sin_f32 take revolutions
+    z1 = r * __builtin_amdgcn_sinf(u2);
+}
+// z[s] = the normal of element thread * NS + s (0 beyond d) for iteration `git` of the chain seeded `seed`
+template <int NS>
+__device__ __forceinline__ void philox_normals(uint32_t seed, long long git, int thread, int d, double (&z)[NS]) {
+    const Philox4 w = philox4x32_10(static_cast<uint32_t>(git), static_cast<uint32_t>(git >> 32), static_cast<uint32_t>(thread),
+                                    0x6c6d636du /* "lmcm": the momentum stream */, seed, 0x4d4f4d31u);
+    float n[4];
+    box_muller_f32(w.c[0], w.c[1], n[0], n[1]);
+    if constexpr (NS > 2) box_muller_f32(w.c[2], w.c[3], n[2], n[3]);
+    static_assert(NS <= 4, "one Philox call per thread");
+#pragma unroll
+    for (int s = 0; s < NS; ++s) z[s] = (thread * NS + s < d) ? static_cast<double>(n[s]) : 0.0;
+}
+
 }  // namespace lmc

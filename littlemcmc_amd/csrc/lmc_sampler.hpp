@@ -68,6 +68,7 @@ struct ChainArrays {
     int* status;          // [C]
     long long* counters;  // [C][kNumCounters]
     const int* stop;      // [1] != 0: every chain leaves its launch at the next iteration boundary (lmc_engine_request_stop)
+    const uint32_t* seed; // [C] the seeds of lmc_engine_seed (key of the counter-based momentum stream, LMC_RNG_PHILOX)
     double* mom_mean;     // [C][dpad] running mean of the post-warm-up draws (nullptr = not kept)
     double* mom_m2;       // [C][dpad] running sum of squared deviations (Welford)
     int* mom_n;           // [C] number of draws accumulated
@@ -100,6 +101,7 @@ struct SamplerParams {
     int lds_doubles;      // LDS doubles used by the subtree stack; the MT19937 state (624 words) follows
     int sdot_mode;        // SdotMode for the float32 start-state kinetic energy
     int chain_begin;      // run_kernel: first chain of this launch (the engine launches its chains as sub-blocks)
+    int rng_mode;         // LMC_RNG_*: which run_kernel instantiation the host launches (informational on the device)
     int step_jitter;      // step_rand (base_hmc.py:154-155) in its one device form: step * uniform(jitter_lo, jitter_hi)
     double jitter_lo, jitter_hi;
 };
@@ -1266,7 +1268,9 @@ __device__ __forceinline__ void diag_mass_update(const CA& A, const PT& P, long 
     ++ms.n_samples;
 }
 
-template <int NS, int W, template <int> class TargetT>
+// RNG = 0: the reference's stream (numpy legacy MT19937 + polar method, same-seed parity); 1: momentum from Philox
+// (philox_normals: the throughput mode, its own kernel instantiation so that the parity kernels are untouched by it)
+template <int NS, int W, template <int> class TargetT, int RNG = 0>
 __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(ChainArrays, SamplerParams, const double* tparams) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const long long t_resident = wall_clock64();   // constant-rate clock: the chain's residence time (kCtWaveTicks)
@@ -1317,6 +1321,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     rng.pos = first_i32(A0.rng_pos[c]);
     rng.has_gauss = first_i32(A0.rng_has_gauss[c]);
     rng.gauss = first_f64(A0.rng_gauss[c]);
+    const uint32_t chain_seed = RNG == 1 ? first_u32(A0.seed[c]) : 0u;
     DualAverage da;
     dual_average_load(A0, c, da);
     int iter_count = first_i32(A0.iter_count[c]);
@@ -1361,16 +1366,24 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         const int stop_word = stop_request_load(ka.A());
 
         // ---- momentum draw (quadpotential.py:221-224 / :374-376)
-        team_normals(tm, rng, d, lds, lds + dpad, rng_bcast);   // level-0 LDS region (2*dpad doubles) = normals + staging
         double p0[NS];
+        if constexpr (RNG == 1) {
+            double z[NS];
+            philox_normals<NS>(chain_seed, git, tid, d, z);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int e = tid * NS + s;
-            const double z = (e < d) ? lds[e] : 0.0;
-            p0[s] = momentum_f32 ? static_cast<double>(inv_std[s] * static_cast<float>(z))
-                                 : z * static_cast<double>(inv_std[s]);
+            for (int s = 0; s < NS; ++s)
+                p0[s] = momentum_f32 ? static_cast<double>(inv_std[s] * static_cast<float>(z[s])) : z[s] * static_cast<double>(inv_std[s]);
+        } else {
+            team_normals(tm, rng, d, lds, lds + dpad, rng_bcast);   // level-0 LDS region (2*dpad doubles) = normals + staging
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int e = tid * NS + s;
+                const double z = (e < d) ? lds[e] : 0.0;
+                p0[s] = momentum_f32 ? static_cast<double>(inv_std[s] * static_cast<float>(z))
+                                     : z * static_cast<double>(inv_std[s]);
+            }
+            tm.sync();
         }
-        tm.sync();
         LMC_PHASE(0)
 
         // ---- start state (integration.py:52-66)

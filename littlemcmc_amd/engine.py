@@ -23,7 +23,7 @@ class Engine:
     def __init__(self, target, chains, kind="nuts", potential="diag_adapt", device=0, lib_path=None,
                  target_accept=0.8, Emax=1000.0, adapt_step_size=True, step_scale=0.25, gamma=0.05, k=0.75,
                  t0=10, path_length=2.0, max_treedepth=10, early_max_treedepth=8, max_steps=1024,
-                 adaptation_window=101, adaptation_window_multiplier=1.0, lds_levels=0, sdot=None):
+                 adaptation_window=101, adaptation_window_multiplier=1.0, lds_levels=0, sdot=None, rng="numpy"):
         self._lib = _abi.load(lib_path or getattr(target, "lib_path", None))
         self._h = C.c_void_p()
         self.target = target
@@ -52,6 +52,7 @@ class Engine:
         cfg.adaptation_window = int(adaptation_window)
         cfg.adaptation_window_multiplier = float(adaptation_window_multiplier)
         cfg.lds_levels = int(lds_levels)
+        cfg.rng_mode = {"numpy": _abi.RNG_NUMPY, "philox": _abi.RNG_PHILOX}[rng]   # include/lmc_hip.h: LMC_RNG_*
         if sdot is None:
             sdot = DEFAULT_SDOT
         if sdot == "auto":   # float32 start-energy rounding of the host's numpy (see _blas_probe.py)
@@ -176,6 +177,11 @@ class Engine:
         rc, wpc, hz = C.c_int32(), C.c_int32(), C.c_double()
         self._check(self._lib.lmc_engine_occupancy(self._h, C.byref(rc), C.byref(wpc), C.byref(hz)))
         return int(rc.value), int(wpc.value), float(hz.value)
+
+    def run_lds_bytes(self):
+        """Dynamic LDS bytes per workgroup of the sampling kernel (None: no fused diagonal-mass kernel)."""
+        n = int(self._lib.lmc_engine_run_lds_bytes(self._h))
+        return n if n >= 0 else None
 
     def resident_chains(self):
         """How many chains the sampling kernel keeps resident on the GPU at once; None for engines without a fused

@@ -35,13 +35,14 @@ class NUTS(BaseHMC):
 
     def __init__(self, logp_dlogp_func, model_ndim=None, scaling=None, is_cov=False, potential=None,
                  target_accept=0.8, Emax=1000, adapt_step_size=True, step_scale=0.25, gamma=0.05, k=0.75,
-                 t0=10, step_rand=None, path_length=2.0, max_treedepth=10, early_max_treedepth=8, size=None):
+                 t0=10, step_rand=None, path_length=2.0, max_treedepth=10, early_max_treedepth=8, size=None, momentum_rng="numpy"):
         if model_ndim is None:
             model_ndim = size if size is not None else getattr(logp_dlogp_func, "d", None)
         super().__init__(logp_dlogp_func=logp_dlogp_func, model_ndim=model_ndim, scaling=scaling, is_cov=is_cov,
                          potential=potential, target_accept=target_accept, Emax=Emax,
                          adapt_step_size=adapt_step_size, step_scale=step_scale, gamma=gamma, k=k, t0=t0,
                          step_rand=step_rand)
+        self._momentum_rng = momentum_rng   # "numpy": the reference's stream; "philox": counter-based throughput mode (include/lmc_hip.h)
         self.max_treedepth = max_treedepth
         self.early_max_treedepth = early_max_treedepth
         self.path_length = path_length

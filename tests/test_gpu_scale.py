@@ -484,3 +484,49 @@ def test_dense_adapt_and_tick_paths_sample_the_target_at_scale():
     y = tr2.reshape(-1, d2)
     assert np.abs(y.mean(axis=0)).max() < 0.01 and np.abs(y.var(axis=0) - 1.0).max() < 0.02
     assert st2["depth"].mean() > 1.5 and not st2["diverging"].any()
+
+
+def test_counter_based_momentum_stream_samples_the_target_and_is_partition_invariant():
+    """LMC_RNG_PHILOX (NUTS(momentum_rng="philox")): the throughput mode's momentum draw is a pure function of (chain seed,
+    iteration, element). It is NOT the reference's stream -- so no oracle chain to compare with -- and is held to what it
+    promises: the draws have the target's moments at scale (65 536 chains x d = 128 standard normal, every dimension within
+    2e-3 after 600 draws per chain -- Monte-Carlo error of a variance ~3e-4; d = 200 exercises NS = 4), a chain does not depend
+    on how the job is cut into launches or chain blocks, and the parity stream of the same job is untouched by the mode's
+    existence."""
+    d, chains, tune, draws = 128, 65536, 300, 600
+    tgt = T.StdNormal(d)
+    seeds = lmc.distributed.global_seeds(20260928, chains)
+    start, step = lmc.init_nuts(tgt, d, random_seed=seeds, momentum_rng="philox")
+    eng = step._make_engine(chains)
+    try:
+        eng.seed(seeds); eng.set_position(start); eng.reset_tuning(); eng.keep_moments(True)
+        eng.reserve(tune + draws, keep_trace=False)
+        eng.run(tune, 0, tune + draws)
+        eng.synchronize()
+        assert not eng.status().any()
+        mean, m2, n = eng.moments()
+        gmean, gvar = _pooled_moments(np.asarray(mean), np.asarray(m2), n)
+        depth = eng.stat_i32(_abi.STAT_DEPTH, tune, draws)
+    finally:
+        eng.close()
+    print("philox momentum stream: max |mean| %.2e, max |var - 1| %.2e, median depth %g" % (
+        np.abs(gmean).max(), np.abs(gvar - 1.0).max(), np.median(depth)))
+    assert np.abs(gmean).max() < 2e-3 and np.abs(gvar - 1.0).max() < 2e-3
+    assert np.median(depth) == 3
+
+    # launch slicing and chain blocks do not change a chain; wider vectors (NS = 4) and a correlated target
+    d2, c2 = 200, 96
+    tgt2 = T.AR1(d2, 0.9)
+    seeds2 = lmc.distributed.global_seeds(7, c2)
+    start2, step2 = lmc.init_nuts(tgt2, d2, random_seed=seeds2, momentum_rng="philox")
+    full, sfull = lmc.sample(tgt2, d2, draws=15, tune=40, chains=c2, random_seed=seeds2, start=start2, step=step2, launch_iters=1000)
+    lo, hi = lmc.distributed.chain_block(c2, 1, 3)
+    _s, step3 = lmc.init_nuts(tgt2, d2, random_seed=seeds2, momentum_rng="philox")
+    part, spart = lmc.sample(tgt2, d2, draws=15, tune=40, chains=hi - lo, random_seed=seeds2[lo:hi], start=start2, step=step3, launch_iters=7)
+    np.testing.assert_array_equal(part, full[lo:hi])
+    np.testing.assert_array_equal(spart["tree_size"], sfull["tree_size"][lo:hi])
+    # the two modes draw different momenta (the parity stream is the default and is what every oracle test runs on)
+    _s, step4 = lmc.init_nuts(tgt2, d2, random_seed=seeds2)
+    ref, _ = lmc.sample(tgt2, d2, draws=15, tune=40, chains=8, random_seed=seeds2[:8], start=start2, step=step4)
+    assert not np.allclose(ref, full[:8])
+    assert np.isfinite(full).all() and abs(full.var() - 1.0) < 0.5

@@ -47,13 +47,22 @@ out = {"command": "rocprofv3 --kernel-trace --stats / --pmc <one group per pass>
        "bench_line_under_profiler": {k: b[k] for k in ("value", "leapfrogs", "wall_s", "ms_per_step", "steps", "warmup")},
        "source_hash": b.get("source_hash"), "workload": b["config"]["workload"], "counters": {},
        "kernel_trace": {"dispatches": len(keep), "dispatches_per_step": int((b.get("roofline") or {}).get("dispatches_per_step", 1)), "avg_ms": sum(dur_ns) / len(dur_ns) / 1e6, "vgpr": vgpr,
-                        "scratch_bytes_per_lane": int(keep[0]["Scratch_Size"]), "lds_bytes_per_block": int(keep[0]["LDS_Block_Size"]),
+                        "scratch_bytes_per_lane": int(keep[0]["Scratch_Size"]), "static_lds_bytes_per_block": int(keep[0]["LDS_Block_Size"]),
+                        "dynamic_lds_bytes_per_block": (b.get("tail") or {}).get("lds_bytes_per_workgroup"),
+                        "resident_chains": (b.get("tail") or {}).get("resident_chains"),
+                        "mean_wave_slot_occupancy": (b.get("tail") or {}).get("mean_wave_slot_occupancy"),
                         "waves_per_simd_by_vgpr": waves_per_simd}}
 n_disp = None
-for f in ["pmc_sq", "pmc_fetch", "pmc_write", "pmc_mem"]:
+for f in ["pmc_sq", "pmc_fetch", "pmc_write", "pmc_mem", "pmc_wait"]:
     agg = collections.defaultdict(float)
     disp = set()
-    for r in csv.DictReader(open(find(f + "_counter_collection.csv"))):
+    try:
+        path = find(f + "_counter_collection.csv")
+    except SystemExit:
+        if f == "pmc_wait":   # optional pass (counters that may not exist on every rocprofv3 build)
+            continue
+        raise
+    for r in csv.DictReader(open(path)):
         if kern_sub in r["Kernel_Name"] and "run_" in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
             disp.add(r["Dispatch_Id"])
