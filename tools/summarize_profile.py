@@ -71,16 +71,20 @@ for f in ["pmc_sq", "pmc_fetch", "pmc_write", "pmc_mem", "pmc_wait"]:
     out["counters"].update(agg)
 out["dispatches"] = n_disp
 dps = int((b.get("roofline") or {}).get("dispatches_per_step", 1))   # the engine launches a step as dps concurrent sub-block dispatches
-leap_total = b["leapfrogs"] * n_disp / (b["steps"] * dps)    # warm-up launches are the same size as timed ones
+if b["warmup"] == 0:   # every dispatch of the kernel belongs to the timed job (dense kernels: launches of different lengths)
+    leap_total = b["leapfrogs"]
+else:
+    leap_total = b["leapfrogs"] * n_disp / (b["steps"] * dps)    # warm-up launches are the same size as timed ones
 c = out["counters"]
 out["per_leapfrog"] = {k: v / leap_total for k, v in c.items()}
 fetch_b, write_b = c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
 dim = int(key.split(":")[1])
+mass = key.split(":")[2] if len(key.split(":")) > 2 and key.split(":")[2] in ("full", "full_adapt") else "diag"
 out["hbm"] = {
     "note": "gfx950 rocprofv3: FETCH_SIZE tallies 128-B requests at 64 B for wide (16 B/lane) coalesced reads -> doubled "
             "(guides/MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated, taken as is; separate --pmc passes",
     "read_bytes_per_leapfrog_corrected": 2 * fetch_b / leap_total, "write_bytes_per_leapfrog": write_b / leap_total,
-    "hbm_bytes_per_leapfrog": (2 * fetch_b + write_b) / leap_total, "algorithmic_bytes_per_leapfrog": 60 * dim,
+    "hbm_bytes_per_leapfrog": (2 * fetch_b + write_b) / leap_total, "algorithmic_bytes_per_leapfrog": 60 * dim + (0 if mass == "diag" else 8 * dim * dim),
     "hbm_bytes_per_launch": (2 * fetch_b + write_b) / n_disp * dps}
 wc = c["SQ_WAVE_CYCLES"]
 out["wave_time_split"] = {"valu_active": c["SQ_ACTIVE_INST_VALU"] / wc, "wait_inst_any": c["SQ_WAIT_INST_ANY"] / wc,
