@@ -73,7 +73,8 @@ extern "C" {
  * parity; the default). PHILOX: a counter-based stream, Philox4x32-10 keyed by the chain's seed and counted by
  * (iteration, element), float32 Box-Muller: the throughput mode for callers that do not need the reference's draws
  * (the momentum draw is ~20 % of a depth-3 iteration on the parity stream). Tree uniforms stay on MT19937 in both.
- * Fused diagonal-mass kernels with one wavefront per chain (dim <= 256) and the built-in densities. */
+ * Fused diagonal-mass kernels with the built-in densities (in a team of wavefronts every thread draws its own
+ * elements: the draw needs no barrier, where the parity stream is produced by wave 0 alone). */
 #define LMC_RNG_NUMPY 0
 #define LMC_RNG_PHILOX 1
 

@@ -559,9 +559,9 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         return fail(nullptr, LMC_ERR_INVALID, "adaptation_window must be >= 1 and its multiplier > 0");
     if (cfg->rng_mode != LMC_RNG_NUMPY && cfg->rng_mode != LMC_RNG_PHILOX)
         return fail(nullptr, LMC_ERR_INVALID, "unknown rng_mode %d", cfg->rng_mode);
-    if (cfg->rng_mode == LMC_RNG_PHILOX && (cfg->dim > 256 || cfg->potential >= LMC_POT_FULL ||
+    if (cfg->rng_mode == LMC_RNG_PHILOX && (cfg->potential >= LMC_POT_FULL ||
                                             cfg->target_family == LMC_TARGET_USER || cfg->target_family == LMC_TARGET_EXTERNAL))
-        return fail(nullptr, LMC_ERR_INVALID, "LMC_RNG_PHILOX runs in the fused diagonal-mass kernels with the built-in densities, dim <= 256");
+        return fail(nullptr, LMC_ERR_INVALID, "LMC_RNG_PHILOX runs in the fused diagonal-mass kernels with the built-in densities");
     if (cfg->max_treedepth < 1 || cfg->max_treedepth > 20 || cfg->early_max_treedepth < 1 ||
         cfg->early_max_treedepth > 20)
         return fail(nullptr, LMC_ERR_INVALID, "max_treedepth must be in [1, 20]");
@@ -1427,6 +1427,13 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
         LMC_LAUNCH((run_kernel<NSV, WV, T>), grid, block, run_lds, st, e->A, P, e->tparams);                   \
     }
 #define RUN_PHILOX(NSV, T) LMC_LAUNCH((run_kernel<NSV, 1, T, 1>), grid, block, run_lds, st, e->A, P, e->tparams);
+#define RUN_PHILOX_TEAM(WV, T)                                                                                 \
+    {                                                                                                          \
+        if (run_lds > 64 * 1024)                                                                               \
+            HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<4, WV, T, 1>),            \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));              \
+        LMC_LAUNCH((run_kernel<4, WV, T, 1>), grid, block, run_lds, st, e->A, P, e->tparams);                  \
+    }
 #define RUN_CALL(T)                                                                                            \
     {                                                                                                          \
         const int shape = e->run_ns * 10 + e->run_w;                                                           \
@@ -1434,6 +1441,8 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
             if (shape == 11) RUN_PHILOX(1, T)                                                                  \
             else if (shape == 21) RUN_PHILOX(2, T)                                                             \
             else if (shape == 41) RUN_PHILOX(4, T)                                                             \
+            else if (shape == 42) RUN_PHILOX_TEAM(2, T)                                                        \
+            else if (shape == 44) RUN_PHILOX_TEAM(4, T)                                                        \
             else return fail(e, LMC_ERR_INVALID, "LMC_RNG_PHILOX: unsupported kernel shape ns=%d w=%d", e->run_ns, e->run_w); \
         } else                                                                                                 \
         if (shape == 11) RUN_ONE(1, 1, T)                                                                      \
@@ -1460,6 +1469,7 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
 #undef RUN_CALL
 #undef RUN_ONE
 #undef RUN_PHILOX
+#undef RUN_PHILOX_TEAM
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, order_external_stream_after_sub_blocks(e));
     return LMC_OK;

@@ -310,10 +310,155 @@ __device__ __forceinline__ double jitter_step_size(TeamT& tm, RngState& rng, con
     const double u = team_uniform(tm, rng, jw);
     return first_f64(step_size * (P.jitter_lo + (P.jitter_hi - P.jitter_lo) * u));
 }
+// normal(size=d) of the chain's numpy-legacy stream by ALL four waves of a team (d > 512). Drawn by wave 0 alone (round 2:
+// ten rounds of 64 polar attempts, eight passes of log / divide / sqrt and four twists per iteration at d = 1000, every
+// instruction at a lone wave's issue latency while three waves wait at a barrier) it is 36 % of C4's iteration; with the
+// draw off the critical path altogether (LMC_RNG_PHILOX) C4 runs 3.05e8 instead of 2.1e8. Here
+//   * a round evaluates one attempt per thread of waves 0..2 in stream order -- a generation of 624 words holds 156;
+//   * wave 3 meanwhile twists the generation OUT OF PLACE into a second LDS buffer (mt_regen_into), so the next
+//     generation is ready when the round's barrier falls; the (at most two) words of the old generation that no whole
+//     attempt used are carried in registers, the buffers swap, and the old buffer is free to receive the generation after;
+//   * the waves' acceptance masks travel through the team's exchange area (the round's one barrier) and every wave then
+//     knows every wave's mask: ranks, pairs taken and, in the last round, the attempt that ends the call are scalar
+//     arithmetic on the masks, identical in every wave -- the stream position is never broadcast;
+//   * the accepted pairs are compacted into `stage` in stream order and the expensive part runs over 256 pairs at a time.
+// Consumption order, accepted set and arithmetic are rng_normals' (lmc_rng.hpp), hence numpy's. On return r.mt points to
+// the buffer that holds the current generation (either of the two).
+// Measured on C4 (tools/phase_timing.py): the draw 27.9 k -> 22.0 k ticks per iteration, 2.06e8 -> 2.23e8 leapfrogs/s. A
+// round now lasts as long as the lone wave's twist (~3.5 k cycles for ~160 dependent-latency instructions); a first
+// version that parallelised the attempts but left twist and generation crossing to wave 0 measured no gain at all.
 template <class TeamT>
-__device__ inline void team_normals(TeamT& tm, RngState& r, int d, double* out, double* stage, double* bcast) {
+__device__ inline void team_normals_parallel(TeamT& tm, RngState& r, int d, double* out, double* stage, uint32_t* buf_a,
+                                             uint32_t* buf_b) {
+    constexpr int W = TeamT::kWaves;
+    static_assert(W == 4, "three attempt waves cover a generation's 156 attempts, the fourth twists");
+    const int tid = tm.tid(), lane = lane_id(), wave = tm.wave();
+    int produced = 0;
+    tm.sync();   // earlier readers of out / stage / the stream state are done
+    if (r.has_gauss && d > 0) {
+        if (tid == 0) out[0] = r.gauss;
+        r.has_gauss = 0;
+        r.gauss = 0.0;
+        produced = 1;
+    }
+    const int need_pairs = first_i32((d - produced + 1) >> 1);
+    int have = 0;
+    int pos = first_i32(r.pos);
+    uint32_t* cur = r.mt;
+    uint32_t carry0 = 0u, carry1 = 0u;
+    int ncarry = 0;          // words of the previous generation ahead of cur[pos] (0 or 2)
+    bool next_ready = false; // the other buffer holds genrand(cur)
+    while (have < need_pairs) {
+        uint32_t* alt = (cur == buf_a) ? buf_b : buf_a;
+        const bool twisting = !next_ready;
+        if (twisting && wave == W - 1) mt_regen_into(cur, alt);
+        // attempts of this round: whole attempts in carry ++ cur[pos, 624), one per thread of waves 0 .. W-2
+        const int navail = (ncarry + kMtN - pos) >> 2;
+        const int n_att = navail < 64 * (W - 1) ? navail : 64 * (W - 1);
+        double x1 = 0.0, x2 = 0.0;
+        unsigned long long mask = 0ull;
+        if (wave < W - 1 && n_att > 0) {
+            const int at = tid < n_att ? tid : n_att - 1;   // a thread beyond n_att re-reads the last whole attempt and is masked out
+            const int base = pos + 4 * at - ncarry;          // -2 for the attempt that starts in the carried words
+            const bool in_carry = base < pos;
+            const uint32_t w0 = in_carry ? carry0 : cur[base < 0 ? 0 : base];
+            const uint32_t w1 = in_carry ? carry1 : cur[base < 0 ? 0 : base + 1];
+            x1 = 2.0 * mt_words_to_double(w0, w1) - 1.0;
+            x2 = 2.0 * mt_words_to_double(cur[base + 2], cur[base + 3]) - 1.0;
+            const double r2 = x1 * x1 + x2 * x2;
+            const int n_here = n_att - 64 * wave;
+            const unsigned long long lanes = n_here >= 64 ? ~0ull : (n_here <= 0 ? 0ull : ((1ull << n_here) - 1ull));
+            mask = ballot64(r2 > 0.0) & ballot64(r2 < 1.0) & lanes;
+        }
+        // the words no whole attempt of this generation can use (read before the barrier: the buffer is twisted over after it)
+        const uint32_t tail0 = first_u32(cur[kMtN - 2]), tail1 = first_u32(cur[kMtN - 1]);
+        double v[2 * (W - 1)];
+#pragma unroll
+        for (int k = 0; k < W - 1; ++k) {   // exact: a 32-bit integer in a double, the other waves' slots contribute 0
+            v[2 * k] = (k == wave) ? static_cast<double>(static_cast<uint32_t>(mask)) : 0.0;
+            v[2 * k + 1] = (k == wave) ? static_cast<double>(static_cast<uint32_t>(mask >> 32)) : 0.0;
+        }
+        tm.template exchange<2 * (W - 1)>(v);   // the round's one barrier: all reads of cur and the whole twist are behind it
+        if (twisting) next_ready = true;
+        int before = 0, total = 0;
+        unsigned long long m[W - 1];
+#pragma unroll
+        for (int k = 0; k < W - 1; ++k) {
+            m[k] = static_cast<unsigned long long>(static_cast<uint32_t>(v[2 * k])) |
+                   (static_cast<unsigned long long>(static_cast<uint32_t>(v[2 * k + 1])) << 32);
+            const int cnt = __popcll(m[k]);
+            if (k < wave) before += cnt;
+            total += cnt;
+        }
+        const int want = need_pairs - have;
+        int consumed = n_att, taken = total;
+        if (total >= want) {   // the want-th accepted attempt of the round ends the call
+            int run = 0;
+#pragma unroll
+            for (int k = 0; k < W - 1; ++k) {
+                const int cnt = __popcll(m[k]);
+                if (run < want && run + cnt >= want) {
+                    unsigned long long mm = m[k];
+                    for (int i = want - run - 1; i > 0; --i) mm &= mm - 1ull;   // drop the accepted attempts before it
+                    consumed = 64 * k + __ffsll(static_cast<long long>(mm));
+                }
+                run += cnt;
+            }
+            taken = want;
+        }
+        if (wave < W - 1) {
+            const int rank = before + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u)));
+            const bool acc = ((mask >> lane) & 1ull) != 0ull;
+            if (acc && rank < want) {
+                stage[2 * (have + rank)] = x1;
+                stage[2 * (have + rank) + 1] = x2;
+            }
+        }
+        have += taken;
+        if (consumed > 0) { pos += 4 * consumed - ncarry; ncarry = 0; }
+        if (have < need_pairs && kMtN - pos < 4 && ncarry == 0) {   // generation used up: carry its last words, move to the next
+            ncarry = kMtN - pos;                      // 0 or 2 (the stream only ever sits at even positions here)
+            carry0 = tail0; carry1 = tail1;
+            cur = alt;
+            pos = 0;
+            next_ready = false;
+        }
+    }
+    r.mt = cur;
+    r.pos = pos;
+    tm.sync();
+    double tail[1] = {0.0};
+    const bool odd_tail = produced + 2 * need_pairs > d;
+    for (int base = 0; base < need_pairs; base += 64 * W) {
+        const int pi = base + tid;
+        if (pi < need_pairs) {
+            const double px1 = stage[2 * pi], px2 = stage[2 * pi + 1];
+            const double r2 = px1 * px1 + px2 * px2;
+            const double f = sqrt(-2.0 * log_unit(r2) / r2);
+            const int idx = produced + 2 * pi;
+            out[idx] = f * px2;
+            const double g1 = f * px1;
+            if (idx + 1 < d) out[idx + 1] = g1;
+            if (odd_tail && pi == need_pairs - 1) tail[0] = g1;   // the last second variate stays in the cache (numpy legacy_gauss)
+        }
+    }
+    if (odd_tail) {   // one thread holds it: its wave's value, the others contribute 0
+        tail[0] = readlane_f64(tail[0], (need_pairs - 1) & 63);
+        if (wave != (((need_pairs - 1) >> 6) % W)) tail[0] = 0.0;
+        tm.template exchange<1>(tail);
+        r.gauss = first_f64(tail[0]);
+        r.has_gauss = 1;
+    }
+    tm.sync();
+}
+template <class TeamT>
+__device__ inline void team_normals(TeamT& tm, RngState& r, int d, double* out, double* stage, double* bcast,
+                                    uint32_t* mt_a, uint32_t* mt_b) {
     if constexpr (TeamT::kWaves == 1) {
         rng_normals(r, d, out, stage);
+    } else if (TeamT::kWaves == 4 && (first_i32(r.pos) & 1) == 0) {   // (an odd position -- a state handed over from the host after a
+        if constexpr (TeamT::kWaves == 4) team_normals_parallel(tm, r, d, out, stage, mt_a, mt_b);   // 32-bit draw -- takes wave 0's word-granular path)
     } else {
         tm.sync();
         if (tm.wave() == 0) {
@@ -1095,8 +1240,8 @@ constexpr int kLdsMtDoubles = 320;
 #define LMC_MT_IN_LDS_W1 1   // one-wave kernels: 1 keeps the MT19937 state in LDS for the launch, 0 uses it in place (L2)
 #endif
 constexpr bool run_mt_in_lds(int w) { return w > 1 || LMC_MT_IN_LDS_W1; }
-constexpr int lds_tail_doubles(int w) {
-    return w == 1 ? (run_mt_in_lds(1) ? kLdsMtDoubles : 0) : kLdsMtDoubles + 2 * w * kTeamSlots + 4;
+constexpr int lds_tail_doubles(int w) {   // W == 4: a second MT19937 buffer behind everything (team_normals_parallel)
+    return w == 1 ? (run_mt_in_lds(1) ? kLdsMtDoubles : 0) : kLdsMtDoubles + 2 * w * kTeamSlots + 4 + (w == 4 ? kLdsMtDoubles : 0);
 }
 
 // ---- pieces of the iteration body shared by the diagonal and the dense-mass kernels ---------------------------
@@ -1310,6 +1455,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     RngState rng;
     uint32_t* mt_glb = A0.mt + static_cast<long long>(c) * kMtN;
     uint32_t* mt_lds = reinterpret_cast<uint32_t*>(lds + lds_doubles);
+    uint32_t* mt_lds2 = reinterpret_cast<uint32_t*>(rng_bcast + 4);   // W == 4 only: the generation being twisted out of place
     constexpr bool kMtInLds = run_mt_in_lds(W);
     if constexpr (kMtInLds) {
         for (int i = tid; i < kMtN; i += 64 * W) mt_lds[i] = mt_glb[i];
@@ -1374,7 +1520,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
             for (int s = 0; s < NS; ++s)
                 p0[s] = momentum_f32 ? static_cast<double>(inv_std[s] * static_cast<float>(z[s])) : z[s] * static_cast<double>(inv_std[s]);
         } else {
-            team_normals(tm, rng, d, lds, lds + dpad, rng_bcast);   // level-0 LDS region (2*dpad doubles) = normals + staging
+            team_normals(tm, rng, d, lds, lds + dpad, rng_bcast, mt_lds, mt_lds2);   // level-0 LDS region (2*dpad doubles) = normals + staging
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int e = tid * NS + s;
@@ -1452,7 +1598,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     KChainArrays& A = ka.A();
     tm.sync();
     if constexpr (kMtInLds) {
-        for (int i = tid; i < kMtN; i += 64 * W) mt_glb[i] = mt_lds[i];
+        for (int i = tid; i < kMtN; i += 64 * W) mt_glb[i] = rng.mt[i];   // (a team's current generation may be in either buffer)
     }
     vstore<NS>(qrow, q);
 #pragma unroll
