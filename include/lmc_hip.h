@@ -47,6 +47,10 @@ extern "C" {
 #define LMC_POT_FULL 2
 #define LMC_POT_FULL_INV 3
 #define LMC_POT_FULL_ADAPT 4
+/* QuadPotentialFull(cov, dtype="float64") (quadpotential.py:431-444, the dtype argument): float64 covariance, float64
+ * velocity (dgemv), float64 momentum solve_triangular(chol.T, float64 normals). Same kernels as FULL_INV (float64 matrix
+ * sweeps); the momentum is the sweep of L^-1, formed once on the host in extended precision. */
+#define LMC_POT_FULL_F64 5
 
 /* built-in device log-densities (littlemcmc_amd/csrc/lmc_targets.hpp); LMC_TARGET_USER exists only in
  * libraries built with a user target header (littlemcmc_amd/targets.py: UserTarget) */
@@ -179,6 +183,7 @@ int lmc_engine_set_potential(lmc_engine* e, const double* initial_mean, const do
  *      FULL:       QuadPotentialFull(cov) (quadpotential.py:431-444): matrix = covariance, cast to float32 and
  *                  factorised (failure -> LMC_ERR_INVALID, as scipy.linalg.cholesky raises).
  *      FULL_INV:   QuadPotentialFullInv(A) (quadpotential.py:391-402): matrix = A (inverse covariance).
+ *      FULL_F64:   QuadPotentialFull(cov, dtype="float64"): matrix = covariance, kept in float64.
  *      FULL_ADAPT: QuadPotentialFullAdapt(n, initial_mean, initial_cov, initial_weight, adaptation_window,
  *                  adaptation_window_multiplier, update_window) (quadpotential.py:474-519); matrix = initial_cov.
  *      initial_mean .. update_window are read for FULL_ADAPT only. Also the state reset_tuning() restores. */

@@ -15,7 +15,7 @@ ABI_VERSION = 4
 OK = 0
 
 KIND_NUTS, KIND_HMC = 0, 1
-POT_DIAG_ADAPT, POT_DIAG, POT_FULL, POT_FULL_INV, POT_FULL_ADAPT = range(5)
+POT_DIAG_ADAPT, POT_DIAG, POT_FULL, POT_FULL_INV, POT_FULL_ADAPT, POT_FULL_F64 = range(6)
 TARGET_STD_NORMAL, TARGET_DIAG_GAUSSIAN, TARGET_AR1, TARGET_FUNNEL, TARGET_NORMAL1D, TARGET_USER, TARGET_EXTERNAL = range(7)
 STATUS_BAD_INITIAL_ENERGY = 1
 SDOT_NATIVE, SDOT_OPENBLAS_SKYLAKEX, SDOT_OPENBLAS_HASWELL = 0, 1, 2

@@ -191,6 +191,7 @@ struct lmc_engine {
     hipStream_t sub_stream[kMaxSub] = {nullptr, nullptr};
     hipEvent_t sub_done[kMaxSub] = {nullptr, nullptr};
     hipEvent_t main_done = nullptr;
+    double* chol64T = nullptr;  // FULL_F64: LT[j][i] = L[i][j] of the covariance's factor (what the state getters hand out; D.fac holds L^-1)
     uint32_t* seeds = nullptr;  // [C] the seeds of lmc_engine_seed (key of LMC_RNG_PHILOX's momentum stream)
     int* stop_flag = nullptr;   // device word the sampling kernels poll once per iteration (lmc_engine_request_stop)
     hipStream_t ctl_stream = nullptr;   // carries the stop request past the kernels in flight
@@ -385,15 +386,18 @@ static int dense_reset(lmc_engine* e) {   // FULL_ADAPT: constructor state for e
     return LMC_OK;
 }
 
+// potentials whose matrices live in float64 on the device (and whose momentum draw is float64)
+static bool pot_f64(int potential) { return potential == LMC_POT_FULL_INV || potential == LMC_POT_FULL_F64; }
+
 #ifdef LMC_USER_TARGET_HEADER
 static const bool kUserCompiledInDense = true;   // a private library around a user density: its dense kernels are the per-wave ones
 #else
 static const bool kUserCompiledInDense = false;
 #endif
 static int dense_run(lmc_engine* e, SamplerParams P) {
-    P.momentum_f32 = e->cfg.potential != LMC_POT_FULL_INV;   // quadpotential.py:452 (float32) vs :413 (float64)
+    P.momentum_f32 = !pot_f64(e->cfg.potential);   // quadpotential.py:452 (float32) vs :413 / dtype="float64" (float64)
     P.adapt_mass = 0;
-    const bool mat_f64 = e->cfg.potential == LMC_POT_FULL_INV;
+    const bool mat_f64 = pot_f64(e->cfg.potential);
     {   // leading matrix rows each wave keeps in LDS (160 KiB per CU, allocation granule 1280 B):
         // measured at d = 128 (65 536 B matrix per chain): 0 / 16 / 32 / 48 / 64 / 96 / 128 cached rows give
         // 7.6 / 8.2 / 9.1 / 10.6 / 10.4 / 9.1 / 6.6 e7 leapfrog-steps/s -- trading waves per CU (8 -> 5) for HBM
@@ -543,7 +547,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
                     LMC_ABI_VERSION);
     if (cfg->chains < 1 || cfg->dim < 1) return fail(nullptr, LMC_ERR_INVALID, "chains and dim must be >= 1");
     if (cfg->dim > 1024) return fail(nullptr, LMC_ERR_INVALID, "dim > 1024 is not supported (one wavefront per chain)");
-    if (cfg->potential < LMC_POT_DIAG_ADAPT || cfg->potential > LMC_POT_FULL_ADAPT)
+    if (cfg->potential < LMC_POT_DIAG_ADAPT || cfg->potential > LMC_POT_FULL_F64)
         return fail(nullptr, LMC_ERR_INVALID, "unknown potential %d", cfg->potential);
     if (cfg->potential >= LMC_POT_FULL && cfg->dim > 256)
         return fail(nullptr, LMC_ERR_INVALID, "dense mass matrices are supported up to dim 256 (got %d)", cfg->dim);
@@ -709,17 +713,18 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         DenseArrays& D = e->D;
         const size_t d = cfg->dim;
         e->d8 = (cfg->dim + 7) / 8 * 8;
-        D.kind = cfg->potential;
+        D.kind = cfg->potential == LMC_POT_FULL_F64 ? static_cast<int>(kDenseFullInv) : cfg->potential;   // device code: float64 sweeps, momentum = sweep of D.fac
         const bool per_chain = cfg->potential == LMC_POT_FULL_ADAPT;
         const size_t P = per_chain ? C : 1;
         const size_t drows = sweep_rows(cfg->dim);
         D.mat_stride = per_chain ? static_cast<long long>(drows * dp) : 0;
         D.fac_stride = per_chain ? static_cast<long long>(e->d8) * static_cast<long long>(dp) : 0;
-        if (cfg->potential == LMC_POT_FULL_INV) {
+        if (pot_f64(cfg->potential)) {
             double *m = nullptr, *f = nullptr;
             if ((rc = dev_alloc(e, &m, drows * dp)) != LMC_OK) return bail(rc);
             if ((rc = dev_alloc(e, &f, drows * dp)) != LMC_OK) return bail(rc);
             D.covT = m; D.fac = f;
+            if (cfg->potential == LMC_POT_FULL_F64 && (rc = dev_alloc(e, &e->chol64T, drows * dp)) != LMC_OK) return bail(rc);
         } else {
             float *m = nullptr, *f = nullptr;
             if ((rc = dev_alloc(e, &m, P * drows * dp)) != LMC_OK) return bail(rc);
@@ -1024,6 +1029,31 @@ int lmc_engine_set_dense_potential(lmc_engine* e, const double* matrix, const do
         HIP_TRY(e, hipMemcpy(e->D.fac, LT.data(), LT.size() * sizeof(double), hipMemcpyHostToDevice));
         return LMC_OK;
     }
+    if (e->cfg.potential == LMC_POT_FULL_F64) {
+        // QuadPotentialFull(cov, dtype="float64"): L = cholesky(cov) in float64 (quadpotential.py:441-443); velocity = cov x
+        // (:446-448); random = solve_triangular(L^T, n) (:450-453) = L^-T n, served by the rows of L^-1 (extended precision)
+        std::vector<double> L(m);
+        if (!host_cholesky(L, d)) return fail(e, LMC_ERR_INVALID, "matrix is not positive definite");
+        std::vector<long double> Li(dd, 0.0L);
+        for (int c = 0; c < d; ++c)
+            for (int i = c; i < d; ++i) {
+                long double acc = (i == c) ? 1.0L : 0.0L;
+                for (int k = c; k < i; ++k) acc -= static_cast<long double>(L[static_cast<size_t>(i) * d + k]) * Li[static_cast<size_t>(k) * d + c];
+                Li[static_cast<size_t>(i) * d + c] = acc / L[static_cast<size_t>(i) * d + i];
+            }
+        const size_t drows = sweep_rows(d);
+        std::vector<double> covT(drows * dp, 0.0), finv(drows * dp, 0.0), LT(drows * dp, 0.0);
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                covT[static_cast<size_t>(j) * dp + i] = m[static_cast<size_t>(i) * d + j];
+                LT[static_cast<size_t>(j) * dp + i] = (j <= i) ? L[static_cast<size_t>(i) * d + j] : 0.0;
+                finv[static_cast<size_t>(i) * dp + j] = (j <= i) ? static_cast<double>(Li[static_cast<size_t>(i) * d + j]) : 0.0;   // row k of L^-1 over i
+            }
+        HIP_TRY(e, hipMemcpy(e->D.covT, covT.data(), covT.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(e->D.fac, finv.data(), finv.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(e->chol64T, LT.data(), LT.size() * sizeof(double), hipMemcpyHostToDevice));
+        return LMC_OK;
+    }
     // QuadPotentialFull / FullAdapt: float32 covariance and its lower Cholesky factor (quadpotential.py:441-443)
     std::vector<float> cov(dd);
     for (size_t i = 0; i < dd; ++i) cov[i] = static_cast<float>(m[i]);
@@ -1090,8 +1120,9 @@ static int dense_state_xfer(lmc_engine* e, const lmc_dense_state* st, bool to_us
     HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
     const size_t C = e->cfg.chains, d = e->cfg.dim, dp = e->dpad, d8 = e->d8;
     const bool adapt = e->cfg.potential == LMC_POT_FULL_ADAPT;
-    const bool inv = e->cfg.potential == LMC_POT_FULL_INV;
+    const bool inv = pot_f64(e->cfg.potential);   // float64 matrices, factor stored transposed
     const DenseArrays& D = e->D;
+    const void* fac_src = e->cfg.potential == LMC_POT_FULL_F64 ? static_cast<const void*>(e->chol64T) : D.fac;
     if (!to_user && !adapt) return fail(e, LMC_ERR_STATE, "only FULL_ADAPT has settable dense state");
     if (!adapt && (st->fore_mean || st->fore_raw_cov || st->fore_n || st->back_mean || st->back_raw_cov || st->back_n ||
                    st->window || st->previous_update || st->chol_failures))
@@ -1121,7 +1152,7 @@ static int dense_state_xfer(lmc_engine* e, const lmc_dense_state* st, bool to_us
     if (to_user) {
         const size_t drows = sweep_rows(e->cfg.dim);
         if (st->cov && (rc = mat_to_user(st->cov, D.covT, drows, inv, true)) != LMC_OK) return rc;
-        if (st->chol && (rc = mat_to_user(st->chol, D.fac, inv ? drows : d8, inv, inv)) != LMC_OK) return rc;
+        if (st->chol && (rc = mat_to_user(st->chol, fac_src, inv ? drows : d8, inv, inv)) != LMC_OK) return rc;
     } else {
         auto mat_from_user = [&](const float* user, float* dev, size_t rows, bool transpose, bool identity_pad) -> int {
             std::vector<float> in(C * d * d), host(C * rows * dp, 0.0f);
@@ -1225,7 +1256,8 @@ int lmc_engine_get_dense_chain(lmc_engine* e, int32_t chain, float* cov, float* 
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
     const size_t d = e->cfg.dim, dp = e->dpad;
-    const bool inv = e->cfg.potential == LMC_POT_FULL_INV;
+    const bool inv = pot_f64(e->cfg.potential);
+    const void* fac_src = e->cfg.potential == LMC_POT_FULL_F64 ? static_cast<const void*>(e->chol64T) : e->D.fac;
     const size_t esz = inv ? sizeof(double) : sizeof(float);
     auto fetch = [&](float* user, const void* dev, long long stride, bool transpose) -> int {
         std::vector<char> raw(d * dp * esz);
@@ -1243,7 +1275,7 @@ int lmc_engine_get_dense_chain(lmc_engine* e, int32_t chain, float* cov, float* 
     };
     int rc;
     if (cov && (rc = fetch(cov, e->D.covT, e->D.mat_stride, true)) != LMC_OK) return rc;
-    if (chol && (rc = fetch(chol, e->D.fac, e->D.fac_stride, inv)) != LMC_OK) return rc;
+    if (chol && (rc = fetch(chol, fac_src, e->D.fac_stride, inv)) != LMC_OK) return rc;
     return LMC_OK;
 }
 
@@ -1511,9 +1543,9 @@ int lmc_engine_tick(lmc_engine* e, const double* logp, const double* grad, int32
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     SamplerParams P = make_params(e, e->K.n_tune, 0, 0);
     if (e->cfg.potential >= LMC_POT_FULL) {
-        P.momentum_f32 = e->cfg.potential != LMC_POT_FULL_INV;
+        P.momentum_f32 = !pot_f64(e->cfg.potential);
         P.adapt_mass = 0;
-        int rc = tick_dense_launch(e->ns, e->cfg.potential == LMC_POT_FULL_INV, main_stream(e), e->A, e->D, e->K, P, logp, grad,
+        int rc = tick_dense_launch(e->ns, pot_f64(e->cfg.potential), main_stream(e), e->A, e->D, e->K, P, logp, grad,
                                    e->adapt_mask);
         if (rc != 0) return dense_fail(e, rc, "tick");
         if (e->cfg.potential == LMC_POT_FULL_ADAPT) {   // update() of the chains that finished a tuning iteration in this tick
@@ -1773,7 +1805,7 @@ int lmc_engine_trajectory(lmc_engine* e, const double* q0, const double* p0, int
     HIP_TRY(e, hipMemcpyAsync(dq0.p, q0, C * d * sizeof(double), hipMemcpyDefault, main_stream(e)));
     HIP_TRY(e, hipMemcpyAsync(dp0.p, p0, C * d * sizeof(double), hipMemcpyDefault, main_stream(e)));
     if (e->cfg.potential >= LMC_POT_FULL) {
-        const int rc = dense_launch_trajectory(e->cfg.target_family, e->ns, e->cfg.potential == LMC_POT_FULL_INV, main_stream(e),
+        const int rc = dense_launch_trajectory(e->cfg.target_family, e->ns, pot_f64(e->cfg.potential), main_stream(e),
                                                e->A, e->D, e->tparams, dq0.p, dp0.p, p0_is_f32,
                                                e->cfg.start_energy_sdot, eps, n_fwd, n_back, oq.p, op.p, ov.p, og.p,
                                                oe.p, ol.p);

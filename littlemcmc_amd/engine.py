@@ -36,7 +36,7 @@ class Engine:
         cfg.kind = {"nuts": _abi.KIND_NUTS, "hmc": _abi.KIND_HMC}[kind]
         cfg.target_family = int(target.family)
         cfg.potential = {"diag_adapt": _abi.POT_DIAG_ADAPT, "diag": _abi.POT_DIAG, "full": _abi.POT_FULL,
-                         "full_inv": _abi.POT_FULL_INV, "full_adapt": _abi.POT_FULL_ADAPT}[potential]
+                         "full_inv": _abi.POT_FULL_INV, "full_adapt": _abi.POT_FULL_ADAPT, "full_f64": _abi.POT_FULL_F64}[potential]
         self.potential = potential
         cfg.adapt_step_size = int(bool(adapt_step_size))
         cfg.target_accept = float(target_accept)

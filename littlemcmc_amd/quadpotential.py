@@ -267,24 +267,37 @@ class _DensePotential(QuadPotential):
 
 
 class QuadPotentialFull(_DensePotential):
-    """quadpotential.py:428-468: float32 covariance ``cov``; velocity = cov @ x, momentum = solve(chol.T, z)."""
+    """quadpotential.py:428-468: covariance ``cov`` in ``dtype`` (float32 by default, like the reference; "float64" keeps
+    the matrix, the velocity cov @ x and the momentum solve(chol.T, z) in float64)."""
 
     _engine_kind = "full"
     _momentum_f32 = True
 
     def __init__(self, cov, dtype=None):
-        if dtype not in (None, "float32", np.float32):
-            raise NotImplementedError("the device mass matrix is float32, like the reference's default")
+        if dtype in (None, "float32", np.float32):
+            self.dtype = "float32"
+        elif dtype in ("float64", np.float64, "d", float):
+            self.dtype = "float64"
+            self._engine_kind = "full_f64"      # include/lmc_hip.h: LMC_POT_FULL_F64
+            self._momentum_f32 = False
+        else:
+            raise NotImplementedError("the device mass matrix is float32 (the reference's default) or float64")
         cov = _square(cov, "cov")
         super().__init__(cov.shape[0])
-        self.dtype = "float32"
         self._matrix = np.array(cov, dtype="d")
-        self._cov = np.array(cov, dtype="float32", copy=True)
+        self._cov = np.array(cov, dtype=self.dtype, copy=True)
         self._chol = None
         self._n_samples = 0
 
     def _matrix_args(self):
         return (self._matrix,)
+
+    def _pull(self, engine, chain=0):
+        cov, chol = engine.dense_chain(chain)          # float32 views of the device's matrices
+        if self.dtype == "float32":
+            self._cov, self._chol = cov, chol
+        else:                                          # the float64 matrix is the caller's own; the factor is reported in float32 precision
+            self._chol = chol.astype("d")
 
     __call__ = QuadPotential.random
 

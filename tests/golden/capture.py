@@ -450,6 +450,39 @@ def capture_dense_e2e():
 
 
 # ---------------------------------------------------------------------------------------
+# 7b. QuadPotentialFull(cov, dtype="float64") (quadpotential.py:431-444: the dtype argument): float64 covariance,
+#     float64 momentum by a float64 triangular solve. Unit values of the potential + one end-to-end NUTS run.
+# ---------------------------------------------------------------------------------------
+def capture_dense_full64():
+    from littlemcmc import quadpotential as rq
+
+    fam, d, chains, tune, draws = "ar1", 12, 2, 200, 100
+    f = targets.make(fam, d)
+    cov = ar1_cov(d, 0.9)
+    pot = rq.QuadPotentialFull(cov, dtype="float64")
+    rs = np.random.RandomState(77)
+    x = rs.randn(d)
+    np.random.seed(4711)
+    rnd = np.array([pot.random() for _ in range(3)])
+    unit = dict(unit_x=x, unit_velocity=pot.velocity(x), unit_energy=np.array(pot.energy(x)), unit_random=rnd,
+                unit_random_seed=np.array(4711), unit_random_dtype=np.array(str(rnd.dtype)), unit_chol=np.array(pot._chol, dtype="d"))
+    step = ref.NUTS(f, d, potential=pot)
+    trace, stats = ref.sample(f, d, draws=draws, tune=tune, step=step, chains=chains, cores=1, progressbar=False,
+                              random_seed=SEED + 41, discard_tuned_samples=False)
+    np.random.seed(SEED + 41)
+    seeds = np.array([np.random.randint(2 ** 30) for _ in range(chains)])
+    arrays = dict(family=np.array(fam), kind=np.array("nuts"), potential=np.array("full64"), d=np.array(d),
+                  chains=np.array(chains), tune=np.array(tune), draws=np.array(draws), seeds=seeds,
+                  random_seed=np.array(SEED + 41), params=f.params(), trace=trace, matrix=cov,
+                  final_da=np.array([float(np.ravel(v)[0]) for v in (step.step_adapt._log_step, step.step_adapt._log_bar,
+                                                                     step.step_adapt._hbar, step.step_adapt._count)]))
+    arrays.update(unit)
+    for k, v in stats.items():
+        arrays["stat_" + k] = v
+    save("e2e_nuts_full64_ar1_12", **arrays)
+
+
+# ---------------------------------------------------------------------------------------
 # 8. QuadPotentialDiagAdapt with a growing adaptation window (adaptation_window_multiplier != 1)
 # ---------------------------------------------------------------------------------------
 def capture_diag_window_multiplier():
@@ -516,7 +549,7 @@ def capture_step_rand():
 
 CAPTURES = {"leapfrog": capture_leapfrog, "transitions": capture_transitions, "adapt": capture_adapt,
             "e2e": capture_e2e, "seeds": capture_seeds, "dense_units": capture_dense_units,
-            "dense_adapt": capture_dense_adapt, "dense_e2e": capture_dense_e2e,
+            "dense_adapt": capture_dense_adapt, "dense_e2e": capture_dense_e2e, "dense_full64": capture_dense_full64,
             "diag_window_multiplier": capture_diag_window_multiplier, "step_rand": capture_step_rand}
 
 if __name__ == "__main__":

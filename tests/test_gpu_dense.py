@@ -166,7 +166,8 @@ def test_full_adapt_singular_estimate_keeps_the_factor(golden_dir):
 # oracle's exact pre-iteration state (one wavefront per iteration)
 # ---------------------------------------------------------------------------------------------------
 DENSE_E2E = ["e2e_nuts_full_ar1_12", "e2e_nuts_fullinv_ar1_12", "e2e_hmc_full_std10",
-             "e2e_nuts_adaptfull_ar1_10_a", "e2e_nuts_adaptfull_ar1_10_b", "e2e_nuts_adaptfull_std70"]
+             "e2e_nuts_adaptfull_ar1_10_a", "e2e_nuts_adaptfull_ar1_10_b", "e2e_nuts_adaptfull_std70",
+             "e2e_nuts_full64_ar1_12"]
 
 
 def _oracle_and_device_steps(g):
@@ -174,10 +175,10 @@ def _oracle_and_device_steps(g):
     potk, kind = str(g["potential"]), str(g["kind"])
     of = otargets.make(str(g["family"]), d)
     tgt = device_target(g["family"], d, g["params"])
-    if potk in ("full", "inv"):
-        opot = orc.quad_potential(g["matrix"], potk == "full")
+    if potk in ("full", "inv", "full64"):
+        opot = orc.FullPotential(g["matrix"], dtype="float64") if potk == "full64" else orc.quad_potential(g["matrix"], potk == "full")
         ostep = orc.Step(of, d, kind=kind, potential=opot)
-        dpot = _pot("full" if potk == "full" else "inv", g["matrix"])
+        dpot = lmc.QuadPotentialFull(g["matrix"], dtype="float64") if potk == "full64" else _pot("full" if potk == "full" else "inv", g["matrix"])
         dstep = (lmc.HamiltonianMC if kind == "hmc" else lmc.NUTS)(tgt, d, potential=dpot)
         start = orc.jitter_start(int(g["seeds"][0]), d)
     else:
@@ -224,7 +225,7 @@ def test_dense_transitions_replay_the_reference_chain(golden_dir, name):
     snaps, outs = _snapshots(ostep, start, int(g["seeds"][0]), tune, draws)
     # the oracle chain IS the reference chain (pinned bit for bit by tests/test_oracle_dense_golden.py)
     np.testing.assert_allclose(np.array([o["q"] for o in outs]), g["trace"][0], rtol=1e-9, atol=1e-300)
-    f32_born = str(g["potential"]) != "inv"
+    f32_born = str(g["potential"]) not in ("inv", "full64")
     tol = REPLAY_F32 if f32_born else REPLAY_F64
     floor = DECISION if f32_born else 1e-9
     checked = skipped = 0
@@ -448,3 +449,30 @@ def test_dense_checkpoint_resume_is_exact():
         eng.run(tune, cut, tune + draws - cut)
         second = eng.trace(cut, tune + draws - cut)
     np.testing.assert_array_equal(np.concatenate([first, second], axis=1), want)
+
+
+def test_full_potential_float64(golden_dir):
+    """QuadPotentialFull(cov, dtype="float64") (quadpotential.py:431-444, the dtype argument; LMC_POT_FULL_F64): velocity,
+    energy and random() on the device against the values captured from the reference -- float64 throughout, so to 1e-12 --
+    and same-seed chains through sample(): the momentum is solve_triangular(chol.T, z) served by the rows of L^-1."""
+    g = _load(golden_dir, "e2e_nuts_full64_ar1_12")
+    d = int(g["d"])
+    pot = lmc.QuadPotentialFull(g["matrix"], dtype="float64")
+    assert pot.dtype == "float64"
+    x = g["unit_x"]
+    np.testing.assert_allclose(pot.velocity(x), g["unit_velocity"], rtol=1e-12)
+    np.testing.assert_allclose(pot.energy(x), float(g["unit_energy"]), rtol=1e-12)
+    np.random.seed(int(g["unit_random_seed"]))
+    draws = np.array([pot.random() for _ in range(3)])
+    assert draws.dtype == np.float64
+    np.testing.assert_allclose(draws, g["unit_random"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(pot._chol, g["unit_chol"], rtol=1e-6, atol=1e-7)      # reported in float32 precision
+    tgt = device_target(g["family"], d, g["params"])
+    step = lmc.NUTS(tgt, d, potential=lmc.QuadPotentialFull(g["matrix"], dtype="float64"))
+    chains, tune, draws_n = int(g["chains"]), int(g["tune"]), int(g["draws"])
+    trace, stats = lmc.sample(tgt, d, draws=draws_n, tune=tune, step=step, chains=chains, cores=1, progressbar=False,
+                              random_seed=int(g["random_seed"]), discard_tuned_samples=False)
+    n = 12   # tuned chains decorrelate geometrically (DESIGN.md section 5): a solid prefix, every iteration is replayed above
+    np.testing.assert_array_equal(stats["tree_size"][:, :n], g["stat_tree_size"][:, :n])
+    np.testing.assert_array_equal(stats["depth"][:, :n], g["stat_depth"][:, :n])
+    np.testing.assert_allclose(trace[:, :n], g["trace"][:, :n], rtol=1e-7, atol=1e-9)

@@ -82,7 +82,8 @@ def test_dense_adapt_singular_estimate_keeps_the_factor(golden_dir):
 
 
 DENSE_E2E = ["e2e_nuts_full_ar1_12", "e2e_nuts_fullinv_ar1_12", "e2e_hmc_full_std10",
-             "e2e_nuts_adaptfull_ar1_10_a", "e2e_nuts_adaptfull_ar1_10_b", "e2e_nuts_adaptfull_std70"]
+             "e2e_nuts_adaptfull_ar1_10_a", "e2e_nuts_adaptfull_ar1_10_b", "e2e_nuts_adaptfull_std70",
+             "e2e_nuts_full64_ar1_12"]
 
 
 def dense_run_from_golden(g):
@@ -90,8 +91,8 @@ def dense_run_from_golden(g):
     d = int(g["d"])
     f = targets.make(str(g["family"]), d)
     potk = str(g["potential"])
-    if potk in ("full", "inv"):
-        pot = orc.quad_potential(g["matrix"], potk == "full")
+    if potk in ("full", "inv", "full64"):
+        pot = orc.FullPotential(g["matrix"], dtype="float64") if potk == "full64" else orc.quad_potential(g["matrix"], potk == "full")
         step = orc.Step(f, d, kind=str(g["kind"]), potential=pot)
         return f, step, dict(random_seed=int(g["random_seed"]))
     return f, None, dict(random_seed=[int(g["seeds"][0])], init=potk)
@@ -112,3 +113,17 @@ def test_dense_e2e_golden(golden_dir, name):
         else:
             np.testing.assert_allclose(stats[name_], want, rtol=RTOL, atol=1e-12, err_msg=name_)
     np.testing.assert_allclose(trace, g["trace"], rtol=RTOL, atol=1e-300)
+
+
+def test_full_potential_float64_units(golden_dir):
+    """QuadPotentialFull(cov, dtype="float64") (quadpotential.py:431-444): velocity, energy, random() of the oracle against
+    the values captured from the reference."""
+    g = _load(golden_dir, "e2e_nuts_full64_ar1_12")
+    pot = orc.FullPotential(g["matrix"], dtype="float64")
+    x = g["unit_x"]
+    np.testing.assert_allclose(pot.velocity(x), g["unit_velocity"], rtol=RTOL)
+    np.testing.assert_allclose(0.5 * x.dot(pot.velocity(x)), float(g["unit_energy"]), rtol=RTOL)
+    rng = np.random.RandomState(int(g["unit_random_seed"]))
+    draws = np.array([pot.random(rng) for _ in range(3)])
+    assert str(draws.dtype) == str(g["unit_random_dtype"]) == "float64"
+    np.testing.assert_allclose(draws, g["unit_random"], rtol=RTOL)
