@@ -164,3 +164,47 @@ def test_two_rank_gloo_reduction_equals_single_process(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
         assert "ok" in o
+
+
+WORKER8 = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+torch.set_num_threads(1)
+from littlemcmc_amd import diagnostics as dg
+from littlemcmc_amd.distributed import chain_block
+from oracle import diagnostics_oracle as odg
+from tests.test_diagnostics_cpu import ar1_chains
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+fft = odg.torch_chain_stats
+for total in (13, 5):          # 13 chains over 8 ranks: blocks of 2 and 1; 5 chains: three ranks own nothing
+    x = ar1_chains(total, 200, 2, 0.9, 17 + total)
+    lo, hi = chain_block(total, rank, world)
+    blk = torch.from_numpy(x[lo:hi]) if hi > lo else torch.zeros((0, 3, 2), dtype=torch.float64)
+    got = dg.summarize(blk, stats_fn=fft)
+    rhat, ess = odg.rhat_ess(x)
+    np.testing.assert_allclose(got["rhat"].numpy(), rhat, rtol=1e-9)
+    np.testing.assert_allclose(got["ess"].numpy(), ess, rtol=1e-7)
+    assert got["n_chains"] == 2.0 * total and got["lag_passes"] >= 2
+    z = dg.summarize(blk, stats_fn=fft, rank_normalized=True)
+    rz, ez = odg.rhat_ess(x, rank_normalized=True)
+    np.testing.assert_allclose(z["rhat"].numpy(), rz, rtol=1e-8)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_eight_rank_gloo_reduction_with_uneven_and_empty_blocks(tmp_path):
+    """The diagnostics reduction as the 8-GPU job issues it (world_size 8, gloo, CPU): uneven chain blocks, ranks that own
+    no chain, several lag passes, the globally rank-normalised variant -- every rank issues the same collectives and gets
+    the all-chain result."""
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", WORLD_SIZE="8", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(8)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+        assert "ok" in o
