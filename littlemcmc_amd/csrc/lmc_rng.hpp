@@ -114,31 +114,16 @@ __device__ inline void mt_regen(RngState& r) {
     r.pos = 0;
 }
 
-// The same twist OUT OF PLACE (one wave): nxt = genrand(cur). With separate buffers a batch writes what it computes at
-// once (no write-after-read hazard), so three wave syncs order the whole twist instead of seven. A team's spare wave runs
-// it while the other waves still read `cur` (lmc_sampler.hpp: team_normals_parallel).
-__device__ inline void mt_regen_into(const uint32_t* cur, uint32_t* nxt) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {   // i in [0, 227): old words only
-        const int i = lane + 64 * k;
-        if (i < 227) nxt[i] = mt_twist(cur[i], cur[i + 1], cur[i + kMtM]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {   // i in [227, 454): new[i - 227] from the first batch
-        const int i = 227 + lane + 64 * k;
-        if (i < 454) nxt[i] = mt_twist(cur[i], cur[i + 1], nxt[i - 227]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {   // i in [454, 623): new[i - 227] from the second batch
-        const int i = 454 + lane + 64 * k;
-        if (i < 623) nxt[i] = mt_twist(cur[i], cur[i + 1], nxt[i - 227]);
-    }
-    wave_sync();
-    if (lane == 0) nxt[623] = mt_twist(cur[623], nxt[0], nxt[396]);
-    wave_sync();
+// The twist decomposes into 227 independent STRANDS: new[s], new[s + 227], new[s + 454] depend on old words and on each
+// other (new[i] needs new[i - 227], and 227 is exactly the batch length), never on another strand; only the last word
+// needs new[0] and new[396]. Out of place, one thread per strand therefore twists a whole generation in three dependent
+// word steps with no synchronisation in between (team_normals_parallel: all four waves of a team, 227 of 256 threads).
+__device__ __forceinline__ void mt_twist_strand(const uint32_t* cur, uint32_t* nxt, int s) {   // s < 227
+    const uint32_t n0 = mt_twist(cur[s], cur[s + 1], cur[s + kMtM]);
+    nxt[s] = n0;
+    const uint32_t n1 = mt_twist(cur[s + 227], cur[s + 228], n0);
+    nxt[s + 227] = n1;
+    if (s + 454 < kMtN - 1) nxt[s + 454] = mt_twist(cur[s + 454], cur[s + 455], n1);
 }
 
 // rk_double: (a >> 5, b >> 6) -> 53-bit fraction. Wave-uniform.

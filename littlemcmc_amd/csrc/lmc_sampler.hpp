@@ -315,18 +315,21 @@ __device__ __forceinline__ double jitter_step_size(TeamT& tm, RngState& rng, con
 // instruction at a lone wave's issue latency while three waves wait at a barrier) it is 36 % of C4's iteration; with the
 // draw off the critical path altogether (LMC_RNG_PHILOX) C4 runs 3.05e8 instead of 2.1e8. Here
 //   * a round evaluates one attempt per thread of waves 0..2 in stream order -- a generation of 624 words holds 156;
-//   * wave 3 meanwhile twists the generation OUT OF PLACE into a second LDS buffer (mt_regen_into), so the next
-//     generation is ready when the round's barrier falls; the (at most two) words of the old generation that no whole
-//     attempt used are carried in registers, the buffers swap, and the old buffer is free to receive the generation after;
+//   * in the same round the team twists the generation OUT OF PLACE into a second LDS buffer, one thread per strand
+//     (mt_twist_strand: three dependent word steps, no synchronisation), so the next generation is ready when the round's
+//     barrier falls (its last word, which needs two other threads' results, right behind the barrier); the (at most two)
+//     words of the old generation that no whole attempt used are carried in registers, the buffers swap, and the old
+//     buffer is free to receive the generation after;
 //   * the waves' acceptance masks travel through the team's exchange area (the round's one barrier) and every wave then
 //     knows every wave's mask: ranks, pairs taken and, in the last round, the attempt that ends the call are scalar
 //     arithmetic on the masks, identical in every wave -- the stream position is never broadcast;
 //   * the accepted pairs are compacted into `stage` in stream order and the expensive part runs over 256 pairs at a time.
 // Consumption order, accepted set and arithmetic are rng_normals' (lmc_rng.hpp), hence numpy's. On return r.mt points to
 // the buffer that holds the current generation (either of the two).
-// Measured on C4 (tools/phase_timing.py): the draw 27.9 k -> 22.0 k ticks per iteration, 2.06e8 -> 2.23e8 leapfrogs/s. A
-// round now lasts as long as the lone wave's twist (~3.5 k cycles for ~160 dependent-latency instructions); a first
-// version that parallelised the attempts but left twist and generation crossing to wave 0 measured no gain at all.
+// History (C4, tools/phase_timing.py: ticks of the draw per iteration / leapfrogs per second): wave 0 alone 27.9 k /
+// 2.06e8; attempts on all waves but twist and generation crossing still wave 0's: no gain; the fourth wave twisting out
+// of place (three dependent batches) beside the attempts: 22.0 k / 2.20e8; the twist by strands on all waves: 20.4 k /
+// 2.27e8. What is left is one team barrier per generation (five per draw at d = 1000) plus three around the second phase.
 template <class TeamT>
 __device__ inline void team_normals_parallel(TeamT& tm, RngState& r, int d, double* out, double* stage, uint32_t* buf_a,
                                              uint32_t* buf_b) {
@@ -348,10 +351,13 @@ __device__ inline void team_normals_parallel(TeamT& tm, RngState& r, int d, doub
     uint32_t carry0 = 0u, carry1 = 0u;
     int ncarry = 0;          // words of the previous generation ahead of cur[pos] (0 or 2)
     bool next_ready = false; // the other buffer holds genrand(cur)
+    uint32_t gen623 = 0u;    // word 623 of cur once cur is a generation twisted in this call (thread 0 stores it behind a
+    bool have623 = false;    // barrier; the waves that need it before the next barrier use this copy)
+    uint32_t next623 = 0u;   // word 623 of the generation in the other buffer
     while (have < need_pairs) {
         uint32_t* alt = (cur == buf_a) ? buf_b : buf_a;
         const bool twisting = !next_ready;
-        if (twisting && wave == W - 1) mt_regen_into(cur, alt);
+        if (twisting && tid < 227) mt_twist_strand(cur, alt, tid);
         // attempts of this round: whole attempts in carry ++ cur[pos, 624), one per thread of waves 0 .. W-2
         const int navail = (ncarry + kMtN - pos) >> 2;
         const int n_att = navail < 64 * (W - 1) ? navail : 64 * (W - 1);
@@ -371,15 +377,19 @@ __device__ inline void team_normals_parallel(TeamT& tm, RngState& r, int d, doub
             mask = ballot64(r2 > 0.0) & ballot64(r2 < 1.0) & lanes;
         }
         // the words no whole attempt of this generation can use (read before the barrier: the buffer is twisted over after it)
-        const uint32_t tail0 = first_u32(cur[kMtN - 2]), tail1 = first_u32(cur[kMtN - 1]);
+        const uint32_t tail0 = first_u32(cur[kMtN - 2]), tail1 = have623 ? gen623 : first_u32(cur[kMtN - 1]);
         double v[2 * (W - 1)];
 #pragma unroll
         for (int k = 0; k < W - 1; ++k) {   // exact: a 32-bit integer in a double, the other waves' slots contribute 0
             v[2 * k] = (k == wave) ? static_cast<double>(static_cast<uint32_t>(mask)) : 0.0;
             v[2 * k + 1] = (k == wave) ? static_cast<double>(static_cast<uint32_t>(mask >> 32)) : 0.0;
         }
-        tm.template exchange<2 * (W - 1)>(v);   // the round's one barrier: all reads of cur and the whole twist are behind it
-        if (twisting) next_ready = true;
+        tm.template exchange<2 * (W - 1)>(v);   // the round's one barrier: all reads of cur and the strands of the twist are behind it
+        if (twisting) {   // the generation's last word: every wave forms it for itself, thread 0 stores it
+            next623 = first_u32(mt_twist(tail1, alt[0], alt[396]));
+            if (tid == 0) alt[kMtN - 1] = next623;
+            next_ready = true;
+        }
         int before = 0, total = 0;
         unsigned long long m[W - 1];
 #pragma unroll
@@ -423,6 +433,7 @@ __device__ inline void team_normals_parallel(TeamT& tm, RngState& r, int d, doub
             cur = alt;
             pos = 0;
             next_ready = false;
+            gen623 = next623; have623 = true;
         }
     }
     r.mt = cur;
