@@ -530,3 +530,23 @@ def test_counter_based_momentum_stream_samples_the_target_and_is_partition_invar
     ref, _ = lmc.sample(tgt2, d2, draws=15, tune=40, chains=8, random_seed=seeds2[:8], start=start2, step=step4)
     assert not np.allclose(ref, full[:8])
     assert np.isfinite(full).all() and abs(full.var() - 1.0) < 0.5
+
+
+@pytest.mark.parametrize("kind,d", [("hmc", 10), ("nuts_fixed_diag", 70), ("nuts_team", 600)])
+def test_counter_based_momentum_stream_other_paths(kind, d):
+    """LMC_RNG_PHILOX through the other instantiations: HamiltonianMC, a fixed diagonal potential (float64 momentum,
+    quadpotential.py:374-376) and a team of wavefronts (every thread draws its own elements, no barrier): the draws have the
+    target's moments."""
+    chains = 2048 if d < 100 else 512
+    tgt = T.StdNormal(d)
+    if kind == "hmc":
+        step = lmc.HamiltonianMC(tgt, d, path_length=2.0, momentum_rng="philox")
+    elif kind == "nuts_fixed_diag":
+        step = lmc.NUTS(tgt, d, scaling=np.full(d, 1.3), is_cov=True, momentum_rng="philox")
+    else:
+        step = lmc.NUTS(tgt, d, momentum_rng="philox")
+    trace, stats = lmc.sample(tgt, d, draws=300, tune=300, step=step, chains=chains, random_seed=5)
+    assert np.isfinite(trace).all() and not stats["diverging"].any()
+    n = chains * 300
+    assert np.abs(trace.mean(axis=(0, 1))).max() < 6.0 / np.sqrt(n) + 5e-3
+    assert np.abs(trace.var(axis=(0, 1)) - 1.0).max() < 0.03
