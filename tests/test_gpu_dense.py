@@ -489,6 +489,7 @@ def test_keyboard_interrupt_in_the_shared_matrix_kernel(monkeypatch):
     cov = 0.9 ** np.abs(idx[:, None] - idx[None, :])
     tgt = lmc.targets.AR1(d, 0.9)
     step = lmc.NUTS(tgt, d, potential=lmc.QuadPotentialFull(cov))
+    lmc.sample(tgt, d, draws=5, tune=5, chains=64, step=lmc.NUTS(tgt, d, potential=lmc.QuadPotentialFull(cov)), random_seed=1)   # code objects loaded
     real_sleep = time.sleep
     fired = []
 

@@ -268,6 +268,7 @@ def test_keyboard_interrupt_returns_the_draws_so_far(monkeypatch):
 
     d, chains, tune, draws = 64, 4096, 50, 20000
     tgt = T.StdNormal(d)
+    lmc.sample(tgt, d, draws=5, tune=5, chains=64, random_seed=1)      # code objects loaded: the clock below starts with the kernels
     real_sleep = time.sleep
     fired = []
 
