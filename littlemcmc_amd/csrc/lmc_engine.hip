@@ -193,8 +193,8 @@ struct lmc_engine {
     hipEvent_t main_done = nullptr;
     double* chol64T = nullptr;  // FULL_F64: LT[j][i] = L[i][j] of the covariance's factor (what the state getters hand out; D.fac holds L^-1)
     uint32_t* seeds = nullptr;  // [C] the seeds of lmc_engine_seed (key of LMC_RNG_PHILOX's momentum stream)
-    int* stop_flag = nullptr;   // device word the sampling kernels poll once per iteration (lmc_engine_request_stop)
-    hipStream_t ctl_stream = nullptr;   // carries the stop request past the kernels in flight
+    int* stop_host = nullptr;   // pinned, device-mapped host word the sampling kernels poll (lmc_engine_request_stop): the host
+                                // sets it with a plain store -- no stream, no copy engine, no command processor in the way
     int step_jitter = 0;        // step_rand as step * uniform(lo, hi) (lmc_engine_set_step_jitter)
     double jitter_lo = 1.0, jitter_hi = 1.0;
     bool sub_pending = false;   // sub-block kernels in flight that the main stream has not been ordered after
@@ -668,8 +668,14 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     TRY_ALLOC(dev_alloc(e, &A.rng_gauss, C));
     TRY_ALLOC(dev_alloc(e, &A.status, C));
     TRY_ALLOC(dev_alloc(e, &A.counters, C * kNumCounters));
-    TRY_ALLOC(dev_alloc(e, &e->stop_flag, 1));
-    A.stop = e->stop_flag;
+    {   // the stop word lives in pinned host memory mapped into the device (uncached, coherent): a request is a host store
+        void* dev_view = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&e->stop_host), 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer(&dev_view, e->stop_host, 0) != hipSuccess)
+            return bail(fail(nullptr, LMC_ERR_HIP, "stop word: %s", hipGetErrorString(hipGetLastError())));
+        *e->stop_host = 0;
+        A.stop = static_cast<const int*>(dev_view);
+    }
     TRY_ALLOC(dev_alloc(e, &e->seeds, C));
     A.seed = e->seeds;
     A.scratch_stride = static_cast<long long>(max_levels - nlds + 1) * 4 * dp + static_cast<long long>(kNumColdSlots) * dp;
@@ -784,7 +790,7 @@ void lmc_engine_destroy(lmc_engine* e) {
         if (e->sub_done[b]) (void)hipEventDestroy(e->sub_done[b]);
     }
     if (e->main_done) (void)hipEventDestroy(e->main_done);
-    if (e->ctl_stream) (void)hipStreamDestroy(e->ctl_stream);
+    if (e->stop_host) (void)hipHostFree(e->stop_host);
     for (void* p : e->allocs)
         if (p) (void)hipFree(p);
     if (e->user_module) (void)hipModuleUnload(e->user_module);
@@ -898,26 +904,20 @@ int lmc_engine_set_step_jitter(lmc_engine* e, int32_t enable, double lo, double 
     return LMC_OK;
 }
 
-// Ctrl-C: every chain leaves its launch at the next iteration boundary; launches still queued return at once.
+// Ctrl-C: every chain leaves its launch within a few iterations; launches still queued return at once. The word is a
+// host store into pinned, device-mapped memory that the kernels read uncached over the host link every 16th iteration
+// (and at the start of every launch). A device word set through a stream (hipStreamWriteValue32 / hipMemcpyAsync on a
+// stream of its own) was tried first: with every wave slot held by sampling kernels the command processor delivered it
+// only after 0.1 s (short waves) to seconds (waves that live as long as the launch), i.e. not at all for whole-job
+// launches (tools/ubench/stop_probe.hip).
 int lmc_engine_request_stop(lmc_engine* e, int32_t stop) {
     if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    static const int kOne = 1, kZero = 0;
-    if (stop) {   // overtakes the kernels in flight: its own stream, not ordered after anything
-        // A stream memory operation (executed by the command processor: needs no compute unit and no DMA engine). With
-        // every wave slot held by sampling kernels it lands in ~0.1 s; hipMemcpyAsync / hipMemsetAsync (a blit kernel that
-        // has to win a wave slot) took 2-30 s in the same situation (tools/ubench/stop_probe.hip).
-        if (!e->ctl_stream) HIP_TRY(e, hipStreamCreateWithFlags(&e->ctl_stream, hipStreamNonBlocking));
-        if (hipStreamWriteValue32(e->ctl_stream, e->stop_flag, 1u, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            HIP_TRY(e, hipMemcpyAsync(e->stop_flag, &kOne, sizeof(int), hipMemcpyHostToDevice, e->ctl_stream));
-        }
-        HIP_TRY(e, hipStreamSynchronize(e->ctl_stream));
-    } else {      // cleared in order: after everything that was launched under the request has drained
-        if (e->ctl_stream) HIP_TRY(e, hipStreamSynchronize(e->ctl_stream));
-        hipStream_t st = main_stream(e);
-        HIP_TRY(e, hipMemcpyAsync(e->stop_flag, &kZero, sizeof(int), hipMemcpyHostToDevice, st));
-        HIP_TRY(e, hipStreamSynchronize(st));
+    if (stop) {
+        __atomic_store_n(e->stop_host, 1, __ATOMIC_RELEASE);
+    } else {   // re-armed in order: after everything that was launched under the request has drained
+        HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
+        __atomic_store_n(e->stop_host, 0, __ATOMIC_RELEASE);
     }
     return LMC_OK;
 }

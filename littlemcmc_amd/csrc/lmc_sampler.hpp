@@ -1257,15 +1257,18 @@ constexpr int lds_tail_doubles(int w) {   // W == 4: a second MT19937 buffer beh
 
 // ---- pieces of the iteration body shared by the diagonal and the dense-mass kernels ---------------------------
 // lmc_engine_request_stop(): the host's Ctrl-C (sampling.py:324-328, :470-471 in the reference: keep what has been drawn).
-// One uncached dword per iteration, REQUESTED when the iteration starts and LOOKED AT when it ends (its latency hides
-// behind the whole iteration; looked at where it is requested it cost a full memory round trip per iteration). A team
+// The stop word is pinned host memory (the host sets it with a plain store; nothing on the device has to be scheduled
+// for the request to arrive). One uncached dword over the host link at the start of a launch and every 16th iteration,
+// REQUESTED when the iteration starts and LOOKED AT when it ends (its latency hides behind the whole iteration). A team
 // agrees on ONE value (thread 0's) so that no wave leaves a barrier behind.
 template <class CA>
-__device__ __forceinline__ int stop_request_load(const CA& A) {
+__device__ __forceinline__ int stop_request_load(const CA& A, int it, long long git) {
+    if (it != 0 && (git & 15) != 0) return 0;   // wave-uniform
     return __hip_atomic_load(A.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 template <class TeamT>
-__device__ __forceinline__ bool stop_requested(TeamT& tm, int loaded, double* bcast) {
+__device__ __forceinline__ bool stop_requested(TeamT& tm, int loaded, double* bcast, bool polled) {
+    if (!polled) return false;   // block-uniform: the same iterations poll in every wave
     if constexpr (TeamT::kWaves == 1) {
         return first_i32(loaded) != 0;
     } else {
@@ -1520,7 +1523,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         const bool tune = git < P.n_tune;
         const bool momentum_f32 = P.momentum_f32 != 0;
         LMC_PHASE(5)
-        const int stop_word = stop_request_load(ka.A());
+        const int stop_word = stop_request_load(ka.A(), it, git);
 
         // ---- momentum draw (quadpotential.py:221-224 / :374-376)
         double p0[NS];
@@ -1602,7 +1605,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
 
         if (A.mom_mean != nullptr && !tune) moments_update<NS>(A, tm, c, row, q);
         write_outputs<NS>(A, c, tid, git, q, out, da.step_now, da.step_bar_now, tune);
-        if (stop_requested(tm, stop_word, rng_bcast)) break;
+        if (stop_requested(tm, stop_word, rng_bcast, it == 0 || (git & 15) == 0)) break;
     }
 
     // ---- store persistent chain state (region 3 of the arguments)
