@@ -227,8 +227,9 @@ int lmc_engine_set_dual_average(lmc_engine* e, double log_step, double log_bar, 
 int lmc_engine_set_step_jitter(lmc_engine* e, int32_t enable, double lo, double hi);
 int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int64_t trace_begin);
 /* KeyboardInterrupt (sampling.py:324-328, :470-471: the reference keeps what has been drawn so far). stop = 1: every
- * chain leaves the launch it is in within 16 iterations and launches still queued return at once -- the stop word is
- * pinned host memory the kernels poll, so the request needs nothing scheduled on the device; chains end at different
+ * chain leaves the launch it is in within ~16 iterations and launches still queued return at once -- the stop word is
+ * pinned host memory that a few relay chains poll and copy to a device word, so the request needs nothing scheduled on
+ * the device; chains end at different
  * iterations (lmc_chain_state.iter_count says where, draws and statistics below the smallest one are complete for every
  * chain). stop = 0 re-arms the engine, ordered after everything launched so far. Fused kernels (diagonal and dense mass);
  * a tick-driven job stops by not ticking. */

@@ -600,7 +600,7 @@ __device__ __forceinline__ void dense_run_chain(const ChainArrays& A, const Dens
     for (int it = 0; it < P.n_iters; ++it) {
         const long long git = P.iter_begin + it;
         const bool tune = git < P.n_tune;
-        const int stop_word = stop_request_load(A, it, git);   // looked at when the iteration ends (lmc_sampler.hpp)
+        const int stop_word = stop_request_load(A, c - P.chain_begin, git);   // looked at when the iteration ends (lmc_sampler.hpp)
 
         // ---- momentum draw
         rng_normals(rng, d, lds, lds + dpad);

@@ -676,6 +676,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         *e->stop_host = 0;
         A.stop = static_cast<const int*>(dev_view);
     }
+    TRY_ALLOC(dev_alloc(e, &A.stop_dev, 1));   // what the relay chains set and every chain reads (zeroed)
     TRY_ALLOC(dev_alloc(e, &e->seeds, C));
     A.seed = e->seeds;
     A.scratch_stride = static_cast<long long>(max_levels - nlds + 1) * 4 * dp + static_cast<long long>(kNumColdSlots) * dp;
@@ -905,8 +906,8 @@ int lmc_engine_set_step_jitter(lmc_engine* e, int32_t enable, double lo, double 
 }
 
 // Ctrl-C: every chain leaves its launch within a few iterations; launches still queued return at once. The word is a
-// host store into pinned, device-mapped memory that the kernels read uncached over the host link every 16th iteration
-// (and at the start of every launch). A device word set through a stream (hipStreamWriteValue32 / hipMemcpyAsync on a
+// host store into pinned, device-mapped memory; every 256th chain of a launch reads it every 16th iteration and relays it
+// to a device word that all chains look at once per iteration (lmc_sampler.hpp: stop_request_load). A device word set through a stream (hipStreamWriteValue32 / hipMemcpyAsync on a
 // stream of its own) was tried first: with every wave slot held by sampling kernels the command processor delivered it
 // only after 0.1 s (short waves) to seconds (waves that live as long as the launch), i.e. not at all for whole-job
 // launches (tools/ubench/stop_probe.hip).
@@ -916,8 +917,11 @@ int lmc_engine_request_stop(lmc_engine* e, int32_t stop) {
     if (stop) {
         __atomic_store_n(e->stop_host, 1, __ATOMIC_RELEASE);
     } else {   // re-armed in order: after everything that was launched under the request has drained
-        HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
+        hipStream_t st = main_stream(e);
+        HIP_TRY(e, hipStreamSynchronize(st));
         __atomic_store_n(e->stop_host, 0, __ATOMIC_RELEASE);
+        HIP_TRY(e, hipMemsetAsync(e->A.stop_dev, 0, sizeof(int), st));
+        HIP_TRY(e, hipStreamSynchronize(st));
     }
     return LMC_OK;
 }

@@ -67,7 +67,8 @@ struct ChainArrays {
     double* rng_gauss;    // [C]
     int* status;          // [C]
     long long* counters;  // [C][kNumCounters]
-    const int* stop;      // [1] != 0: every chain leaves its launch at the next iteration boundary (lmc_engine_request_stop)
+    const int* stop;      // [1] pinned host word, != 0: stop requested (lmc_engine_request_stop); read by a few relay chains only
+    int* stop_dev;        // [1] device word the relay chains copy it to: what every chain looks at, once per iteration
     const uint32_t* seed; // [C] the seeds of lmc_engine_seed (key of the counter-based momentum stream, LMC_RNG_PHILOX)
     double* mom_mean;     // [C][dpad] running mean of the post-warm-up draws (nullptr = not kept)
     double* mom_m2;       // [C][dpad] running sum of squared deviations (Welford)
@@ -1257,18 +1258,24 @@ constexpr int lds_tail_doubles(int w) {   // W == 4: a second MT19937 buffer beh
 
 // ---- pieces of the iteration body shared by the diagonal and the dense-mass kernels ---------------------------
 // lmc_engine_request_stop(): the host's Ctrl-C (sampling.py:324-328, :470-471 in the reference: keep what has been drawn).
-// The stop word is pinned host memory (the host sets it with a plain store; nothing on the device has to be scheduled
-// for the request to arrive). One uncached dword over the host link at the start of a launch and every 16th iteration,
-// REQUESTED when the iteration starts and LOOKED AT when it ends (its latency hides behind the whole iteration). A team
-// agrees on ONE value (thread 0's) so that no wave leaves a barrier behind.
+// The request is a host store into pinned memory -- nothing on the device has to be scheduled for it to arrive (a device
+// word set through a stream reached whole-job launches only after the job, tools/ubench/stop_probe.hip). Reading host
+// memory is slow, though (an uncached dword over the host link: every chain doing it every 16th iteration halved the rate
+// of short iterations), so only every 256th chain of a launch reads it, every 16th iteration, and RELAYS a set word to a
+// device word; that one every chain looks at once per iteration -- requested when the iteration starts, looked at when it
+// ends (its latency hides behind the whole iteration). A team agrees on ONE value (thread 0's) so that no wave leaves a
+// barrier behind.
 template <class CA>
-__device__ __forceinline__ int stop_request_load(const CA& A, int it, long long git) {
-    if (it != 0 && (git & 15) != 0) return 0;   // wave-uniform
-    return __hip_atomic_load(A.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+__device__ __forceinline__ int stop_request_load(const CA& A, int chain_in_launch, long long git) {
+    int* dev = A.stop_dev;
+    if ((chain_in_launch & 255) == 0 && (git & 15) == 0) {   // wave-uniform
+        if (__hip_atomic_load(A.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)
+            __hip_atomic_store(dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return __hip_atomic_load(dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <class TeamT>
-__device__ __forceinline__ bool stop_requested(TeamT& tm, int loaded, double* bcast, bool polled) {
-    if (!polled) return false;   // block-uniform: the same iterations poll in every wave
+__device__ __forceinline__ bool stop_requested(TeamT& tm, int loaded, double* bcast) {
     if constexpr (TeamT::kWaves == 1) {
         return first_i32(loaded) != 0;
     } else {
@@ -1523,7 +1530,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         const bool tune = git < P.n_tune;
         const bool momentum_f32 = P.momentum_f32 != 0;
         LMC_PHASE(5)
-        const int stop_word = stop_request_load(ka.A(), it, git);
+        const int stop_word = stop_request_load(ka.A(), static_cast<int>(blockIdx.x), git);
 
         // ---- momentum draw (quadpotential.py:221-224 / :374-376)
         double p0[NS];
@@ -1605,7 +1612,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
 
         if (A.mom_mean != nullptr && !tune) moments_update<NS>(A, tm, c, row, q);
         write_outputs<NS>(A, c, tid, git, q, out, da.step_now, da.step_bar_now, tune);
-        if (stop_requested(tm, stop_word, rng_bcast, it == 0 || (git & 15) == 0)) break;
+        if (stop_requested(tm, stop_word, rng_bcast)) break;
     }
 
     // ---- store persistent chain state (region 3 of the arguments)
