@@ -208,9 +208,17 @@ def main():
     ap.add_argument("--no-rccl-check", action="store_true", help="N = 1: do not bring up the one-rank RCCL group")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (nccl = RCCL; gloo only to exercise the multi-rank path on one GPU)")
+    ap.add_argument("--launcher", default="ranks", choices=["ranks", "inproc"],
+                    help="how N GPUs are driven. ranks (default): one process per GPU under torch.distributed.run, RCCL for "
+                         "the diagnostics all-reduce and the timing reductions. inproc: ONE process, one engine per GPU on "
+                         "its chain block, launches enqueued on all devices before anything is waited for (what "
+                         "lmc.sample(..., devices=[...]) does); no process group, so a RCCL / launcher bring-up failure "
+                         "cannot cost the scaling curve. The line records which one ran (`launcher`). If there are fewer "
+                         "GPUs than N (the one-GPU test box) the engines share devices round-robin.")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    inproc = args.launcher == "inproc"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not inproc:
         sys.exit(self_launch(args.gpus))
     # stdout carries ONE line, the JSON record: whatever the libraries print (RCCL's version banner, c10d warnings) goes
     # to stderr -- at the file-descriptor level, C stdio included -- and the record is written to the real stdout last
@@ -224,7 +232,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if inproc:
+        if world != 1:
+            raise SystemExit("--launcher inproc is ONE process driving all GPUs; do not start it under torch.distributed.run")
+        args.no_rccl_check = True
+    elif world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (start bench.py without WORLD_SIZE to let it launch its own "
                          "ranks, or under torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
@@ -273,19 +285,31 @@ def main():
     K, W, ips = args.steps, args.warmup, args.iters_per_step
     n_total = K * ips
     n_tune = n_total // 2
-    chains_total = args.chains if args.scaling == "strong" else args.chains * world
-    if args.scaling == "strong":
-        lo, hi = chain_block(chains_total, rank, world)
-    else:
-        lo, hi = rank * args.chains, (rank + 1) * args.chains
-    chains = hi - lo
-    if chains < 1:
-        raise SystemExit("rank %d owns no chain (%d chains over %d ranks)" % (rank, chains_total, world))
+    n_units = args.gpus if inproc else world          # GPUs (chain blocks) of the job
+    chains_total = args.chains if args.scaling == "strong" else args.chains * n_units
 
-    # seeds: sample()'s own derivation over the GLOBAL chain index space (prefix stable), block per rank
+    def unit_block(u):
+        return chain_block(chains_total, u, n_units) if args.scaling == "strong" else (u * args.chains, (u + 1) * args.chains)
+
+    # the chain blocks THIS process drives: one (its rank's) under the process-per-GPU launcher, all of them in-process
+    n_dev = torch.cuda.device_count()
+    if inproc:
+        parts = [{"unit": u, "dev": u % n_dev, "lo": unit_block(u)[0], "hi": unit_block(u)[1]} for u in range(n_units)]
+    else:
+        parts = [{"unit": rank, "dev": local_rank, "lo": unit_block(rank)[0], "hi": unit_block(rank)[1]}]
+    for p_ in parts:
+        if p_["hi"] - p_["lo"] < 1:
+            raise SystemExit("GPU %d owns no chain (%d chains over %d GPUs)" % (p_["unit"], chains_total, n_units))
+    chains = parts[0]["hi"] - parts[0]["lo"]          # the first block: the GPU the roofline / tail figures are taken on
+    devs_here = sorted({p_["dev"] for p_ in parts})
+
+    def sync_all():
+        for dv in devs_here:
+            torch.cuda.synchronize(dv)
+
+    # seeds: sample()'s own derivation over the GLOBAL chain index space (prefix stable), block per GPU
     np.random.seed(SEED)
     seeds_all = np.array([np.random.randint(2 ** 30) for _ in range(chains_total)], dtype=np.uint32)
-    seeds = seeds_all[lo:hi]
 
     def all_reduce(vals, op):
         t = torch.tensor(vals, dtype=torch.float64, device=red_dev)
@@ -306,7 +330,7 @@ def main():
                  "philox": "Philox4x32-10 momentum stream (throughput mode: NOT the reference's draws), tree uniforms MT19937"}
 
     def run_job(target_name, dim, with_ess, rng="numpy"):
-        """The timed job on this rank's chain block -> dict of measurements (wall / leapfrogs reduced over ranks)."""
+        """The timed job on this process's chain block(s) -> dict of measurements (wall / leapfrogs reduced over ranks)."""
         target, target_desc = make_target(lmc, target_name, dim)
         np.random.seed(int(seeds_all[0]))
         start = 2 * np.random.rand(dim) - 1            # init_nuts jitter (sampling.py:574-584)
@@ -330,10 +354,10 @@ def main():
         kw["lds_levels"] = args.lds_levels
         kw["rng"] = rng
 
-        def new_job(capacity, trace_from, keep_trace):
-            eng = lmc.Engine(target, chains=chains, device=local_rank, **kw)
+        def new_job(part, capacity, trace_from, keep_trace):
+            eng = lmc.Engine(target, chains=part["hi"] - part["lo"], device=part["dev"], **kw)
             step.potential._push_initial(eng)
-            eng.seed(seeds)
+            eng.seed(seeds_all[part["lo"]:part["hi"]])
             eng.set_position(start)
             eng.reset_tuning()
             eng.reserve(capacity, keep_trace=keep_trace, trace_begin=trace_from)
@@ -342,11 +366,12 @@ def main():
         def tail_block(eng, ct, kernel_s, nst, target, step, kw, start):
             """Why the job cannot be faster than its busiest chain (ragged trees): per launch every sub-block waits for its
             slowest chain, and a chain is one wavefront (or team) whose leapfrogs run back to back."""
+            dev0 = int(eng.cfg.device)
             resident, wpc, hz = eng.occupancy()
             leap_chain = ct[:, _abi.CT_LEAPFROGS]
             # tree_size of every iteration, where it lives: [chains][capacity] int32 in HBM -> leapfrogs per chain per launch
             ts = torch.as_tensor(_DevView(eng.stat_i32_device_ptr() + 4 * _abi.STAT_TREE_SIZE * chains * n_total,
-                                          (chains, n_total), "<i4"), device="cuda:%d" % local_rank)
+                                          (chains, n_total), "<i4"), device="cuda:%d" % dev0)
             per_launch = ts.reshape(chains, K, ips).sum(dim=2, dtype=torch.int64)                 # [chains, K]
             bounds = [chains * b // nst for b in range(nst + 1)]
             crit = max(int(per_launch[bounds[b]:bounds[b + 1]].max(dim=0).values.sum()) for b in range(nst))
@@ -358,9 +383,9 @@ def main():
                         "resident_chains": resident, "waves_per_chain": wpc, "lds_bytes_per_workgroup": lds_bytes,
                         "mean_wave_slot_occupancy": (float(ct[:, _abi.CT_WAVE_TICKS].sum()) / hz / (resident * wpc * kernel_s)) if resident else None}
             # a lone chain on an otherwise idle GPU: the issue latency of one wavefront (team) of this kernel
-            lone = lmc.Engine(target, chains=1, device=local_rank, **kw)
+            lone = lmc.Engine(target, chains=1, device=dev0, **kw)
             step.potential._push_initial(lone)
-            lone.seed(seeds[:1])
+            lone.seed(seeds_all[:1])
             lone.set_position(start)
             lone.reset_tuning()
             n_l = 2 * ips
@@ -389,100 +414,121 @@ def main():
                         "sub-blocks of the sum over launches of that chain's leapfrogs; x the leapfrog latency of a lone "
                         "wavefront (measured on a 1-chain engine of the same kernel, %d post-tuning iterations) = a lower "
                         "bound on the wall time whatever the number of GPUs; occupancy = resident wave time (device "
-                        "counter) / (wave slots x kernel time)" % (n_l - n_l // 2),
+                        "counter) / (wave slots x kernel time); first chain block of the job" % (n_l - n_l // 2),
             }
 
         if W > 0:   # warm-up: W launches of a throw-away copy of the job
-            warm = new_job(W * ips, (W * ips) // 2, keep_trace=False)
-            for s in range(W):
-                warm.run((W * ips) // 2, s * ips, ips)
-            warm.synchronize()
-            warm.close()
+            warm = [new_job(p_, W * ips, (W * ips) // 2, keep_trace=False) for p_ in parts]
+            for s_ in range(W):
+                for w_ in warm:
+                    w_.run((W * ips) // 2, s_ * ips, ips)
+            for w_ in warm:
+                w_.synchronize()
+                w_.close()
 
         # draws stay in HBM; if the requested job is longer than the memory allows, keep the most recent draws only
         trace_begin = n_tune
         keep_trace = with_ess and not args.no_trace
         if keep_trace:
-            free_b, _tot = torch.cuda.mem_get_info()
-            per_draw = chains * dim * 8
-            fit = int(0.6 * free_b // per_draw)
-            if n_total - n_tune > fit:
-                trace_begin = n_total - max(fit, 1)
-        eng = new_job(n_total, trace_begin, keep_trace=keep_trace)
-        # HIP events on the streams the kernel is launched on: the engine launches its chains as sub-blocks (two halves on
-        # two internal streams, lmc_engine_run_streams), so a step is `len(run_streams)` concurrent dispatches
-        run_streams = [torch.cuda.ExternalStream(h, device=torch.device("cuda", local_rank)) for h in eng.run_streams()]
-        nst = len(run_streams)
-        ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nst)] for _ in range(K)]
-        torch.cuda.synchronize()
+            for dv in devs_here:
+                free_b, _tot = torch.cuda.mem_get_info(dv)
+                per_draw = sum(p_["hi"] - p_["lo"] for p_ in parts if p_["dev"] == dv) * dim * 8
+                fit = int(0.6 * free_b // per_draw)
+                if n_total - trace_begin > fit:
+                    trace_begin = n_total - max(fit, 1)
+        engs = [new_job(p_, n_total, trace_begin, keep_trace=keep_trace) for p_ in parts]
+        # HIP events on the streams the kernel is launched on: an engine launches its chains as sub-blocks (two halves on
+        # two internal streams, lmc_engine_run_streams), so a step is `len(run_streams)` concurrent dispatches per GPU
+        run_streams = [[torch.cuda.ExternalStream(h, device=torch.device("cuda", p_["dev"])) for h in e_.run_streams()]
+                       for e_, p_ in zip(engs, parts)]
+        nst = len(run_streams[0])
+
+        def new_event(dv):
+            with torch.cuda.device(dv):
+                return torch.cuda.Event(enable_timing=True)
+
+        ev = [[[(new_event(p_["dev"]), new_event(p_["dev"])) for _ in st_] for st_, p_ in zip(run_streams, parts)] for _ in range(K)]
+        sync_all()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync_all()
         t0 = time.perf_counter()
-        for s in range(K):
-            for b in range(nst):
-                ev[s][b][0].record(run_streams[b])
-            eng.run(n_tune, s * ips, ips)
-            for b in range(nst):
-                ev[s][b][1].record(run_streams[b])
-        torch.cuda.synchronize()
+        for s_ in range(K):          # every launch goes out on all GPUs before anything is waited for
+            for k_, e_ in enumerate(engs):
+                for b_, st_ in enumerate(run_streams[k_]):
+                    ev[s_][k_][b_][0].record(st_)
+                e_.run(n_tune, s_ * ips, ips)
+                for b_, st_ in enumerate(run_streams[k_]):
+                    ev[s_][k_][b_][1].record(st_)
+        sync_all()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync_all()
         wall = time.perf_counter() - t0
 
-        dispatch_ms = [[a.elapsed_time(b) for a, b in ev[s]] for s in range(K)]          # per dispatch, what rocprofv3 lists
+        dispatch_ms = [[a.elapsed_time(b) for a, b in ev[s_][0]] for s_ in range(K)]     # per dispatch, what rocprofv3 lists (first block)
 
-        def span_ms(s0):   # kernel-busy time from the start of step s0 to the end of the last step
-            return max(ev[s0][b0][0].elapsed_time(ev[K - 1][b1][1]) for b0 in range(nst) for b1 in range(nst))
+        def span_ms(s0, k_=0):   # kernel-busy time of GPU k_ from the start of step s0 to the end of the last step
+            n_b = len(run_streams[k_])
+            return max(ev[s0][k_][b0][0].elapsed_time(ev[K - 1][k_][b1][1]) for b0 in range(n_b) for b1 in range(n_b))
 
-        kernel_ms = [span_ms(0) / K] * K                                                  # per step, all sub-blocks
-        ct = eng.counters()
-        leap_local = float(ct[:, _abi.CT_LEAPFROGS].sum())
-        tail = tail_block(eng, ct, span_ms(0) / 1e3, nst, target, step, kw, start)
-        status = eng.status()
-        if status.any():
-            raise SystemExit("chains reported failure status bits: %s" % np.unique(status))
+        kernel_ms = [span_ms(0) / K] * K                                                  # per step, all sub-blocks, first block's GPU
+        cts = [e_.counters() for e_ in engs]
+        ct = cts[0]
+        leaps = [float(c_[:, _abi.CT_LEAPFROGS].sum()) for c_ in cts]
+        leap_local = leaps[0]
+        tail = tail_block(engs[0], ct, span_ms(0) / 1e3, nst, target, step, kw, start)
+        for e_ in engs:
+            status = e_.status()
+            if status.any():
+                raise SystemExit("chains reported failure status bits: %s" % np.unique(status))
         n_last = min(ips, n_total - n_tune)
-        depth_mean = float(eng.stat_i32(_abi.STAT_DEPTH, n_total - n_last, n_last).mean()) if n_last > 0 else 0.0
-        div_after = int(ct[:, _abi.CT_DIVS_AFTER_TUNE].sum())
+        depth_mean = (float(np.concatenate([e_.stat_i32(_abi.STAT_DEPTH, n_total - n_last, n_last).ravel() for e_ in engs]).mean())
+                      if n_last > 0 else 0.0)
+        div_after = int(sum(c_[:, _abi.CT_DIVS_AFTER_TUNE].sum() for c_ in cts))
 
         # ESS/sec (the second half of BASELINE.json's metric): split-R-hat / ESS of the post-warm-up draws, computed
-        # where they live (HBM) and reduced across ranks with ONE all-reduce (RCCL) of per-dimension sufficient
-        # statistics -- the only collective of the multi-GPU path.
+        # where they live (HBM) and reduced across GPUs with ONE exchange of per-dimension sufficient statistics -- an
+        # all-reduce (RCCL) between ranks, a device-to-device copy of the (3 + 16) x d block in-process: the only
+        # collective of the multi-GPU path.
         ess = None
         if keep_trace and not args.no_ess and n_total - n_tune >= 8:
             from littlemcmc_amd import diagnostics as dg
 
             # one-time costs (loading the code objects of the statistics kernel and of the torch ops of the finalize
             # step, ~0.7 s in a fresh process) are paid on a 64-chain slice first and reported separately
-            torch.cuda.synchronize()
+            views = [dg.trace_tensor(e_) for e_ in engs]
+            sync_all()
             t_first = time.perf_counter()
-            dg.summarize(dg.trace_tensor(eng)[:64], reduce_device=red_dev)
-            torch.cuda.synchronize()
+            dg.summarize([v_[:64] for v_ in views] if len(views) > 1 else views[0][:64], reduce_device=red_dev)
+            sync_all()
             diag_first_s = time.perf_counter() - t_first
             t_ess = time.perf_counter()
-            diag = dg.summarize(dg.trace_tensor(eng), reduce_device=red_dev)
-            torch.cuda.synchronize()
+            diag = dg.summarize(views if len(views) > 1 else views[0], reduce_device=red_dev)
+            sync_all()
             diag_s = time.perf_counter() - t_ess
             s_draw = min(K - 1, -(-trace_begin // ips))
-            draw_s = span_ms(s_draw) / 1e3      # kernel-busy time of the steps that produced the kept draws
+            draw_s = max(span_ms(s_draw, k_) for k_ in range(len(engs))) / 1e3   # kernel-busy time of the steps that produced the kept draws
             e = diag["ess"]
             ess = {"min": float(e.min()), "median": float(e.median()), "rhat_max": float(diag["rhat"].max()),
                    "lag_passes": int(diag.get("lag_passes", 0)),
                    "draw_seconds": draw_s, "chains_total": int(diag["n_chains"] / 2), "draws": n_total - trace_begin,
                    "diagnostics_seconds": diag_s, "diagnostics_process_warmup_seconds": diag_first_s, "definition": diag.get("definition", "")}
-        eng.close()
+        for e_ in engs:
+            e_.close()
 
-        per_rank = all_gather([leap_local, span_ms(0) / 1e3, wall, float(chains)])
+        if inproc:
+            per_rank = [[leaps[k_], span_ms(0, k_) / 1e3, wall, float(p_["hi"] - p_["lo"]), float(p_["dev"])] for k_, p_ in enumerate(parts)]
+        else:
+            per_rank = all_gather([leap_local, span_ms(0) / 1e3, wall, float(chains), float(local_rank)])
         wall_max, = all_reduce([wall], dist.ReduceOp.MAX)
-        leap_all, div_all = all_reduce([leap_local, float(div_after)], dist.ReduceOp.SUM)
+        leap_all, div_all = all_reduce([sum(leaps), float(div_after)], dist.ReduceOp.SUM)
         if ess is not None:   # post-warm-up time of the slowest rank
             ess["draw_seconds"], ess["diagnostics_seconds"] = all_reduce([ess["draw_seconds"], ess["diagnostics_seconds"]],
                                                                          dist.ReduceOp.MAX)
         method = ("NUTS max_treedepth=%d" % args.max_treedepth) if args.kind == "nuts" else "HMC path_length=2"
         label = config_label(target_name, dim, chains_total, args.max_treedepth, args.kind, args.mass)
-        part = ("%d chains on this GPU" % chains) if world == 1 else ("%d chains in blocks of ~%d per GPU" % (chains_total, chains))
+        part = ("%d chains on this GPU" % chains) if n_units == 1 else ("%d chains in blocks of ~%d per GPU" % (chains_total, chains))
         return {
             "label": label, "target": target_name, "dim": dim, "start": start, "mass_desc": mass_desc, "rng": RNG_LABEL[rng], "rng_mode": rng,
             "workload": "%s: %d chains x dim %d %s, %s, %s, tune %d + draws %d in %d launches of %d iterations; %s" % (
@@ -490,11 +536,13 @@ def main():
             "wall": wall_max, "leap_all": leap_all, "leap_local": leap_local, "kernel_ms": kernel_ms,
             "dispatch_ms_avg": float(np.mean(dispatch_ms)), "dispatches_per_step": nst,
             "depth_mean": depth_mean, "div_after": int(div_all), "ess": ess, "tail": tail,
-            "per_rank": [{"rank": r, "chains": int(v[3]), "leapfrogs": v[0], "kernel_s": v[1], "wall_s": v[2]}
+            "per_rank": [{"rank": r, "chains": int(v[3]), "leapfrogs": v[0], "kernel_s": v[1], "wall_s": v[2], "device": int(v[4])}
                          for r, v in enumerate(per_rank)],
         }
 
-    src_hash = _build.source_hash()
+    # identity of the BINARY this process loaded (compiled into it: lmc_build_hash), not of the source tree it sits in:
+    # counters from profiles/ are quoted only for that very build
+    src_hash = _abi.load().lmc_build_hash().decode()
 
     def roofline(job):
         kern_s = sum(job["kernel_ms"]) / 1e3
@@ -561,14 +609,14 @@ def main():
         ess = primary["ess"]
         out = {
             "metric": "leapfrog-steps/sec (all chains)", "value": value, "unit": "leapfrog-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": primary["wall"] * 1e3 / K,
+            "n_gpus": n_units, "steps": K, "warmup": W, "ms_per_step": primary["wall"] * 1e3 / K,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": primary["workload"], "chains_total": chains_total, "chains_this_gpu": chains,
                 "dim": args.dim, "target": args.target, "tune": n_tune, "draws": n_total - n_tune,
                 "rng": primary["rng"],
-                "trace_in_hbm": not args.no_trace, "parallelism": "chain-block x%d (%s scaling)" % (world, args.scaling),
+                "trace_in_hbm": not args.no_trace, "parallelism": "chain-block x%d (%s scaling)" % (n_units, args.scaling),
             },
             "leapfrogs": primary["leap_all"], "wall_s": primary["wall"], "mean_depth_draws": primary["depth_mean"],
             "ess_per_sec": None if ess is None else {
@@ -586,8 +634,10 @@ def main():
             "roofline": roofline(primary),
             "tail": primary["tail"],
             "per_rank": primary["per_rank"],
-            "rccl_ranks": rccl_ranks, "rccl_error": rccl_error, "backend": args.backend,
-            "source_hash": src_hash,
+            "rccl_ranks": rccl_ranks, "rccl_error": rccl_error, "backend": None if inproc else args.backend,
+            "launcher": ("inproc: one process, one engine per GPU (littlemcmc_amd.sample(devices=...)'s path), no process group"
+                         if inproc else "ranks: one process per GPU under torch.distributed.run, %s" % args.backend),
+            "source_hash": src_hash, "source_tree_hash": _build.source_hash(),
         }
         if secondary is not None:
             out["secondary"] = [{
@@ -603,7 +653,7 @@ def main():
                 "ms_per_step": philox_line["wall"] * 1e3 / K, "leapfrogs": philox_line["leap_all"], "wall_s": philox_line["wall"],
                 "mean_depth_draws": philox_line["depth_mean"], "divergences_after_tune": philox_line["div_after"],
                 "roofline": roofline(philox_line), "tail": philox_line["tail"], "per_rank": philox_line["per_rank"]})
-        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
+        if not args.no_cpu_baseline and n_units == 1:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.target, args.dim, seeds_all[:64], primary["start"], args.cpu_iters, args.mass)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

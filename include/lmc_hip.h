@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LMC_ABI_VERSION 4
+#define LMC_ABI_VERSION 5
 
 /* status codes */
 #define LMC_OK 0
@@ -155,6 +155,14 @@ void lmc_config_defaults(lmc_config* cfg, int32_t chains, int32_t dim);
 /* Library-wide: message of the last failure on this thread (engine may be NULL). */
 const char* lmc_last_error(const lmc_engine* e);
 int32_t lmc_abi_version(void);
+/* Identity of THIS binary: the hash of the sources, header and compiler flags it was compiled from
+ * (littlemcmc_amd/_build.py: source_hash(), passed as -DLMC_SOURCE_HASH at build time; "unstamped" for a build made
+ * any other way). Measurements under profiles/ are only quoted for the binary whose hash they carry. */
+const char* lmc_build_hash(void);
+/* HIP devices visible to this process (0: none, or no usable HIP runtime). One engine runs on one of them
+ * (lmc_config.device); a job on several is one engine per device on a contiguous chain block each -- the reference's
+ * `cores` (sampling.py:117-129) with GPUs in the place of worker processes. */
+int32_t lmc_device_count(void);
 /* 1 if this library was built with the given LMC_TARGET_* family. */
 int32_t lmc_has_target(int32_t family);
 
@@ -234,6 +242,12 @@ int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int64_t trace_begin);
  * chain). stop = 0 re-arms the engine, ordered after everything launched so far. Fused kernels (diagonal and dense mass);
  * a tick-driven job stops by not ticking. */
 int lmc_engine_request_stop(lmc_engine* e, int32_t stop);
+/* The `callback` of the reference's drivers (sampling.py:272-277, :307-308: called per draw, "sampling can be interrupted
+ * by throwing a KeyboardInterrupt in the callback") needs to know where a running job is WITHOUT waiting for it:
+ * progress() is the iteration index a relay chain of the launch in flight last started, read from pinned host memory (no
+ * stream is touched; updated every 16th iteration). A hint: chains advance at their own pace; what every chain has
+ * completed is lmc_chain_state.iter_count. */
+int64_t lmc_engine_progress(lmc_engine* e);
 int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters);
 int lmc_engine_run_streams(lmc_engine* e, void** streams, int32_t capacity);
 

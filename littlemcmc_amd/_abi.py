@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LMC_HIP_LIB") or os.path.join(_HERE, "liblmc_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OK = 0
 
 KIND_NUTS, KIND_HMC = 0, 1
@@ -74,6 +74,8 @@ _SIGNATURES = {
     "lmc_config_defaults": (None, [C.POINTER(Config), C.c_int32, C.c_int32]),
     "lmc_last_error": (C.c_char_p, [_P]),
     "lmc_abi_version": (C.c_int32, []),
+    "lmc_build_hash": (C.c_char_p, []),
+    "lmc_device_count": (C.c_int32, []),
     "lmc_has_target": (C.c_int32, [C.c_int32]),
     "lmc_engine_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "lmc_engine_destroy": (None, [_P]),
@@ -125,6 +127,7 @@ _SIGNATURES = {
     "lmc_engine_kernel_shape": (C.c_int, [_P, _P, _P, _P]),
     "lmc_engine_occupancy": (C.c_int, [_P, _P, _P, _P]),
     "lmc_engine_request_stop": (C.c_int, [_P, C.c_int32]),
+    "lmc_engine_progress": (C.c_int64, [_P]),
     "lmc_engine_run_lds_bytes": (C.c_int32, [_P]),
     "lmc_engine_load_user_kernels": (C.c_int, [_P, _P, C.c_char_p, C.c_char_p, C.c_char_p]),
     "lmc_diag_lags_per_pass": (C.c_int, []),

@@ -24,16 +24,18 @@ def sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))]
 
 
-def source_hash():
+def source_hash(extra_flags=()):
     """Identity of a build: sha256 over the kernel sources, the C header and the compiler flags (16 hex digits).
-    Profiles under profiles/ record it, so a measurement is only quoted for the build it was taken on."""
+    It is compiled INTO the library (-DLMC_SOURCE_HASH -> lmc_build_hash()), so what a process reports is the hash of
+    the binary it loaded, not of the tree it happens to sit in. Profiles under profiles/ record it, and a measurement is
+    only quoted for the build it was taken on."""
     import hashlib
 
     h = hashlib.sha256()
     for path in sources() + [os.path.join(os.path.dirname(HERE), "include", "lmc_hip.h")]:
         with open(path, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(HIPCC_FLAGS).encode())
+    h.update(" ".join(list(HIPCC_FLAGS) + list(extra_flags)).encode())
     return h.hexdigest()[:16]
 
 
@@ -41,25 +43,42 @@ def lib_path():
     return os.path.join(HERE, LIB_NAME)
 
 
-def needs_build(out=None):
-    out = out or lib_path()
-    if not os.path.exists(out):
-        return True
-    t = os.path.getmtime(out)
-    deps = sources() + [os.path.join(os.path.dirname(HERE), "include", "lmc_hip.h")]
-    return any(os.path.getmtime(s) > t for s in deps)
+_STAMP = b"LMC_BUILD_HASH="
+
+
+def binary_hash(path=None):
+    """The source hash a built library carries (csrc/lmc_engine.hip: kBuildStamp = -DLMC_SOURCE_HASH at compile time),
+    read from the file without loading it; None if the file is missing or carries no stamp. The loaded library reports
+    the same string through lmc_build_hash()."""
+    path = path or lib_path()
+    try:
+        with open(path, "rb") as fh:
+            blob = fh.read()
+    except OSError:
+        return None
+    i = blob.find(_STAMP)
+    if i < 0:
+        return None
+    j = blob.find(b"\0", i)
+    return blob[i + len(_STAMP):j].decode("ascii", "replace")
+
+
+def needs_build(out=None, extra_flags=()):
+    """A library is current when the hash stamped into the BINARY equals the hash of the sources as they are now --
+    not when its mtime is newer (a stale .so restored by a checkout or a copy would otherwise pass for the tree's)."""
+    return binary_hash(out or lib_path()) != source_hash(extra_flags)
 
 
 def build(out=None, extra_flags=(), force=False, verbose=False):
     """Compile csrc/*.hip -> liblmc_hip.so (one hipcc process per translation unit, then a link). Raises on
     failure (no fallback)."""
     out = out or lib_path()
-    if not force and not needs_build(out):
+    if not force and not needs_build(out, extra_flags):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + ['-DLMC_SOURCE_HASH="%s"' % source_hash(extra_flags)]
     units = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
     objdir = tempfile.mkdtemp(prefix="lmc_build_")
     try:

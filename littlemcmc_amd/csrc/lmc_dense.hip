@@ -105,16 +105,16 @@ int dense_launch_momentum(int ns, hipStream_t stream, const ChainArrays& A, cons
 }
 
 int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, double multiplier,
-                       int update_window, int* mask, int chain_begin, int n_chains) {
+                       int update_window, int* mask, int chain_begin, int n_chains, int expect_iter) {
     const int lds = dense_adapt_lds_bytes(A.d, A.dpad);
     const dim3 grid(n_chains > 0 ? n_chains : A.chains);
     (void)hipGetLastError();
     if (dense_adapt_grid(A.d) == 8)
-        hipLaunchKernelGGL(dense_adapt_kernel<8>, grid, dim3(64), lds, stream, A, D, multiplier, update_window, mask, chain_begin);
+        hipLaunchKernelGGL(dense_adapt_kernel<8>, grid, dim3(64), lds, stream, A, D, multiplier, update_window, mask, chain_begin, expect_iter);
     else if (dense_adapt_grid(A.d) == 16)
-        hipLaunchKernelGGL(dense_adapt_kernel<16>, grid, dim3(256), lds, stream, A, D, multiplier, update_window, mask, chain_begin);
+        hipLaunchKernelGGL(dense_adapt_kernel<16>, grid, dim3(256), lds, stream, A, D, multiplier, update_window, mask, chain_begin, expect_iter);
     else
-        hipLaunchKernelGGL(dense_adapt_kernel<32>, grid, dim3(1024), lds, stream, A, D, multiplier, update_window, mask, chain_begin);
+        hipLaunchKernelGGL(dense_adapt_kernel<32>, grid, dim3(1024), lds, stream, A, D, multiplier, update_window, mask, chain_begin, expect_iter);
     return static_cast<int>(hipGetLastError());
 }
 

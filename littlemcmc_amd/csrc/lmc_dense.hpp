@@ -600,7 +600,7 @@ __device__ __forceinline__ void dense_run_chain(const ChainArrays& A, const Dens
     for (int it = 0; it < P.n_iters; ++it) {
         const long long git = P.iter_begin + it;
         const bool tune = git < P.n_tune;
-        const int stop_word = stop_request_load(A, c - P.chain_begin, git);   // looked at when the iteration ends (lmc_sampler.hpp)
+        const int stop_word = stop_request_load(A, P, c - P.chain_begin, it, git);   // looked at when the iteration ends (lmc_sampler.hpp)
 
         // ---- momentum draw
         rng_normals(rng, d, lds, lds + dpad);
@@ -672,6 +672,7 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void run_dense_kernel
     const int c = blockIdx.x + P.chain_begin;   // the engine launches its chains as sub-blocks (lmc_engine_run)
     const int dpad = A.dpad;
     const int tid = LMC_CHAIN_THREAD;
+    if (stop_at_entry<1>(A.stop_dev, nullptr)) return;   // queued behind a Ctrl-C: nothing runs, nothing is touched
     if (A.status[c] & kStatusBadInitialEnergy) return;
     const MatT* M = static_cast<const MatT*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
     MatT* mcache = reinterpret_cast<MatT*>(lds + dense_lds_doubles(dpad));
@@ -711,6 +712,7 @@ __global__ __launch_bounds__(64 * kCoopWaves, 2) void run_dense_coop_kernel(Chai
     const int slots = D.lds_slots;
     double* priv = dout + 16 * xs + 2 + wave * (dense_lds_doubles(dpad) + slots * dpad);
     const float* M = static_cast<const float*>(D.covT);
+    if (stop_at_entry<kCoopWaves>(A.stop_dev, n_active)) return;   // queued behind a Ctrl-C (one value for the eight chains)
     DenseCoop cc;
     // the matrix: all 512 threads, rows of the stored transposed matrix are contiguous (coalesced)
     for (int idx = threadIdx.x; idx < k_rows * dpad; idx += 64 * kCoopWaves) {
@@ -921,12 +923,18 @@ __device__ inline bool cholesky_registers(const float* covT, float* fac, int d, 
 
 template <int T>
 __global__ __launch_bounds__(T * T) void dense_adapt_kernel(ChainArrays A, DenseArrays D, double multiplier,
-                                                            int update_window, int* mask, int chain_begin) {
+                                                            int update_window, int* mask, int chain_begin, int expect_iter) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int kThreads = T * T;
     const int c = blockIdx.x + chain_begin, tid = threadIdx.x;
     // mask != nullptr (tick path): only the chains that finished a tuning iteration in the last tick take part
     if (mask != nullptr && mask[c] == 0) return;
+    // expect_iter >= 0 (sample(): the update that follows iteration expect_iter - 1): under a stop request the chains whose
+    // iteration launch was skipped (run_dense_kernel: stop_at_entry) have nothing new to learn from -- every thread of the
+    // workgroup reads the same two words, and iter_count is final once the iteration's launch is over
+    if (expect_iter >= 0 && __hip_atomic_load(A.stop_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+        A.iter_count[c] != expect_iter)
+        return;
     const int d = A.d, dpad = A.dpad;
     double* oldf = lds;            // [d] x - mean_before (foreground)
     double* newf = lds + d;        // [d] x - mean_after

@@ -387,6 +387,14 @@ static int dense_reset(lmc_engine* e) {   // FULL_ADAPT: constructor state for e
 }
 
 // potentials whose matrices live in float64 on the device (and whose momentum draw is float64)
+// stop word: one chain in (mask + 1) of a launch of n chains relays the host's word (lmc_sampler.hpp: stop_request_load);
+// mask + 1 = the power of two >= n, at most 256, so that a launch of any size has a relay within 16 * (mask + 1) iterations
+static int relay_mask_for(long long n) {
+    int m = 1;
+    while (m < n && m < 256) m *= 2;
+    return m - 1;
+}
+
 static bool pot_f64(int potential) { return potential == LMC_POT_FULL_INV || potential == LMC_POT_FULL_F64; }
 
 #ifdef LMC_USER_TARGET_HEADER
@@ -455,6 +463,7 @@ static int dense_run(lmc_engine* e, SamplerParams P) {
             Q.iter_begin = it;
             Q.n_iters = static_cast<int>(n);
             Q.chain_begin = static_cast<int>(lo);
+            Q.relay_mask = relay_mask_for(hi - lo);
             int rc;
             if (coop)   // one matrix for all chains: eight chains per workgroup, the product on the matrix cores
                 rc = dense_launch_run_coop(e->cfg.target_family, e->ns, st, e->A, e->D, Q, e->tparams, static_cast<int>(hi - lo));
@@ -463,7 +472,7 @@ static int dense_run(lmc_engine* e, SamplerParams P) {
             if (rc != 0) return dense_fail(e, rc, "run");
             if (adapt) {
                 rc = dense_launch_adapt(st, e->A, e->D, e->dense_multiplier, e->dense_update_window, nullptr,
-                                        static_cast<int>(lo), static_cast<int>(hi - lo));
+                                        static_cast<int>(lo), static_cast<int>(hi - lo), static_cast<int>(it + 1));   // (skipped under a stop request unless the chain completed iteration `it`)
                 if (rc != 0) return dense_fail(e, rc, "dense update");
             }
         }
@@ -483,6 +492,19 @@ static int ns_for_dim(int d) {
 extern "C" {
 
 int32_t lmc_abi_version(void) { return LMC_ABI_VERSION; }
+
+#ifndef LMC_SOURCE_HASH
+#define LMC_SOURCE_HASH "unstamped"
+#endif
+// the marker makes the stamp findable in the file without loading it (littlemcmc_amd/_build.py: binary_hash)
+static const char kBuildStamp[] = "LMC_BUILD_HASH=" LMC_SOURCE_HASH;
+const char* lmc_build_hash(void) { return kBuildStamp + 15; }
+
+int32_t lmc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
 
 int32_t lmc_has_target(int32_t family) {
 #if !(defined(LMC_USER_TARGET_HEADER) && defined(LMC_ONLY_USER))
@@ -670,11 +692,14 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     TRY_ALLOC(dev_alloc(e, &A.counters, C * kNumCounters));
     {   // the stop word lives in pinned host memory mapped into the device (uncached, coherent): a request is a host store
         void* dev_view = nullptr;
-        if (hipHostMalloc(reinterpret_cast<void**>(&e->stop_host), 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        // (two words a cache line apart: the stop request the host writes and the device reads, and the progress hint the
+        //  device writes and the host reads)
+        if (hipHostMalloc(reinterpret_cast<void**>(&e->stop_host), 128, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostGetDevicePointer(&dev_view, e->stop_host, 0) != hipSuccess)
             return bail(fail(nullptr, LMC_ERR_HIP, "stop word: %s", hipGetErrorString(hipGetLastError())));
-        *e->stop_host = 0;
+        std::memset(e->stop_host, 0, 128);
         A.stop = static_cast<const int*>(dev_view);
+        A.progress = static_cast<int*>(dev_view) + 16;
     }
     TRY_ALLOC(dev_alloc(e, &A.stop_dev, 1));   // what the relay chains set and every chain reads (zeroed)
     TRY_ALLOC(dev_alloc(e, &e->seeds, C));
@@ -924,6 +949,15 @@ int lmc_engine_request_stop(lmc_engine* e, int32_t stop) {
         HIP_TRY(e, hipStreamSynchronize(st));
     }
     return LMC_OK;
+}
+
+// Where the job is, without touching a stream: the iteration index a relay chain of the running launch last started
+// (written into pinned host memory every 16th iteration, next to reading the stop word). A hint -- chains advance at their
+// own pace and relays take turns -- for progress lines and callbacks; what every chain has COMPLETED is iter_count
+// (lmc_engine_get_chain_state), which waits for the launches.
+int64_t lmc_engine_progress(lmc_engine* e) {
+    if (!e || !e->stop_host) return 0;
+    return static_cast<int64_t>(__atomic_load_n(e->stop_host + 16, __ATOMIC_ACQUIRE));
 }
 
 int lmc_engine_set_stream(lmc_engine* e, void* hip_stream) {
@@ -1367,6 +1401,7 @@ int lmc_engine_get_position(lmc_engine* e, double* q) {
 int lmc_engine_reset_tuning(lmc_engine* e) {
     if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (e->stop_host) __atomic_store_n(e->stop_host + 16, 0, __ATOMIC_RELEASE);   // progress hint: iteration 0 again
     // QuadPotentialDiag.reset() is a no-op (quadpotential.py:138-140): only the adaptive potential resets
     int rc = launch_reset(e, 1, e->cfg.potential == LMC_POT_DIAG_ADAPT ? 1 : 0);
     if (rc != LMC_OK) return rc;
@@ -1436,6 +1471,7 @@ static SamplerParams make_params(const lmc_engine* e, int64_t n_tune, int64_t it
     P.step_jitter = e->step_jitter;
     P.jitter_lo = e->jitter_lo;
     P.jitter_hi = e->jitter_hi;
+    P.relay_mask = 255;
     return P;
 }
 
@@ -1491,6 +1527,7 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
     for (int b = 0; b < n_sub; ++b) {
         const long long lo = static_cast<long long>(e->cfg.chains) * b / n_sub, hi = static_cast<long long>(e->cfg.chains) * (b + 1) / n_sub;
         P.chain_begin = static_cast<int>(lo);
+        P.relay_mask = relay_mask_for(hi - lo);
         const dim3 grid(static_cast<unsigned>(hi - lo));
         hipStream_t st = n_sub > 1 ? e->sub_stream[b] : main_stream(e);
         if (n_sub > 1) e->sub_pending = true;

@@ -69,6 +69,8 @@ struct ChainArrays {
     long long* counters;  // [C][kNumCounters]
     const int* stop;      // [1] pinned host word, != 0: stop requested (lmc_engine_request_stop); read by a few relay chains only
     int* stop_dev;        // [1] device word the relay chains copy it to: what every chain looks at, once per iteration
+    int* progress;        // [1] pinned host word: the iteration index a relay chain last started (lmc_engine_progress: a hint the
+                          //     host reads without touching a stream)
     const uint32_t* seed; // [C] the seeds of lmc_engine_seed (key of the counter-based momentum stream, LMC_RNG_PHILOX)
     double* mom_mean;     // [C][dpad] running mean of the post-warm-up draws (nullptr = not kept)
     double* mom_m2;       // [C][dpad] running sum of squared deviations (Welford)
@@ -105,6 +107,8 @@ struct SamplerParams {
     int rng_mode;         // LMC_RNG_*: which run_kernel instantiation the host launches (informational on the device)
     int step_jitter;      // step_rand (base_hmc.py:154-155) in its one device form: step * uniform(jitter_lo, jitter_hi)
     double jitter_lo, jitter_hi;
+    int relay_mask;       // stop word: one chain in (relay_mask + 1) of a launch reads the host's word (stop_request_load)
+    int reserved1;
 };
 
 // ---- kernel arguments, re-read where they are used ---------------------------------------------------------------
@@ -1261,16 +1265,25 @@ constexpr int lds_tail_doubles(int w) {   // W == 4: a second MT19937 buffer beh
 // The request is a host store into pinned memory -- nothing on the device has to be scheduled for it to arrive (a device
 // word set through a stream reached whole-job launches only after the job, tools/ubench/stop_probe.hip). Reading host
 // memory is slow, though (an uncached dword over the host link: every chain doing it every 16th iteration halved the rate
-// of short iterations), so only every 256th chain of a launch reads it, every 16th iteration, and RELAYS a set word to a
-// device word; that one every chain looks at once per iteration -- requested when the iteration starts, looked at when it
-// ends (its latency hides behind the whole iteration). A team agrees on ONE value (thread 0's) so that no wave leaves a
-// barrier behind.
-template <class CA>
-__device__ __forceinline__ int stop_request_load(const CA& A, int chain_in_launch, long long git) {
+// of short iterations), so only one chain in (relay_mask + 1) <= 256 of a launch reads it, at the first iteration of the
+// launch and then every 16th iteration, and RELAYS a set word to a device word; that one every chain looks at once per
+// iteration -- requested when the iteration starts, looked at when it ends (its latency hides behind the whole iteration).
+// WHICH chains relay rotates with the iteration index (chain + git / 16 = 0 mod the mask), so that no particular chain
+// has to be alive for the word to arrive (a chain that stopped with "Bad initial energy" used to be able to take the
+// relay with it). A team agrees on ONE value (thread 0's) so that no wave leaves a barrier behind.
+// A launch that STARTS under a request does nothing at all (stop_at_entry): sample() enqueues all launches of a job up
+// front, and the ones still queued when Ctrl-C arrives must neither run an iteration nor touch iter_count.
+template <class CA, class PT>
+__device__ __forceinline__ int stop_request_load(const CA& A, const PT& P, int chain_in_launch, int it, long long git) {
     int* dev = A.stop_dev;
-    if ((chain_in_launch & 255) == 0 && (git & 15) == 0) {   // wave-uniform
+    const int mask = P.relay_mask;
+    const bool relay = (it == 0) ? ((chain_in_launch & mask) == 0)
+                                 : ((git & 15) == 0 && ((chain_in_launch + static_cast<int>(git >> 4)) & mask) == 0);
+    if (relay) {   // wave-uniform
         if (__hip_atomic_load(A.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)
             __hip_atomic_store(dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ... and leaves word of where the job is (a posted store into the same pinned block)
+        __hip_atomic_store(A.progress, static_cast<int>(git), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     return __hip_atomic_load(dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1283,6 +1296,21 @@ __device__ __forceinline__ bool stop_requested(TeamT& tm, int loaded, double* bc
         if (tm.tid() == 0) bcast[3] = static_cast<double>(loaded);
         tm.sync();
         return first_f64(bcast[3]) != 0.0;
+    }
+}
+// the device word as a launch finds it; `word` = one LDS int the workgroup may use for the agreement (W > 1: the waves of
+// a team could otherwise read different values and part at the first barrier)
+template <int W>
+__device__ __forceinline__ bool stop_at_entry(const int* stop_dev, int* word) {
+    const int s = __hip_atomic_load(const_cast<int*>(stop_dev), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (W == 1) {
+        return first_i32(s) != 0;
+    } else {
+        if (threadIdx.x == 0) *word = s;
+        __syncthreads();
+        const int agreed = *word;
+        __syncthreads();   // the word's LDS may be reused right away
+        return first_i32(agreed) != 0;
     }
 }
 struct DualAverage {   // step_sizes.py:49-99, wave-uniform
@@ -1454,6 +1482,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     double* rng_bcast = tm.xbuf + 2 * W * kTeamSlots;
     const int tid = tm.tid();
 
+    if (stop_at_entry<W>(A0.stop_dev, reinterpret_cast<int*>(lds))) return;   // queued behind a Ctrl-C: nothing runs, nothing is touched
     if (A0.status[c] & kStatusBadInitialEnergy) return;   // chain already aborted (ValueError on host)
 
     TargetT<NS> tgt;
@@ -1530,7 +1559,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         const bool tune = git < P.n_tune;
         const bool momentum_f32 = P.momentum_f32 != 0;
         LMC_PHASE(5)
-        const int stop_word = stop_request_load(ka.A(), static_cast<int>(blockIdx.x), git);
+        const int stop_word = stop_request_load(ka.A(), P, static_cast<int>(blockIdx.x), it, git);
 
         // ---- momentum draw (quadpotential.py:221-224 / :374-376)
         double p0[NS];

@@ -38,7 +38,8 @@ def _hip_chain_stats(x, t0, n, lag0):
     from . import _abi
 
     lib = _abi.load()
-    c, stride, d = x.shape
+    c, _n, d = x.shape
+    stride = x.stride(0) // d if c > 1 else _n     # rows of a chain lie d apart; chains `stride` rows apart (_row_major)
     out = torch.empty((3 + LAGS_PER_PASS, d), dtype=torch.float64, device=x.device)
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
@@ -49,7 +50,30 @@ def _hip_chain_stats(x, t0, n, lag0):
     return out
 
 
+def _row_major(x):
+    """x[chains, draws, d] as the kernel reads it: a draw is d contiguous doubles, a chain's draws follow each other, and
+    chains are a whole number of rows apart -- a contiguous tensor, or the leading draws of one (trace_tensor(e, n))."""
+    c, n, d = x.shape
+    return x.stride(2) == 1 and x.stride(1) == d and (c <= 1 or (x.stride(0) % d == 0 and x.stride(0) >= n * d))
+
+
+def _blocks(x):
+    """x is one tensor [chains, draws, d], or a list of them: the chain blocks of ONE job that this process holds on
+    several GPUs (sample(..., devices=[...]) -> trace_tensor(group)). Reductions land on the first block's device."""
+    return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
 def chain_stats_pass(x, ranges, lag0, stats_fn=None):
+    if isinstance(x, (list, tuple)):   # one kernel per device, all enqueued before the first result is moved
+        parts = [chain_stats_pass(b, ranges, lag0, stats_fn) for b in x]
+        tot = parts[0]
+        for p_ in parts[1:]:
+            tot = tot + p_.to(tot.device)
+        return tot
+    return _chain_stats_pass_one(x, ranges, lag0, stats_fn)
+
+
+def _chain_stats_pass_one(x, ranges, lag0, stats_fn=None):
     """Statistics block [3 + 16, d] of one pass, summed over the sub-series ``ranges`` = [(t0, n), ...] of every
     chain of x (the two halves for split diagnostics). ``stats_fn(x, t0, n, lag0)`` replaces the HIP kernel (tests of
     the reduction logic only)."""
@@ -62,7 +86,7 @@ def chain_stats_pass(x, ranges, lag0, stats_fn=None):
 
             raise HipLibraryError("diagnostics run on draws in HBM (a ROCm tensor, e.g. diagnostics.trace_tensor(engine)); "
                                   "got a CPU tensor and there is no host implementation")
-        if x.dtype != torch.float64 or not x.is_contiguous():
+        if x.dtype != torch.float64 or not _row_major(x):
             x = x.to(torch.float64).contiguous()
         fn = _hip_chain_stats
     tot = None
@@ -107,11 +131,21 @@ def _geyer_ended(stats):
 
 
 def sufficient_stats(x, split=True, max_lag=None, group=None, reduce_device=None, stats_fn=None):
-    """Reduced (over chains, halves and ranks) sufficient statistics of x[chains, draws, d] (this rank's block).
-    Every quantity that steers the pass loop -- the draw count, the lag limit, "Geyer's sequence has ended" -- is a
-    REDUCED one, so all ranks issue the same collectives whatever their blocks hold (a rank may own no chain at all)."""
-    c, n_all, d = x.shape
-    dev = x.device
+    """Reduced (over chains, halves and ranks) sufficient statistics of x[chains, draws, d] (this rank's block, or the
+    list of this process's per-GPU blocks). Every quantity that steers the pass loop -- the draw count, the lag limit,
+    "Geyer's sequence has ended" -- is a REDUCED one, so all ranks issue the same collectives whatever their blocks hold
+    (a rank may own no chain at all)."""
+    blocks = _blocks(x)
+    held = [b for b in blocks if b.shape[0] > 0]
+    if len({int(b.shape[1]) for b in held}) > 1:
+        raise ValueError("the chain blocks hold different numbers of draws per chain: %s" % [int(b.shape[1]) for b in held])
+    c = sum(int(b.shape[0]) for b in blocks)
+    n_all, d = (held[0].shape[1], held[0].shape[2]) if held else (blocks[0].shape[1], blocks[0].shape[2])
+    dev = blocks[0].device
+    if len(blocks) > 1:
+        x = held if held else blocks[:1]
+    else:
+        x = blocks[0]
     # the draw count is agreed first: ranks that own chains must have the same, ranks that own none adopt it
     big = float(2 ** 52)
     mine = torch.tensor([float(n_all), -float(n_all)] if c > 0 else [0.0, -big], dtype=torch.float64, device=dev)
@@ -193,6 +227,8 @@ def rank_normalize(x, chunk_dims=8, group=None, reduce_device=None):
     N(0, 1) separately and erase exactly the between-rank differences R-hat is there to detect."""
     import torch.distributed as dist
 
+    if isinstance(x, (list, tuple)):
+        return _rank_normalize_blocks(list(x), chunk_dims, group)
     c, n, d = x.shape
     S_local = c * n
     active = _group_active(group)
@@ -205,6 +241,8 @@ def rank_normalize(x, chunk_dims=8, group=None, reduce_device=None):
         sizes = [int(v) for v in _all_reduce(cnt, group, reduce_device)]
         S = sum(sizes)
     out = torch.empty((c, n, d), dtype=torch.float64, device=x.device)
+    if active:   # the gathered pools of a chunk are world x chunk x (largest block) doubles on every rank: keep them <= ~1 GiB
+        chunk_dims = max(1, min(int(chunk_dims), (1 << 30) // max(1, 8 * len(sizes) * max(sizes))))
     for lo in range(0, d, chunk_dims):
         hi = min(lo + chunk_dims, d)
         blk = x[:, :, lo:hi].reshape(S_local, hi - lo).to(torch.float64).t().contiguous()      # [k, S_local]
@@ -233,9 +271,43 @@ def rank_normalize(x, chunk_dims=8, group=None, reduce_device=None):
     return out
 
 
+def _rank_normalize_blocks(blocks, chunk_dims, group):
+    """rank_normalize for the per-GPU chain blocks of one process: global ranks over ALL blocks. Every device sorts its
+    own block of a chunk of dimensions; every device then counts its draws' insertion points in every sorted pool
+    (copied device to device), exactly as the multi-process form does with all-gathered pools."""
+    if _group_active(group):
+        raise ValueError("per-GPU blocks inside one rank of a process group are not supported: use one device per rank")
+    S = sum(int(b.shape[0]) * int(b.shape[1]) for b in blocks)
+    d = int(blocks[0].shape[2])
+    outs = [torch.empty(tuple(b.shape), dtype=torch.float64, device=b.device) for b in blocks]
+    largest = max(int(b.shape[0]) * int(b.shape[1]) for b in blocks)
+    chunk_dims = max(1, min(int(chunk_dims), (1 << 30) // max(1, 8 * len(blocks) * max(largest, 1))))
+    for lo in range(0, d, chunk_dims):
+        hi = min(lo + chunk_dims, d)
+        flat = [b[:, :, lo:hi].reshape(-1, hi - lo).to(torch.float64).t().contiguous() for b in blocks]   # [k, S_b]
+        pools = [torch.sort(f, dim=1).values for f in flat]
+        for b, f, out in zip(blocks, flat, outs):
+            if f.shape[1] == 0:
+                continue
+            less = torch.zeros_like(f)
+            leq = torch.zeros_like(f)
+            for pool in pools:
+                if pool.shape[1] == 0:
+                    continue
+                pl = pool.to(f.device)
+                less += torch.searchsorted(pl, f, right=False).to(torch.float64)
+                leq += torch.searchsorted(pl, f, right=True).to(torch.float64)
+            ranks = less + 0.5 * (leq - less + 1.0)
+            p = (ranks - 0.375) / (S + 0.25)
+            z = math.sqrt(2.0) * torch.erfinv(2.0 * p - 1.0)
+            out[:, :, lo:hi] = z.t().reshape(b.shape[0], b.shape[1], hi - lo)
+    return outs
+
+
 def summarize(x, split=True, max_lag=None, group=None, reduce_device=None, rank_normalized=False, chunk=None,
               stats_fn=None):
-    """x[chains, draws, d] (this rank's chain block) -> dict(rhat[d], ess[d], mean[d], var[d]) over ALL ranks.
+    """x[chains, draws, d] (this rank's chain block; or the list of this process's per-GPU blocks, trace_tensor(group))
+    -> dict(rhat[d], ess[d], mean[d], var[d]) over ALL chains of ALL ranks.
     ``rank_normalized=True``: the rank-normalised split-R-hat / bulk ESS (diagnostics of the z-scores of the GLOBAL
     ranks). ``stats_fn`` replaces the HIP kernel (tests of the reduction logic only)."""
     if rank_normalized:
@@ -279,8 +351,14 @@ class _DevicePtr:
                                          "version": 2}
 
 
-def trace_tensor(engine):
-    """Zero-copy torch view [chains, capacity - trace_begin, dim] of the engine's draws in HBM."""
+def trace_tensor(engine, n_draws=None):
+    """Zero-copy torch view [chains, capacity - trace_begin, dim] of the engine's draws in HBM (an EngineGroup: the list
+    of its engines' views, one per GPU -- summarize() takes it as it is). ``n_draws`` keeps the first n_draws draws of
+    every chain only: the rows an interrupted run has actually written."""
+    if hasattr(engine, "engines"):
+        return [trace_tensor(e, n_draws) for e in engine.engines]
+    if n_draws is not None:
+        return trace_tensor(engine)[:, :max(int(n_draws), 0)]
     ptr = engine.trace_device_ptr()
     if not ptr:
         raise RuntimeError("the engine keeps no trace (reserve(keep_trace=False))")

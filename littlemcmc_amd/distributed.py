@@ -104,8 +104,11 @@ def sample_distributed(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, 
     elif diagnostics:
         from . import diagnostics as dg
 
-        # a rank without chains joins every collective with an empty block of the SAME draw count as the others
-        x = dg.trace_tensor(eng) if eng is not None else torch.zeros((0, n_keep, int(model_ndim)), dtype=torch.float64, device=dev)
+        # a rank without chains joins every collective with an empty block (the draw count is agreed among the ranks
+        # that hold chains). Only the rows sample() returned are looked at: after a Ctrl-C the trace buffer's tail is
+        # unwritten, and ranks that stopped at different iterations fail the agreed-draw-count check instead of
+        # producing statistics of garbage
+        x = dg.trace_tensor(eng, n_draws=trace.shape[1]) if eng is not None else torch.zeros((0, 0, int(model_ndim)), dtype=torch.float64, device=dev)
         diag = dg.summarize(x, group=group, reduce_device=red, rank_normalized=(diagnostics == "rank_normalized"))
         diag = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in diag.items()}
     if eng is not None:

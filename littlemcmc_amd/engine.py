@@ -1,6 +1,7 @@
 """Thin object wrapper over the C ABI handle (include/lmc_hip.h): one Engine == one GPU == one
 block of chains, each chain a wavefront. Host arrays in, host arrays out; the zero-copy device
-pointers are exposed for consumers that keep results in HBM (bench.py, diagnostics)."""
+pointers are exposed for consumers that keep results in HBM (bench.py, diagnostics). EngineGroup (below) is several
+engines -- one per GPU -- behind the same methods: what sample(..., devices=[...]) drives."""
 import ctypes as C
 
 import numpy as np
@@ -166,6 +167,11 @@ class Engine:
     def request_stop(self, stop=True):
         """Ctrl-C for the device: every chain leaves its launch at its next iteration boundary (include/lmc_hip.h)."""
         self._check(self._lib.lmc_engine_request_stop(self._h, int(bool(stop))))
+
+    def progress(self):
+        """Iteration index the running job has reached -- a hint read from pinned host memory, no stream is touched
+        (lmc_engine_progress); what every chain has COMPLETED is completed_iterations(), which waits for the launches."""
+        return int(self._lib.lmc_engine_progress(self._h))
 
     def completed_iterations(self):
         """Iterations EVERY chain has completed since reset_tuning() (the smallest per-chain iteration count)."""
@@ -430,3 +436,141 @@ class Engine:
         out = np.empty((self.chains, self.dim))
         self._check(self._lib.lmc_engine_draw_momentum(self._h, _abi.ptr(out)))
         return out
+
+
+class EngineGroup:
+    """One job on several GPUs driven from ONE process: engine k owns the contiguous chain block ``blocks[k]`` of the
+    job's global chain index space on device ``devices[k]`` (the reference fans its chains out from inside ``sample()``
+    too: one worker per chain up to ``cores``, sampling.py:124-129,186-201 -> parallel_sampling.py). Chains share
+    nothing, so there is no data path between the engines: every call is the same call on each engine with its slice of
+    the arguments, launches are enqueued on all devices before anything is waited for, and results are concatenated in
+    chain order -- the group reads like one Engine of ``chains`` chains (same seeds -> the same draws, chain for chain,
+    as one engine holding them all). A device may appear more than once (two engines sharing a GPU: how the one-GPU test
+    box exercises this path)."""
+
+    def __init__(self, engines, blocks):
+        assert len(engines) == len(blocks) and engines
+        self.engines = list(engines)
+        self.blocks = [(int(lo), int(hi)) for lo, hi in blocks]
+        self.chains = self.blocks[-1][1]
+        self.dim = engines[0].dim
+        self.target = engines[0].target
+        self.kind = engines[0].kind
+        self.potential = engines[0].potential
+        self.cfg = engines[0].cfg        # shape / method fields; cfg.device and cfg.chains are the FIRST engine's
+        self.devices = [int(e.cfg.device) for e in engines]
+
+    # ---- plumbing -----------------------------------------------------------------------------------------------
+    def _each(self, name, *args, **kw):
+        return [getattr(e, name)(*args, **kw) for e in self.engines]
+
+    def _cat(self, name, *args, **kw):
+        return np.concatenate(self._each(name, *args, **kw), axis=0)
+
+    def _locate(self, chain):
+        chain = int(chain) % self.chains
+        for k, (lo, hi) in enumerate(self.blocks):
+            if lo <= chain < hi:
+                return self.engines[k], chain - lo
+        raise IndexError(chain)
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def synchronize(self):
+        self._each("synchronize")
+
+    # ---- state ----------------------------------------------------------------------------------------------------
+    def seed(self, seeds):
+        seeds = np.asarray(seeds)
+        assert seeds.shape == (self.chains,)
+        for e, (lo, hi) in zip(self.engines, self.blocks):
+            e.seed(seeds[lo:hi])
+
+    def set_position(self, q):
+        q = np.asarray(q, dtype=np.float64)
+        for e, (lo, hi) in zip(self.engines, self.blocks):
+            e.set_position(q if q.ndim == 1 else np.ascontiguousarray(q[lo:hi]))
+
+    def get_position(self):
+        return self._cat("get_position")
+
+    def reset_tuning(self):
+        self._each("reset_tuning")
+
+    def keep_moments(self, enable=True):
+        self._each("keep_moments", enable)
+
+    def moments(self):
+        parts = self._each("moments")
+        return tuple(np.concatenate([p[i] for p in parts], axis=0) for i in range(3))
+
+    def set_step_jitter(self, lo, hi, enable=True):
+        self._each("set_step_jitter", lo, hi, enable)
+
+    # ---- sampling ---------------------------------------------------------------------------------------------------
+    def reserve(self, capacity, keep_trace=True, trace_begin=0):
+        self._each("reserve", capacity, keep_trace=keep_trace, trace_begin=trace_begin)
+        self.capacity, self.keep_trace, self.trace_begin = (self.engines[0].capacity, self.engines[0].keep_trace,
+                                                            self.engines[0].trace_begin)
+
+    def run(self, n_tune, iter_begin, n_iters):
+        """Asynchronous on every device (fused kernels): the launch is enqueued everywhere before anyone waits."""
+        self._each("run", n_tune, iter_begin, n_iters)
+
+    def request_stop(self, stop=True):
+        self._each("request_stop", stop)
+
+    def progress(self):
+        return min(self._each("progress"))
+
+    def completed_iterations(self):
+        return min(self._each("completed_iterations"))
+
+    def resident_chains(self):
+        """Resident slots of ONE device's kernel (the engines are alike): what launch sizing compares a block with."""
+        return self.engines[0].resident_chains()
+
+    def occupancy(self):
+        return self.engines[0].occupancy()
+
+    def trace(self, iter_begin=None, n_iters=None):
+        return self._cat("trace", iter_begin, n_iters)
+
+    def stat_f64(self, stat, iter_begin=0, n_iters=None):
+        return self._cat("stat_f64", stat, iter_begin, n_iters)
+
+    def stat_i32(self, stat, iter_begin=0, n_iters=None):
+        return self._cat("stat_i32", stat, iter_begin, n_iters)
+
+    def stat_u8(self, stat, iter_begin=0, n_iters=None):
+        return self._cat("stat_u8", stat, iter_begin, n_iters)
+
+    def status(self):
+        return self._cat("status")
+
+    def counters(self):
+        return self._cat("counters")
+
+    def adapt_state(self):
+        parts = self._each("adapt_state")
+        return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
+
+    def get_chain_state(self, fields=None):
+        parts = self._each("get_chain_state", fields)
+        return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
+
+    def get_dense_state(self, fields=None):
+        parts = self._each("get_dense_state", fields)
+        return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
+
+    def dense_chain(self, chain=0):
+        e, c = self._locate(chain)
+        return e.dense_chain(c)

@@ -5,7 +5,8 @@ Same call signature, same seed derivation, same start-point logic, same return l
 sampling.py:207-220). What changed is everything underneath: instead of one Python loop per chain
 (sampling.py:331-521) or one OS process per chain (parallel_sampling.py), all chains run as
 wavefronts of one HIP kernel (csrc/lmc_sampler.hpp) and the host only slices the run into a few
-launches. ``cores``, ``mp_ctx`` and ``pickle_backend`` are accepted and ignored.
+launches. ``cores`` caps the number of GPUs a job is spread over (the reference: worker processes); ``mp_ctx`` and
+``pickle_backend`` are accepted and ignored.
 """
 import logging
 import os
@@ -69,7 +70,23 @@ def init_nuts(logp_dlogp_func, model_ndim=None, init="auto", random_seed=None, s
     return start, step
 
 
-def _run_job(eng, tune, n_total, per_launch, progressbar):
+class JobProgress:
+    """What ``callback(trace=None, draw=...)`` receives while a job runs (the reference calls its callback once per draw
+    with the draw, sampling.py:272-277, :307-308; here all chains advance inside device launches, so the callback is
+    called from the host's wait loop whenever the job has moved on): ``iteration`` = the iteration the chains have
+    reached (a device-written hint, Engine.progress()), ``total``, ``tuning`` (still below ``tune``), ``chains``,
+    ``launches_done``. Raising KeyboardInterrupt in the callback interrupts sampling, as in the reference."""
+
+    __slots__ = ("iteration", "total", "tuning", "chains", "launches_done")
+
+    def __init__(self, iteration, total, tuning, chains, launches_done):
+        self.iteration, self.total, self.tuning, self.chains, self.launches_done = iteration, total, tuning, chains, launches_done
+
+    def __repr__(self):
+        return "JobProgress(iteration=%d, total=%d, tuning=%s, chains=%d)" % (self.iteration, self.total, self.tuning, self.chains)
+
+
+def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None):
     """Enqueue the job's launches, then wait for them in a way Ctrl-C can reach (sampling.py:324-328, :470-471 in the
     reference: a KeyboardInterrupt ends sampling and what has been drawn so far is returned).
 
@@ -77,16 +94,20 @@ def _run_job(eng, tune, n_total, per_launch, progressbar):
     boundaries), so the host does not step in between them: it polls the completion events of the launches it queued,
     logs progress as they complete (``progressbar=True``; the reference's per-draw bar, sampling.py:455-459, at launch
     granularity) and, on Ctrl-C, asks the device to stop -- every chain leaves its launch at its next iteration
-    boundary (lmc_engine_request_stop). Returns (iterations completed by EVERY chain, interrupted)."""
+    boundary and the launches still queued do nothing (lmc_engine_request_stop). With several GPUs (an EngineGroup)
+    every launch is enqueued on all devices before anything is waited for, and a launch counts as complete when it is
+    complete everywhere. Returns (iterations completed by EVERY chain, interrupted)."""
     import time
 
-    marks = []   # (iterations enqueued so far, [event per run stream]) per launch
+    engines = getattr(eng, "engines", [eng])
+    marks = []   # (iterations enqueued so far, [event per run stream of every engine]) per launch
     events_ok = eng.target.family != _abi.TARGET_EXTERNAL
     torch = None
     if events_ok:
         try:
             import torch
-            streams = [torch.cuda.ExternalStream(h, device=torch.device("cuda", int(eng.cfg.device))) for h in eng.run_streams()]
+            streams = [torch.cuda.ExternalStream(h, device=torch.device("cuda", int(e_.cfg.device)))
+                       for e_ in engines for h in e_.run_streams()]
         except Exception:   # no torch: plain blocking wait (no progress lines, Ctrl-C acts when the job ends)
             torch = None
     t0 = time.perf_counter()
@@ -97,17 +118,28 @@ def _run_job(eng, tune, n_total, per_launch, progressbar):
             eng.run(tune, it, n)
             it += n
             if torch is not None:
-                evs = [torch.cuda.Event() for _ in streams]
-                for e_, s_ in zip(evs, streams):
-                    e_.record(s_)
+                evs = []
+                for s_ in streams:
+                    with torch.cuda.device(s_.device):
+                        ev_ = torch.cuda.Event()
+                        ev_.record(s_)
+                    evs.append(ev_)
                 marks.append((it, evs))
         if torch is None:
             eng.synchronize()
         else:
             reported = 0
+            launches_done = 0
+            seen = -1
             while marks:
+                if callback is not None:
+                    at = eng.progress()
+                    if at != seen:
+                        seen = at
+                        callback(trace=None, draw=JobProgress(at, n_total, at < tune, eng.chains, launches_done))
                 if all(e_.query() for e_ in marks[0][1]):
                     done = marks.pop(0)[0]
+                    launches_done += 1
                     if progressbar and done != reported:
                         reported = done
                         _log.info("Sampling %d chains: %d/%d iterations (%s), %.1f s" % (
@@ -127,20 +159,66 @@ def _run_job(eng, tune, n_total, per_launch, progressbar):
         return n_done, True
 
 
+def visible_devices():
+    """HIP devices this process can see (lmc_device_count: 0 when there is none)."""
+    return int(_abi.load().lmc_device_count())
+
+
+def _resolve_devices(devices, device, cores, chains, probe):
+    """Which GPUs a job of ``chains`` chains runs on -- the reference's ``cores`` logic (sampling.py:117-129: one worker
+    per chain, at most ``cores`` at a time) with GPUs in the place of cores.
+
+    * ``devices=[...]`` (HIP ordinals, repeats allowed) or ``devices=N`` (the first N GPUs): exactly those.
+    * ``device=k``: that one GPU (what a one-process-per-GPU launcher passes: distributed.sample_distributed).
+    * neither: under a multi-process launcher (WORLD_SIZE > 1) GPU LOCAL_RANK; otherwise ``cores=N`` -> the first
+      min(N, visible) GPUs, and with ``cores`` unset as many GPUs as the chains fill -- one more GPU per
+      ``probe()`` = resident wavefront slots of the sampling kernel, i.e. no GPU is brought in to run below full residency.
+    Never more devices than chains."""
+    if devices is not None:
+        if isinstance(devices, (int, np.integer)):
+            devices = list(range(int(devices)))
+        devices = [int(d_) for d_ in devices]
+        if not devices:
+            raise ValueError("devices must name at least one GPU")
+    elif device is not None:
+        devices = [int(device)]
+    elif int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        devices = [int(os.environ.get("LOCAL_RANK", "0"))]
+    else:
+        n_vis = visible_devices()
+        if n_vis <= 1:
+            devices = [0]
+        elif cores is not None:
+            devices = list(range(max(1, min(int(cores), n_vis))))
+        else:
+            slots = probe() or 1024   # (kernels that do not report their residency: a block of 1024 chains per GPU)
+            devices = list(range(max(1, min(n_vis, chains // slots))))
+    return devices[:max(1, min(len(devices), chains))]
+
 def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, init="auto", chains=None,
            cores=None, start=None, progressbar=True, random_seed=None, discard_tuned_samples=True,
-           chain_idx=0, callback=None, mp_ctx=None, pickle_backend="pickle", size=None, device=0,
+           chain_idx=0, callback=None, mp_ctx=None, pickle_backend="pickle", size=None, device=None, devices=None,
            launch_iters=None, return_engine=False, keep_moments=False, **kwargs):
-    """Draw samples with many chains on one MI355X (reference signature: sampling.py:35-53).
+    """Draw samples with many chains on the MI355X(s) of this node (reference signature: sampling.py:35-53).
 
-    Extra keywords: ``size`` (alias of ``model_ndim``), ``device`` (HIP ordinal), ``launch_iters``
+    Where the reference fans its chains out over ``cores`` worker processes (sampling.py:124-129,186-201), this fans
+    them out over GPUs: the chains are dealt to the devices in contiguous blocks (distributed.chain_block) on the seeds
+    of the global chain index space, one engine per device, all driven from this process -- the result is the one-GPU
+    result chain for chain. ``cores=N`` means "at most N GPUs"; by default a job takes as many visible GPUs as its chains
+    fill (see _resolve_devices); ``devices=[...]`` / ``device=k`` pin the choice.
+
+    Extra keywords: ``size`` (alias of ``model_ndim``), ``device`` / ``devices`` (HIP ordinals), ``launch_iters``
     (iterations per kernel launch; default: the whole run in at most a few launches),
-    ``return_engine`` (also return the live Engine, e.g. to read device pointers), ``keep_moments`` (the kernel
-    also keeps every chain's running mean / M2 of the post-warm-up draws: ``Engine.moments()``).
+    ``return_engine`` (also return the live Engine -- an EngineGroup on several GPUs -- e.g. to read device pointers),
+    ``keep_moments`` (the kernel also keeps every chain's running mean / M2 of the post-warm-up draws:
+    ``Engine.moments()``). ``callback(trace=None, draw=JobProgress)`` is called from the wait loop as the job advances
+    and may raise KeyboardInterrupt to stop it (sampling.py:272-277 of the reference); ``mp_ctx`` and
+    ``pickle_backend`` are accepted and ignored (no worker processes).
     """
     if model_ndim is None:
         model_ndim = size if size is not None else getattr(logp_dlogp_func, "d", None)
     target = require_device_target(logp_dlogp_func, model_ndim)
+    gpu_cap = cores                # the caller's own `cores` (None = not given) caps the number of GPUs
     if cores is None:
         cores = min(4, os.cpu_count() or 1)
     if chains is None:
@@ -171,7 +249,34 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
             raise ValueError("start must have shape (model_ndim,) or (chains, model_ndim)")
 
     n_total = int(tune) + int(draws)
-    eng = step._make_engine(chains, device=device)
+
+    def _probe_slots():   # resident wavefront slots of this job's sampling kernel on one GPU (a one-chain engine knows)
+        if target.family == _abi.TARGET_EXTERNAL:
+            return chains + 1     # a host / torch callable is evaluated on one device: no automatic fan-out
+        probe = step._make_engine(1, device=0)
+        try:
+            return probe.resident_chains()
+        finally:
+            probe.close()
+
+    devs = _resolve_devices(devices, device, gpu_cap, chains, _probe_slots)
+    if len(devs) == 1:
+        eng = step._make_engine(chains, device=devs[0])
+    else:
+        from .distributed import chain_block
+        from .engine import EngineGroup
+
+        blocks = [chain_block(chains, k, len(devs)) for k in range(len(devs))]
+        made = []
+        try:
+            for dv, (b_lo, b_hi) in zip(devs, blocks):
+                made.append(step._make_engine(b_hi - b_lo, device=dv))
+        except BaseException:
+            for e_ in made:
+                e_.close()
+            raise
+        eng = EngineGroup(made, blocks)
+        _log.info("Sampling %d chains on %d GPUs %s (contiguous blocks of ~%d chains)" % (chains, len(devs), devs, blocks[0][1]))
     try:
         eng.seed(seeds)                       # np.random.seed(random_seed[i]) per chain (sampling.py:496-497)
         eng.set_position(np.ascontiguousarray(starts))
@@ -188,11 +293,12 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
             # would then run in a few job-long rounds with the last one part empty. In segments of 100 iterations the
             # engine's two sub-block streams keep the slots filled across segment boundaries (+22 % at 8 192 x d=128).
             slots = eng.resident_chains()
-            if slots and slots < chains < 6 * slots:
+            per_dev = -(-chains // len(devs))     # what one GPU holds
+            if slots and slots < per_dev < 6 * slots:
                 per_launch = min(per_launch, 100)
         if target.family == _abi.TARGET_EXTERNAL and not launch_iters:
             per_launch = max(n_total, 1)   # ticks: chains never wait for each other inside one request
-        n_done, interrupted = _run_job(eng, int(tune), n_total, per_launch, progressbar)
+        n_done, interrupted = _run_job(eng, int(tune), n_total, per_launch, progressbar, callback)
         raise_for_status(eng.status())
 
         n_out = max(n_done - lo, 0)

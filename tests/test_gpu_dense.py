@@ -478,31 +478,31 @@ def test_full_potential_float64(golden_dir):
     np.testing.assert_allclose(trace[:, :n], g["trace"][:, :n], rtol=1e-7, atol=1e-9)
 
 
-def test_keyboard_interrupt_in_the_shared_matrix_kernel(monkeypatch):
+def test_keyboard_interrupt_in_the_shared_matrix_kernel():
     """Ctrl-C while eight chains per workgroup meet at barriers (run_dense_coop_kernel): a chain that sees the stop word
     leaves its iteration loop and keeps answering the group's barriers until every chain of the group has left -- no wave is
-    left waiting, the draws every chain completed come back (sampling.py:324-328 of the reference)."""
-    import time
-
+    left waiting, the draws every chain completed come back (sampling.py:324-328 of the reference) and equal the
+    uninterrupted job's. The interrupt is raised from the callback when the device reports iteration 40 (no wall clock)."""
     d = 32
     idx = np.arange(d)
     cov = 0.9 ** np.abs(idx[:, None] - idx[None, :])
     tgt = lmc.targets.AR1(d, 0.9)
-    step = lmc.NUTS(tgt, d, potential=lmc.QuadPotentialFull(cov))
-    lmc.sample(tgt, d, draws=5, tune=5, chains=64, step=lmc.NUTS(tgt, d, potential=lmc.QuadPotentialFull(cov)), random_seed=1)   # code objects loaded
-    real_sleep = time.sleep
     fired = []
 
-    def sleep_then_interrupt(dt):
-        if not fired:
-            fired.append(1)
-            real_sleep(0.2)
+    def cb(trace, draw):
+        if not fired and draw.iteration >= 40:
+            fired.append(draw.iteration)
             raise KeyboardInterrupt
-        real_sleep(dt)
 
-    monkeypatch.setattr(time, "sleep", sleep_then_interrupt)
-    trace, stats = lmc.sample(tgt, d, draws=20000, tune=100, chains=2048, step=step, random_seed=3, discard_tuned_samples=False)
-    monkeypatch.setattr(time, "sleep", real_sleep)
+    total = 100 + 40000
+    trace, stats = lmc.sample(tgt, d, draws=40000, tune=100, chains=2048, step=lmc.NUTS(tgt, d, potential=lmc.QuadPotentialFull(cov)),
+                              random_seed=3, discard_tuned_samples=False, callback=cb, progressbar=False)
     n = trace.shape[1]
-    assert fired and 0 < n < 20100 and np.isfinite(trace).all()
+    print("interrupt at device iteration %s: %d of %d iterations" % (fired, n, total))
+    assert fired and fired[0] <= n < total and np.isfinite(trace).all()
     assert stats["tree_size"].shape == (2048, n, 1)
+    full, fstats = lmc.sample(tgt, d, draws=max(n - 100, 0), tune=min(n, 100), chains=2048,
+                              step=lmc.NUTS(tgt, d, potential=lmc.QuadPotentialFull(cov)), random_seed=3,
+                              discard_tuned_samples=False, progressbar=False)
+    np.testing.assert_array_equal(trace, full[:, :n])
+    np.testing.assert_array_equal(stats["tree_size"], fstats["tree_size"][:, :n])

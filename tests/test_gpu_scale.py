@@ -259,39 +259,86 @@ def test_north_star_shape_moments_within_1e3():
     assert np.abs(gvar - 1.0).max() < 1e-3, np.abs(gvar - 1.0).max()
 
 
-def test_keyboard_interrupt_returns_the_draws_so_far(monkeypatch):
+class _InterruptAt:
+    """callback for sample(): raises KeyboardInterrupt once the DEVICE says the job has reached iteration `at` (the
+    engine's progress word, written by the sampling kernel) -- no wall-clock assumption about how fast the job runs."""
+
+    def __init__(self, at):
+        self.at, self.fired_at, self.calls = at, None, 0
+
+    def __call__(self, trace, draw):
+        self.calls += 1
+        if self.fired_at is None and draw.iteration >= self.at:
+            self.fired_at = draw.iteration
+            raise KeyboardInterrupt
+
+
+def test_keyboard_interrupt_returns_the_draws_so_far():
     """sampling.py:324-328 / :470-471: Ctrl-C ends sampling and the draws so far are returned. On the device every chain
     leaves its launch at its next iteration boundary (lmc_engine_request_stop); the iterations EVERY chain completed are
-    returned and are, bit for bit, the prefix of the uninterrupted job. The interrupt is raised where a real one would
-    arrive: in the host's wait loop, 50 ms into a job of 20 050 iterations."""
-    import time
-
-    d, chains, tune, draws = 64, 4096, 50, 20000
+    returned and are, bit for bit, the prefix of the uninterrupted job -- every returned row, not a sample of them. The
+    interrupt is raised where the reference allows it (sampling.py:277: a KeyboardInterrupt thrown in the callback), when
+    the device reports iteration 48 of 100 050: the job is ~1 s long, the stop takes ~16 iterations to arrive."""
+    d, chains, tune, draws = 32, 2048, 50, 100000
     tgt = T.StdNormal(d)
-    lmc.sample(tgt, d, draws=5, tune=5, chains=64, random_seed=1)      # code objects loaded: the clock below starts with the kernels
-    real_sleep = time.sleep
-    fired = []
-
-    def sleep_then_interrupt(dt):
-        if not fired:
-            fired.append(1)
-            real_sleep(0.05)
-            raise KeyboardInterrupt
-        real_sleep(dt)
-
-    monkeypatch.setattr(time, "sleep", sleep_then_interrupt)
-    trace, stats = lmc.sample(tgt, d, draws=draws, tune=tune, chains=chains, random_seed=12, discard_tuned_samples=False)
-    monkeypatch.setattr(time, "sleep", real_sleep)
+    cb = _InterruptAt(48)
+    trace, stats = lmc.sample(tgt, d, draws=draws, tune=tune, chains=chains, random_seed=12, discard_tuned_samples=False,
+                              callback=cb, progressbar=False)
     n = trace.shape[1]
-    print("interrupted after %d of %d iterations" % (n, tune + draws))
-    assert fired and 0 < n < tune + draws
+    print("interrupt raised at device iteration %d; %d of %d iterations completed by every chain" % (cb.fired_at, n, tune + draws))
+    assert cb.fired_at is not None and cb.fired_at <= n < tune + draws
     assert trace.shape == (chains, n, d) and stats["depth"].shape == (chains, n, 1)
-    m = min(n, 80)
-    full, fstats = lmc.sample(tgt, d, draws=30, tune=tune, chains=chains, random_seed=12, discard_tuned_samples=False)
-    np.testing.assert_array_equal(trace[:, :m], full[:, :m])
-    np.testing.assert_array_equal(stats["tree_size"][:, :m], fstats["tree_size"][:, :m])
+    full, fstats = lmc.sample(tgt, d, draws=max(n - tune, 0), tune=min(n, tune), chains=chains, random_seed=12,
+                              discard_tuned_samples=False, progressbar=False)
     # the engine is re-armed by the next job: a fresh sample() after an interrupted one runs to the end
-    assert full.shape == (chains, tune + 30, d)
+    assert full.shape == (chains, n, d)
+    np.testing.assert_array_equal(trace, full)
+    for name in fstats:
+        np.testing.assert_array_equal(stats[name], fstats[name], err_msg=name)
+
+
+def test_keyboard_interrupt_with_many_queued_launches_returns_only_written_rows():
+    """sample() enqueues every launch of a job up front. The launches still queued when Ctrl-C arrives must do NOTHING:
+    a launch that ran even one iteration at its own iter_begin would raise iter_count past rows nobody wrote and pollute
+    the tuning counters (found by review in round 3: the stop word was only tested at the END of an iteration). Here the
+    job is 500 launches of 8 iterations; after the interrupt every returned row equals the uninterrupted job's, no
+    chain's iteration count ran ahead into another launch, and the per-chain counters are those of the rows returned."""
+    from littlemcmc_amd import _abi
+
+    d, chains, tune, draws = 16, 1024, 30, 3970
+    tgt = T.StdNormal(d)
+    cb = _InterruptAt(40)
+    trace, stats, eng = lmc.sample(tgt, d, draws=draws, tune=tune, chains=chains, random_seed=5, discard_tuned_samples=False,
+                                   callback=cb, progressbar=False, launch_iters=8, return_engine=True)
+    try:
+        n = trace.shape[1]
+        it_c = eng.get_chain_state(fields=("iter_count",))["iter_count"]
+        ct = eng.counters()
+    finally:
+        eng.close()
+    print("interrupted at %d: %d rows; iter_count %d..%d" % (cb.fired_at, n, it_c.min(), it_c.max()))
+    assert cb.fired_at is not None and 0 < n < tune + draws
+    assert it_c.min() == n
+    # a chain stops at the end of the iteration in which it saw the request -- inside ONE launch of 8 iterations; the
+    # launches behind it did not run, so nobody is more than a launch ahead of the slowest chain
+    assert it_c.max() - it_c.min() <= 8 + 8, (it_c.min(), it_c.max())
+    np.testing.assert_array_equal(ct[:, _abi.CT_SAMPLES_AFTER_TUNE], np.maximum(it_c - tune, 0))
+    full, fstats = lmc.sample(tgt, d, draws=max(n - tune, 0), tune=min(n, tune), chains=chains, random_seed=5,
+                              discard_tuned_samples=False, progressbar=False, launch_iters=8)
+    np.testing.assert_array_equal(trace, full)
+    for name in fstats:
+        np.testing.assert_array_equal(stats[name], fstats[name], err_msg=name)
+
+
+def test_callback_sees_the_job_advance():
+    """`callback` (sampling.py:49, :272-277 of the reference) is called as the job advances, with where it is."""
+    seen = []
+    d = 8
+    lmc.sample(T.StdNormal(d), d, draws=3000, tune=1000, chains=256, random_seed=2, progressbar=False,
+               callback=lambda trace, draw: seen.append((draw.iteration, draw.tuning, draw.total, draw.chains)))
+    its = [s[0] for s in seen]
+    assert len(seen) >= 2 and max(its) > 1000 and all(s[2] == 4000 and s[3] == 256 for s in seen)
+    assert all((i < 1000) == t for i, t, _n, _c in seen)
 
 
 def _pooled_moments(mean, m2, n):

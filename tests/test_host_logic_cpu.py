@@ -96,3 +96,118 @@ def test_chain_block_seeds_are_prefix_stable():
     assert seeds[:8] == global_seeds(20260928, 8)
     blocks = [chain_block(64, r, 8) for r in range(8)]
     assert sum((seeds[a:b] for a, b in blocks), []) == seeds
+
+
+# ---- several GPUs behind sample(): device choice and the engine group (no GPU needed: stand-in engines) --------------
+def test_device_choice_follows_the_references_cores_logic(monkeypatch):
+    """sampling.py:117-129 of the reference with GPUs in the place of worker processes."""
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sampling, "visible_devices", lambda: 8)
+    slots = lambda: 3072   # noqa: E731
+    R = sampling._resolve_devices
+    assert R([3, 3], None, None, 100, slots) == [3, 3]                 # explicit, repeats allowed (two engines on one GPU)
+    assert R(4, None, None, 100, slots) == [0, 1, 2, 3]                # devices=N: the first N
+    assert R(None, 5, None, 100000, slots) == [5]                      # device=k pins one GPU (launcher ranks)
+    assert R(None, None, 2, 100000, slots) == [0, 1]                   # cores=N: at most N GPUs
+    assert R(None, None, 64, 100000, slots) == list(range(8))          # ... of those that exist
+    assert R(None, None, None, 65536, slots) == list(range(8))         # default: as many GPUs as the chains fill
+    assert R(None, None, None, 8192, slots) == [0, 1]                  # 8192 // 3072 = 2: no GPU below full residency
+    assert R(None, None, None, 64, slots) == [0]
+    assert R(4, None, None, 3, slots) == [0, 1, 2]                     # never more devices than chains
+    monkeypatch.setattr(sampling, "visible_devices", lambda: 1)
+    assert R(None, None, None, 65536, slots) == [0]
+    monkeypatch.setenv("WORLD_SIZE", "8")                              # under a process-per-GPU launcher: this rank's GPU
+    monkeypatch.setenv("LOCAL_RANK", "6")
+    monkeypatch.setattr(sampling, "visible_devices", lambda: 8)
+    assert R(None, None, None, 65536, slots) == [6]
+    with pytest.raises(ValueError):
+        R([], None, None, 4, slots)
+
+
+class FakeBlockEngine(FakeEngine):
+    """A stand-in that also holds per-chain arrays, so that the group's slicing / concatenation can be checked."""
+
+    def __init__(self, chains, device, done):
+        super().__init__(chains=chains, done_when_stopped=done)
+        self.cfg = types.SimpleNamespace(device=device, chains=chains)
+        self.dim, self.kind, self.potential = 3, "nuts", "diag_adapt"
+        self.seeds = self.q = None
+
+    def seed(self, s):
+        self.seeds = np.asarray(s).copy()
+
+    def set_position(self, q):
+        self.q = np.broadcast_to(np.asarray(q, dtype="d"), (self.chains, self.dim)).copy()
+
+    def trace(self, lo=None, n=None):
+        return self.q[:, None, :] + np.arange(n)[None, :, None]
+
+    def status(self):
+        return np.zeros(self.chains, dtype=np.int32)
+
+    def counters(self):
+        return np.tile(self.seeds[:, None].astype(np.int64), (1, _abi.NUM_COUNTERS))
+
+    def adapt_state(self):
+        return {"var": self.q.astype(np.float32), "count": self.seeds.astype(np.int32)}
+
+    def dense_chain(self, chain=0):
+        return ("cov", int(self.seeds[chain]))
+
+    def close(self):
+        self.calls.append(("close",))
+
+
+def test_engine_group_deals_chain_blocks_and_concatenates_in_chain_order():
+    from littlemcmc_amd.distributed import chain_block
+    from littlemcmc_amd.engine import EngineGroup
+
+    chains, devs = 11, [0, 1, 1]
+    blocks = [chain_block(chains, k, len(devs)) for k in range(len(devs))]
+    engines = [FakeBlockEngine(hi - lo, dv, done=40 + 7 * k) for k, (dv, (lo, hi)) in enumerate(zip(devs, blocks))]
+    g = EngineGroup(engines, blocks)
+    assert (g.chains, g.devices) == (chains, devs)
+    seeds = np.arange(100, 100 + chains)
+    q0 = np.arange(chains * 3, dtype="d").reshape(chains, 3)
+    g.seed(seeds)
+    g.set_position(q0)
+    for e, (lo, hi) in zip(engines, blocks):          # every engine got ITS slice of the global arrays
+        np.testing.assert_array_equal(e.seeds, seeds[lo:hi])
+        np.testing.assert_array_equal(e.q, q0[lo:hi])
+    np.testing.assert_array_equal(g.trace(0, 2)[:, 0], q0)             # results come back in global chain order
+    np.testing.assert_array_equal(g.counters()[:, 0], seeds)
+    np.testing.assert_array_equal(g.adapt_state()["count"], seeds)
+    assert g.dense_chain(chains - 1) == ("cov", int(seeds[-1])) and g.dense_chain(4) == ("cov", int(seeds[4]))
+    assert g.completed_iterations() == 40                               # what EVERY chain of EVERY block completed
+    g.set_position(q0[0])                                               # one start for all chains
+    assert all((e.q == q0[0]).all() for e in engines)
+    # the job loop drives the group like one engine: every launch on every device, one wait, stop reaches all of them
+    n_done, interrupted = sampling._run_job(g, tune=5, n_total=25, per_launch=10, progressbar=False)
+    assert (n_done, interrupted) == (25, False)
+    for e in engines:
+        assert [c for c in e.calls if c[0] == "run"] == [("run", 5, 0, 10), ("run", 5, 10, 10), ("run", 5, 20, 5)]
+    engines[1]._interrupt = True
+    n_done, interrupted = sampling._run_job(g, tune=5, n_total=100, per_launch=50, progressbar=False)
+    assert (n_done, interrupted) == (40, True)
+    for e in engines:
+        assert ("stop", True) in e.calls and e.calls[-1] == ("stop", False)
+    g.close()
+    assert all(e.calls[-1] == ("close",) for e in engines)
+
+
+def test_the_build_hash_is_compiled_into_the_binary(tmp_path):
+    """needs_build() compares the stamp INSIDE the library with the sources as they are (not mtimes), and the loaded
+    library reports the same stamp through the C ABI: a stale binary cannot pass for the tree's."""
+    from littlemcmc_amd import _build
+
+    lib = _abi.load()
+    stamp = lib.lmc_build_hash().decode()
+    assert stamp == _build.binary_hash() and len(stamp) == 16 and stamp != "unstamped"
+    assert (stamp == _build.source_hash()) == (not _build.needs_build())
+    # a binary without a stamp, or with another build's stamp, needs a build whatever its mtime says
+    fake = tmp_path / "liblmc_hip.so"
+    fake.write_bytes(b"\x7fELF....LMC_BUILD_HASH=0123456789abcdef\0....")
+    assert _build.binary_hash(str(fake)) == "0123456789abcdef" and _build.needs_build(str(fake))
+    fake.write_bytes(b"\x7fELF no stamp at all")
+    assert _build.binary_hash(str(fake)) is None and _build.needs_build(str(fake))
+    assert _build.source_hash(("-DX",)) != _build.source_hash()          # private builds carry their own identity
