@@ -233,6 +233,16 @@ int lmc_engine_set_dual_average(lmc_engine* e, double log_step, double log_bar, 
  * step_rand = lambda s: s * np.random.uniform(lo, hi) -- one double of the chain's own stream per iteration, drawn
  * between the start state and the trajectory. enable = 0 switches it off (the default). */
 int lmc_engine_set_step_jitter(lmc_engine* e, int32_t enable, double lo, double hi);
+/* step_rand as an ARBITRARY host function (base_hmc.py:46,123,154-155: `step_size = self._step_rand(step_size)` once per
+ * iteration): the caller evaluates it for every chain and hands the results over; the next lmc_engine_run() integrates
+ * with step_sizes[chain] (HOST or DEVICE pointer, [chains]) instead of exp(log_step) / exp(log_bar) -- run ONE iteration
+ * per call and refresh the values in between. NULL switches back. Dual averaging is untouched (the reference adapts the
+ * un-jittered step size too). */
+int lmc_engine_set_step_sizes(lmc_engine* e, const double* step_sizes);
+/* potential.update(sample = the chain's current position, grad, tune) of QuadPotentialDiagAdapt for every chain as a call
+ * of its own (quadpotential.py:231-245; the fixed potentials' update is the base class's `pass`, :112-118): the device
+ * function lmc_engine_run() applies after every tuning iteration. The dense counterpart is lmc_engine_dense_update(). */
+int lmc_engine_diag_update(lmc_engine* e, int32_t tune);
 int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int64_t trace_begin);
 /* KeyboardInterrupt (sampling.py:324-328, :470-471: the reference keeps what has been drawn so far). stop = 1: every
  * chain leaves the launch it is in within ~16 iterations and launches still queued return at once -- the stop word is

@@ -103,6 +103,8 @@ _SIGNATURES = {
     "lmc_engine_run": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32]),
     "lmc_engine_run_streams": (C.c_int, [_P, _P, C.c_int32]),
     "lmc_engine_set_step_jitter": (C.c_int, [_P, C.c_int32, C.c_double, C.c_double]),
+    "lmc_engine_set_step_sizes": (C.c_int, [_P, _P]),
+    "lmc_engine_diag_update": (C.c_int, [_P, C.c_int32]),
     "lmc_engine_get_trace": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "lmc_engine_get_stat_f64": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int64]),
     "lmc_engine_get_stat_i32": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int64]),

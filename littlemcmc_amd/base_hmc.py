@@ -47,8 +47,13 @@ class StepRandUniform:
     """``step_rand`` (base_hmc.py:46,123,154-155) in the form the device can honour with same-seed parity:
     ``StepRandUniform(lo, hi)`` is ``lambda s: s * np.random.uniform(lo, hi)`` -- one double of the chain's own legacy stream
     per iteration, drawn where the reference calls the function (after the momentum draw and the start state, before the
-    trajectory). Calling the object does exactly that on the host, so it can be handed to the reference too; an arbitrary
-    Python callable cannot run inside the sampling kernel and is refused."""
+    trajectory). Calling the object does exactly that on the host, so it can be handed to the reference too.
+
+    Any OTHER callable is honoured as well, on the host: it is evaluated once per chain per iteration BEFORE that iteration
+    is launched (one launch per iteration, lmc_engine_set_step_sizes), with the step size the reference would pass it. A
+    deterministic function (``lambda s: 0.9 * s``, a schedule, ...) gives the reference's chain; one that draws from
+    ``np.random`` sees the host's global stream, not the chain's, and at another point of the iteration -- statistically
+    the same sampler, not the same draws (use StepRandUniform for those)."""
 
     def __init__(self, lo, hi):
         self.lo, self.hi = float(lo), float(hi)
@@ -71,10 +76,8 @@ class BaseHMC:
     def __init__(self, logp_dlogp_func, model_ndim, scaling, is_cov, potential, target_accept, Emax,
                  adapt_step_size, step_scale, gamma, k, t0, step_rand):
         self._logp_dlogp_func = require_device_target(logp_dlogp_func, model_ndim)
-        if step_rand is not None and not isinstance(step_rand, StepRandUniform):
-            raise NotImplementedError(
-                "an arbitrary step_rand callable cannot run inside the sampling kernel; the device form is "
-                "littlemcmc_amd.StepRandUniform(lo, hi) == lambda s: s * np.random.uniform(lo, hi)")
+        if step_rand is not None and not callable(step_rand):
+            raise TypeError("step_rand must be callable (base_hmc.py:154-155 calls it with the step size)")
         self.adapt_step_size = adapt_step_size
         self.Emax = Emax
         self.iter_count = 0
@@ -118,9 +121,19 @@ class BaseHMC:
 
         eng = Engine(self._logp_dlogp_func, chains=chains, device=device, **self._engine_kwargs())
         self.potential._push_initial(eng)
-        if self._step_rand is not None:
+        if isinstance(self._step_rand, StepRandUniform):
             eng.set_step_jitter(self._step_rand.lo, self._step_rand.hi)
         return eng
+
+    def _host_step_rand(self):
+        """The step_rand callable the HOST has to evaluate per iteration (None: none, or the device's own uniform form)."""
+        return None if isinstance(self._step_rand, StepRandUniform) else self._step_rand
+
+    def _host_step_sizes(self, eng, tune):
+        """step_rand(step size of the coming iteration) for every chain of ``eng`` (base_hmc.py:151-155)."""
+        st = eng.adapt_state()
+        base = np.exp(st["log_step"] if (tune and self.adapt_step_size) else st["log_bar"])
+        return np.array([float(self._step_rand(float(b))) for b in base])
 
     def _engine(self):
         if self._eng1 is None:
@@ -156,6 +169,10 @@ class BaseHMC:
         # the step size this iteration integrates with (base_hmc.py:151-153), from the adaptation state before the update
         self.step_size = float(np.exp(self.step_adapt._log_step if (self.tune and self.adapt_step_size)
                                       else self.step_adapt._log_bar))
+        if self._host_step_rand() is not None:   # base_hmc.py:154-155 (evaluated before the launch: see StepRandUniform)
+            self.step_size = float(self._step_rand(self.step_size))
+            eng.set_step_sizes([self.step_size])
+            eng.set_rng_state(0, np.random.get_state())   # the callable may have drawn from the global stream
         eng.run(1 if self.tune else 0, 0, 1)
         np.random.set_state(eng.get_rng_state(0))
         raise_for_status(eng.status())

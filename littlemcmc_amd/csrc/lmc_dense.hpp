@@ -623,7 +623,7 @@ __device__ __forceinline__ void dense_run_chain(const ChainArrays& A, const Dens
             break;
         }
         const bool adapt_step = tune && P.adapt_step_size;
-        const double step_size = jitter_step_size(tm, rng, P, adapt_step ? da.step_now : da.step_bar_now);
+        const double step_size = jitter_step_size(tm, rng, A, P, c, adapt_step ? da.step_now : da.step_bar_now);
 
         TransitionOut out;
         if (P.kind == 0) {

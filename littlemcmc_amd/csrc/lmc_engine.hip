@@ -163,6 +163,45 @@ __global__ void set_da_kernel(ChainArrays A, double log_step, double log_bar, do
     A.da_count[c] = count;
 }
 
+// QuadPotentialDiagAdapt.update(sample = the chain's current position, grad, tune = True) as a call of its own
+// (quadpotential.py:231-245): the very device function the sampling kernel runs after every tuning iteration.
+template <int NS>
+__global__ __launch_bounds__(64) void mass_update_kernel(ChainArrays A, SamplerParams P) {
+    const int c = blockIdx.x;
+    const int tid = lane_id();
+    const long long row = static_cast<long long>(c) * A.dpad;
+    double q[NS], vard[NS];
+    float var[NS], inv_std[NS];
+    vload<NS>(A.q + row, q);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        var[s] = A.var[row + tid * NS + s];
+        inv_std[s] = A.inv_std[row + tid * NS + s];
+        vard[s] = static_cast<double>(var[s]);
+    }
+    MassScalars ms;
+    ms.n_samples = first_i32(A.n_samples[c]);
+    ms.wsel = first_i32(A.wsel[c]);
+    ms.wsum_f = first_f64(A.wsum[c * 2 + ms.wsel]);
+    ms.wsum_b = first_f64(A.wsum[c * 2 + (1 - ms.wsel)]);
+    ms.window = first_i32(A.awindow[c]);
+    double wm[NS], wr[NS], wmb[NS], wrb[NS];
+    diag_mass_prefetch<NS>(A, row, ms, wm, wr, wmb, wrb);
+    diag_mass_update<NS>(A, P, row, tid, q, var, inv_std, vard, ms, wm, wr, wmb, wrb);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        A.var[row + tid * NS + s] = var[s];
+        A.inv_std[row + tid * NS + s] = inv_std[s];
+    }
+    if (tid == 0) {
+        A.n_samples[c] = ms.n_samples;
+        A.wsel[c] = ms.wsel;
+        A.awindow[c] = ms.window;
+        A.wsum[c * 2 + ms.wsel] = ms.wsum_f;
+        A.wsum[c * 2 + (1 - ms.wsel)] = ms.wsum_b;
+    }
+}
+
 // After lmc_engine_set_chain_state(): inv_std = 1 / sqrt(var) in float32 (quadpotential.py:226-229).
 __global__ void derive_inv_std_kernel(ChainArrays A) {
     const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -195,7 +234,8 @@ struct lmc_engine {
     uint32_t* seeds = nullptr;  // [C] the seeds of lmc_engine_seed (key of LMC_RNG_PHILOX's momentum stream)
     int* stop_host = nullptr;   // pinned, device-mapped host word the sampling kernels poll (lmc_engine_request_stop): the host
                                 // sets it with a plain store -- no stream, no copy engine, no command processor in the way
-    int step_jitter = 0;        // step_rand as step * uniform(lo, hi) (lmc_engine_set_step_jitter)
+    int step_jitter = 0;        // step_rand as step * uniform(lo, hi) (lmc_engine_set_step_jitter); 2: values from the host (lmc_engine_set_step_sizes)
+    double* step_override = nullptr;   // [C] the host's step sizes for the next iteration
     double jitter_lo = 1.0, jitter_hi = 1.0;
     bool sub_pending = false;   // sub-block kernels in flight that the main stream has not been ordered after
     bool main_dirty = true;     // work enqueued on the main stream that the sub-streams have not been ordered after
@@ -918,6 +958,39 @@ static int user_launch(lmc_engine* e, hipFunction_t f, hipStream_t st, unsigned 
                                         "the density compiled in (UserTarget(..., jit=\"hipcc\"))");
     (void)hipGetLastError();
     HIP_TRY(e, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, lds, st, args, nullptr));
+    return LMC_OK;
+}
+
+int lmc_engine_set_step_sizes(lmc_engine* e, const double* step_sizes) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (!step_sizes) {   // back to the adapted step sizes (or the device's own jitter, if that was set before)
+        if (e->step_jitter == 2) e->step_jitter = 0;
+        return LMC_OK;
+    }
+    if (!e->step_override) {
+        int rc = dev_alloc(e, &e->step_override, static_cast<size_t>(e->cfg.chains));
+        if (rc != LMC_OK) return rc;
+        e->A.step_override = e->step_override;
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->step_override, step_sizes, sizeof(double) * e->cfg.chains, hipMemcpyDefault, main_stream(e)));
+    HIP_TRY(e, hipStreamSynchronize(main_stream(e)));   // the caller's array may be reused at once
+    e->step_jitter = 2;
+    return LMC_OK;
+}
+
+int lmc_engine_diag_update(lmc_engine* e, int32_t tune) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    if (e->cfg.potential != LMC_POT_DIAG_ADAPT) return LMC_OK;   // QuadPotential.update of the fixed potentials: `pass` (quadpotential.py:112-118)
+    if (!tune) return LMC_OK;                                    // quadpotential.py:233-234
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    SamplerParams P;
+    std::memset(&P, 0, sizeof(P));
+    P.window = e->cfg.adaptation_window;
+    P.window_multiplier = e->cfg.adaptation_window_multiplier;
+    const dim3 grid(e->cfg.chains), block(64);
+    LMC_NS_SWITCH(e, e->ns, LMC_LAUNCH((mass_update_kernel<NS>), grid, block, 0, main_stream(e), e->A, P))
+    HIP_TRY(e, hipGetLastError());
     return LMC_OK;
 }
 

@@ -69,6 +69,7 @@ struct ChainArrays {
     long long* counters;  // [C][kNumCounters]
     const int* stop;      // [1] pinned host word, != 0: stop requested (lmc_engine_request_stop); read by a few relay chains only
     int* stop_dev;        // [1] device word the relay chains copy it to: what every chain looks at, once per iteration
+    const double* step_override;   // [C] step sizes chosen by the host for the next iteration (P.step_jitter == 2), else nullptr
     int* progress;        // [1] pinned host word: the iteration index a relay chain last started (lmc_engine_progress: a hint the
                           //     host reads without touching a stream)
     const uint32_t* seed; // [C] the seeds of lmc_engine_seed (key of the counter-based momentum stream, LMC_RNG_PHILOX)
@@ -307,9 +308,12 @@ __device__ inline double team_uniform(TeamT& tm, RngState& r, UniformWindow& w) 
 // step_rand (base_hmc.py:46,123,154-155) for  lambda s: s * np.random.uniform(lo, hi): ONE double of the chain's own
 // stream, drawn where the reference calls it -- after the momentum draw and the start state, before the trajectory
 // (np.random.uniform(lo, hi) = lo + (hi - lo) * random_sample())
-template <class TeamT, class PT>
-__device__ __forceinline__ double jitter_step_size(TeamT& tm, RngState& rng, const PT& P, double step_size) {
+// step_jitter == 2: an arbitrary Python step_rand callable, evaluated by the HOST for every chain before the (one-iteration)
+// launch; the kernel takes the value it left in A.step_override (lmc_engine_set_step_sizes).
+template <class TeamT, class CA, class PT>
+__device__ __forceinline__ double jitter_step_size(TeamT& tm, RngState& rng, const CA& A, const PT& P, int c, double step_size) {
     if (!P.step_jitter) return step_size;
+    if (P.step_jitter == 2) return first_f64(A.step_override[c]);
     UniformWindow jw;
     window_reset(jw);
     const double u = team_uniform(tm, rng, jw);
@@ -1599,7 +1603,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
 
         // ---- step size for this iteration (base_hmc.py:151-153)
         const bool adapt_step = tune && P.adapt_step_size;
-        const double step_size = jitter_step_size(tm, rng, P, adapt_step ? da.step_now : da.step_bar_now);   // exp(log_step) / exp(log_bar)
+        const double step_size = jitter_step_size(tm, rng, ka.A(), P, c, adapt_step ? da.step_now : da.step_bar_now);   // exp(log_step) / exp(log_bar)
 
         LMC_PHASE(1)
         TransitionOut out;

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void tick_dense_kerne
             return;
         }
         const bool adapt_step = tune && P.adapt_step_size;
-        step_size = jitter_step_size(tm, rng, P, adapt_step ? da.step_now : da.step_bar_now);
+        step_size = jitter_step_size(tm, rng, A, P, c, adapt_step ? da.step_now : da.step_bar_now);
         n_leap = 0;
         if (P.kind == 0) {
             max_depth = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;

@@ -164,6 +164,19 @@ class Engine:
         """step_rand as step * uniform(lo, hi) drawn from each chain's own stream (include/lmc_hip.h)."""
         self._check(self._lib.lmc_engine_set_step_jitter(self._h, int(bool(enable)), float(lo), float(hi)))
 
+    def set_step_sizes(self, step_sizes):
+        """The step size every chain integrates its NEXT iteration with (an arbitrary host step_rand evaluated by the
+        caller, include/lmc_hip.h: lmc_engine_set_step_sizes); None switches back to the adapted ones."""
+        if step_sizes is None:
+            self._check(self._lib.lmc_engine_set_step_sizes(self._h, None))
+            return
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(step_sizes, dtype=np.float64), (self.chains,)))
+        self._check(self._lib.lmc_engine_set_step_sizes(self._h, _abi.ptr(a)))
+
+    def diag_update(self, tune=True):
+        """potential.update(current position, grad, tune) of QuadPotentialDiagAdapt for every chain (quadpotential.py:231-245)."""
+        self._check(self._lib.lmc_engine_diag_update(self._h, int(bool(tune))))
+
     def request_stop(self, stop=True):
         """Ctrl-C for the device: every chain leaves its launch at its next iteration boundary (include/lmc_hip.h)."""
         self._check(self._lib.lmc_engine_request_stop(self._h, int(bool(stop))))
@@ -514,6 +527,14 @@ class EngineGroup:
 
     def set_step_jitter(self, lo, hi, enable=True):
         self._each("set_step_jitter", lo, hi, enable)
+
+    def set_step_sizes(self, step_sizes):
+        if step_sizes is None:
+            self._each("set_step_sizes", None)
+            return
+        a = np.broadcast_to(np.asarray(step_sizes, dtype=np.float64), (self.chains,))
+        for e, (lo, hi) in zip(self.engines, self.blocks):
+            e.set_step_sizes(a[lo:hi])
 
     # ---- sampling ---------------------------------------------------------------------------------------------------
     def reserve(self, capacity, keep_trace=True, trace_begin=0):

@@ -141,9 +141,8 @@ class QuadPotential:
         return p.astype(np.float32) if self._momentum_f32 else p
 
     def update(self, sample, grad, tune):
-        raise NotImplementedError(
-            "mass-matrix adaptation runs inside the sampling kernel (per tuning iteration); it is not a "
-            "separate host call in littlemcmc_amd")
+        """quadpotential.py:112-118: the fixed potentials learn nothing from a sample (the base class's `pass`)."""
+        return None
 
     def raise_ok(self, vmap=None):
         return None
@@ -194,6 +193,17 @@ class QuadPotentialDiagAdapt(QuadPotential):
         super()._pull(engine, chain)
         if self.adaptation_window_multiplier != 1.0:
             self.adaptation_window = int(engine.get_chain_state(fields=("window",))["window"][chain])
+
+    def update(self, sample, grad, tune):
+        """quadpotential.py:231-245 as one device call: both Welford estimators take the sample, the foreground one becomes
+        the float32 variance, the window switches (the kernel function lmc_engine_run applies after every tuning iteration).
+        During sample() this runs inside the sampling kernel; the host call is the reference's protocol method."""
+        if not tune:
+            return
+        eng = self._eng()
+        eng.set_position(np.asarray(sample, dtype="d").reshape(1, self._n))
+        eng.diag_update(True)
+        self._pull(eng)
 
     def _push_initial(self, engine):
         engine.set_potential(self._initial_mean, self._initial_diag.astype("d"), float(self._initial_weight))

@@ -48,17 +48,18 @@ class _Welford:
 
 
 class DiagAdaptPotential:
-    """quadpotential.py:148-245 (QuadPotentialDiagAdapt); all mass arrays float32."""
+    """quadpotential.py:148-245 (QuadPotentialDiagAdapt); all mass arrays in ``dtype`` (float32 unless the caller says
+    "float64", quadpotential.py:175-176), and with them the momentum draw (:223) and the start state's velocity / energy."""
 
-    momentum_f32 = True
-
-    def __init__(self, n, initial_mean, initial_diag=None, initial_weight=0, window=101, multiplier=1):
+    def __init__(self, n, initial_mean, initial_diag=None, initial_weight=0, window=101, multiplier=1, dtype="float32"):
         self.n = n
+        self.dtype = np.dtype(dtype).name
+        self.momentum_f32 = self.dtype == "float32"
         if initial_diag is None:  # quadpotential.py:178-180
-            initial_diag = np.ones(n, dtype="float32")
+            initial_diag = np.ones(n, dtype=self.dtype)
             initial_weight = 1
         else:
-            initial_diag = np.asarray(initial_diag).astype("float32")
+            initial_diag = np.asarray(initial_diag).astype(self.dtype)
         self._initial_mean = np.array(initial_mean, dtype="d")
         self._initial_diag = initial_diag
         self._initial_weight = initial_weight
@@ -67,7 +68,7 @@ class DiagAdaptPotential:
         self.reset()
 
     def reset(self):  # quadpotential.py:195-204
-        self.var = np.array(self._initial_diag, dtype="float32", copy=True)
+        self.var = np.array(self._initial_diag, dtype=self.dtype, copy=True)
         self.stds = np.sqrt(self._initial_diag)
         self.inv_stds = 1.0 / self.stds
         self.fore = _Welford(self.n, self._initial_mean, self._initial_diag, self._initial_weight)
@@ -84,7 +85,7 @@ class DiagAdaptPotential:
         np.multiply(self.var, x, out=out)
 
     def random(self, rng):  # :221-224
-        vals = rng.normal(size=self.n).astype("float32")
+        vals = rng.normal(size=self.n).astype(self.dtype)
         return self.inv_stds * vals
 
     def update(self, sample, tune):  # :231-245
@@ -92,7 +93,7 @@ class DiagAdaptPotential:
             return
         self.fore.add(sample)
         self.back.add(sample)
-        np.divide(self.fore.raw_var, self.fore.w_sum, out=self.var)  # f64 quotient -> f32
+        np.divide(self.fore.raw_var, self.fore.w_sum, out=self.var)  # f64 quotient -> dtype
         np.sqrt(self.var, out=self.stds)
         np.divide(1, self.stds, out=self.inv_stds)
         if self.n_samples > 0 and self.n_samples % self.window == 0:
@@ -609,7 +610,9 @@ class Step:
         adapt_step = self.tune and self.adapt_step_size
         step_size = self.adapt.current(adapt_step)
         self.step_size = step_size
-        if self.step_rand is not None:   # base_hmc.py:154-155
+        if callable(self.step_rand):     # base_hmc.py:154-155, any function of the step size (a deterministic one here:
+            step_size = self.step_rand(step_size)   # this restatement threads its RandomState explicitly, np.random is not the chain's)
+        elif self.step_rand is not None:
             lo, hi = self.step_rand
             step_size = step_size * rng.uniform(lo, hi)
         if self.kind == "nuts":

@@ -547,10 +547,96 @@ def capture_step_rand():
     save("e2e_step_rand", **out)
 
 
+# ---------------------------------------------------------------------------------------
+# round 4: QuadPotentialDiagAdapt(dtype="float64") (quadpotential.py:159,175-184), a deterministic step_rand callable
+# (base_hmc.py:154-155), and shapes beyond the fused kernels' vector widths (model_ndim 2000 diagonal, 384 dense)
+# ---------------------------------------------------------------------------------------
+def capture_diag_float64():
+    fam, d, chains, tune, draws = "ar1", 12, 2, 230, 40
+    f = targets.make(fam, d)
+    rs = np.random.RandomState(5)
+    # unit values + an update sequence across a window switch
+    pot = QuadPotentialDiagAdapt(d, np.full(d, 0.25), 0.5 + rs.rand(d), 10, adaptation_window=20, dtype="float64")
+    x = rs.randn(d)
+    np.random.seed(99)
+    rnd = np.array([pot.random() for _ in range(3)])
+    out = dict(unit_x=x, unit_velocity=pot.velocity(x), unit_energy=np.array(pot.energy(x)), unit_random=rnd,
+               unit_random_dtype=np.array(str(rnd.dtype)), unit_random_seed=np.array(99),
+               unit_initial_mean=np.full(d, 0.25), unit_initial_diag=np.array(pot._initial_diag, dtype="d"))
+    samples = rs.randn(60, d) * np.linspace(0.2, 5.0, d) - 0.5
+    seq = []
+    for smp in samples:
+        pot.update(smp, None, True)
+        seq.append(np.array(pot._var, dtype="d"))
+    out.update(seq_samples=samples, seq_var=np.array(seq), seq_var_dtype=np.array(str(pot._var.dtype)),
+               seq_n_samples=np.array(pot._n_samples))
+    # one run end to end
+    np.random.seed(SEED + 7)
+    seeds = np.array([np.random.randint(2 ** 30) for _ in range(chains)])
+    np.random.seed(int(seeds[0]))
+    start = 2 * np.random.rand(d) - 1
+    pot2 = QuadPotentialDiagAdapt(d, start, np.ones(d), 10, dtype="float64")
+    step = ref.NUTS(f, d, potential=pot2)
+    trace, stats = ref.sample(f, d, draws=draws, tune=tune, step=step, start=start, chains=chains, cores=1,
+                              progressbar=False, random_seed=list(seeds), discard_tuned_samples=False)
+    out.update(family=np.array(fam), d=np.array(d), chains=np.array(chains), tune=np.array(tune), draws=np.array(draws),
+               seeds=seeds, start=start, params=f.params(), trace=trace, final_var=np.array(pot2._var),
+               final_var_dtype=np.array(str(pot2._var.dtype)))
+    for k, v in stats.items():
+        out["stat_" + k] = v
+    save("e2e_nuts_diag64_ar1_12", **out)
+
+
+def capture_step_rand_callable():
+    shrink = lambda s: 0.9 * s   # noqa: E731
+    f = targets.make("ar1", 12)
+    trace, stats = ref.sample(f, 12, draws=15, tune=60, chains=2, cores=1, progressbar=False, random_seed=SEED + 3,
+                              discard_tuned_samples=False, step_rand=shrink)
+    out = dict(factor=np.array(0.9), random_seed=np.array(SEED + 3), family=np.array("ar1"), d=np.array(12),
+               chains=np.array(2), tune=np.array(60), draws=np.array(15), trace=trace)
+    for k, v in stats.items():
+        out["stat_" + k] = v
+    save("e2e_step_rand_callable", **out)
+
+
+def capture_wide():
+    from littlemcmc import quadpotential as rq
+
+    # model_ndim = 2000, diagonal mass adaptation (C4's family at twice its size), one chain through the plain API
+    fam, d, tune, draws = "diag_gaussian", 2000, 45, 5
+    f = targets.make(fam, d)
+    trace, stats = ref.sample(f, d, draws=draws, tune=tune, chains=1, cores=1, progressbar=False, random_seed=SEED + 11,
+                              discard_tuned_samples=False)
+    np.random.seed(SEED + 11)
+    seeds = np.array([np.random.randint(2 ** 30)])
+    np.random.seed(int(seeds[0]))
+    start = 2 * np.random.rand(d) - 1
+    out = dict(family=np.array(fam), d=np.array(d), chains=np.array(1), tune=np.array(tune), draws=np.array(draws),
+               random_seed=np.array(SEED + 11), seeds=seeds, start=start, params=f.params(), trace=trace)
+    for k, v in stats.items():
+        out["stat_" + k] = v
+    save("e2e_nuts_diag2000", **out)
+    # model_ndim = 384, QuadPotentialFull with the target's covariance (quadpotential.py:430-468)
+    fam, d, tune, draws = "ar1", 384, 40, 10
+    f = targets.make(fam, d)
+    pot = rq.QuadPotentialFull(ar1_cov(d, 0.9))
+    step = ref.NUTS(f, d, potential=pot)
+    trace, stats = ref.sample(f, d, draws=draws, tune=tune, step=step, chains=1, cores=1, progressbar=False,
+                              random_seed=SEED + 12, discard_tuned_samples=False)
+    np.random.seed(SEED + 12)
+    seeds = np.array([np.random.randint(2 ** 30)])
+    out = dict(family=np.array(fam), d=np.array(d), chains=np.array(1), tune=np.array(tune), draws=np.array(draws),
+               random_seed=np.array(SEED + 12), seeds=seeds, rho=np.array(0.9), params=f.params(), trace=trace)
+    for k, v in stats.items():
+        out["stat_" + k] = v
+    save("e2e_nuts_full_ar1_384", **out)
+
+
 CAPTURES = {"leapfrog": capture_leapfrog, "transitions": capture_transitions, "adapt": capture_adapt,
             "e2e": capture_e2e, "seeds": capture_seeds, "dense_units": capture_dense_units,
             "dense_adapt": capture_dense_adapt, "dense_e2e": capture_dense_e2e, "dense_full64": capture_dense_full64,
-            "diag_window_multiplier": capture_diag_window_multiplier, "step_rand": capture_step_rand}
+            "diag_window_multiplier": capture_diag_window_multiplier, "step_rand": capture_step_rand,
+            "diag_float64": capture_diag_float64, "step_rand_callable": capture_step_rand_callable, "wide": capture_wide}
 
 if __name__ == "__main__":
     # capture.py [group | e2e:<name>[,<name>...]] ...   (no argument: everything)
