@@ -146,9 +146,17 @@ typedef struct lmc_config {
     int32_t start_energy_sdot;    /* LMC_SDOT_*: summation order of the float32 start-state kinetic energy */
     double adaptation_window_multiplier; /* 1.0: QuadPotentialDiagAdapt's window grows by this factor at every switch (quadpotential.py:243) */
     int32_t rng_mode;             /* LMC_RNG_*; 0 = the reference's stream */
-    int32_t reserved0;
+    int32_t mass_f64;             /* QuadPotentialDiagAdapt(dtype="float64") (quadpotential.py:159,175-184): variance, standard deviations
+                                   * and the momentum draw stay float64; 0 = the reference's default float32. General kernels (below). */
 } lmc_config;
 
+/* Which kernels an engine runs. The FUSED kernels (one chain = one wavefront or a team of 2 / 4, the tree in registers and
+ * LDS) cover dim <= 1024 with diagonal and dim <= 256 with dense mass matrices, float32 adaptive masses. Everything else the
+ * reference accepts -- dim up to 16 384 (base_hmc.py:102 has no limit), QuadPotentialFull / FullInv up to dim 2048
+ * (quadpotential.py:388-468), QuadPotentialDiagAdapt(dtype="float64") -- runs in the GENERAL kernels (csrc/lmc_wide.hpp: one
+ * chain = a workgroup of 16 wavefronts, the tree in the chain's HBM row): the same algorithm, statement for statement, an
+ * order of magnitude slower per leapfrog. Not in the general kernels: FULL_ADAPT beyond dim 256, LMC_TARGET_EXTERNAL,
+ * LMC_RNG_PHILOX. */
 /* Fill *cfg with the reference's defaults for the given shape. */
 void lmc_config_defaults(lmc_config* cfg, int32_t chains, int32_t dim);
 
@@ -299,6 +307,7 @@ typedef struct lmc_chain_state {
     int32_t* da_count;      /* step_adapt._count */
     int32_t* iter_count;    /* step.iter_count */
     int32_t* window;        /* potential.adaptation_window (grows by the multiplier at every switch) */
+    double* var64;          /* potential._var of a float64 QuadPotentialDiagAdapt (general kernels only; LMC_ERR_STATE otherwise) */
 } lmc_chain_state;
 int lmc_engine_get_chain_state(lmc_engine* e, const lmc_chain_state* dst);
 int lmc_engine_set_chain_state(lmc_engine* e, const lmc_chain_state* src);

@@ -40,7 +40,7 @@ class Config(C.Structure):
         ("max_treedepth", C.c_int32), ("early_max_treedepth", C.c_int32),
         ("path_length", C.c_double), ("max_steps", C.c_int32), ("adaptation_window", C.c_int32),
         ("lds_levels", C.c_int32), ("start_energy_sdot", C.c_int32), ("adaptation_window_multiplier", C.c_double),
-        ("rng_mode", C.c_int32), ("reserved0", C.c_int32),
+        ("rng_mode", C.c_int32), ("mass_f64", C.c_int32),
     ]
 
 
@@ -54,7 +54,7 @@ class ChainState(C.Structure):
               ("back_mean", np.float64, True), ("back_raw_var", np.float64, True), ("fore_w_sum", np.float64, False),
               ("back_w_sum", np.float64, False), ("n_samples", np.int32, False), ("log_step", np.float64, False),
               ("log_bar", np.float64, False), ("hbar", np.float64, False), ("da_count", np.int32, False),
-              ("iter_count", np.int32, False), ("window", np.int32, False))
+              ("iter_count", np.int32, False), ("window", np.int32, False), ("var64", np.float64, True))
     _fields_ = [(name, C.c_void_p) for name, _dt, _vec in FIELDS]
 
 

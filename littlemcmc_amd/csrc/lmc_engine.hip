@@ -18,6 +18,7 @@
 #include "lmc_unit_kernels.hpp"
 #include "lmc_dense_launch.hpp"
 #include "lmc_tick_launch.hpp"
+#include "lmc_wide_launch.hpp"
 #ifdef LMC_USER_TARGET_HEADER
 #include LMC_USER_TARGET_HEADER
 #endif
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(64) void momentum_kernel(ChainArrays A, int momentu
 
 // QuadPotentialDiagAdapt.reset() (quadpotential.py:195-204) / QuadPotentialDiag.__init__ (:349-365)
 // + DualAverageAdaptation.reset() (step_sizes.py:49-56) + iter_count = 0.
-__global__ void reset_kernel(ChainArrays A, const double* init_mean, const float* init_diag, double init_weight,
+__global__ void reset_kernel(ChainArrays A, const double* init_mean, const float* init_diag, const double* init_diag64,
+                             int mass_f64, double init_weight,
                              int adapt, double log_step0, double mu, int reset_step, int reset_mass, int window) {
     const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     const long long n = static_cast<long long>(A.chains) * A.dpad;
@@ -123,10 +125,16 @@ __global__ void reset_kernel(ChainArrays A, const double* init_mean, const float
         const float sd = sqrtf(diag);
         A.var[idx] = diag;
         A.inv_std[idx] = 1.0f / sd;
+        double diag_d = static_cast<double>(diag);
+        if (A.var64 != nullptr) {   // wide kernels: the diagonal in float64 (float32-valued unless the potential's dtype is float64)
+            diag_d = (e < A.d) ? init_diag64[idx] : 1.0;
+            A.var64[idx] = diag_d;
+            A.inv_std64[idx] = mass_f64 ? 1.0 / sqrt(diag_d) : static_cast<double>(1.0f / sd);
+        }
         if (adapt) {
             // foreground: mean = initial_mean, raw_var = initial_diag * weight; background: zeros
             A.wmean[idx] = (e < A.d) ? init_mean[idx] : 0.0;
-            A.wraw[idx] = (e < A.d) ? static_cast<double>(diag) * init_weight : 0.0;
+            A.wraw[idx] = (e < A.d) ? diag_d * init_weight : 0.0;
             A.wmean[n + idx] = 0.0;
             A.wraw[n + idx] = 0.0;
         }
@@ -203,12 +211,24 @@ __global__ __launch_bounds__(64) void mass_update_kernel(ChainArrays A, SamplerP
 }
 
 // After lmc_engine_set_chain_state(): inv_std = 1 / sqrt(var) in float32 (quadpotential.py:226-229).
-__global__ void derive_inv_std_kernel(ChainArrays A) {
+// from64: the float64 diagonal was set (QuadPotentialDiagAdapt(dtype="float64")), the float32 views follow it.
+__global__ void derive_inv_std_kernel(ChainArrays A, int from64) {
     const long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     const long long n = static_cast<long long>(A.chains) * A.dpad;
     if (idx >= n) return;
+    if (from64) {
+        const double v = A.var64[idx];
+        A.inv_std64[idx] = 1.0 / sqrt(v);
+        A.var[idx] = static_cast<float>(v);
+        A.inv_std[idx] = static_cast<float>(A.inv_std64[idx]);
+        return;
+    }
     const float sd = sqrtf(A.var[idx]);
     A.inv_std[idx] = 1.0f / sd;
+    if (A.var64 != nullptr) {
+        A.var64[idx] = static_cast<double>(A.var[idx]);
+        A.inv_std64[idx] = static_cast<double>(A.inv_std[idx]);
+    }
 }
 
 }  // namespace lmc
@@ -221,6 +241,9 @@ static thread_local std::string g_last_error;
 struct lmc_engine {
     lmc_config cfg;
     int ns = 0, dpad = 0, nlds = 1, lds_bytes = 0;   // ns: vector width of the W = 1 unit kernels (dpad = 64 * ns)
+    bool wide = false;          // the general kernels (lmc_wide.hpp): one chain = 16 wavefronts, dpad = 1024 * ns -- model_ndim > 1024,
+                                // dense matrices beyond 256 dimensions, float64 adaptive diagonals
+    double* init_diag64 = nullptr;   // [C][dpad] wide: the initial diagonal in float64
     int run_ns = 0, run_w = 1;                       // shape of the sampling kernel: dpad = 64 * run_ns * run_w
     hipStream_t own_stream = nullptr, stream_ = nullptr;   // stream_: use main_stream(e), which orders sub-block launches first
     // run() deals the chains to n_sub contiguous sub-blocks, each launched on its own stream: the tail of one sub-block's
@@ -583,7 +606,7 @@ void lmc_config_defaults(lmc_config* cfg, int32_t chains, int32_t dim) {
     cfg->adaptation_window = 101;
     cfg->adaptation_window_multiplier = 1.0;
     cfg->rng_mode = LMC_RNG_NUMPY;
-    cfg->reserved0 = 0;
+    cfg->mass_f64 = 0;
     cfg->lds_levels = 0;
     cfg->start_energy_sdot = LMC_SDOT_OPENBLAS_SKYLAKEX;
 }
@@ -595,7 +618,7 @@ static int launch_reset(lmc_engine* e, int reset_step, int reset_mass) {
     const double log_step0 = std::log(e->initial_step);         // step_sizes.py:51
     const double mu = std::log(10 * e->initial_step);           // step_sizes.py:55
     LMC_LAUNCH(reset_kernel, dim3(blocks), dim3(threads), 0, main_stream(e), e->A, e->init_mean, e->init_diag,
-                       e->init_weight, e->cfg.potential == LMC_POT_DIAG_ADAPT ? 1 : 0, log_step0, mu, reset_step,
+                       e->init_diag64, e->cfg.mass_f64, e->init_weight, e->cfg.potential == LMC_POT_DIAG_ADAPT ? 1 : 0, log_step0, mu, reset_step,
                        reset_mass, e->cfg.adaptation_window);
     HIP_TRY(e, hipGetLastError());
     return LMC_OK;
@@ -608,11 +631,35 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         return fail(nullptr, LMC_ERR_INVALID, "ABI version mismatch: header %d, library %d", cfg->abi_version,
                     LMC_ABI_VERSION);
     if (cfg->chains < 1 || cfg->dim < 1) return fail(nullptr, LMC_ERR_INVALID, "chains and dim must be >= 1");
-    if (cfg->dim > 1024) return fail(nullptr, LMC_ERR_INVALID, "dim > 1024 is not supported (one wavefront per chain)");
     if (cfg->potential < LMC_POT_DIAG_ADAPT || cfg->potential > LMC_POT_FULL_F64)
         return fail(nullptr, LMC_ERR_INVALID, "unknown potential %d", cfg->potential);
-    if (cfg->potential >= LMC_POT_FULL && cfg->dim > 256)
-        return fail(nullptr, LMC_ERR_INVALID, "dense mass matrices are supported up to dim 256 (got %d)", cfg->dim);
+    if (cfg->mass_f64 && cfg->potential > LMC_POT_DIAG)
+        return fail(nullptr, LMC_ERR_INVALID, "mass_f64 is the dtype of the diagonal potentials (LMC_POT_DIAG_ADAPT / LMC_POT_DIAG)");
+    // Shapes the fused kernels are not instantiated for run in the general kernels (lmc_wide.hpp: one chain = 16 wavefronts)
+    // (... and a density compiled at run time meets a dense mass matrix there: hiprtc instantiates the general kernel for it)
+    const bool rtc_dense = cfg->target_family == LMC_TARGET_USER && !kUserCompiledInDense && cfg->potential >= LMC_POT_FULL &&
+                           cfg->potential != LMC_POT_FULL_ADAPT;
+    // LMC_FORCE_WIDE=1 (a test knob like LMC_RUN_SHAPE): every shape the general kernels can run takes them, so that the
+    // goldens of the small shapes replay through them too
+    bool forced = false;
+    if (const char* env = std::getenv("LMC_FORCE_WIDE"))
+        forced = std::atoi(env) != 0 && cfg->potential != LMC_POT_FULL_ADAPT && cfg->target_family != LMC_TARGET_EXTERNAL &&
+                 cfg->rng_mode == LMC_RNG_NUMPY;
+    const bool wide = cfg->dim > 1024 || (cfg->potential >= LMC_POT_FULL && cfg->dim > 256) || cfg->mass_f64 != 0 || rtc_dense || forced;
+    if (wide) {
+        if (cfg->dim > kWideMaxDim)
+            return fail(nullptr, LMC_ERR_INVALID, "dim %d is beyond the general kernels' %d", cfg->dim, kWideMaxDim);
+        if (cfg->potential >= LMC_POT_FULL && cfg->dim > kWideMaxDenseDim)
+            return fail(nullptr, LMC_ERR_INVALID, "dense mass matrices are supported up to dim %d (got %d)", kWideMaxDenseDim, cfg->dim);
+        if (cfg->potential == LMC_POT_FULL_ADAPT)
+            return fail(nullptr, LMC_ERR_INVALID, "per-chain adapted dense matrices (FULL_ADAPT) run in the fused kernels only: dim <= 256 "
+                                                  "(got %d), float32, built-in or compiled-in densities", cfg->dim);
+        if (cfg->target_family == LMC_TARGET_EXTERNAL)
+            return fail(nullptr, LMC_ERR_INVALID, "an externally evaluated density runs up to dim 1024 (dense matrices: 256) with float32 "
+                                                  "adaptive masses; give the density as a device functor for larger shapes");
+        if (cfg->rng_mode != LMC_RNG_NUMPY)
+            return fail(nullptr, LMC_ERR_INVALID, "LMC_RNG_PHILOX runs in the fused kernels only");
+    }
     if (!lmc_has_target(cfg->target_family))
         return fail(nullptr, LMC_ERR_INVALID, "target family %d is not built into this library", cfg->target_family);
     if (cfg->target_family == LMC_TARGET_NORMAL1D && cfg->dim != 1)
@@ -641,14 +688,22 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     lmc_engine* e = new (std::nothrow) lmc_engine();
     if (!e) return fail(nullptr, LMC_ERR_INVALID, "out of host memory");
     e->cfg = *cfg;
+    e->wide = wide;
     e->ns = ns_for_dim(cfg->dim);
     e->dpad = 64 * e->ns;
+    if (wide) {   // thread t of the chain's 1024 owns elements t*ns .. t*ns+ns-1
+        int wns = 1;
+        while (kWideBlock * wns < cfg->dim) wns *= 2;
+        e->ns = e->run_ns = wns;
+        e->run_w = kWideBlock / 64;
+        e->dpad = kWideBlock * wns;
+    } else
     // sampling kernel: one wave per chain up to 128 elements, then 2 or 4 waves per chain
     if (e->ns <= 2) { e->run_ns = e->ns; e->run_w = 1; }
     else if (e->ns == 4) { e->run_ns = 4; e->run_w = 1; }
     else if (e->ns == 8) { e->run_ns = 4; e->run_w = 2; }
     else { e->run_ns = 4; e->run_w = 4; }
-    if (const char* shape = std::getenv("LMC_RUN_SHAPE")) {   // tuning knob: "ns,w" with 64*ns*w == dpad
+    if (const char* shape = wide ? nullptr : std::getenv("LMC_RUN_SHAPE")) {   // tuning knob: "ns,w" with 64*ns*w == dpad
         int a = 0, b = 0;
         if (std::sscanf(shape, "%d,%d", &a, &b) == 2 && 64 * a * b == e->dpad) { e->run_ns = a; e->run_w = b; }
     }
@@ -665,7 +720,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     e->stream_ = e->own_stream;
     // sub-blocks: two halves of the chains on two streams (measured on C3's kernel: +2 % at 65 536 chains, +11 % at
     // 16 384, +22 % at 8 192, +36 % at 4 096 -- the per-launch tail of one half is covered by the other half's next launch)
-    e->n_sub = cfg->chains >= 128 ? lmc_engine::kMaxSub : 1;
+    e->n_sub = (cfg->chains >= 128 && !wide) ? lmc_engine::kMaxSub : 1;
     if (const char* env = std::getenv("LMC_SUB_BLOCKS")) {
         const int v = std::atoi(env);
         if (v >= 1 && v <= lmc_engine::kMaxSub && v <= cfg->chains) e->n_sub = v;
@@ -688,7 +743,10 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     // granule taken as 1280 B -- measured: 12 800 B per wave keeps 12 waves/CU, 12 960 B does not); behind it the tail
     // (MT19937 state, team exchange). The rest of the stack goes to the chain's scratch row.
     int nlds = 1;
-    {
+    if (wide) {
+        e->nlds = 1;
+        e->lds_bytes = wide_lds_bytes(e->dpad);
+    } else {
         const int waves_per_cu = 4 * run_waves_per_simd(e->run_ns);
         const int blocks_per_cu = waves_per_cu / e->run_w > 0 ? waves_per_cu / e->run_w : 1;
         const long budget = (163840L / blocks_per_cu) / 1280 * 1280 - lds_tail_doubles(e->run_w) * 8L;
@@ -749,6 +807,12 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     if (dense) A.scratch_stride = static_cast<long long>(dense_scratch_vectors(max_levels)) * dp;
     const bool external = cfg->target_family == LMC_TARGET_EXTERNAL;
     if (external) A.scratch_stride = static_cast<long long>(dense ? tick_dense_scratch_vectors(max_levels) : tick_scratch_vectors(max_levels)) * dp;
+    if (wide) {
+        A.scratch_stride = static_cast<long long>(wide_scratch_slots(max_levels)) * dp;
+        TRY_ALLOC(dev_alloc(e, &A.var64, C * dp));
+        TRY_ALLOC(dev_alloc(e, &A.inv_std64, C * dp));
+        TRY_ALLOC(dev_alloc(e, &e->init_diag64, C * dp));
+    }
     TRY_ALLOC(dev_alloc(e, &A.scratch, C * static_cast<size_t>(A.scratch_stride), false));
     TRY_ALLOC(dev_alloc(e, &e->init_mean, C * dp));
     TRY_ALLOC(dev_alloc(e, &e->init_diag, C * dp));
@@ -890,7 +954,7 @@ int lmc_engine_occupancy(lmc_engine* e, int32_t* resident_chains, int32_t* waves
     }
     if (!resident_chains) return LMC_OK;
     *resident_chains = 0;
-    if (e->cfg.target_family == LMC_TARGET_EXTERNAL || e->cfg.potential >= LMC_POT_FULL) return LMC_OK;
+    if (e->cfg.target_family == LMC_TARGET_EXTERNAL || e->cfg.potential >= LMC_POT_FULL || e->wide) return LMC_OK;
     int cus = 0;
     HIP_TRY(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device));
     const int run_lds = e->lds_bytes + lds_tail_doubles(e->run_w) * 8;
@@ -928,7 +992,8 @@ int lmc_engine_occupancy(lmc_engine* e, int32_t* resident_chains, int32_t* waves
 }
 
 int32_t lmc_engine_run_lds_bytes(lmc_engine* e) {
-    if (!e || e->cfg.target_family == LMC_TARGET_EXTERNAL || e->cfg.potential >= LMC_POT_FULL) return -1;
+    if (!e || e->cfg.target_family == LMC_TARGET_EXTERNAL || (e->cfg.potential >= LMC_POT_FULL && !e->wide)) return -1;
+    if (e->wide) return e->lds_bytes;
     return e->lds_bytes + lds_tail_doubles(e->run_w) * 8;
 }
 
@@ -953,9 +1018,9 @@ static int user_launch(lmc_engine* e, hipFunction_t f, hipStream_t st, unsigned 
     if (!f)
         return fail(e, LMC_ERR_STATE, "the user density's kernels are not loaded: call lmc_engine_load_user_kernels() "
                                       "(littlemcmc_amd.targets.UserTarget does)");
-    if (e->cfg.potential >= LMC_POT_FULL)
-        return fail(e, LMC_ERR_INVALID, "a run-time compiled user density runs with diagonal mass matrices; dense ones need "
-                                        "the density compiled in (UserTarget(..., jit=\"hipcc\"))");
+    if (e->cfg.potential >= LMC_POT_FULL && !e->wide)
+        return fail(e, LMC_ERR_INVALID, "a run-time compiled user density runs with diagonal mass matrices in the fused kernels; "
+                                        "dense ones (Full / FullInv) take the general kernels, FullAdapt needs the density compiled in (UserTarget(..., jit=\"hipcc\"))");
     (void)hipGetLastError();
     HIP_TRY(e, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, lds, st, args, nullptr));
     return LMC_OK;
@@ -988,6 +1053,12 @@ int lmc_engine_diag_update(lmc_engine* e, int32_t tune) {
     std::memset(&P, 0, sizeof(P));
     P.window = e->cfg.adaptation_window;
     P.window_multiplier = e->cfg.adaptation_window_multiplier;
+    P.mass_f64 = e->cfg.mass_f64 ? 1 : 0;
+    if (e->wide) {
+        const int rc = wide_launch_mass_update(e->ns, main_stream(e), e->A, P);
+        if (rc != 0) return dense_fail(e, rc, "diag_update (general kernel)");
+        return LMC_OK;
+    }
     const dim3 grid(e->cfg.chains), block(64);
     LMC_NS_SWITCH(e, e->ns, LMC_LAUNCH((mass_update_kernel<NS>), grid, block, 0, main_stream(e), e->A, P))
     HIP_TRY(e, hipGetLastError());
@@ -1082,13 +1153,17 @@ int lmc_engine_set_potential(lmc_engine* e, const double* initial_mean, const do
         if (!(hdiag[i] > 0.0))   // partial_check_positive_definite (quadpotential.py:68-77)
             return fail(e, LMC_ERR_INVALID, "Scaling is not positive definite: diagonal entry %zu is %g", i, hdiag[i]);
     std::vector<float> fdiag(static_cast<size_t>(C) * dp, 1.0f);
-    std::vector<double> fmean(static_cast<size_t>(C) * dp, 0.0);
+    std::vector<double> fmean(static_cast<size_t>(C) * dp, 0.0), ddiag(e->wide ? static_cast<size_t>(C) * dp : 0, 1.0);
     for (int c = 0; c < C; ++c)
         for (int i = 0; i < d; ++i) {
             const size_t src = static_cast<size_t>(per_chain ? c : 0) * d + i;
             fdiag[static_cast<size_t>(c) * dp + i] = static_cast<float>(hdiag[src]);
             fmean[static_cast<size_t>(c) * dp + i] = hmean[src];
+            if (e->wide)   // initial_diag.astype(dtype) (quadpotential.py:181-183)
+                ddiag[static_cast<size_t>(c) * dp + i] = e->cfg.mass_f64 ? hdiag[src] : static_cast<double>(static_cast<float>(hdiag[src]));
         }
+    if (e->wide)
+        HIP_TRY(e, hipMemcpyAsync(e->init_diag64, ddiag.data(), ddiag.size() * sizeof(double), hipMemcpyHostToDevice, main_stream(e)));
     HIP_TRY(e, hipMemcpyAsync(e->init_diag, fdiag.data(), fdiag.size() * sizeof(float), hipMemcpyHostToDevice, main_stream(e)));
     HIP_TRY(e, hipMemcpyAsync(e->init_mean, fmean.data(), fmean.size() * sizeof(double), hipMemcpyHostToDevice, main_stream(e)));
     e->init_weight = initial_weight;
@@ -1520,8 +1595,9 @@ static SamplerParams make_params(const lmc_engine* e, int64_t n_tune, int64_t it
     SamplerParams P;
     std::memset(&P, 0, sizeof(P));
     P.kind = e->cfg.kind;
-    P.momentum_f32 = e->cfg.potential == LMC_POT_DIAG_ADAPT;
+    P.momentum_f32 = e->cfg.potential == LMC_POT_DIAG_ADAPT && !e->cfg.mass_f64;   // quadpotential.py:223: normals.astype(dtype)
     P.adapt_mass = e->cfg.potential == LMC_POT_DIAG_ADAPT;
+    P.mass_f64 = e->cfg.mass_f64 ? 1 : 0;
     P.adapt_step_size = e->cfg.adapt_step_size;
     P.target_accept = e->cfg.target_accept;
     P.emax = e->cfg.emax;
@@ -1548,6 +1624,22 @@ static SamplerParams make_params(const lmc_engine* e, int64_t n_tune, int64_t it
     return P;
 }
 
+// lmc_engine_run() for the shapes the fused kernels are not instantiated for (lmc_wide.hpp)
+static int wide_run(lmc_engine* e, SamplerParams P) {
+    if (e->cfg.potential >= LMC_POT_FULL) P.momentum_f32 = !pot_f64(e->cfg.potential);
+    if (e->cfg.potential != LMC_POT_DIAG_ADAPT) P.adapt_mass = 0;
+    P.chain_begin = 0;
+    P.relay_mask = relay_mask_for(e->cfg.chains);
+    hipStream_t st = main_stream(e);
+    if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledInDense) {
+        void* args[] = {&e->A, &e->D, &P, &e->tparams};
+        return user_launch(e, e->user_run, st, static_cast<unsigned>(e->cfg.chains), kWideBlock, static_cast<unsigned>(e->lds_bytes), args);
+    }
+    const int rc = wide_launch_run(e->cfg.target_family, e->ns, st, e->A, e->D, P, e->tparams, e->cfg.chains);
+    if (rc != 0) return dense_fail(e, rc, "run (general kernel)");
+    return LMC_OK;
+}
+
 int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters) {
     if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
     if (e->A.cap <= 0 || !e->A.stat_f64) return fail(e, LMC_ERR_STATE, "lmc_engine_reserve() must be called before run()");
@@ -1559,6 +1651,7 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
         return fail(e, LMC_ERR_STATE, "the density is evaluated by the caller: drive the chains with lmc_engine_tick_begin() / lmc_engine_tick()");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     SamplerParams P = make_params(e, n_tune, iter_begin, n_iters);
+    if (e->wide) return wide_run(e, P);
     if (e->cfg.potential >= LMC_POT_FULL) return dense_run(e, P);
     const int run_lds = e->lds_bytes + lds_tail_doubles(e->run_w) * 8;   // subtree stack + MT19937 + team exchange
     const dim3 block(64 * e->run_w);
@@ -1836,6 +1929,10 @@ static int chain_state_xfer(lmc_engine* e, const lmc_chain_state* st, bool to_us
         }
     }
     if (st->var && (rc = copy_vec_rows(e, st->var, A.var, sizeof(float), to_user)) != LMC_OK) return rc;
+    if (st->var64) {
+        if (!A.var64) return fail(e, LMC_ERR_STATE, "var64 is the state of the general kernels (float64 adaptive diagonal)");
+        if ((rc = copy_vec_rows(e, st->var64, A.var64, sizeof(double), to_user)) != LMC_OK) return rc;
+    }
     if (!to_user) {
         if (st->fore_mean && (rc = copy_vec_rows(e, st->fore_mean, A.wmean, sizeof(double), false)) != LMC_OK) return rc;
         if (st->fore_raw_var && (rc = copy_vec_rows(e, st->fore_raw_var, A.wraw, sizeof(double), false)) != LMC_OK) return rc;
@@ -1891,9 +1988,9 @@ static int chain_state_xfer(lmc_engine* e, const lmc_chain_state* st, bool to_us
     if ((rc = ints(st->da_count, A.da_count)) != LMC_OK) return rc;
     if ((rc = ints(st->iter_count, A.iter_count)) != LMC_OK) return rc;
     if ((rc = ints(st->window, A.awindow)) != LMC_OK) return rc;
-    if (!to_user && st->var) {
+    if (!to_user && (st->var || st->var64)) {
         const long long n = static_cast<long long>(C) * e->dpad;
-        LMC_LAUNCH(derive_inv_std_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, main_stream(e), e->A);
+        LMC_LAUNCH(derive_inv_std_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, main_stream(e), e->A, st->var64 ? 1 : 0);
         HIP_TRY(e, hipGetLastError());
         HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
     }
@@ -1918,7 +2015,20 @@ int lmc_engine_trajectory(lmc_engine* e, const double* q0, const double* p0, int
     HIP_TRY(e, oe.alloc(C * ns)); HIP_TRY(e, ol.alloc(C * ns));
     HIP_TRY(e, hipMemcpyAsync(dq0.p, q0, C * d * sizeof(double), hipMemcpyDefault, main_stream(e)));
     HIP_TRY(e, hipMemcpyAsync(dp0.p, p0, C * d * sizeof(double), hipMemcpyDefault, main_stream(e)));
-    if (e->cfg.potential >= LMC_POT_FULL) {
+    if (e->wide) {
+        if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledInDense) {
+            int sdot = e->cfg.start_energy_sdot, p32 = p0_is_f32, nf = n_fwd, nb = n_back;
+            double eps_ = eps;
+            void* args[] = {&e->A, &e->D, &e->tparams, &dq0.p, &dp0.p, &p32, &sdot, &eps_, &nf, &nb, &oq.p, &op.p, &ov.p, &og.p, &oe.p, &ol.p};
+            const int rc = user_launch(e, e->user_trajectory, main_stream(e), static_cast<unsigned>(e->cfg.chains), kWideBlock,
+                                       static_cast<unsigned>(e->lds_bytes), args);
+            if (rc != LMC_OK) return rc;
+        } else {
+            const int rc = wide_launch_trajectory(e->cfg.target_family, e->ns, main_stream(e), e->A, e->D, e->tparams, dq0.p, dp0.p,
+                                                  p0_is_f32, e->cfg.start_energy_sdot, eps, n_fwd, n_back, oq.p, op.p, ov.p, og.p, oe.p, ol.p);
+            if (rc != 0) return dense_fail(e, rc, "trajectory (general kernel)");
+        }
+    } else if (e->cfg.potential >= LMC_POT_FULL) {
         const int rc = dense_launch_trajectory(e->cfg.target_family, e->ns, pot_f64(e->cfg.potential), main_stream(e),
                                                e->A, e->D, e->tparams, dq0.p, dp0.p, p0_is_f32,
                                                e->cfg.start_energy_sdot, eps, n_fwd, n_back, oq.p, op.p, ov.p, og.p,
@@ -1960,9 +2070,12 @@ int lmc_engine_logp_dlogp(lmc_engine* e, const double* q, double* logp, double* 
     HIP_TRY(e, dq.alloc(C * d)); HIP_TRY(e, dl.alloc(C)); HIP_TRY(e, dg.alloc(C * d));
     HIP_TRY(e, hipMemcpyAsync(dq.p, q, C * d * sizeof(double), hipMemcpyDefault, main_stream(e)));
     const dim3 grid(e->cfg.chains), block(64);
-    if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledIn) {
+    if (e->wide && !(e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledIn)) {
+        const int rc = wide_launch_logp(e->cfg.target_family, e->ns, main_stream(e), e->A, e->tparams, dq.p, dl.p, dg.p);
+        if (rc != 0) return dense_fail(e, rc, "logp_dlogp (general kernel)");
+    } else if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledIn) {
         void* args[] = {&e->A, &e->tparams, &dq.p, &dl.p, &dg.p};
-        const int rc = user_launch(e, e->user_logp, main_stream(e), grid.x, block.x, 0, args);
+        const int rc = user_launch(e, e->user_logp, main_stream(e), grid.x, e->wide ? kWideBlock : block.x, e->wide ? 2 * 16 * 8 * 8 : 0, args);
         if (rc != LMC_OK) return rc;
     } else {
 #define LOGP_CALL(T) \
@@ -2006,7 +2119,11 @@ int lmc_engine_draw_momentum(lmc_engine* e, double* out) {
     const size_t C = e->cfg.chains, d = e->cfg.dim;
     DevBuf<double> dout;
     HIP_TRY(e, dout.alloc(C * d));
-    if (e->cfg.potential >= LMC_POT_FULL) {
+    if (e->wide) {
+        const int f32 = e->cfg.potential == LMC_POT_DIAG_ADAPT && !e->cfg.mass_f64;
+        const int rc = wide_launch_momentum(e->ns, main_stream(e), e->A, e->D, f32, dout.p);
+        if (rc != 0) return dense_fail(e, rc, "draw_momentum (general kernel)");
+    } else if (e->cfg.potential >= LMC_POT_FULL) {
         const int rc = dense_launch_momentum(e->ns, main_stream(e), e->A, e->D, dout.p);
         if (rc != 0) return dense_fail(e, rc, "draw_momentum");
     } else {

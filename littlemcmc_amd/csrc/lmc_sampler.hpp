@@ -49,6 +49,8 @@ struct ChainArrays {
     double* q;            // [C][dpad]
     float* var;           // [C][dpad]
     float* inv_std;       // [C][dpad]
+    double* var64;        // [C][dpad] wide kernels (lmc_wide.hpp) only, else nullptr: the diagonal as float64 -- float32-valued
+    double* inv_std64;    // [C][dpad]   unless the potential's dtype is float64
     double* wmean;        // [2][C][dpad]   Welford means (slot wsel = foreground)
     double* wraw;         // [2][C][dpad]
     double* wsum;         // [C][2]
@@ -109,7 +111,7 @@ struct SamplerParams {
     int step_jitter;      // step_rand (base_hmc.py:154-155) in its one device form: step * uniform(jitter_lo, jitter_hi)
     double jitter_lo, jitter_hi;
     int relay_mask;       // stop word: one chain in (relay_mask + 1) of a launch reads the host's word (stop_request_load)
-    int reserved1;
+    int mass_f64;         // QuadPotentialDiagAdapt(dtype="float64"): the adapted diagonal is NOT rounded to float32 (wide kernels)
 };
 
 // ---- kernel arguments, re-read where they are used ---------------------------------------------------------------

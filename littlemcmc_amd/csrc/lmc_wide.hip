@@ -1,0 +1,114 @@
+// Third translation unit of liblmc_hip.so: the general ("wide") kernels (lmc_wide.hpp) and their launchers -- model_ndim
+// beyond 1024, dense mass matrices beyond 256 dimensions, float64 adaptive diagonals. Compiled in parallel with
+// lmc_engine.hip and lmc_dense.hip.
+#include <hip/hip_runtime.h>
+
+#include "../../include/lmc_hip.h"
+#include "lmc_wide.hpp"
+#include "lmc_wide_launch.hpp"
+#ifdef LMC_USER_TARGET_HEADER
+#include LMC_USER_TARGET_HEADER
+#endif
+
+namespace lmc {
+
+static_assert(kWideBlock == kWideThreads, "launcher and kernel agree on the team size");
+
+#ifdef LMC_USER_TARGET_HEADER
+#define WIDE_USER_CASE(CALL) case LMC_TARGET_USER: { CALL(UserTarget); } break;
+#else
+#define WIDE_USER_CASE(CALL)
+#endif
+
+#if defined(LMC_USER_TARGET_HEADER) && defined(LMC_ONLY_USER)
+#define WIDE_FAMILY_SWITCH(family, CALL) \
+    switch (family) {                    \
+        WIDE_USER_CASE(CALL)             \
+        default: return kWideUnsupported; \
+    }
+#else
+#define WIDE_FAMILY_SWITCH(family, CALL)                                    \
+    switch (family) {                                                       \
+        case LMC_TARGET_STD_NORMAL: { CALL(StdNormalTarget); } break;       \
+        case LMC_TARGET_DIAG_GAUSSIAN: { CALL(DiagGaussianTarget); } break; \
+        case LMC_TARGET_AR1: { CALL(AR1Target); } break;                    \
+        case LMC_TARGET_FUNNEL: { CALL(FunnelTarget); } break;              \
+        case LMC_TARGET_NORMAL1D: { CALL(Normal1DTarget); } break;          \
+        WIDE_USER_CASE(CALL)                                                \
+        default: return kWideUnsupported;                                   \
+    }
+#endif
+
+#define WIDE_NS_SWITCH(ns, BODY)                           \
+    switch (ns) {                                          \
+        case 1: { constexpr int NS = 1; BODY; } break;     \
+        case 2: { constexpr int NS = 2; BODY; } break;     \
+        case 4: { constexpr int NS = 4; BODY; } break;     \
+        case 8: { constexpr int NS = 8; BODY; } break;     \
+        case 16: { constexpr int NS = 16; BODY; } break;   \
+        default: return kWideUnsupported;                  \
+    }
+
+int wide_scratch_slots(int max_levels) { return wide_scratch_vectors(max_levels); }
+int wide_lds_bytes(int dpad) { return wide_lds_doubles(dpad) * 8; }
+
+#define WIDE_LDS_ATTR(KERNEL)                                                                                   \
+    if (lds > 64 * 1024) {                                                                                      \
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL),                            \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);                  \
+        if (err != hipSuccess) return static_cast<int>(err);                                                    \
+    }
+
+int wide_launch_run(int family, int ns, hipStream_t stream, const ChainArrays& A, const DenseArrays& D, const SamplerParams& P,
+                    const double* tparams, int n_chains) {
+    const dim3 grid(n_chains > 0 ? n_chains : A.chains), block(kWideThreads);
+    const int lds = wide_lds_bytes(A.dpad);
+    (void)hipGetLastError();
+#define RUN_CALL(T) \
+    WIDE_NS_SWITCH(ns, { WIDE_LDS_ATTR((run_wide_kernel<NS, T>)) hipLaunchKernelGGL((run_wide_kernel<NS, T>), grid, block, lds, stream, A, D, P, tparams); })
+    WIDE_FAMILY_SWITCH(family, RUN_CALL)
+#undef RUN_CALL
+    return static_cast<int>(hipGetLastError());
+}
+
+int wide_launch_logp(int family, int ns, hipStream_t stream, const ChainArrays& A, const double* tparams, const double* q,
+                     double* logp, double* grad) {
+    const dim3 grid(A.chains), block(kWideThreads);
+    const int lds = 2 * kWideWaves * kTeamSlots * 8;
+    (void)hipGetLastError();
+#define LOGP_CALL(T) WIDE_NS_SWITCH(ns, hipLaunchKernelGGL((wide_logp_kernel<NS, T>), grid, block, lds, stream, A, tparams, q, logp, grad))
+    WIDE_FAMILY_SWITCH(family, LOGP_CALL)
+#undef LOGP_CALL
+    return static_cast<int>(hipGetLastError());
+}
+
+int wide_launch_trajectory(int family, int ns, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
+                           const double* tparams, const double* q0, const double* p0, int p0_is_f32, int sdot_mode, double eps,
+                           int n_fwd, int n_back, double* oq, double* op, double* ov, double* og, double* oe, double* ol) {
+    const dim3 grid(A.chains), block(kWideThreads);
+    const int lds = wide_lds_bytes(A.dpad);
+    (void)hipGetLastError();
+#define TRAJ_CALL(T)                                                                                                       \
+    WIDE_NS_SWITCH(ns, { WIDE_LDS_ATTR((wide_trajectory_kernel<NS, T>)) hipLaunchKernelGGL((wide_trajectory_kernel<NS, T>), grid, block, lds, stream, A, D, \
+                                           tparams, q0, p0, p0_is_f32, sdot_mode, eps, n_fwd, n_back, oq, op, ov, og, oe, ol); })
+    WIDE_FAMILY_SWITCH(family, TRAJ_CALL)
+#undef TRAJ_CALL
+    return static_cast<int>(hipGetLastError());
+}
+
+int wide_launch_momentum(int ns, hipStream_t stream, const ChainArrays& A, const DenseArrays& D, int momentum_f32, double* out) {
+    const dim3 grid(A.chains), block(kWideThreads);
+    const int lds = wide_lds_bytes(A.dpad);
+    (void)hipGetLastError();
+    WIDE_NS_SWITCH(ns, { WIDE_LDS_ATTR((wide_momentum_kernel<NS>)) hipLaunchKernelGGL((wide_momentum_kernel<NS>), grid, block, lds, stream, A, D, momentum_f32, out); })
+    return static_cast<int>(hipGetLastError());
+}
+
+int wide_launch_mass_update(int ns, hipStream_t stream, const ChainArrays& A, const SamplerParams& P) {
+    const dim3 grid(A.chains), block(kWideThreads);
+    (void)hipGetLastError();
+    WIDE_NS_SWITCH(ns, hipLaunchKernelGGL((wide_mass_update_kernel<NS>), grid, block, 0, stream, A, P))
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace lmc

@@ -24,7 +24,8 @@ class Engine:
     def __init__(self, target, chains, kind="nuts", potential="diag_adapt", device=0, lib_path=None,
                  target_accept=0.8, Emax=1000.0, adapt_step_size=True, step_scale=0.25, gamma=0.05, k=0.75,
                  t0=10, path_length=2.0, max_treedepth=10, early_max_treedepth=8, max_steps=1024,
-                 adaptation_window=101, adaptation_window_multiplier=1.0, lds_levels=0, sdot=None, rng="numpy"):
+                 adaptation_window=101, adaptation_window_multiplier=1.0, lds_levels=0, sdot=None, rng="numpy",
+                 mass_dtype="float32"):
         self._lib = _abi.load(lib_path or getattr(target, "lib_path", None))
         self._h = C.c_void_p()
         self.target = target
@@ -54,6 +55,9 @@ class Engine:
         cfg.adaptation_window_multiplier = float(adaptation_window_multiplier)
         cfg.lds_levels = int(lds_levels)
         cfg.rng_mode = {"numpy": _abi.RNG_NUMPY, "philox": _abi.RNG_PHILOX}[rng]   # include/lmc_hip.h: LMC_RNG_*
+        # QuadPotentialDiagAdapt(dtype=...) (quadpotential.py:159,175-184); float64 runs in the general kernels
+        self.mass_f64 = np.dtype(mass_dtype) == np.float64 and potential in ("diag_adapt", "diag")
+        cfg.mass_f64 = int(self.mass_f64)
         if sdot is None:
             sdot = DEFAULT_SDOT
         if sdot == "auto":   # float32 start-energy rounding of the host's numpy (see _blas_probe.py)
@@ -73,6 +77,13 @@ class Engine:
         self.capacity = 0
         self.keep_trace = False
         self.trace_begin = 0
+        self.wide = self.kernel_shape()[2] == 16   # the general kernels (include/lmc_hip.h: "Which kernels an engine runs")
+
+    def kernel_shape(self):
+        """(unit_ns, run_ns, run_w) of this engine's kernels (lmc_engine_kernel_shape)."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._lib.lmc_engine_kernel_shape(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
 
     # ---- plumbing ---------------------------------------------------------------------------------
     def _check(self, rc, handle=True):
@@ -317,6 +328,8 @@ class Engine:
         ns = np.empty(self.chains, dtype=np.int32)
         self._check(self._lib.lmc_engine_get_adapt_state(self._h, _abi.ptr(var), _abi.ptr(da), _abi.ptr(cnt),
                                                          _abi.ptr(ns)))
+        if self.mass_f64:   # the potential's own dtype
+            var = self.get_chain_state(fields=("var64",))["var64"]
         return {"var": var, "log_step": da[:, 0], "log_bar": da[:, 1], "hbar": da[:, 2], "mu": da[:, 3],
                 "count": cnt, "n_samples": ns}
 
@@ -326,6 +339,8 @@ class Engine:
         out = {}
         for name, dt, vec in _abi.ChainState.FIELDS:
             if fields is not None and name not in fields:
+                continue
+            if name == "var64" and not self.mass_f64:   # state of a float64 adaptive diagonal only
                 continue
             out[name] = np.empty((self.chains, self.dim) if vec else (self.chains,), dtype=dt)
             setattr(st, name, out[name].ctypes.data)

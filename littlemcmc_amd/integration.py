@@ -27,7 +27,9 @@ class HipLeapfrogIntegrator:
         if self._engine is None:
             from .engine import Engine
 
-            self._engine = Engine(self._logp_dlogp_func, chains=1, potential=self._potential._engine_kind)
+            kind = self._potential._engine_kind
+            self._engine = Engine(self._logp_dlogp_func, chains=1, potential=kind,
+                                  mass_dtype=getattr(self._potential, "dtype", "float32") if kind in ("diag_adapt", "diag") else "float32")
             self._potential._bind(self._engine)
         return self._engine
 

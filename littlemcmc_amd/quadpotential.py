@@ -89,7 +89,8 @@ class QuadPotential:
         if self._engine is None:
             from .engine import Engine
 
-            self._engine = Engine(_targets.StdNormal(self._n), chains=1, potential=self._engine_kind)
+            self._engine = Engine(_targets.StdNormal(self._n), chains=1, potential=self._engine_kind,
+                                  mass_dtype=getattr(self, "dtype", "float32") if self._engine_kind in ("diag_adapt", "diag") else "float32")
             self._own_engine = True
             self._push_initial(self._engine)
         return self._engine
@@ -171,15 +172,19 @@ class QuadPotentialDiagAdapt(QuadPotential):
             raise ValueError("Wrong shape for initial_diag: expected %s got %s" % (n, len(initial_diag)))
         if len(initial_mean) != n:
             raise ValueError("Wrong shape for initial_mean: expected %s got %s" % (n, len(initial_mean)))
-        if dtype not in (None, "float32", np.float32):
-            raise NotImplementedError("the device mass matrix is float32, like the reference's default")
+        if dtype is None:   # quadpotential.py:175-176
+            dtype = "float32"
+        dtype = np.dtype(dtype).name
+        if dtype not in ("float32", "float64"):
+            raise NotImplementedError("the device mass matrix is float32 (the reference's default) or float64")
         super().__init__(n)
-        self.dtype = "float32"
+        self.dtype = dtype
+        self._momentum_f32 = dtype == "float32"   # quadpotential.py:223: normal(size=n).astype(dtype)
         if initial_diag is None:  # quadpotential.py:178-180
-            initial_diag = np.ones(n, dtype="float32")
+            initial_diag = np.ones(n, dtype=dtype)
             initial_weight = 1
         self._initial_mean = np.array(initial_mean, dtype="d")
-        self._initial_diag = initial_diag.astype("float32")
+        self._initial_diag = initial_diag.astype(dtype)
         self._initial_weight = initial_weight
         self.adaptation_window = int(adaptation_window)
         self._initial_adaptation_window = int(adaptation_window)
@@ -191,6 +196,9 @@ class QuadPotentialDiagAdapt(QuadPotential):
 
     def _pull(self, engine, chain=0):
         super()._pull(engine, chain)
+        if self.dtype == "float64":   # quadpotential.py:226-229 in the potential's dtype
+            self._stds = np.sqrt(self._var)
+            self._inv_stds = 1.0 / self._stds
         if self.adaptation_window_multiplier != 1.0:
             self.adaptation_window = int(engine.get_chain_state(fields=("window",))["window"][chain])
 
@@ -221,11 +229,12 @@ class QuadPotentialDiag(QuadPotential):
 
     def __init__(self, v, dtype=None):
         v = np.asarray(v)
-        if dtype not in (None, "float32", np.float32):
-            raise NotImplementedError("the device mass matrix is float32, like the reference's default")
+        dtype = np.dtype("float32" if dtype is None else dtype).name   # quadpotential.py:358-359
+        if dtype not in ("float32", "float64"):
+            raise NotImplementedError("the device mass matrix is float32 (the reference's default) or float64")
         super().__init__(v.shape[0])
-        self.dtype = "float32"
-        self.v = v.astype("float32")
+        self.dtype = dtype
+        self.v = v.astype(dtype)
         self.s = self.v ** 0.5
         self.inv_s = 1.0 / self.s
         self._n_samples = 0
@@ -237,7 +246,8 @@ class QuadPotentialDiag(QuadPotential):
         pass
 
 
-MAX_DENSE_NDIM = 256
+MAX_DENSE_NDIM = 2048        # QuadPotentialFull / FullInv: fused kernels up to 256, the general kernels beyond (include/lmc_hip.h)
+MAX_DENSE_ADAPT_NDIM = 256   # QuadPotentialFullAdapt: one matrix per chain, refreshed + factorised every tuning iteration
 
 
 def _square(a, what):
@@ -359,8 +369,9 @@ class QuadPotentialFullAdapt(_DensePotential):
             raise ValueError("Wrong shape for initial_mean: expected %s got %s" % (n, len(initial_mean)))
         if dtype not in (None, "float32", np.float32):
             raise NotImplementedError("the device mass matrix is float32, like the reference's default")
-        if n > MAX_DENSE_NDIM:
-            raise NotImplementedError("dense mass matrices run on the device up to model_ndim = %d" % MAX_DENSE_NDIM)
+        if n > MAX_DENSE_ADAPT_NDIM:
+            raise NotImplementedError("per-chain adapted dense mass matrices run on the device up to model_ndim = %d"
+                                      % MAX_DENSE_ADAPT_NDIM)
         super().__init__(n)
         self.dtype = "float32"
         if initial_cov is None:  # quadpotential.py:501-503

@@ -153,16 +153,28 @@ class UserTarget(DeviceTarget):
         key = (int(unit_ns), int(run_ns), int(run_w))
         if key in self._code:
             return self._code[key]
-        names = ["lmc::run_kernel<%d, %d, lmc::UserTarget>" % (key[1], key[2]),
-                 "lmc::trajectory_kernel<%d, lmc::UserTarget>" % key[0],
-                 "lmc::logp_kernel<%d, lmc::UserTarget>" % key[0]]
-        tu = ('#include "lmc_sampler.hpp"\n#include "lmc_unit_kernels.hpp"\n' + self.source +
-              "\nnamespace lmc {\n"
-              "template __global__ void run_kernel<%d, %d, UserTarget>(ChainArrays, SamplerParams, const double*);\n"
-              "template __global__ void trajectory_kernel<%d, UserTarget>(ChainArrays, const double*, const double*, const double*, "
-              "int, int, double, int, int, double*, double*, double*, double*, double*, double*);\n"
-              "template __global__ void logp_kernel<%d, UserTarget>(ChainArrays, const double*, const double*, double*, double*);\n"
-              "}\n" % (key[1], key[2], key[0], key[0]))
+        if key[2] == 16:   # the general kernels (csrc/lmc_wide.hpp): model_ndim > 1024, dense mass matrices, float64 masses
+            names = ["lmc::run_wide_kernel<%d, lmc::UserTarget>" % key[1],
+                     "lmc::wide_trajectory_kernel<%d, lmc::UserTarget>" % key[0],
+                     "lmc::wide_logp_kernel<%d, lmc::UserTarget>" % key[0]]
+            tu = ('#include "lmc_wide.hpp"\n' + self.source +
+                  "\nnamespace lmc {\n"
+                  "template __global__ void run_wide_kernel<%d, UserTarget>(ChainArrays, DenseArrays, SamplerParams, const double*);\n"
+                  "template __global__ void wide_trajectory_kernel<%d, UserTarget>(ChainArrays, DenseArrays, const double*, const double*, "
+                  "const double*, int, int, double, int, int, double*, double*, double*, double*, double*, double*);\n"
+                  "template __global__ void wide_logp_kernel<%d, UserTarget>(ChainArrays, const double*, const double*, double*, double*);\n"
+                  "}\n" % (key[1], key[0], key[0]))
+        else:
+            names = ["lmc::run_kernel<%d, %d, lmc::UserTarget>" % (key[1], key[2]),
+                     "lmc::trajectory_kernel<%d, lmc::UserTarget>" % key[0],
+                     "lmc::logp_kernel<%d, lmc::UserTarget>" % key[0]]
+            tu = ('#include "lmc_sampler.hpp"\n#include "lmc_unit_kernels.hpp"\n' + self.source +
+                  "\nnamespace lmc {\n"
+                  "template __global__ void run_kernel<%d, %d, UserTarget>(ChainArrays, SamplerParams, const double*);\n"
+                  "template __global__ void trajectory_kernel<%d, UserTarget>(ChainArrays, const double*, const double*, const double*, "
+                  "int, int, double, int, int, double*, double*, double*, double*, double*, double*);\n"
+                  "template __global__ void logp_kernel<%d, UserTarget>(ChainArrays, const double*, const double*, double*, double*);\n"
+                  "}\n" % (key[1], key[2], key[0], key[0]))
         cache = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_user_targets")
         os.makedirs(cache, exist_ok=True)
         path = os.path.join(cache, "user_%s_%d_%d_%d.hsaco" % (self._digest("hiprtc"), key[0], key[1], key[2]))

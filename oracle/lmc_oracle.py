@@ -285,11 +285,20 @@ def quad_potential_diag(scaling, is_cov):
 # --------------------------------------------------------------------------------------
 # integration.py
 # --------------------------------------------------------------------------------------
+# Test hook (tools/same_seed_evidence.py): a function (x, y) -> float32 that stands in for the host BLAS's sdot in the ONE
+# place its summation order decides how long two same-seed chains stay together -- the float32 kinetic energy of the start
+# state. None (always, except in that tool): numpy's own dot, i.e. what the reference computes on this host.
+START_SDOT = None
+
+
 def compute_state(pot, f, q, p):
     """integration.py:52-66. With a float32 p this leaves v and the kinetic term float32."""
     logp, g = f(q)
     v = pot.velocity(p)
-    kinetic = 0.5 * p.dot(v)
+    if START_SDOT is not None and p.dtype == np.float32 and v.dtype == np.float32:
+        kinetic = np.float32(0.5) * START_SDOT(p, v)
+    else:
+        kinetic = 0.5 * p.dot(v)
     return State(q, p, v, g, kinetic - logp, logp)
 
 

@@ -138,6 +138,8 @@ def replay_iterations_on_device(step, snaps, outs, label=""):
             if "fore_mean" in snaps[idx[0]]:
                 for k in ("fore_mean", "fore_raw_var", "back_mean", "back_raw_var", "fore_w_sum", "back_w_sum", "window"):
                     state[k] = np.stack([np.asarray(snaps[i][k]) for i in idx])
+            if eng.mass_f64:   # QuadPotentialDiagAdapt(dtype="float64"): the diagonal travels in its own dtype
+                state["var64"] = state.pop("var")
             eng.set_chain_state(state)
             eng.reserve(1, keep_trace=True)
             eng.run(1 if tune_flag else 0, 0, 1)
@@ -162,6 +164,8 @@ def replay_iterations_on_device(step, snaps, outs, label=""):
                 if i + 1 < len(snaps):   # adaptation state after the iteration == oracle's next snapshot
                     nxt = snaps[i + 1]
                     np.testing.assert_allclose(after["var"][c], nxt["var"], rtol=2e-7, err_msg=tag + " var")
+                    if eng.mass_f64:
+                        np.testing.assert_allclose(after["var64"][c], nxt["var"], rtol=1e-12, err_msg=tag + " var64")
                     for k in ("log_step", "log_bar", "hbar"):
                         assert np.isclose(after[k][c], nxt[k], rtol=1e-11, atol=1e-13), (tag, k, after[k][c], nxt[k])
                     assert after["da_count"][c] == nxt["da_count"] and after["n_samples"][c] == nxt["n_samples"], tag

@@ -126,8 +126,14 @@ def test_reference_argument_errors():
         lmc.init_nuts(tgt, 3, init="nope")
     start, step = lmc.init_nuts(tgt, 3, init="adapt_full")   # sampling.py:588-592 (host objects only: no GPU needed)
     assert isinstance(step.potential, lmc.QuadPotentialFullAdapt) and not start.any()
-    with pytest.raises(NotImplementedError):          # dense mass matrices live on the device up to 256 dimensions
-        lmc.QuadPotentialFull(np.eye(257))
+    with pytest.raises(NotImplementedError):          # per-chain adapted dense matrices: the fused kernels, up to 256 dimensions
+        lmc.QuadPotentialFullAdapt(257, np.zeros(257), np.eye(257), 1)
+    with pytest.raises(NotImplementedError):          # shared dense matrices: the general kernels take over up to 2048
+        lmc.QuadPotentialFull(np.eye(2049))
+    assert lmc.QuadPotentialFull(np.eye(300))._n == 300
+    assert lmc.QuadPotentialDiagAdapt(3, np.zeros(3), np.ones(3), 1, dtype="float64").dtype == "float64"   # quadpotential.py:159
+    with pytest.raises(NotImplementedError):
+        lmc.QuadPotentialDiagAdapt(3, np.zeros(3), np.ones(3), 1, dtype="float16")
     with pytest.raises(ValueError, match="two-dimensional"):   # quadpotential.py:485-486
         lmc.QuadPotentialFullAdapt(3, np.zeros(3), np.ones(3), 1)
     from littlemcmc_amd.quadpotential import PositiveDefiniteError

@@ -29,8 +29,13 @@ def test_largest_dimension_and_beyond():
     d = 1024
     tr, st = lmc.sample(T.StdNormal(d), d, draws=3, tune=5, chains=2, random_seed=2)
     assert tr.shape == (2, 3, d) and np.isfinite(tr).all()
-    with pytest.raises(_abi.HipLibraryError, match="dim > 1024"):
-        lmc.Engine(T.StdNormal(1025), chains=1)
+    eng = lmc.Engine(T.StdNormal(1025), chains=1)        # beyond the fused kernels: the general kernels (tests/test_gpu_wide.py)
+    try:
+        assert eng.wide and eng.kernel_shape()[2] == 16
+    finally:
+        eng.close()
+    with pytest.raises(_abi.HipLibraryError, match="beyond the general kernels"):
+        lmc.Engine(T.StdNormal(16385), chains=1)
     with pytest.raises(_abi.HipLibraryError, match="requires dim == 1"):
         t = T.Normal1D()
         t.d = 2

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""How long do two same-seed chains stay together when ONE float32 rounding differs? (CPU only; writes
+profiles/r04_same_seed_decorrelation.json)
+
+north_star asks for draws whose per-chain moments "match the reference CPU sampler on identical RNG seeds". Whole tuned
+chains cannot agree bit for bit across machines: dual averaging feeds the acceptance statistic back into the step size
+(gain ~ sqrt(t) / ((t + t0) gamma) ~ 3 early on), so a 1-ulp difference in one energy doubles every iteration or two
+until a tree decision flips. This tool measures that on the CPU alone, with the ORACLE against ITSELF: the same chain is
+run twice, once with numpy's own float32 dot for the start state's kinetic energy (the host BLAS: OpenBLAS
+sdot_k_SKYLAKEX on AVX-512 hosts) and once with the summation order of the other x86-64 OpenBLAS kernel
+(sdot_k_HASWELL, what the reference computes on an AVX2 host; littlemcmc_amd/_blas_probe.py restates both). Nothing
+else differs -- same seeds, same algorithm, same float64 arithmetic -- and the two CPU chains part after a few dozen
+iterations, exactly like a device chain and the oracle do. The table lists, per golden configuration and chain, the
+first iteration whose integer statistics differ."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from littlemcmc_amd import _abi  # noqa: E402
+from littlemcmc_amd._blas_probe import detect_sdot_mode, emulate_sdot  # noqa: E402
+from oracle import lmc_oracle as orc  # noqa: E402
+from oracle import targets as OT  # noqa: E402
+
+RUNS = [("e2e_nuts_std64", "std_normal", 64, 2, 250, 150), ("e2e_nuts_std128", "std_normal", 128, 2, 110, 20),
+        ("e2e_nuts_ar1_16", "ar1", 16, 4, 250, 150), ("e2e_nuts_ar1_128", "ar1", 128, 2, 250, 50),
+        ("e2e_nuts_diag50", "diag_gaussian", 50, 2, 250, 100)]
+SEED = 20260928
+
+
+def first_difference(a, b):
+    bad = None
+    for k in ("depth", "tree_size", "diverging"):
+        idx = np.nonzero(a[k] != b[k])[0]
+        if len(idx) and (bad is None or idx[0] < bad):
+            bad = int(idx[0])
+    return bad
+
+
+def main():
+    host = detect_sdot_mode()
+    other = _abi.SDOT_OPENBLAS_HASWELL if host == _abi.SDOT_OPENBLAS_SKYLAKEX else _abi.SDOT_OPENBLAS_SKYLAKEX
+    names = {_abi.SDOT_OPENBLAS_SKYLAKEX: "sdot_k_SKYLAKEX", _abi.SDOT_OPENBLAS_HASWELL: "sdot_k_HASWELL"}
+    rows = []
+    for name, fam, d, chains, tune, draws in RUNS:
+        f = OT.make(fam, d)
+        out = {}
+        for label, hook in (("host", None), ("other", lambda x, y: emulate_sdot(x, y, other))):
+            orc.START_SDOT = hook
+            try:
+                _tr, st = orc.sample(f, d, draws=draws, tune=tune, chains=chains, random_seed=SEED, discard_tuned_samples=False)
+            finally:
+                orc.START_SDOT = None
+            out[label] = st
+        for c in range(chains):
+            a = {k: out["host"][k][c, :, 0] for k in out["host"]}
+            b = {k: out["other"][k][c, :, 0] for k in out["other"]}
+            fd = first_difference(a, b)
+            rel = np.abs(a["energy"] - b["energy"]) / (1.0 + np.abs(a["energy"]))
+            first_ulp = int(np.nonzero(rel > 0)[0][0]) if (rel > 0).any() else None
+            rows.append({"golden": name, "target": fam, "dim": d, "chain": c, "iterations": tune + draws,
+                         "first_iteration_with_any_energy_difference": first_ulp,
+                         "first_iteration_with_a_different_tree": fd})
+            print("%-20s chain %d: energies differ from iteration %s, trees from iteration %s of %d"
+                  % (name, c, first_ulp, fd, tune + draws))
+    doc = {"what": __doc__.split("\n\n")[1].replace("\n", " "),
+           "host_sdot": names[host], "other_sdot": names[other], "rows": rows,
+           "summary": {"median_first_different_tree": float(np.median([r["first_iteration_with_a_different_tree"] for r in rows
+                                                                       if r["first_iteration_with_a_different_tree"] is not None])),
+                       "chains_never_differing": sum(r["first_iteration_with_a_different_tree"] is None for r in rows)}}
+    path = os.path.join(ROOT, "profiles", "r04_same_seed_decorrelation.json")
+    with open(path, "w") as fh:
+        json.dump(doc, fh, indent=1)
+    print("wrote", path, doc["summary"])
+
+
+if __name__ == "__main__":
+    main()
