@@ -90,7 +90,9 @@ class QuadPotential:
             from .engine import Engine
 
             self._engine = Engine(_targets.StdNormal(self._n), chains=1, potential=self._engine_kind,
-                                  mass_dtype=getattr(self, "dtype", "float32") if self._engine_kind in ("diag_adapt", "diag") else "float32")
+                                  mass_dtype=getattr(self, "dtype", "float32") if self._engine_kind in ("diag_adapt", "diag") else "float32",
+                                  adaptation_window=getattr(self, "_initial_adaptation_window", 101),
+                                  adaptation_window_multiplier=getattr(self, "adaptation_window_multiplier", 1.0))
             self._own_engine = True
             self._push_initial(self._engine)
         return self._engine

@@ -1,0 +1,123 @@
+"""-m gpu: north_star's same-seed clause, MEASURED at the benchmarked shape: "draws whose per-chain means / variances
+match the reference CPU sampler on identical RNG seeds within a stated floating-point tolerance (bit-exact for
+tree-depth / divergence counts)".
+
+What "match" can mean. A tuned chain is chaotic in its rounding: the oracle run against ITSELF with the other x86-64
+OpenBLAS sdot order parts from its twin after 4-60 iterations (tools/same_seed_evidence.py ->
+profiles/r04_same_seed_decorrelation.json), so no two machines -- CPU or GPU -- reproduce a 2000-iteration chain bit for
+bit. The identity that does hold is per iteration (tests/test_gpu_parity.py: every iteration of every golden from the
+oracle's state, integer statistics exact) and over a same-seed prefix; beyond the prefix a device chain and the oracle
+chain with the same seed are two realisations of the same Markov kernel. THIS test holds them to that at C3's own
+shape -- 64 chains x d = 128 AR(1), tune 1000 + draws 1000, the seeds of the 65 536-chain job -- with the tolerance
+stated in Monte-Carlo standard errors:
+  * the first iterations of every chain agree exactly (depth, tree_size, diverging) and to 1e-7 (positions);
+  * per chain and dimension, (mean_device - mean_oracle) / sqrt(MCSE_d^2 + MCSE_o^2) behaves like N(0, 1) over the
+    64 x 128 entries: |average| < 0.06, standard deviation within [0.85, 1.15], no entry beyond 5.5; the same for the
+    per-chain variances;
+  * the distributions of tree depth and of the acceptance statistic over all post-warm-up draws agree (total variation
+    distance of the depth histograms < 0.02, mean acceptance within 0.01, adapted step sizes within 3 %)."""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import littlemcmc_amd as lmc
+from littlemcmc_amd import targets as T
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+D, CHAINS, TUNE, DRAWS, SEED, TOTAL_CHAINS = 128, 64, 1000, 1000, 20260928, 65536
+
+
+def _oracle_chain(args):
+    seed, start = args
+    sys.path.insert(0, ROOT)
+    try:
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(1)
+    except Exception:
+        pass
+    from oracle import lmc_oracle as orc
+    from oracle import targets as OT
+
+    f = OT.AR1(D, 0.9)
+    step = orc.Step(f, D, kind="nuts", potential=orc.DiagAdaptPotential(D, start, np.ones(D), 10))
+    tr, st = orc.sample(f, D, draws=DRAWS, tune=TUNE, step=step, chains=1, start=start, random_seed=[int(seed)],
+                        discard_tuned_samples=False)
+    return tr[0], {k: v[0, :, 0] for k, v in st.items()}
+
+
+def _mcse_of_mean(x, batches=20):
+    """Batch-means Monte-Carlo standard error of the mean of x[draws, d] (per dimension)."""
+    n = x.shape[0] // batches * batches
+    bm = x[:n].reshape(batches, n // batches, -1).mean(axis=1)
+    return bm.std(axis=0, ddof=1) / np.sqrt(batches)
+
+
+def _usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def test_same_seed_chains_at_the_benchmarked_shape():
+    from oracle import lmc_oracle as orc
+
+    seeds = orc.derive_seeds(SEED, TOTAL_CHAINS)[:CHAINS]            # prefix stable: the first 64 seeds of the C3 job
+    start = orc.jitter_start(orc.derive_seeds(SEED, TOTAL_CHAINS)[0], D)
+    with mp.get_context("fork").Pool(min(_usable_cores(), CHAINS)) as pool:
+        res = pool.map(_oracle_chain, [(s, start) for s in seeds])
+    otrace = np.stack([r[0] for r in res])
+    ostats = {k: np.stack([r[1][k] for r in res]) for k in res[0][1]}
+
+    tgt = T.AR1(D, 0.9)
+    step = lmc.NUTS(tgt, D, potential=lmc.QuadPotentialDiagAdapt(D, start, np.ones(D), 10))
+    trace, stats = lmc.sample(tgt, D, draws=DRAWS, tune=TUNE, step=step, start=start, chains=CHAINS, random_seed=seeds,
+                              discard_tuned_samples=False, progressbar=False)
+    stats = {k: v[:, :, 0] for k, v in stats.items()}
+
+    # ---- the same-seed prefix: exact
+    n = 8
+    np.testing.assert_array_equal(stats["depth"][:, :n], ostats["depth"][:, :n])
+    np.testing.assert_array_equal(stats["tree_size"][:, :n], ostats["tree_size"][:, :n])
+    np.testing.assert_array_equal(stats["diverging"][:, :n], ostats["diverging"][:, :n])
+    np.testing.assert_allclose(trace[:, :n], otrace[:, :n], rtol=1e-7, atol=1e-9)
+    together = [int(np.argmax(np.any([stats[k][c] != ostats[k][c] for k in ("depth", "tree_size")], axis=0)))
+                if np.any([stats[k][c] != ostats[k][c] for k in ("depth", "tree_size")]) else TUNE + DRAWS for c in range(CHAINS)]
+    print("iterations until a device chain and its same-seed oracle chain first differ in a tree: min %d, median %d, max %d"
+          % (min(together), int(np.median(together)), max(together)))
+    assert min(together) >= n and np.median(together) >= 12
+
+    # ---- per-chain moments within Monte-Carlo error
+    post_d, post_o = trace[:, TUNE:], otrace[:, TUNE:]
+    for label, fd, fo in (("mean", post_d, post_o), ("variance", (post_d - post_d.mean(axis=1, keepdims=True)) ** 2,
+                                                    (post_o - post_o.mean(axis=1, keepdims=True)) ** 2)):
+        z = np.empty((CHAINS, D))
+        for c in range(CHAINS):
+            z[c] = (fd[c].mean(axis=0) - fo[c].mean(axis=0)) / np.sqrt(_mcse_of_mean(fd[c]) ** 2 + _mcse_of_mean(fo[c]) ** 2)
+        print("per-chain %s, (device - oracle) / MCSE over %d x %d entries: average %.3f, std %.3f, max |z| %.2f"
+              % (label, CHAINS, D, z.mean(), z.std(), np.abs(z).max()))
+        assert abs(z.mean()) < 0.06, (label, z.mean())
+        assert 0.85 < z.std() < 1.15, (label, z.std())     # (batch-means errors with 20 batches: t-like, a little wider than 1)
+        assert np.abs(z).max() < 5.5, (label, np.abs(z).max())
+
+    # ---- sampler statistics: the same distributions
+    hd = np.bincount(stats["depth"][:, TUNE:].ravel().astype(int), minlength=12)[:12] / float(CHAINS * DRAWS)
+    ho = np.bincount(ostats["depth"][:, TUNE:].ravel().astype(int), minlength=12)[:12] / float(CHAINS * DRAWS)
+    tv = 0.5 * np.abs(hd - ho).sum()
+    acc_d, acc_o = stats["mean_tree_accept"][:, TUNE:].mean(), ostats["mean_tree_accept"][:, TUNE:].mean()
+    step_d, step_o = stats["step_size_bar"][:, -1], ostats["step_size_bar"][:, -1]
+    print("depth histograms: total variation %.4f; mean acceptance %.4f vs %.4f; adapted step size (median) %.5f vs %.5f; "
+          "divergences %d vs %d" % (tv, acc_d, acc_o, np.median(step_d), np.median(step_o),
+                                    stats["diverging"][:, TUNE:].sum(), ostats["diverging"][:, TUNE:].sum()))
+    assert tv < 0.02 and abs(acc_d - acc_o) < 0.01
+    assert abs(np.median(step_d) / np.median(step_o) - 1.0) < 0.03
+    assert stats["diverging"][:, TUNE:].sum() == ostats["diverging"][:, TUNE:].sum() == 0
