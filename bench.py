@@ -370,8 +370,7 @@ def main():
             resident, wpc, hz = eng.occupancy()
             leap_chain = ct[:, _abi.CT_LEAPFROGS]
             # tree_size of every iteration, where it lives: [chains][capacity] int32 in HBM -> leapfrogs per chain per launch
-            ts = torch.as_tensor(_DevView(eng.stat_i32_device_ptr() + 4 * _abi.STAT_TREE_SIZE * chains * n_total,
-                                          (chains, n_total), "<i4"), device="cuda:%d" % dev0)
+            ts = torch.as_tensor(eng.tree_size_view(), device="cuda:%d" % dev0)
             per_launch = ts.reshape(chains, K, ips).sum(dim=2, dtype=torch.int64)                 # [chains, K]
             bounds = [chains * b // nst for b in range(nst + 1)]
             crit = max(int(per_launch[bounds[b]:bounds[b + 1]].max(dim=0).values.sum()) for b in range(nst))

@@ -274,12 +274,16 @@ int lmc_engine_get_trace(lmc_engine* e, double* dst, int64_t iter_begin, int64_t
 int lmc_engine_get_stat_f64(lmc_engine* e, int32_t stat, double* dst, int64_t iter_begin, int64_t n_iters);
 int lmc_engine_get_stat_i32(lmc_engine* e, int32_t stat, int32_t* dst, int64_t iter_begin, int64_t n_iters);
 int lmc_engine_get_stat_u8(lmc_engine* e, int32_t stat, uint8_t* dst, int64_t iter_begin, int64_t n_iters);
-/* Device pointers of the engine-owned outputs for zero-copy consumers (trace layout
- * [chains][capacity - trace_begin][dim], stats [n_stats][chains][capacity]); valid until the next
- * reserve()/destroy(). */
+/* Device pointers of the engine-owned outputs for zero-copy consumers; valid until the next reserve()/destroy().
+ * Trace: [chains][capacity - trace_begin][dim] float64. Statistics: [chains][capacity] records of LMC_STAT_RECORD_BYTES
+ * = 64 bytes, one per draw, written by the sampling kernel in one coalesced store:
+ *     bytes  0..55  the seven float64 statistics in LMC_STAT_* (f64) order
+ *     bytes 56..59  int32  tree_size (NUTS) / n_steps (HMC): the leapfrog steps of the draw
+ *     bytes 60..63  uint32 bits 0-15 NUTS depth, bit 16 diverging, bit 17 tune, bit 18 accepted
+ * (lmc_engine_get_stat_*() gather one statistic out of the records into a dense [chains][n_iters] array.) */
+#define LMC_STAT_RECORD_BYTES 64
 void* lmc_engine_trace_device_ptr(lmc_engine* e);
-void* lmc_engine_stat_f64_device_ptr(lmc_engine* e);
-void* lmc_engine_stat_i32_device_ptr(lmc_engine* e);
+void* lmc_engine_stat_records_device_ptr(lmc_engine* e);
 int64_t lmc_engine_trace_begin(lmc_engine* e);
 int64_t lmc_engine_capacity(lmc_engine* e);
 

@@ -26,6 +26,7 @@ STAT_DEPTH, STAT_TREE_SIZE = 0, 1
 STAT_DIVERGING, STAT_TUNE, STAT_ACCEPTED = 0, 1, 2
 CT_REACHED_MAX_TREEDEPTH, CT_DIVS_AFTER_TUNE, CT_SAMPLES_AFTER_TUNE, CT_LEAPFROGS, CT_WAVE_TICKS = range(5)
 NUM_COUNTERS = 5
+STAT_RECORD_BYTES = 64   # include/lmc_hip.h: one record of sampler statistics per draw
 
 
 class Config(C.Structure):
@@ -110,8 +111,7 @@ _SIGNATURES = {
     "lmc_engine_get_stat_i32": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int64]),
     "lmc_engine_get_stat_u8": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int64]),
     "lmc_engine_trace_device_ptr": (_P, [_P]),
-    "lmc_engine_stat_f64_device_ptr": (_P, [_P]),
-    "lmc_engine_stat_i32_device_ptr": (_P, [_P]),
+    "lmc_engine_stat_records_device_ptr": (_P, [_P]),
     "lmc_engine_trace_begin": (C.c_int64, [_P]),
     "lmc_engine_capacity": (C.c_int64, [_P]),
     "lmc_engine_get_adapt_state": (C.c_int, [_P, _P, _P, _P, _P]),

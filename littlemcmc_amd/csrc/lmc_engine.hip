@@ -210,6 +210,19 @@ __global__ __launch_bounds__(64) void mass_update_kernel(ChainArrays A, SamplerP
     }
 }
 
+// One statistic of the draws [iter_begin, iter_begin + n) of every chain out of the 64-byte records: out[c][i].
+// kind 0: f64 slot `idx`; 1: i32 (0 depth / n_steps, 1 tree_size); 2: u8 flag (0 diverging, 1 tune, 2 accepted)
+__global__ void stat_gather_kernel(const StatRecord* rec, long long cap, int chains, long long iter_begin, long long n, int kind,
+                                   int idx, int hmc, void* out) {
+    const long long k = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= static_cast<long long>(chains) * n) return;
+    const long long c = k / n, i = k - c * n;
+    const StatRecord& r = rec[c * cap + iter_begin + i];
+    if (kind == 0) static_cast<double*>(out)[k] = r.f64[idx];
+    else if (kind == 1) static_cast<int*>(out)[k] = (idx == kSiTreeSize || hmc) ? r.tree_size : static_cast<int>(r.depth_flags & 0xffffu);
+    else static_cast<unsigned char*>(out)[k] = static_cast<unsigned char>((r.depth_flags >> (16 + idx)) & 1u);
+}
+
 // After lmc_engine_set_chain_state(): inv_std = 1 / sqrt(var) in float32 (quadpotential.py:226-229).
 // from64: the float64 diagonal was set (QuadPotentialDiagAdapt(dtype="float64")), the float32 views follow it.
 __global__ void derive_inv_std_kernel(ChainArrays A, int from64) {
@@ -1576,16 +1589,12 @@ int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int64_t trace_begin) {
     HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
     ChainArrays& A = e->A;
     dev_free(e, A.trace); A.trace = nullptr;
-    dev_free(e, A.stat_f64); A.stat_f64 = nullptr;
-    dev_free(e, A.stat_i32); A.stat_i32 = nullptr;
-    dev_free(e, A.stat_u8); A.stat_u8 = nullptr;
+    dev_free(e, A.stat_rec); A.stat_rec = nullptr;
     const size_t C = e->cfg.chains, cap = static_cast<size_t>(capacity);
     int rc;
     if (keep_trace && (rc = dev_alloc(e, &A.trace, C * (cap - static_cast<size_t>(trace_begin)) * e->cfg.dim, false)) != LMC_OK) return rc;
     A.trace_begin = keep_trace ? trace_begin : 0;
-    if ((rc = dev_alloc(e, &A.stat_f64, kNumStatF64 * C * cap)) != LMC_OK) return rc;
-    if ((rc = dev_alloc(e, &A.stat_i32, kNumStatI32 * C * cap)) != LMC_OK) return rc;
-    if ((rc = dev_alloc(e, &A.stat_u8, kNumStatU8 * C * cap)) != LMC_OK) return rc;
+    if ((rc = dev_alloc(e, &A.stat_rec, C * cap)) != LMC_OK) return rc;
     A.cap = capacity;
     HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
     return LMC_OK;
@@ -1642,7 +1651,7 @@ static int wide_run(lmc_engine* e, SamplerParams P) {
 
 int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters) {
     if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
-    if (e->A.cap <= 0 || !e->A.stat_f64) return fail(e, LMC_ERR_STATE, "lmc_engine_reserve() must be called before run()");
+    if (e->A.cap <= 0 || !e->A.stat_rec) return fail(e, LMC_ERR_STATE, "lmc_engine_reserve() must be called before run()");
     if (iter_begin < 0 || n_iters < 0 || iter_begin + n_iters > e->A.cap)
         return fail(e, LMC_ERR_INVALID, "iterations [%lld, %lld) exceed reserved capacity %lld", (long long)iter_begin,
                     (long long)(iter_begin + n_iters), (long long)e->A.cap);
@@ -1729,7 +1738,7 @@ int lmc_engine_tick_begin(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int
     if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
     if (e->cfg.target_family != LMC_TARGET_EXTERNAL)
         return fail(e, LMC_ERR_STATE, "lmc_engine_tick*() needs cfg.target_family = LMC_TARGET_EXTERNAL");
-    if (e->A.cap <= 0 || !e->A.stat_f64) return fail(e, LMC_ERR_STATE, "lmc_engine_reserve() must be called before tick_begin()");
+    if (e->A.cap <= 0 || !e->A.stat_rec) return fail(e, LMC_ERR_STATE, "lmc_engine_reserve() must be called before tick_begin()");
     if (iter_begin < 0 || n_iters < 0 || iter_begin + n_iters > e->A.cap)
         return fail(e, LMC_ERR_INVALID, "iterations [%lld, %lld) exceed reserved capacity %lld", (long long)iter_begin,
                     (long long)(iter_begin + n_iters), (long long)e->A.cap);
@@ -1809,33 +1818,43 @@ int lmc_engine_get_trace(lmc_engine* e, double* dst, int64_t iter_begin, int64_t
     return LMC_OK;
 }
 
+// one statistic out of the per-draw records (lmc_sampler.hpp: StatRecord) into the caller's [chains][n_iters] array
+static int gather_stat(lmc_engine* e, void* dst, size_t elem, int kind, int idx, int64_t iter_begin, int64_t n_iters) {
+    const size_t n = static_cast<size_t>(e->cfg.chains) * static_cast<size_t>(n_iters);
+    DevBuf<char> tmp;
+    HIP_TRY(e, tmp.alloc(n * elem));
+    hipStream_t st = main_stream(e);
+    LMC_LAUNCH(stat_gather_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, e->A.stat_rec, e->A.cap,
+               e->cfg.chains, iter_begin, n_iters, kind, idx, e->cfg.kind == LMC_KIND_HMC ? 1 : 0, static_cast<void*>(tmp.p));
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipMemcpyAsync(dst, tmp.p, n * elem, hipMemcpyDefault, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    return LMC_OK;
+}
+
 int lmc_engine_get_stat_f64(lmc_engine* e, int32_t stat, double* dst, int64_t iter_begin, int64_t n_iters) {
     int rc = check_window(e, dst, iter_begin, n_iters);
     if (rc != LMC_OK) return rc;
-    if (stat < 0 || stat >= kNumStatF64) return fail(e, LMC_ERR_INVALID, "bad f64 stat %d", stat);
-    return copy_rows(e, dst, e->A.stat_f64 + static_cast<size_t>(stat) * e->cfg.chains * e->A.cap, sizeof(double),
-                     iter_begin, n_iters, 1);
+    if (stat < 0 || stat >= kNumStatF64) return fail(e, LMC_ERR_INVALID, "unknown f64 stat %d", stat);
+    return gather_stat(e, dst, sizeof(double), 0, stat, iter_begin, n_iters);
 }
 
 int lmc_engine_get_stat_i32(lmc_engine* e, int32_t stat, int32_t* dst, int64_t iter_begin, int64_t n_iters) {
     int rc = check_window(e, dst, iter_begin, n_iters);
     if (rc != LMC_OK) return rc;
-    if (stat < 0 || stat >= kNumStatI32) return fail(e, LMC_ERR_INVALID, "bad i32 stat %d", stat);
-    return copy_rows(e, dst, e->A.stat_i32 + static_cast<size_t>(stat) * e->cfg.chains * e->A.cap, sizeof(int32_t),
-                     iter_begin, n_iters, 1);
+    if (stat < 0 || stat >= kNumStatI32) return fail(e, LMC_ERR_INVALID, "unknown i32 stat %d", stat);
+    return gather_stat(e, dst, sizeof(int32_t), 1, stat, iter_begin, n_iters);
 }
 
 int lmc_engine_get_stat_u8(lmc_engine* e, int32_t stat, uint8_t* dst, int64_t iter_begin, int64_t n_iters) {
     int rc = check_window(e, dst, iter_begin, n_iters);
     if (rc != LMC_OK) return rc;
-    if (stat < 0 || stat >= kNumStatU8) return fail(e, LMC_ERR_INVALID, "bad u8 stat %d", stat);
-    return copy_rows(e, dst, e->A.stat_u8 + static_cast<size_t>(stat) * e->cfg.chains * e->A.cap, sizeof(uint8_t),
-                     iter_begin, n_iters, 1);
+    if (stat < 0 || stat >= kNumStatU8) return fail(e, LMC_ERR_INVALID, "unknown u8 stat %d", stat);
+    return gather_stat(e, dst, sizeof(uint8_t), 2, stat, iter_begin, n_iters);
 }
 
 void* lmc_engine_trace_device_ptr(lmc_engine* e) { return e ? e->A.trace : nullptr; }
-void* lmc_engine_stat_f64_device_ptr(lmc_engine* e) { return e ? e->A.stat_f64 : nullptr; }
-void* lmc_engine_stat_i32_device_ptr(lmc_engine* e) { return e ? e->A.stat_i32 : nullptr; }
+void* lmc_engine_stat_records_device_ptr(lmc_engine* e) { return e ? static_cast<void*>(e->A.stat_rec) : nullptr; }
 int64_t lmc_engine_trace_begin(lmc_engine* e) { return e ? e->A.trace_begin : 0; }
 int64_t lmc_engine_capacity(lmc_engine* e) { return e ? e->A.cap : 0; }
 

@@ -43,6 +43,17 @@ enum StatI32 : int { kSiDepth = 0 /* HMC: n_steps */, kSiTreeSize = 1 /* leapfro
 enum StatU8 : int { kSbDiverging = 0, kSbTune = 1, kSbAccepted = 2, kNumStatU8 = 3 };
 enum Counter : int { kCtMaxTreedepth = 0, kCtDivsSample = 1, kCtSamplesAfterTune = 2, kCtLeapfrogs = 3, kCtWaveTicks = 4, kNumCounters = 5 };
 
+// The sampler statistics of ONE draw (nuts.py:87-101 / hmc.py:36-50: eleven named values) as one 64-byte record, written
+// by eight lanes in ONE coalesced store. (Until round 4 lane 0 issued twelve scattered 1-8-byte stores into per-statistic
+// planes: 14 memory instructions and ~95 scalar address instructions per draw, each store dirtying its own cache line.)
+struct StatRecord {
+    double f64[kNumStatF64];   // kSf* order
+    int tree_size;             // NUTS tree_size / HMC n_steps (= leapfrogs of the draw)
+    unsigned depth_flags;      // bits 0-15 NUTS depth (HMC: n_steps is tree_size), bit 16 diverging, 17 tune, 18 accepted
+};
+static_assert(sizeof(StatRecord) == 64, "one cache-line-sized record per draw");
+constexpr unsigned kRecDiverging = 1u << 16, kRecTune = 1u << 17, kRecAccepted = 1u << 18;
+
 struct ChainArrays {
     int chains, d, dpad;
     // persistent state
@@ -83,9 +94,7 @@ struct ChainArrays {
     // outputs (row = iteration index relative to the engine's reserved capacity)
     double* trace;        // [C][cap - trace_begin][d] or nullptr
     long long trace_begin; // first iteration whose draw is stored
-    double* stat_f64;     // [kNumStatF64][C][cap]
-    int* stat_i32;        // [kNumStatI32][C][cap]
-    unsigned char* stat_u8;  // [kNumStatU8][C][cap]
+    StatRecord* stat_rec; // [C][cap]: one 64-byte record of sampler statistics per draw
     long long cap;
 };
 
@@ -543,17 +552,48 @@ __device__ __forceinline__ void leapfrog(TeamT& tm, const Target& tgt, const dou
 // and ties up both the LDS and the vector-memory counters).
 typedef __attribute__((address_space(3))) double lds_double;
 typedef __attribute__((address_space(1))) double glb_double;
+// LDS, four elements per thread: a thread's 32-byte slice read with two ds_read_b128 at a lane stride of 32 bytes puts lanes
+// l and l + 8 on the same banks (a 2-way conflict on every access: ~200 conflict cycles per leapfrog on C4, round 3's
+// counters). Vector slots in LDS are private to their threads -- nobody else ever reads a thread's elements -- so the two
+// halves of a slice may live anywhere: they are kept in two PLANES of the slot (elements {0, 1} of thread t at doubles
+// [2t, 2t + 2), elements {2, 3} at [2T + 2t, 2T + 2t + 2), T = threads of the chain), lane stride 16 bytes, conflict free.
+#ifndef LMC_CHAIN_THREADS
+#define LMC_CHAIN_THREADS static_cast<int>(blockDim.x)
+#endif
+#ifndef LMC_LDS_PLANES
+#define LMC_LDS_PLANES 1
+#endif
+template <class PTR> struct IsLdsPtr { static constexpr bool value = false; };
+template <> struct IsLdsPtr<lds_double*> { static constexpr bool value = true; };
+template <> struct IsLdsPtr<const lds_double*> { static constexpr bool value = true; };
 template <int NS, class PTR>
 __device__ __forceinline__ void vload_as(PTR base, double (&x)[NS]) {
-    PTR p = base + LMC_CHAIN_THREAD * NS;
+    if constexpr (NS == 4 && IsLdsPtr<PTR>::value && LMC_LDS_PLANES) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        typedef const __attribute__((address_space(3))) d2 lds_d2;
+        lds_d2* p = (lds_d2*)(base + LMC_CHAIN_THREAD * 2);
+        const d2 a = p[0], b = p[LMC_CHAIN_THREADS];
+        x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
+    } else {
+        PTR p = base + LMC_CHAIN_THREAD * NS;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) x[s] = p[s];
+        for (int s = 0; s < NS; ++s) x[s] = p[s];
+    }
 }
 template <int NS, class PTR>
 __device__ __forceinline__ void vstore_as(PTR base, const double (&x)[NS]) {
-    PTR p = base + LMC_CHAIN_THREAD * NS;
+    if constexpr (NS == 4 && IsLdsPtr<PTR>::value && LMC_LDS_PLANES) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) d2 lds_d2;
+        lds_d2* p = (lds_d2*)(base + LMC_CHAIN_THREAD * 2);
+        d2 a, b;
+        a.x = x[0]; a.y = x[1]; b.x = x[2]; b.y = x[3];
+        p[0] = a; p[LMC_CHAIN_THREADS] = b;
+    } else {
+        PTR p = base + LMC_CHAIN_THREAD * NS;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) p[s] = x[s];
+        for (int s = 0; s < NS; ++s) p[s] = x[s];
+    }
 }
 // Tree weights are kept in the LINEAR domain: w = exp(-dE - c) with one offset c per transition.
 // The reference carries log-weights and pays logaddexp (exp + log1p) twice plus log(U) per merge
@@ -1387,20 +1427,19 @@ __device__ __forceinline__ void write_outputs(const CA& A, int c, int tid, long 
             if (e < d) tr[e] = q[s];
         }
     }
-    if (tid == 0) {
-        const long long fs = static_cast<long long>(A.chains) * A.cap;
-        A.stat_f64[kSfStepSize * fs + orow] = step_now;
-        A.stat_f64[kSfStepSizeBar * fs + orow] = step_bar_now;
-        A.stat_f64[kSfAccept * fs + orow] = out.accept;
-        A.stat_f64[kSfEnergyError * fs + orow] = out.energy_error;
-        A.stat_f64[kSfEnergy * fs + orow] = out.energy;
-        A.stat_f64[kSfMaxEnergyError * fs + orow] = out.max_energy_error;
-        A.stat_f64[kSfModelLogp * fs + orow] = out.model_logp;
-        A.stat_i32[kSiDepth * fs + orow] = out.depth;
-        A.stat_i32[kSiTreeSize * fs + orow] = out.n_leapfrog;
-        A.stat_u8[kSbDiverging * fs + orow] = static_cast<unsigned char>(out.diverging);
-        A.stat_u8[kSbTune * fs + orow] = static_cast<unsigned char>(tune);
-        A.stat_u8[kSbAccepted * fs + orow] = static_cast<unsigned char>(out.accepted);
+    if (tid < 8) {   // lane k < 7: statistic k; lane 7: the integers. ONE 64-byte store.
+        double v = step_now;
+        v = (tid == kSfStepSizeBar) ? step_bar_now : v;
+        v = (tid == kSfAccept) ? out.accept : v;
+        v = (tid == kSfEnergyError) ? out.energy_error : v;
+        v = (tid == kSfEnergy) ? out.energy : v;
+        v = (tid == kSfMaxEnergyError) ? out.max_energy_error : v;
+        v = (tid == kSfModelLogp) ? out.model_logp : v;
+        const unsigned flags = (static_cast<unsigned>(out.depth) & 0xffffu) | (out.diverging ? kRecDiverging : 0u) |
+                               (tune ? kRecTune : 0u) | (out.accepted ? kRecAccepted : 0u);
+        const double ints = __hiloint2double(static_cast<int>(flags), out.n_leapfrog);
+        v = (tid == 7) ? ints : v;
+        reinterpret_cast<double*>(A.stat_rec + orow)[tid] = v;
     }
 }
 

@@ -315,11 +315,22 @@ class Engine:
     def trace_device_ptr(self):
         return self._lib.lmc_engine_trace_device_ptr(self._h)
 
-    def stat_i32_device_ptr(self):
-        return self._lib.lmc_engine_stat_i32_device_ptr(self._h)
+    def stat_records_device_ptr(self):
+        """[chains][capacity] records of 64 bytes, one per draw (layout: include/lmc_hip.h)."""
+        return self._lib.lmc_engine_stat_records_device_ptr(self._h)
 
-    def stat_f64_device_ptr(self):
-        return self._lib.lmc_engine_stat_f64_device_ptr(self._h)
+    def tree_size_view(self):
+        """__cuda_array_interface__ object: tree_size [chains, capacity] int32 where it lies in the per-draw records (strided)."""
+        rec = _abi.STAT_RECORD_BYTES
+
+        class _V:
+            pass
+
+        v = _V()
+        v.__cuda_array_interface__ = {"shape": (self.chains, self.capacity), "typestr": "<i4", "version": 2,
+                                      "data": (int(self.stat_records_device_ptr()) + 56, False),
+                                      "strides": (self.capacity * rec, rec)}
+        return v
 
     def adapt_state(self):
         var = np.empty((self.chains, self.dim), dtype=np.float32)

@@ -8,7 +8,7 @@ bash tools/profile_round.sh $out/c3 > /dev/null 2>&1
 bash tools/profile_round.sh $out/std128 --target std_normal > /dev/null 2>&1
 bash tools/profile_round.sh $out/std128_philox --target std_normal --rng philox > /dev/null 2>&1
 bash tools/profile_round.sh $out/c2 --target std_normal --dim 64 --chains 4096 > /dev/null 2>&1
-bash tools/profile_round.sh $out/c4 --target diag --dim 1000 --chains 8192 --steps 10 > /dev/null 2>&1
+bash tools/profile_round.sh $out/c4 --target diag --dim 1000 --chains 8192 > /dev/null 2>&1
 bash tools/profile_round.sh $out/c5 --target funnel --dim 256 --chains 16384 --max-treedepth 12 > /dev/null 2>&1
 bash tools/profile_round.sh $out/dense_full --mass full --warmup 0 > /dev/null 2>&1
 bash tools/profile_round.sh $out/dense_full_adapt --mass full_adapt --chains 16384 --steps 4 --iters-per-step 50 --warmup 0 > /dev/null 2>&1
