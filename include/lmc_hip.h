@@ -335,6 +335,9 @@ int lmc_engine_get_dense_state(lmc_engine* e, const lmc_dense_state* dst);
 int lmc_engine_set_dense_state(lmc_engine* e, const lmc_dense_state* src);
 /* cov / chol [dim][dim] of ONE chain (the host mirror of step.potential after sample()). */
 int lmc_engine_get_dense_chain(lmc_engine* e, int32_t chain, float* cov, float* chol);
+/* The lower Cholesky factor [dim][dim] in float64 of the float64 potentials: QuadPotentialFull(cov, dtype="float64")._chol
+ * (quadpotential.py:441-443) / QuadPotentialFullInv.L (:402), as the device holds it. */
+int lmc_engine_get_dense_factor_f64(lmc_engine* e, double* chol);
 /* Test entry: potential.update(sample = current position, grad, tune) for every chain (quadpotential.py:528-552).
  * During lmc_engine_run() the same kernel runs after every tuning iteration. */
 int lmc_engine_dense_update(lmc_engine* e, int32_t tune);

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "lmc_engine_tick_positions": (_P, [_P]),
     "lmc_engine_tick": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int32)]),
     "lmc_engine_get_dense_chain": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "lmc_engine_get_dense_factor_f64": (C.c_int, [_P, _P]),
     "lmc_engine_seed": (C.c_int, [_P, _P]),
     "lmc_engine_set_rng_state": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_double]),
     "lmc_engine_get_rng_state": (C.c_int, [_P, C.c_int32, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32),

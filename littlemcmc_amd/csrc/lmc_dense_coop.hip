@@ -6,7 +6,6 @@
 #include <hip/hip_runtime.h>
 
 #define LMC_CHAIN_THREAD (static_cast<int>(threadIdx.x) & 63)
-#define LMC_CHAIN_THREADS 64
 #define LMC_DENSE_COOP 1
 #include "../../include/lmc_hip.h"
 #include "lmc_dense.hpp"

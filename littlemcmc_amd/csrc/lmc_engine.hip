@@ -979,13 +979,22 @@ int lmc_engine_occupancy(lmc_engine* e, int32_t* resident_chains, int32_t* waves
         *resident_chains = per_cu * cus;
         return LMC_OK;
     }
+    // (the very instantiation run() launches: the counter-based momentum stream is its own kernel with its own registers)
 #define OCC_ONE(NSV, WV, T)                                                                                    \
     {                                                                                                          \
-        if (run_lds > 64 * 1024)                                                                               \
-            HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NSV, WV, T>),             \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));              \
-        HIP_TRY(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, run_kernel<NSV, WV, T>, block,        \
-                                                                static_cast<size_t>(run_lds)));                \
+        if (e->cfg.rng_mode == LMC_RNG_PHILOX) {                                                               \
+            if (run_lds > 64 * 1024)                                                                           \
+                HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NSV, WV, T, 1>),      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));          \
+            HIP_TRY(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, run_kernel<NSV, WV, T, 1>, block, \
+                                                                    static_cast<size_t>(run_lds)));            \
+        } else {                                                                                               \
+            if (run_lds > 64 * 1024)                                                                           \
+                HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NSV, WV, T>),         \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));          \
+            HIP_TRY(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, run_kernel<NSV, WV, T>, block,    \
+                                                                    static_cast<size_t>(run_lds)));            \
+        }                                                                                                      \
     }
 #define OCC_CALL(T)                                                                                            \
     {                                                                                                          \
@@ -1475,6 +1484,21 @@ int lmc_engine_get_dense_chain(lmc_engine* e, int32_t chain, float* cov, float* 
     int rc;
     if (cov && (rc = fetch(cov, e->D.covT, e->D.mat_stride, true)) != LMC_OK) return rc;
     if (chol && (rc = fetch(chol, fac_src, e->D.fac_stride, inv)) != LMC_OK) return rc;
+    return LMC_OK;
+}
+
+int lmc_engine_get_dense_factor_f64(lmc_engine* e, double* chol) {
+    if (!e || !chol) return fail(e, LMC_ERR_INVALID, "null argument");
+    if (!pot_f64(e->cfg.potential)) return fail(e, LMC_ERR_STATE, "the float64 factor exists for LMC_POT_FULL_F64 / LMC_POT_FULL_INV");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
+    const size_t d = e->cfg.dim, dp = e->dpad;
+    const double* src = e->cfg.potential == LMC_POT_FULL_F64 ? e->chol64T : static_cast<const double*>(e->D.fac);   // LT[j][i] = L[i][j]
+    std::vector<double> raw(d * dp), out(d * d);
+    HIP_TRY(e, hipMemcpy(raw.data(), src, raw.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < d; ++i)
+        for (size_t j = 0; j < d; ++j) out[i * d + j] = raw[j * dp + i];
+    HIP_TRY(e, hipMemcpy(chol, out.data(), out.size() * sizeof(double), hipMemcpyDefault));
     return LMC_OK;
 }
 

@@ -338,7 +338,9 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 }
 // two standard normals (float32 precision) from two 32-bit words
 __device__ __forceinline__ void box_muller_f32(uint32_t a, uint32_t b, float& z0, float& z1) {
-    const float u1 = static_cast<float>(a >> 8) * 5.9604645e-08f + 2.9802322e-08f;   // (0, 1): (k + 1/2) 2^-24
+    // (0, 1]: (k + 1) 2^-24, exact in float32 for every 24-bit k (the half-offset form (k + 1/2) 2^-24 rounded to 1.0 at
+    // k = 2^24 - 1, i.e. a (0, 0) pair, and lost its offset above 1/2: round-3 review)
+    const float u1 = static_cast<float>((a >> 8) + 1u) * 5.9604645e-08f;
     const float u2 = static_cast<float>(b >> 8) * 5.9604645e-08f;                    // [0, 1) of a revolution
     const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), v_log_f32 is log2
     z0 = r * __builtin_amdgcn_cosf(u2);   // v_cos_f32 / v_sin_f32 take revolutions

@@ -552,48 +552,20 @@ __device__ __forceinline__ void leapfrog(TeamT& tm, const Target& tgt, const dou
 // and ties up both the LDS and the vector-memory counters).
 typedef __attribute__((address_space(3))) double lds_double;
 typedef __attribute__((address_space(1))) double glb_double;
-// LDS, four elements per thread: a thread's 32-byte slice read with two ds_read_b128 at a lane stride of 32 bytes puts lanes
-// l and l + 8 on the same banks (a 2-way conflict on every access: ~200 conflict cycles per leapfrog on C4, round 3's
-// counters). Vector slots in LDS are private to their threads -- nobody else ever reads a thread's elements -- so the two
-// halves of a slice may live anywhere: they are kept in two PLANES of the slot (elements {0, 1} of thread t at doubles
-// [2t, 2t + 2), elements {2, 3} at [2T + 2t, 2T + 2t + 2), T = threads of the chain), lane stride 16 bytes, conflict free.
-#ifndef LMC_CHAIN_THREADS
-#define LMC_CHAIN_THREADS static_cast<int>(blockDim.x)
-#endif
-#ifndef LMC_LDS_PLANES
-#define LMC_LDS_PLANES 1
-#endif
-template <class PTR> struct IsLdsPtr { static constexpr bool value = false; };
-template <> struct IsLdsPtr<lds_double*> { static constexpr bool value = true; };
-template <> struct IsLdsPtr<const lds_double*> { static constexpr bool value = true; };
+// (Round 4, measured and dropped: the two halves of a four-element slice in two LDS planes -- lane stride 16 bytes, no 2-way
+// bank conflict of the ds_read_b128 pairs -- C4 2.09e8 either way, C5 -2.7 %: the conflicts the counters show are not on this
+// path's critical path, and the second address costs an SGPR.)
 template <int NS, class PTR>
 __device__ __forceinline__ void vload_as(PTR base, double (&x)[NS]) {
-    if constexpr (NS == 4 && IsLdsPtr<PTR>::value && LMC_LDS_PLANES) {
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        typedef const __attribute__((address_space(3))) d2 lds_d2;
-        lds_d2* p = (lds_d2*)(base + LMC_CHAIN_THREAD * 2);
-        const d2 a = p[0], b = p[LMC_CHAIN_THREADS];
-        x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
-    } else {
-        PTR p = base + LMC_CHAIN_THREAD * NS;
+    PTR p = base + LMC_CHAIN_THREAD * NS;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) x[s] = p[s];
-    }
+    for (int s = 0; s < NS; ++s) x[s] = p[s];
 }
 template <int NS, class PTR>
 __device__ __forceinline__ void vstore_as(PTR base, const double (&x)[NS]) {
-    if constexpr (NS == 4 && IsLdsPtr<PTR>::value && LMC_LDS_PLANES) {
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        typedef __attribute__((address_space(3))) d2 lds_d2;
-        lds_d2* p = (lds_d2*)(base + LMC_CHAIN_THREAD * 2);
-        d2 a, b;
-        a.x = x[0]; a.y = x[1]; b.x = x[2]; b.y = x[3];
-        p[0] = a; p[LMC_CHAIN_THREADS] = b;
-    } else {
-        PTR p = base + LMC_CHAIN_THREAD * NS;
+    PTR p = base + LMC_CHAIN_THREAD * NS;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) p[s] = x[s];
-    }
+    for (int s = 0; s < NS; ++s) p[s] = x[s];
 }
 // Tree weights are kept in the LINEAR domain: w = exp(-dE - c) with one offset c per transition.
 // The reference carries log-weights and pays logaddexp (exp + log1p) twice plus log(U) per merge

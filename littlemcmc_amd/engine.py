@@ -391,6 +391,12 @@ class Engine:
         self._check(self._lib.lmc_engine_get_dense_chain(self._h, int(chain), _abi.ptr(cov), _abi.ptr(chol)))
         return cov, chol
 
+    def dense_factor_f64(self):
+        """Lower Cholesky factor [dim, dim] float64 of the float64 dense potentials (Full(dtype="float64"), FullInv)."""
+        L = np.empty((self.dim, self.dim))
+        self._check(self._lib.lmc_engine_get_dense_factor_f64(self._h, _abi.ptr(L)))
+        return L
+
     def get_dense_state(self, fields=None):
         """cov / chol of every chain; for "full_adapt" also the two covariance estimators and the window state.
         ``fields`` restricts the copy (the matrices are chains x dim x dim)."""
@@ -621,3 +627,6 @@ class EngineGroup:
     def dense_chain(self, chain=0):
         e, c = self._locate(chain)
         return e.dense_chain(c)
+
+    def dense_factor_f64(self):
+        return self.engines[0].dense_factor_f64()

@@ -318,8 +318,8 @@ class QuadPotentialFull(_DensePotential):
         cov, chol = engine.dense_chain(chain)          # float32 views of the device's matrices
         if self.dtype == "float32":
             self._cov, self._chol = cov, chol
-        else:                                          # the float64 matrix is the caller's own; the factor is reported in float32 precision
-            self._chol = chol.astype("d")
+        else:                                          # the float64 matrix is the caller's own; the factor as the device holds it
+            self._chol = engine.dense_factor_f64()
 
     __call__ = QuadPotential.random
 
@@ -341,8 +341,8 @@ class QuadPotentialFullInv(_DensePotential):
         return (self._matrix,)
 
     def _pull(self, engine, chain=0):
-        self._cov, chol = engine.dense_chain(chain)
-        self.L = chol.astype("d")
+        self._cov, _chol32 = engine.dense_chain(chain)
+        self.L = engine.dense_factor_f64()
 
 
 class QuadPotentialFullAdapt(_DensePotential):
