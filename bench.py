@@ -624,7 +624,10 @@ def main():
                 "median_including_diagnostics": ess["median"] / (ess["draw_seconds"] + ess["diagnostics_seconds"]),
                 "ess_min": ess["min"], "ess_median": ess["median"], "rhat_max": ess["rhat_max"],
                 "definition": "%s over all %d chains x %d post-warm-up draws; per second of post-warm-up kernel time "
-                              "(slowest rank), and per second of kernel + diagnostics time" % (
+                              "(slowest rank), and per second of kernel + diagnostics time. The definition is this build's own: "
+                              "the reference has no ESS / R-hat (ArviZ appears in a docs recipe only), so the figure is checked "
+                              "against a numpy restatement and an analytic AR(1) autocorrelation time, not against a reference "
+                              "implementation (parity unpinned)" % (
                                   ess["definition"], ess["chains_total"], ess["draws"]),
                 "draw_seconds": ess["draw_seconds"], "diagnostics_seconds": ess["diagnostics_seconds"],
                 "lag_passes": ess["lag_passes"],

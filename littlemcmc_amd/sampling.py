@@ -313,13 +313,19 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
         # the longest trees run alone (ragged targets: DESIGN.md section 6), so fewer, longer launches are faster
         per_launch = int(launch_iters) if launch_iters else max(1, min(n_total, 4000))
         if not launch_iters:
-            # ...except when the chains outnumber the resident wavefront slots only a few times over: whole-job launches
-            # would then run in a few job-long rounds with the last one part empty. In segments of 100 iterations the
+            # ...except when the chains outnumber the resident wavefront slots. Only a few times over: whole-job launches
+            # would run in a few job-long rounds with the last one part empty, while in segments of 100 iterations the
             # engine's two sub-block streams keep the slots filled across segment boundaries (+22 % at 8 192 x d=128).
+            # Many times over: a launch is also the granularity of Ctrl-C for the chains whose wavefronts have not started
+            # yet (a workgroup that starts under a stop request does nothing: interrupting ONE job-long launch of 20 rounds of
+            # residency would return no draw at all), so the job is cut into launches of 500 iterations -- few enough that
+            # the per-launch tail of ragged targets stays small.
             slots = eng.resident_chains()
             per_dev = -(-chains // len(devs))     # what one GPU holds
             if slots and slots < per_dev < 6 * slots:
                 per_launch = min(per_launch, 100)
+            elif slots and per_dev >= 6 * slots:
+                per_launch = min(per_launch, 500)
         if target.family == _abi.TARGET_EXTERNAL and not launch_iters:
             per_launch = max(n_total, 1)   # ticks: chains never wait for each other inside one request
         if getattr(step, "_host_step_rand", lambda: None)() is not None:
