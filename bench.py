@@ -241,14 +241,46 @@ def main():
                          "ranks, or under torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
-    if args.backend == "gloo":          # test mode: several ranks may share one GPU
+    if args.backend == "gloo" or os.environ.get("LMC_BENCH_FAIL_RCCL"):          # test modes: several ranks may share one GPU
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     rccl_error = None
+    launcher_fallback = None
     if world > 1:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            # The multi-GPU curve must not hinge on RCCL coming up: the sampling path needs no collective at all. If the
+            # process group cannot be brought up (or its first all-reduce fails), rank 0 runs the SAME job through the
+            # in-process launcher -- one engine per GPU from this one process -- the other ranks leave, and the line says
+            # what happened (`launcher`, `rccl_error`). Chains, seeds, blocks and the timed region are the same either way.
+            try:
+                import datetime
+
+                if os.environ.get("LMC_BENCH_FAIL_RCCL"):   # test hook: exercise the fallback without breaking RCCL
+                    raise RuntimeError("LMC_BENCH_FAIL_RCCL is set")
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                        timeout=datetime.timedelta(seconds=180))
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError("all-reduce over %d ranks returned %d" % (world, int(probe.item())))
+            except Exception as err:
+                rccl_error = "%s: %s" % (type(err).__name__, str(err)[:300])
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:
+                    pass
+                if rank != 0:
+                    print("rank %d: RCCL bring-up failed (%s); rank 0 runs the job in-process" % (rank, rccl_error), file=sys.stderr)
+                    os._exit(0)
+                launcher_fallback = "ranks -> inproc: the RCCL process group did not come up (%s)" % rccl_error
+                inproc = True
+                world, rank, local_rank = 1, 0, 0
+                torch.cuda.set_device(0)
+                args.no_rccl_check = True
+                time.sleep(5.0)   # the other ranks release their GPUs
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     elif args.backend == "nccl" and not args.no_rccl_check:
@@ -639,6 +671,7 @@ def main():
             "rccl_ranks": rccl_ranks, "rccl_error": rccl_error, "backend": None if inproc else args.backend,
             "launcher": ("inproc: one process, one engine per GPU (littlemcmc_amd.sample(devices=...)'s path), no process group"
                          if inproc else "ranks: one process per GPU under torch.distributed.run, %s" % args.backend),
+            "launcher_fallback": launcher_fallback,
             "source_hash": src_hash, "source_tree_hash": _build.source_hash(),
         }
         if secondary is not None:

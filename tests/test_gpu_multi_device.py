@@ -136,3 +136,23 @@ def test_bench_inproc_launcher_adds_up_to_the_one_gpu_job():
     assert two["backend"] is None and two["rccl_ranks"] is None
     assert abs(two["ess_per_sec"]["ess_min"] / one["ess_per_sec"]["ess_min"] - 1.0) < 1e-9
     assert one["source_hash"] == two["source_hash"] == one["source_tree_hash"]          # the binary's own stamp
+
+
+def test_bench_falls_back_to_the_inproc_launcher_when_rccl_does_not_come_up():
+    """The driver's own form for N > 1 (torch.distributed.run, nccl). If the RCCL process group cannot be brought up, rank 0
+    runs the same job in-process and the line says so -- the scaling curve does not hinge on a collective the sampling path
+    never needs. (LMC_BENCH_FAIL_RCCL simulates the failure.)"""
+    one = _bench(["--gpus", "1", "--no-rccl-check"])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["LMC_BENCH_FAIL_RCCL"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29583", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0",
+           "--chains", "512", "--no-cpu-baseline", "--no-secondary"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["leapfrogs"] == one["leapfrogs"]
+    assert two["launcher"].startswith("inproc") and "RCCL" in two["launcher_fallback"] and two["rccl_error"]
+    assert [r["chains"] for r in two["per_rank"]] == [256, 256]
