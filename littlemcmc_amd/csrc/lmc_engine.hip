@@ -656,8 +656,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     // goldens of the small shapes replay through them too
     bool forced = false;
     if (const char* env = std::getenv("LMC_FORCE_WIDE"))
-        forced = std::atoi(env) != 0 && cfg->potential != LMC_POT_FULL_ADAPT && cfg->target_family != LMC_TARGET_EXTERNAL &&
-                 cfg->rng_mode == LMC_RNG_NUMPY;
+        forced = std::atoi(env) != 0 && cfg->potential != LMC_POT_FULL_ADAPT && cfg->rng_mode == LMC_RNG_NUMPY &&
+                 (cfg->target_family != LMC_TARGET_EXTERNAL || cfg->potential < LMC_POT_FULL);
     const bool wide = cfg->dim > 1024 || (cfg->potential >= LMC_POT_FULL && cfg->dim > 256) || cfg->mass_f64 != 0 || rtc_dense || forced;
     if (wide) {
         if (cfg->dim > kWideMaxDim)
@@ -667,9 +667,9 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         if (cfg->potential == LMC_POT_FULL_ADAPT)
             return fail(nullptr, LMC_ERR_INVALID, "per-chain adapted dense matrices (FULL_ADAPT) run in the fused kernels only: dim <= 256 "
                                                   "(got %d), float32, built-in or compiled-in densities", cfg->dim);
-        if (cfg->target_family == LMC_TARGET_EXTERNAL)
-            return fail(nullptr, LMC_ERR_INVALID, "an externally evaluated density runs up to dim 1024 (dense matrices: 256) with float32 "
-                                                  "adaptive masses; give the density as a device functor for larger shapes");
+        if (cfg->target_family == LMC_TARGET_EXTERNAL && (cfg->potential >= LMC_POT_FULL || cfg->mass_f64))
+            return fail(nullptr, LMC_ERR_INVALID, "an externally evaluated density runs with diagonal float32 mass matrices at any dim up to %d, "
+                                                  "with dense ones up to dim 256; give the density as a device functor for the other shapes", kWideMaxDim);
         if (cfg->rng_mode != LMC_RNG_NUMPY)
             return fail(nullptr, LMC_ERR_INVALID, "LMC_RNG_PHILOX runs in the fused kernels only");
     }
@@ -821,7 +821,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     const bool external = cfg->target_family == LMC_TARGET_EXTERNAL;
     if (external) A.scratch_stride = static_cast<long long>(dense ? tick_dense_scratch_vectors(max_levels) : tick_scratch_vectors(max_levels)) * dp;
     if (wide) {
-        A.scratch_stride = static_cast<long long>(wide_scratch_slots(max_levels)) * dp;
+        if (!external) A.scratch_stride = static_cast<long long>(wide_scratch_slots(max_levels)) * dp;
         TRY_ALLOC(dev_alloc(e, &A.var64, C * dp));
         TRY_ALLOC(dev_alloc(e, &A.inv_std64, C * dp));
         TRY_ALLOC(dev_alloc(e, &e->init_diag64, C * dp));
@@ -1769,7 +1769,8 @@ int lmc_engine_tick_begin(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     e->K.iter_end = iter_begin + n_iters;
     e->K.n_tune = n_tune;
-    const int rc = tick_launch_begin(e->ns, main_stream(e), e->A, e->K, iter_begin);
+    const int rc = e->wide ? tick_wide_launch_begin(e->ns, main_stream(e), e->A, e->K, iter_begin)
+                           : tick_launch_begin(e->ns, main_stream(e), e->A, e->K, iter_begin);
     if (rc != 0) return fail(e, LMC_ERR_HIP, "tick_begin: %s", rc < 0 ? "unsupported vector width" : hipGetErrorString(static_cast<hipError_t>(rc)));
     e->ticking = true;
     return LMC_OK;
@@ -1793,7 +1794,8 @@ int lmc_engine_tick(lmc_engine* e, const double* logp, const double* grad, int32
             if (rc != 0) return dense_fail(e, rc, "dense update");
         }
     } else {
-        const int rc = tick_launch(e->ns, main_stream(e), e->A, e->K, P, logp, grad);
+        const int rc = e->wide ? tick_wide_launch(e->ns, main_stream(e), e->A, e->K, P, logp, grad)
+                               : tick_launch(e->ns, main_stream(e), e->A, e->K, P, logp, grad);
         if (rc != 0) return fail(e, LMC_ERR_HIP, "tick: %s", rc < 0 ? "unsupported vector width" : hipGetErrorString(static_cast<hipError_t>(rc)));
     }
     if (n_active) {

@@ -5,6 +5,7 @@
 
 #include "../../include/lmc_hip.h"
 #include "lmc_wide.hpp"
+#include "lmc_tick_wide.hpp"
 #include "lmc_wide_launch.hpp"
 #ifdef LMC_USER_TARGET_HEADER
 #include LMC_USER_TARGET_HEADER
@@ -101,6 +102,23 @@ int wide_launch_momentum(int ns, hipStream_t stream, const ChainArrays& A, const
     const int lds = wide_lds_bytes(A.dpad);
     (void)hipGetLastError();
     WIDE_NS_SWITCH(ns, { WIDE_LDS_ATTR((wide_momentum_kernel<NS>)) hipLaunchKernelGGL((wide_momentum_kernel<NS>), grid, block, lds, stream, A, D, momentum_f32, out); })
+    return static_cast<int>(hipGetLastError());
+}
+
+// the tick kernels of the wide shapes (lmc_tick_wide.hpp, generated from lmc_tick.hpp): externally evaluated densities
+int tick_wide_launch(int ns, hipStream_t stream, const ChainArrays& A, const TickArrays& K, const SamplerParams& P,
+                     const double* logp, const double* grad) {
+    const dim3 grid(A.chains), block(kWideThreads);
+    const int lds = wide_lds_bytes(A.dpad);
+    (void)hipGetLastError();
+    WIDE_NS_SWITCH(ns, { WIDE_LDS_ATTR((tick_wide_kernel<NS>)) hipLaunchKernelGGL((tick_wide_kernel<NS>), grid, block, lds, stream, A, K, P, logp, grad); })
+    return static_cast<int>(hipGetLastError());
+}
+
+int tick_wide_launch_begin(int ns, hipStream_t stream, const ChainArrays& A, const TickArrays& K, long long iter_begin) {
+    const dim3 grid(A.chains), block(kWideThreads);
+    (void)hipGetLastError();
+    WIDE_NS_SWITCH(ns, hipLaunchKernelGGL((tick_wide_begin_kernel<NS>), grid, block, 0, stream, A, K, iter_begin))
     return static_cast<int>(hipGetLastError());
 }
 

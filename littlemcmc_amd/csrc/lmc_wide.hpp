@@ -150,6 +150,37 @@ __device__ inline void wide_normals(WideTeam& tm, RngState& r, int d, const Wide
     tm.sync();
 }
 
+// the same into registers (thread t receives elements t*NS .. t*NS+NS-1): the tick kernel of the wide shapes, which has no
+// scratch slot to spare for the normals
+template <int NS>
+__device__ inline void wide_normals_regs(WideTeam& tm, RngState& r, int d, double* stage, double* bcast, double (&z)[NS]) {
+    const int t = tm.tid();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) z[s] = 0.0;
+    for (int off = 0; off < d; off += kWideChunk) {
+        const int n = d - off < kWideChunk ? d - off : kWideChunk;
+        tm.sync();
+        if (tm.wave() == 0) {
+            rng_normals(r, n, stage, stage + kWideChunk);
+            if (lane_id() == 0) {
+                bcast[0] = static_cast<double>(r.pos);
+                bcast[1] = static_cast<double>(r.has_gauss);
+                bcast[2] = r.gauss;
+            }
+        }
+        tm.sync();
+        r.pos = first_i32(static_cast<int>(bcast[0]));
+        r.has_gauss = first_i32(static_cast<int>(bcast[1]));
+        r.gauss = first_f64(bcast[2]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int e = t * NS + s;
+            if (e >= off && e < off + n) z[s] = stage[e - off];
+        }
+    }
+    tm.sync();
+}
+
 // solve_triangular(chol.T, float32(z)) (quadpotential.py:450-453): the column sweep of the reference BLAS strsv over the
 // row-major float32 factor (x_j /= L_jj, then x_i -= L_ji x_j for i < j, j descending), one team barrier per column
 template <int NS>

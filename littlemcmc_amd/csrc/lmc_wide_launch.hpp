@@ -24,5 +24,9 @@ int wide_launch_trajectory(int family, int ns, hipStream_t stream, const ChainAr
                            int n_fwd, int n_back, double* oq, double* op, double* ov, double* og, double* oe, double* ol);
 int wide_launch_momentum(int ns, hipStream_t stream, const ChainArrays& A, const DenseArrays& D, int momentum_f32, double* out);
 int wide_launch_mass_update(int ns, hipStream_t stream, const ChainArrays& A, const SamplerParams& P);
+struct TickArrays;
+int tick_wide_launch(int ns, hipStream_t stream, const ChainArrays& A, const TickArrays& K, const SamplerParams& P,
+                     const double* logp, const double* grad);
+int tick_wide_launch_begin(int ns, hipStream_t stream, const ChainArrays& A, const TickArrays& K, long long iter_begin);
 
 }  // namespace lmc

@@ -295,7 +295,8 @@ class TorchTarget(DeviceTarget):
     the chains ever waiting for each other. Nothing is computed on the CPU.
 
     ``TorchTarget.from_logp(d, logp_fn)`` builds the gradient with autograd from ``logp_fn(q) -> [chains]``.
-    Limits: d <= 1024 (one wavefront per chain); dense mass matrices (QuadPotentialFull*, init="adapt_full") as for
+    Limits: d <= 16 384 with diagonal mass matrices (beyond 1 024 the chain is a workgroup of 16 wavefronts:
+    csrc/lmc_tick_wide.hpp); dense mass matrices (QuadPotentialFull*, init="adapt_full") as for
     the fused kernels up to d = 256. A fused ``UserTarget`` is several times faster (no HBM round trip of
     the chain state per leapfrog); this is the path for "cannot write device code".
     """

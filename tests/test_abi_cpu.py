@@ -235,3 +235,16 @@ def test_generated_dense_tick_kernel_is_current():
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
     assert open(gen.OUT).read() == gen.TEXT
+
+
+def test_generated_wide_tick_kernel_is_current():
+    """csrc/lmc_tick_wide.hpp (the tick state machine for model_ndim > 1024, one chain = 16 wavefronts) is generated from
+    csrc/lmc_tick.hpp by tools/gen_tick_wide.py: the committed file must be what the generator produces."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_tick_wide", os.path.join(root, "tools", "gen_tick_wide.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert open(gen.OUT).read() == gen.TEXT

@@ -295,3 +295,56 @@ def test_wide_engines_on_several_devices_and_interrupts():
     full, _ = lmc.sample(T.StdNormal(d), d, draws=max(n - 50, 0), tune=min(n, 50), chains=64, random_seed=4,
                          discard_tuned_samples=False, progressbar=False)
     np.testing.assert_array_equal(tr, full)
+
+
+# ---- externally evaluated densities (Python / torch callables) beyond 1024 dimensions: csrc/lmc_tick_wide.hpp ----------
+@pytest.mark.parametrize("name", ["e2e_nuts_ar1_16", "e2e_hmc_c1", "e2e_nuts_std64"])
+def test_goldens_replay_through_the_wide_tick_kernel(golden_dir, name, monkeypatch):
+    """LMC_FORCE_WIDE=1 with a torch callable: every iteration of the captured reference chains through the tick state
+    machine of the general kernels (generated from the one-wavefront tick kernel by tools/gen_tick_wide.py)."""
+    from tests.test_gpu_torch_target import torch_ar1, torch_std_normal
+
+    monkeypatch.setenv("LMC_FORCE_WIDE", "1")
+    g = _load(golden_dir, name)
+    d, tune, draws = int(g["d"]), int(g["tune"]), int(g["draws"])
+    kw = kwargs_from(g)
+    fam = str(g["family"])
+    f = OT.make(fam, d)
+    tgt = torch_ar1(d) if fam == "ar1" else torch_std_normal(d)
+    seeds = [int(s) for s in g["seeds"]]
+    if str(g["kind"]) == "hmc":
+        ostep, step = orc.Step(f, d, kind="hmc", **kw), lmc.HamiltonianMC(tgt, d, **kw)
+    else:
+        _s, ostep = orc.init_nuts(f, d, seeds=seeds, **kw)
+        _s2, step = lmc.init_nuts(tgt, d, random_seed=seeds, **kw)
+    eng = step._make_engine(1)
+    try:
+        assert eng.wide
+    finally:
+        eng.close()
+    snaps, outs = oracle_chain_snapshots(ostep, g["start"], seeds[0], tune, draws)
+    checked, fragile = replay_iterations_on_device(step, snaps, outs, label=name + " (wide ticks)")
+    assert checked >= 0.99 * (tune + draws), (checked, fragile)
+
+
+@pytest.mark.parametrize("d", [1100, 2500])
+def test_callables_beyond_1024_dimensions(d):
+    """The reference's own plug-in forms at model_ndim > 1024: a batched torch callable replayed against the oracle, and a
+    plain per-point Python callable (integration.py:40) through sample() -- the same chains as the device functor's."""
+    from tests.test_gpu_torch_target import torch_ar1
+
+    f = OT.make("ar1", d)
+    seeds = orc.derive_seeds(77 + d, 2)
+    tune, draws = 12, 4
+    _s, ostep = orc.init_nuts(f, d, seeds=seeds)
+    start, step = lmc.init_nuts(torch_ar1(d), d, random_seed=seeds)
+    snaps, outs = oracle_chain_snapshots(ostep, start, seeds[1], tune, draws)
+    checked, fragile = replay_iterations_on_device(step, snaps, outs, label="torch callable d=%d" % d)
+    assert checked >= tune + draws - 1
+    if d > 2000:
+        return
+    kw = dict(draws=6, tune=10, chains=2, random_seed=5, discard_tuned_samples=False, progressbar=False)
+    a = lmc.sample(lambda q: f(q), d, **kw)                      # a plain Python callable: the reference's signature
+    b = lmc.sample(T.AR1(d, 0.9), d, **kw)                       # the device functor
+    np.testing.assert_array_equal(a[1]["tree_size"], b[1]["tree_size"])
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-6, atol=1e-8)   # (numpy vs device density: last-bit differences, amplified by tuning)
