@@ -253,12 +253,16 @@ int lmc_engine_set_step_sizes(lmc_engine* e, const double* step_sizes);
 int lmc_engine_diag_update(lmc_engine* e, int32_t tune);
 int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int64_t trace_begin);
 /* KeyboardInterrupt (sampling.py:324-328, :470-471: the reference keeps what has been drawn so far). stop = 1: every
- * chain leaves the launch it is in within ~16 iterations and launches still queued return at once -- the stop word is
- * pinned host memory that a few relay chains poll and copy to a device word, so the request needs nothing scheduled on
- * the device; chains end at different
- * iterations (lmc_chain_state.iter_count says where, draws and statistics below the smallest one are complete for every
- * chain). stop = 0 re-arms the engine, ordered after everything launched so far. Fused kernels (diagonal and dense mass);
- * a tick-driven job stops by not ticking. */
+ * chain leaves the launch it is in at the end of an iteration within ~16 iterations, and a workgroup that STARTS under the
+ * request does nothing at all -- launches still queued neither run an iteration nor touch iter_count, and chains of the
+ * current launch whose wavefronts had not started yet stay where the previous launch left them. The stop word is pinned
+ * host memory that one chain in at most 256 of a launch (taking turns) polls and copies to a device word, so the request
+ * needs nothing scheduled on the device. Chains end at different iterations: lmc_chain_state.iter_count says where; draws
+ * and statistics below its MINIMUM are complete for every chain. Consequence for callers: with many more chains than
+ * resident wavefront slots (lmc_engine_occupancy), a launch is the granularity at which the not-yet-started chains are
+ * cut off -- littlemcmc_amd.sample() therefore cuts such jobs into launches of at most 500 iterations. stop = 0 re-arms
+ * the engine, ordered after everything launched so far. Fused, dense and general kernels; a tick-driven job stops by not
+ * ticking. */
 int lmc_engine_request_stop(lmc_engine* e, int32_t stop);
 /* The `callback` of the reference's drivers (sampling.py:272-277, :307-308: called per draw, "sampling can be interrupted
  * by throwing a KeyboardInterrupt in the callback") needs to know where a running job is WITHOUT waiting for it:
