@@ -326,6 +326,8 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
                 per_launch = min(per_launch, 100)
             elif slots and per_dev >= 6 * slots:
                 per_launch = min(per_launch, 500)
+            elif not slots and getattr(getattr(eng, "engines", [eng])[0], "wide", False):
+                per_launch = min(per_launch, 200)   # general kernels (one workgroup per chain, a few hundred resident): same reason
         if target.family == _abi.TARGET_EXTERNAL and not launch_iters:
             per_launch = max(n_total, 1)   # ticks: chains never wait for each other inside one request
         if getattr(step, "_host_step_rand", lambda: None)() is not None:
