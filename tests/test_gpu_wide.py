@@ -348,3 +348,30 @@ def test_callables_beyond_1024_dimensions(d):
     b = lmc.sample(T.AR1(d, 0.9), d, **kw)                       # the device functor
     np.testing.assert_array_equal(a[1]["tree_size"], b[1]["tree_size"])
     np.testing.assert_allclose(a[0], b[0], rtol=1e-6, atol=1e-8)   # (numpy vs device density: last-bit differences, amplified by tuning)
+
+
+# ---- rare paths through the general kernels: weight-offset moves, divergences in deep trees, depth caps -------------------
+@pytest.mark.parametrize("path", ["fused", "dense", "ticks"])
+def test_rare_weight_offset_paths_through_the_general_kernels(path, monkeypatch):
+    """tests/test_gpu_reference_suite.py::test_weight_offset_moves_when_the_energy_drops_by_more_than_600 with
+    LMC_FORCE_WIDE=1: the linear-domain weight offset moving inside accepted and rejected subtrees, in the general sampling
+    kernel (diagonal and dense mass) and in the general tick kernel."""
+    from tests.test_gpu_reference_suite import test_weight_offset_moves_when_the_energy_drops_by_more_than_600 as body
+
+    monkeypatch.setenv("LMC_FORCE_WIDE", "1")
+    body(path)
+
+
+def test_rare_paths_differential_fuzz_through_the_general_kernels():
+    """tools/fuzz_rare.py under LMC_FORCE_WIDE=1: far starts, step sizes up to the stability limit, d = 1 ... 300, depth caps,
+    every sampler statistic of the first iterations against the oracle."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LMC_FORCE_WIDE="1")
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_rare.py"), "60", "23"], capture_output=True,
+                         text=True, timeout=900, cwd=root, env=env)
+    tail = "\n".join(res.stdout.strip().split("\n")[-6:])
+    assert res.returncode == 0, tail + "\n" + res.stderr[-2000:]
+    assert "failures: 0" in tail
