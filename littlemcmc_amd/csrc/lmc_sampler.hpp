@@ -1256,6 +1256,9 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
 // Occupancy target per vector width (waves per SIMD; the VGPR budget is 512 / waves): the per-chain state
 // is register resident, so wider per-thread slices trade occupancy for registers. Chains longer than
 // 128 elements are spread over W waves (dpad = 64 * NS * W) instead of growing NS further.
+#ifndef LMC_NORMALS_IN_REGS
+#define LMC_NORMALS_IN_REGS 1
+#endif
 #ifndef LMC_WAVES_NS1
 #define LMC_WAVES_NS1 4
 #endif
@@ -1587,15 +1590,22 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
             for (int s = 0; s < NS; ++s)
                 p0[s] = momentum_f32 ? static_cast<double>(inv_std[s] * static_cast<float>(z[s])) : z[s] * static_cast<double>(inv_std[s]);
         } else {
-            team_normals(tm, rng, d, lds, lds + dpad, rng_bcast, mt_lds, mt_lds2);   // level-0 LDS region (2*dpad doubles) = normals + staging
+            double zr[NS];
+            if constexpr (W == 1 && LMC_NORMALS_IN_REGS) {
+                rng_normals_owned<NS>(rng, d, lds, lds + dpad, zr);   // even d: the variates never travel through LDS
+            } else {
+                team_normals(tm, rng, d, lds, lds + dpad, rng_bcast, mt_lds, mt_lds2);   // level-0 LDS region (2*dpad doubles) = normals + staging
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int e = tid * NS + s;
-                const double z = (e < d) ? lds[e] : 0.0;
-                p0[s] = momentum_f32 ? static_cast<double>(inv_std[s] * static_cast<float>(z))
-                                     : z * static_cast<double>(inv_std[s]);
+                for (int s = 0; s < NS; ++s) {
+                    const int e = tid * NS + s;
+                    zr[s] = (e < d) ? lds[e] : 0.0;
+                }
+                tm.sync();
             }
-            tm.sync();
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                p0[s] = momentum_f32 ? static_cast<double>(inv_std[s] * static_cast<float>(zr[s]))
+                                     : zr[s] * static_cast<double>(inv_std[s]);
         }
         LMC_PHASE(0)
 
