@@ -208,3 +208,22 @@ def test_eight_rank_gloo_reduction_with_uneven_and_empty_blocks(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
         assert "ok" in o
+
+
+def test_per_gpu_blocks_in_one_process_reduce_like_one_block():
+    """sample(devices=[...]) hands the diagnostics a LIST of per-GPU trace views (diagnostics.trace_tensor(group)): the
+    (3 + 16) x d blocks of the parts are added, global ranks are counted over every part's sorted pool (ties averaged) --
+    the result is the one-block result whatever the split, uneven and empty parts included."""
+    x = ar1_chains(11, 160, 5, 0.8, 3)
+    x[3, 40:60] = x[3, 40:41]                       # a stuck stretch: tied values for the rank normalisation
+    whole = torch.from_numpy(x)
+    for cuts in ([0, 4, 11], [0, 1, 1, 7, 11], [0, 11, 11]):
+        parts = [whole[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+        for rn in (False, True):
+            ref = dg.summarize(whole, rank_normalized=rn, stats_fn=odg.torch_chain_stats)
+            got = dg.summarize(parts, rank_normalized=rn, stats_fn=odg.torch_chain_stats)
+            for k in ("rhat", "ess", "mean", "var"):
+                np.testing.assert_allclose(got[k].numpy(), ref[k].numpy(), rtol=1e-10, atol=1e-12, err_msg="%s %s %s" % (cuts, rn, k))
+            assert got["n_chains"] == ref["n_chains"] and got["n_draws"] == ref["n_draws"]
+    with pytest.raises(ValueError, match="different numbers of draws"):
+        dg.summarize([whole[:4], whole[4:, :100]], stats_fn=odg.torch_chain_stats)
