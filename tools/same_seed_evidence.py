@@ -41,6 +41,39 @@ def first_difference(a, b):
     return bad
 
 
+def one_ulp_experiment():
+    """The same question with the smallest possible difference: ONE accept statistic of ONE iteration moved by one unit in
+    the last place (what a device exp() that differs from glibc's by an ulp does, once). Everything else identical."""
+    rows = []
+    for name, fam, d, chains, tune, draws in RUNS:
+        f = OT.make(fam, d)
+        base = orc.sample(f, d, draws=draws, tune=tune, chains=1, random_seed=SEED, discard_tuned_samples=False)[1]
+        real_update = orc.DualAverage.update
+        state = {"n": 0}
+
+        def perturbed(self, accept, tune_flag, _real=real_update, _st=state):
+            _st["n"] += 1
+            if _st["n"] == 11:                     # the eleventh iteration's statistic, nudged by one ulp
+                accept = np.nextafter(accept, 2.0)
+            return _real(self, accept, tune_flag)
+
+        orc.DualAverage.update = perturbed
+        try:
+            pert = orc.sample(f, d, draws=draws, tune=tune, chains=1, random_seed=SEED, discard_tuned_samples=False)[1]
+        finally:
+            orc.DualAverage.update = real_update
+        a = {k: base[k][0, :, 0] for k in base}
+        b = {k: pert[k][0, :, 0] for k in pert}
+        fd = first_difference(a, b)
+        rel = np.abs(a["step_size"] - b["step_size"]) / a["step_size"]
+        growth = [float(rel[i]) for i in (11, 20, 30, 40) if i < len(rel)]
+        rows.append({"golden": name, "dim": d, "first_iteration_with_a_different_tree": fd,
+                     "relative_step_size_difference_at_iterations_11_20_30_40": growth})
+        print("%-20s one ulp in one accept statistic (iteration 10): trees differ from iteration %s; step-size difference %s"
+              % (name, fd, ["%.1e" % g for g in growth]))
+    return rows
+
+
 def main():
     host = detect_sdot_mode()
     other = _abi.SDOT_OPENBLAS_HASWELL if host == _abi.SDOT_OPENBLAS_SKYLAKEX else _abi.SDOT_OPENBLAS_SKYLAKEX
@@ -67,7 +100,9 @@ def main():
                          "first_iteration_with_a_different_tree": fd})
             print("%-20s chain %d: energies differ from iteration %s, trees from iteration %s of %d"
                   % (name, c, first_ulp, fd, tune + draws))
+    ulp_rows = one_ulp_experiment()
     doc = {"what": __doc__.split("\n\n")[1].replace("\n", " "),
+           "one_ulp_experiment": {"what": one_ulp_experiment.__doc__.replace("\n", " "), "rows": ulp_rows},
            "host_sdot": names[host], "other_sdot": names[other], "rows": rows,
            "summary": {"median_first_different_tree": float(np.median([r["first_iteration_with_a_different_tree"] for r in rows
                                                                        if r["first_iteration_with_a_different_tree"] is not None])),
