@@ -154,9 +154,9 @@ typedef struct lmc_config {
  * LDS) cover dim <= 1024 with diagonal and dim <= 256 with dense mass matrices, float32 adaptive masses. Everything else the
  * reference accepts -- dim up to 16 384 (base_hmc.py:102 has no limit), QuadPotentialFull / FullInv up to dim 2048
  * (quadpotential.py:388-468), QuadPotentialDiagAdapt(dtype="float64") -- runs in the GENERAL kernels (csrc/lmc_wide.hpp: one
- * chain = a workgroup of 16 wavefronts, the tree in the chain's HBM row): the same algorithm, statement for statement, an
- * order of magnitude slower per leapfrog. Not in the general kernels: FULL_ADAPT beyond dim 256, LMC_TARGET_EXTERNAL,
- * LMC_RNG_PHILOX. */
+ * chain = one wavefront up to dim 512, a workgroup of 16 wavefronts beyond, the tree in the chain's HBM row): the same
+ * algorithm, statement for statement, several times slower per leapfrog. Not in the general kernels: FULL_ADAPT beyond dim
+ * 256, LMC_RNG_PHILOX, and LMC_TARGET_EXTERNAL with anything but a float32 diagonal. */
 /* Fill *cfg with the reference's defaults for the given shape. */
 void lmc_config_defaults(lmc_config* cfg, int32_t chains, int32_t dim);
 
@@ -391,6 +391,10 @@ int lmc_engine_draw_momentum(lmc_engine* e, double* out);
  * 40,62,115) becomes a device function linked into the leapfrog kernel without hipcc on the machine. Diagonal mass
  * matrices only; littlemcmc_amd.targets.UserTarget drives it. */
 int lmc_engine_kernel_shape(lmc_engine* e, int32_t* unit_ns, int32_t* run_ns, int32_t* run_w);
+/* 1 if this engine runs the general kernels ("Which kernels an engine runs", above): one wavefront per chain up to dim 512
+ * (run_w = 1), sixteen beyond (run_w = 16); a run-time compiled density then instantiates run_wide_kernel<run_ns, run_w,
+ * UserTarget>, wide_trajectory_kernel and wide_logp_kernel instead of the fused kernels. */
+int32_t lmc_engine_uses_general_kernels(lmc_engine* e);
 /* How the sampling kernel of this engine occupies the GPU (asked of the HIP runtime for the very kernel, block size and
  * dynamic LDS lmc_engine_run() launches with): resident_chains = chains that run concurrently (compute units x
  * workgroups per unit; 0 for engines without a fused sampling kernel), waves_per_chain, and the rate of the constant

@@ -128,6 +128,7 @@ _SIGNATURES = {
     "lmc_engine_rng_draw": (C.c_int, [_P, _P, C.c_int32, _P]),
     "lmc_engine_draw_momentum": (C.c_int, [_P, _P]),
     "lmc_engine_kernel_shape": (C.c_int, [_P, _P, _P, _P]),
+    "lmc_engine_uses_general_kernels": (C.c_int32, [_P]),
     "lmc_engine_occupancy": (C.c_int, [_P, _P, _P, _P]),
     "lmc_engine_request_stop": (C.c_int, [_P, C.c_int32]),
     "lmc_engine_progress": (C.c_int64, [_P]),

@@ -704,12 +704,18 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     e->wide = wide;
     e->ns = ns_for_dim(cfg->dim);
     e->dpad = 64 * e->ns;
-    if (wide) {   // thread t of the chain's 1024 owns elements t*ns .. t*ns+ns-1
+    if (wide) {   // thread t of the chain's team owns elements t*ns .. t*ns+ns-1
+        // one wavefront per chain up to 8 elements per lane (dim <= 512: 2-6x the team's rate there, tools/wide_team_ab.py),
+        // else 16 wavefronts; an externally evaluated density always takes the large team (lmc_tick_wide.hpp is instantiated
+        // for it only). LMC_WIDE_TEAM=16 is a test knob: the large team at every shape, so the small goldens replay through it too
+        const char* team_env = std::getenv("LMC_WIDE_TEAM");
+        const bool large_team = cfg->dim > kWideOneWaveMaxDim || cfg->target_family == LMC_TARGET_EXTERNAL || (team_env && std::atoi(team_env) == 16);
+        const int threads = large_team ? kWideBlock : 64;
         int wns = 1;
-        while (kWideBlock * wns < cfg->dim) wns *= 2;
+        while (threads * wns < cfg->dim) wns *= 2;
         e->ns = e->run_ns = wns;
-        e->run_w = kWideBlock / 64;
-        e->dpad = kWideBlock * wns;
+        e->run_w = threads / 64;
+        e->dpad = threads * wns;
     } else
     // sampling kernel: one wave per chain up to 128 elements, then 2 or 4 waves per chain
     if (e->ns <= 2) { e->run_ns = e->ns; e->run_w = 1; }
@@ -956,6 +962,8 @@ int lmc_engine_kernel_shape(lmc_engine* e, int32_t* unit_ns, int32_t* run_ns, in
     return LMC_OK;
 }
 
+int32_t lmc_engine_uses_general_kernels(lmc_engine* e) { return (e && e->wide) ? 1 : 0; }
+
 int lmc_engine_occupancy(lmc_engine* e, int32_t* resident_chains, int32_t* waves_per_chain, double* wall_clock_hz) {
     if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
@@ -1077,7 +1085,7 @@ int lmc_engine_diag_update(lmc_engine* e, int32_t tune) {
     P.window_multiplier = e->cfg.adaptation_window_multiplier;
     P.mass_f64 = e->cfg.mass_f64 ? 1 : 0;
     if (e->wide) {
-        const int rc = wide_launch_mass_update(e->ns, main_stream(e), e->A, P);
+        const int rc = wide_launch_mass_update(e->ns, e->run_w, main_stream(e), e->A, P);
         if (rc != 0) return dense_fail(e, rc, "diag_update (general kernel)");
         return LMC_OK;
     }
@@ -1666,9 +1674,9 @@ static int wide_run(lmc_engine* e, SamplerParams P) {
     hipStream_t st = main_stream(e);
     if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledInDense) {
         void* args[] = {&e->A, &e->D, &P, &e->tparams};
-        return user_launch(e, e->user_run, st, static_cast<unsigned>(e->cfg.chains), kWideBlock, static_cast<unsigned>(e->lds_bytes), args);
+        return user_launch(e, e->user_run, st, static_cast<unsigned>(e->cfg.chains), 64u * e->run_w, static_cast<unsigned>(e->lds_bytes), args);
     }
-    const int rc = wide_launch_run(e->cfg.target_family, e->ns, st, e->A, e->D, P, e->tparams, e->cfg.chains);
+    const int rc = wide_launch_run(e->cfg.target_family, e->ns, e->run_w, st, e->A, e->D, P, e->tparams, e->cfg.chains);
     if (rc != 0) return dense_fail(e, rc, "run (general kernel)");
     return LMC_OK;
 }
@@ -2065,11 +2073,11 @@ int lmc_engine_trajectory(lmc_engine* e, const double* q0, const double* p0, int
             int sdot = e->cfg.start_energy_sdot, p32 = p0_is_f32, nf = n_fwd, nb = n_back;
             double eps_ = eps;
             void* args[] = {&e->A, &e->D, &e->tparams, &dq0.p, &dp0.p, &p32, &sdot, &eps_, &nf, &nb, &oq.p, &op.p, &ov.p, &og.p, &oe.p, &ol.p};
-            const int rc = user_launch(e, e->user_trajectory, main_stream(e), static_cast<unsigned>(e->cfg.chains), kWideBlock,
+            const int rc = user_launch(e, e->user_trajectory, main_stream(e), static_cast<unsigned>(e->cfg.chains), 64u * e->run_w,
                                        static_cast<unsigned>(e->lds_bytes), args);
             if (rc != LMC_OK) return rc;
         } else {
-            const int rc = wide_launch_trajectory(e->cfg.target_family, e->ns, main_stream(e), e->A, e->D, e->tparams, dq0.p, dp0.p,
+            const int rc = wide_launch_trajectory(e->cfg.target_family, e->ns, e->run_w, main_stream(e), e->A, e->D, e->tparams, dq0.p, dp0.p,
                                                   p0_is_f32, e->cfg.start_energy_sdot, eps, n_fwd, n_back, oq.p, op.p, ov.p, og.p, oe.p, ol.p);
             if (rc != 0) return dense_fail(e, rc, "trajectory (general kernel)");
         }
@@ -2116,11 +2124,11 @@ int lmc_engine_logp_dlogp(lmc_engine* e, const double* q, double* logp, double* 
     HIP_TRY(e, hipMemcpyAsync(dq.p, q, C * d * sizeof(double), hipMemcpyDefault, main_stream(e)));
     const dim3 grid(e->cfg.chains), block(64);
     if (e->wide && !(e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledIn)) {
-        const int rc = wide_launch_logp(e->cfg.target_family, e->ns, main_stream(e), e->A, e->tparams, dq.p, dl.p, dg.p);
+        const int rc = wide_launch_logp(e->cfg.target_family, e->ns, e->run_w, main_stream(e), e->A, e->tparams, dq.p, dl.p, dg.p);
         if (rc != 0) return dense_fail(e, rc, "logp_dlogp (general kernel)");
     } else if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledIn) {
         void* args[] = {&e->A, &e->tparams, &dq.p, &dl.p, &dg.p};
-        const int rc = user_launch(e, e->user_logp, main_stream(e), grid.x, e->wide ? kWideBlock : block.x, e->wide ? 2 * 16 * 8 * 8 : 0, args);
+        const int rc = user_launch(e, e->user_logp, main_stream(e), grid.x, e->wide ? 64u * e->run_w : block.x, e->wide ? 2 * 16 * 8 * 8 : 0, args);
         if (rc != LMC_OK) return rc;
     } else {
 #define LOGP_CALL(T) \
@@ -2166,7 +2174,7 @@ int lmc_engine_draw_momentum(lmc_engine* e, double* out) {
     HIP_TRY(e, dout.alloc(C * d));
     if (e->wide) {
         const int f32 = e->cfg.potential == LMC_POT_DIAG_ADAPT && !e->cfg.mass_f64;
-        const int rc = wide_launch_momentum(e->ns, main_stream(e), e->A, e->D, f32, dout.p);
+        const int rc = wide_launch_momentum(e->ns, e->run_w, main_stream(e), e->A, e->D, f32, dout.p);
         if (rc != 0) return dense_fail(e, rc, "draw_momentum (general kernel)");
     } else if (e->cfg.potential >= LMC_POT_FULL) {
         const int rc = dense_launch_momentum(e->ns, main_stream(e), e->A, e->D, dout.p);

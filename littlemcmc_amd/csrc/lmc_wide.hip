@@ -40,15 +40,31 @@ static_assert(kWideBlock == kWideThreads, "launcher and kernel agree on the team
     }
 #endif
 
-#define WIDE_NS_SWITCH(ns, BODY)                           \
-    switch (ns) {                                          \
-        case 1: { constexpr int NS = 1; BODY; } break;     \
-        case 2: { constexpr int NS = 2; BODY; } break;     \
-        case 4: { constexpr int NS = 4; BODY; } break;     \
-        case 8: { constexpr int NS = 8; BODY; } break;     \
-        case 16: { constexpr int NS = 16; BODY; } break;   \
-        default: return kWideUnsupported;                  \
+#define WIDE_NS_CASE(n, ...) case n: { constexpr int NS = n; __VA_ARGS__; } break;
+#define WIDE_NS_SWITCH(ns, ...)                                                                        \
+    switch (ns) {                                                                                      \
+        WIDE_NS_CASE(1, __VA_ARGS__) WIDE_NS_CASE(2, __VA_ARGS__) WIDE_NS_CASE(4, __VA_ARGS__)         \
+        WIDE_NS_CASE(8, __VA_ARGS__) WIDE_NS_CASE(16, __VA_ARGS__)                                     \
+        default: return kWideUnsupported;                                                              \
     }
+// (elements per thread, wavefronts per chain): one wavefront with up to 8 elements per lane (model_ndim <= 512), the
+// 16-wavefront team beyond -- the measured crossover (tools/wide_team_ab.py)
+#define WIDE_SHAPE_SWITCH(ns, w, ...)                                                                  \
+    if ((w) == 1) {                                                                                    \
+        constexpr int W = 1;                                                                           \
+        switch (ns) {                                                                                  \
+            WIDE_NS_CASE(1, __VA_ARGS__) WIDE_NS_CASE(2, __VA_ARGS__) WIDE_NS_CASE(4, __VA_ARGS__)     \
+            WIDE_NS_CASE(8, __VA_ARGS__)                                                               \
+            default: return kWideUnsupported;                                                          \
+        }                                                                                              \
+    } else if ((w) == kWideWaves) {                                                                    \
+        constexpr int W = kWideWaves;                                                                  \
+        switch (ns) {                                                                                  \
+            WIDE_NS_CASE(1, __VA_ARGS__) WIDE_NS_CASE(2, __VA_ARGS__) WIDE_NS_CASE(4, __VA_ARGS__)     \
+            WIDE_NS_CASE(8, __VA_ARGS__) WIDE_NS_CASE(16, __VA_ARGS__)                                 \
+            default: return kWideUnsupported;                                                          \
+        }                                                                                              \
+    } else return kWideUnsupported;
 
 int wide_scratch_slots(int max_levels) { return wide_scratch_vectors(max_levels); }
 int wide_lds_bytes(int dpad) { return wide_lds_doubles(dpad) * 8; }
@@ -60,48 +76,48 @@ int wide_lds_bytes(int dpad) { return wide_lds_doubles(dpad) * 8; }
         if (err != hipSuccess) return static_cast<int>(err);                                                    \
     }
 
-int wide_launch_run(int family, int ns, hipStream_t stream, const ChainArrays& A, const DenseArrays& D, const SamplerParams& P,
+int wide_launch_run(int family, int ns, int w, hipStream_t stream, const ChainArrays& A, const DenseArrays& D, const SamplerParams& P,
                     const double* tparams, int n_chains) {
-    const dim3 grid(n_chains > 0 ? n_chains : A.chains), block(kWideThreads);
+    const dim3 grid(n_chains > 0 ? n_chains : A.chains), block(64 * w);
     const int lds = wide_lds_bytes(A.dpad);
     (void)hipGetLastError();
 #define RUN_CALL(T) \
-    WIDE_NS_SWITCH(ns, { WIDE_LDS_ATTR((run_wide_kernel<NS, T>)) hipLaunchKernelGGL((run_wide_kernel<NS, T>), grid, block, lds, stream, A, D, P, tparams); })
+    WIDE_SHAPE_SWITCH(ns, w, { WIDE_LDS_ATTR((run_wide_kernel<NS, W, T>)) hipLaunchKernelGGL((run_wide_kernel<NS, W, T>), grid, block, lds, stream, A, D, P, tparams); })
     WIDE_FAMILY_SWITCH(family, RUN_CALL)
 #undef RUN_CALL
     return static_cast<int>(hipGetLastError());
 }
 
-int wide_launch_logp(int family, int ns, hipStream_t stream, const ChainArrays& A, const double* tparams, const double* q,
+int wide_launch_logp(int family, int ns, int w, hipStream_t stream, const ChainArrays& A, const double* tparams, const double* q,
                      double* logp, double* grad) {
-    const dim3 grid(A.chains), block(kWideThreads);
+    const dim3 grid(A.chains), block(64 * w);
     const int lds = 2 * kWideWaves * kTeamSlots * 8;
     (void)hipGetLastError();
-#define LOGP_CALL(T) WIDE_NS_SWITCH(ns, hipLaunchKernelGGL((wide_logp_kernel<NS, T>), grid, block, lds, stream, A, tparams, q, logp, grad))
+#define LOGP_CALL(T) WIDE_SHAPE_SWITCH(ns, w, hipLaunchKernelGGL((wide_logp_kernel<NS, W, T>), grid, block, lds, stream, A, tparams, q, logp, grad))
     WIDE_FAMILY_SWITCH(family, LOGP_CALL)
 #undef LOGP_CALL
     return static_cast<int>(hipGetLastError());
 }
 
-int wide_launch_trajectory(int family, int ns, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
+int wide_launch_trajectory(int family, int ns, int w, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
                            const double* tparams, const double* q0, const double* p0, int p0_is_f32, int sdot_mode, double eps,
                            int n_fwd, int n_back, double* oq, double* op, double* ov, double* og, double* oe, double* ol) {
-    const dim3 grid(A.chains), block(kWideThreads);
+    const dim3 grid(A.chains), block(64 * w);
     const int lds = wide_lds_bytes(A.dpad);
     (void)hipGetLastError();
 #define TRAJ_CALL(T)                                                                                                       \
-    WIDE_NS_SWITCH(ns, { WIDE_LDS_ATTR((wide_trajectory_kernel<NS, T>)) hipLaunchKernelGGL((wide_trajectory_kernel<NS, T>), grid, block, lds, stream, A, D, \
+    WIDE_SHAPE_SWITCH(ns, w, { WIDE_LDS_ATTR((wide_trajectory_kernel<NS, W, T>)) hipLaunchKernelGGL((wide_trajectory_kernel<NS, W, T>), grid, block, lds, stream, A, D, \
                                            tparams, q0, p0, p0_is_f32, sdot_mode, eps, n_fwd, n_back, oq, op, ov, og, oe, ol); })
     WIDE_FAMILY_SWITCH(family, TRAJ_CALL)
 #undef TRAJ_CALL
     return static_cast<int>(hipGetLastError());
 }
 
-int wide_launch_momentum(int ns, hipStream_t stream, const ChainArrays& A, const DenseArrays& D, int momentum_f32, double* out) {
-    const dim3 grid(A.chains), block(kWideThreads);
+int wide_launch_momentum(int ns, int w, hipStream_t stream, const ChainArrays& A, const DenseArrays& D, int momentum_f32, double* out) {
+    const dim3 grid(A.chains), block(64 * w);
     const int lds = wide_lds_bytes(A.dpad);
     (void)hipGetLastError();
-    WIDE_NS_SWITCH(ns, { WIDE_LDS_ATTR((wide_momentum_kernel<NS>)) hipLaunchKernelGGL((wide_momentum_kernel<NS>), grid, block, lds, stream, A, D, momentum_f32, out); })
+    WIDE_SHAPE_SWITCH(ns, w, { WIDE_LDS_ATTR((wide_momentum_kernel<NS, W>)) hipLaunchKernelGGL((wide_momentum_kernel<NS, W>), grid, block, lds, stream, A, D, momentum_f32, out); })
     return static_cast<int>(hipGetLastError());
 }
 
@@ -122,10 +138,10 @@ int tick_wide_launch_begin(int ns, hipStream_t stream, const ChainArrays& A, con
     return static_cast<int>(hipGetLastError());
 }
 
-int wide_launch_mass_update(int ns, hipStream_t stream, const ChainArrays& A, const SamplerParams& P) {
-    const dim3 grid(A.chains), block(kWideThreads);
+int wide_launch_mass_update(int ns, int w, hipStream_t stream, const ChainArrays& A, const SamplerParams& P) {
+    const dim3 grid(A.chains), block(64 * w);
     (void)hipGetLastError();
-    WIDE_NS_SWITCH(ns, hipLaunchKernelGGL((wide_mass_update_kernel<NS>), grid, block, 0, stream, A, P))
+    WIDE_SHAPE_SWITCH(ns, w, hipLaunchKernelGGL((wide_mass_update_kernel<NS, W>), grid, block, 0, stream, A, P))
     return static_cast<int>(hipGetLastError());
 }
 

@@ -5,8 +5,8 @@
 //   QuadPotentialDiagAdapt(dtype="float64") (quadpotential.py:159,175-184)
 //   a run-time compiled user density with a dense mass matrix
 //
-// One chain = one workgroup of 16 wavefronts (Team<16>, 1024 threads); thread t owns elements t*NS .. t*NS+NS-1
-// (dpad = 1024 * NS, NS <= 16: model_ndim <= 16 384), so the density functors of lmc_targets.hpp -- and a user's -- run
+// One chain = one team of W wavefronts (W = 16: 1024 threads, or W = 1, below); thread t owns elements t*NS .. t*NS+NS-1
+// (dpad = 64 * W * NS, NS <= 16: model_ndim <= 16 384), so the density functors of lmc_targets.hpp -- and a user's -- run
 // unchanged. It is the plain statement of the algorithm, leaf by leaf, with EVERY vector of the
 // tree in the chain's HBM scratch row (L2 resident) and only the operands of the operation at hand in registers: nothing
 // here depends on what fits a register file or an LDS budget. Slow next to the fused kernels (a barrier per reduction,
@@ -21,10 +21,15 @@
 
 namespace lmc {
 
+// Two team sizes: W = 16 (1024 threads, dpad = 1024 * NS: model_ndim up to 16 384) and, for model_ndim <= 512 (a float64
+// diagonal, a dense matrix beyond the fused kernels' 256 dimensions, a run-time compiled density with a dense matrix),
+// W = 1 (dpad = 64 * NS, NS <= 8): the same code with wave-level reductions and no barriers, and sixteen times as many
+// chains resident -- 2-6x the large team's rate at those shapes; at 16 elements per lane the large team wins
+// (tools/wide_team_ab.py; lmc_wide_launch.hpp: kWideOneWaveMaxDim).
 constexpr int kWideWaves = 16;
 constexpr int kWideThreads = 64 * kWideWaves;
 constexpr int kWideChunk = 1024;   // normals per rng_normals() call (the stream semantics do not depend on the chunking)
-typedef Team<kWideWaves> WideTeam;
+typedef Team<kWideWaves> WideTeam;   // the tick kernel of the wide shapes (lmc_tick_wide.hpp) always uses the large team
 
 // vectors of the chain's scratch row (dpad doubles each)
 enum WideSlot : int {
@@ -59,8 +64,8 @@ struct WideVec {   // the chain's scratch row
 };
 
 // ---- sum_j M[j][i] x[j] for this thread's elements i (matrix rows contiguous over i: coalesced; operand from LDS) ----
-template <int NS, class MatT>
-__device__ __forceinline__ void wide_matvec(WideTeam& tm, const MatT* M, int d, int dpad, lds_double* xop,
+template <int NS, class MatT, class TeamT>
+__device__ __forceinline__ void wide_matvec(TeamT& tm, const MatT* M, int d, int dpad, lds_double* xop,
                                             const double (&x)[NS], double (&out)[NS]) {
     const int t = tm.tid();
     tm.sync();   // earlier readers of the operand area are done
@@ -91,8 +96,8 @@ __device__ __forceinline__ void wide_matvec(WideTeam& tm, const MatT* M, int d, 
 }
 
 // velocity(x) = M^-1 x (quadpotential.py:206-208 diagonal: one rounded product per element; :446-448 / :404-409 dense)
-template <int NS>
-__device__ __forceinline__ void wide_velocity(WideTeam& tm, const WideMass& M, const double (&vard)[NS], lds_double* xop,
+template <int NS, class TeamT>
+__device__ __forceinline__ void wide_velocity(TeamT& tm, const WideMass& M, const double (&vard)[NS], lds_double* xop,
                                               const double (&p)[NS], double (&v)[NS]) {
     if (M.kind == 0) {
 #pragma unroll
@@ -105,8 +110,8 @@ __device__ __forceinline__ void wide_velocity(WideTeam& tm, const WideMass& M, c
 }
 
 // integration.py:100-121. In/out: q, p, g; out: v = velocity(p'), energy, logp.
-template <int NS, class Target>
-__device__ __forceinline__ void wide_leapfrog(WideTeam& tm, const Target& tgt, const WideMass& M, const double (&vard)[NS],
+template <int NS, class Target, class TeamT>
+__device__ __forceinline__ void wide_leapfrog(TeamT& tm, const Target& tgt, const WideMass& M, const double (&vard)[NS],
                                               lds_double* xop, double eps, double (&q)[NS], double (&p)[NS], double (&g)[NS],
                                               double (&v)[NS], double& energy, double& logp) {
     const double dt = 0.5 * eps;
@@ -124,8 +129,8 @@ __device__ __forceinline__ void wide_leapfrog(WideTeam& tm, const Target& tgt, c
 
 // normal(size=d) of the chain's stream into the scratch slot kWZ, kWideChunk at a time (wave 0 draws: numpy's legacy
 // stream is sequential; its state is re-broadcast to the other waves)
-template <int NS>
-__device__ inline void wide_normals(WideTeam& tm, RngState& r, int d, const WideVec<NS>& V, double* stage, double* bcast) {
+template <int NS, class TeamT>
+__device__ inline void wide_normals(TeamT& tm, RngState& r, int d, const WideVec<NS>& V, double* stage, double* bcast) {
     glb_double* z = V.base + static_cast<long long>(kWZ) * V.dpad;
     for (int off = 0; off < d; off += kWideChunk) {
         const int n = d - off < kWideChunk ? d - off : kWideChunk;
@@ -142,18 +147,18 @@ __device__ inline void wide_normals(WideTeam& tm, RngState& r, int d, const Wide
         r.pos = first_i32(static_cast<int>(bcast[0]));
         r.has_gauss = first_i32(static_cast<int>(bcast[1]));
         r.gauss = first_f64(bcast[2]);
-        for (int i = tm.tid(); i < n; i += kWideThreads) z[off + i] = stage[i];
+        for (int i = tm.tid(); i < n; i += TeamT::kThreads) z[off + i] = stage[i];
     }
     // padding of the slot: zero
-    for (int i = d + tm.tid(); i < V.dpad; i += kWideThreads) z[i] = 0.0;
+    for (int i = d + tm.tid(); i < V.dpad; i += TeamT::kThreads) z[i] = 0.0;
     __threadfence_block();
     tm.sync();
 }
 
 // the same into registers (thread t receives elements t*NS .. t*NS+NS-1): the tick kernel of the wide shapes, which has no
 // scratch slot to spare for the normals
-template <int NS>
-__device__ inline void wide_normals_regs(WideTeam& tm, RngState& r, int d, double* stage, double* bcast, double (&z)[NS]) {
+template <int NS, class TeamT>
+__device__ inline void wide_normals_regs(TeamT& tm, RngState& r, int d, double* stage, double* bcast, double (&z)[NS]) {
     const int t = tm.tid();
 #pragma unroll
     for (int s = 0; s < NS; ++s) z[s] = 0.0;
@@ -183,8 +188,8 @@ __device__ inline void wide_normals_regs(WideTeam& tm, RngState& r, int d, doubl
 
 // solve_triangular(chol.T, float32(z)) (quadpotential.py:450-453): the column sweep of the reference BLAS strsv over the
 // row-major float32 factor (x_j /= L_jj, then x_i -= L_ji x_j for i < j, j descending), one team barrier per column
-template <int NS>
-__device__ inline void wide_momentum_strsv(WideTeam& tm, const float* L, int d, int dpad, const double (&z)[NS], double* bc,
+template <int NS, class TeamT>
+__device__ inline void wide_momentum_strsv(TeamT& tm, const float* L, int d, int dpad, const double (&z)[NS], double* bc,
                                            double (&p0)[NS]) {
     const int t = tm.tid();
     float x[NS];
@@ -271,8 +276,8 @@ __device__ __forceinline__ void wide_diag_update(const CA& A, const PT& P, long 
 }
 
 // float32 kinetic energy of the start state, 0.5f * sdot(p, v) in the host BLAS's order (see start_kinetic_f32)
-template <int NS>
-__device__ inline float wide_start_kinetic_f32(WideTeam& tm, const float (&pf)[NS], const float (&vf)[NS], int d, int mode,
+template <int NS, class TeamT>
+__device__ inline float wide_start_kinetic_f32(TeamT& tm, const float (&pf)[NS], const float (&vf)[NS], int d, int mode,
                                                float* scratch, int dpad) {
     if (mode == kSdotNative) {
         double part = 0.0;
@@ -299,8 +304,8 @@ struct WideCtx {   // what every stage of an iteration needs
 // ---- NUTS transition, leaf form with the tree in the scratch row (nuts.py:204-224, _Tree :251-435) --------
 // In: kWLq.. / kWRq.. hold the start state at both ends (velocity slots = the stored start velocity), kWPsum = p0,
 // kWProp = q. Out: kWProp = the proposal.
-template <int NS, class Target>
-__device__ inline void wide_nuts_transition(WideTeam& tm, const Target& tgt, const WideMass& M, const double (&vard)[NS],
+template <int NS, class Target, class TeamT>
+__device__ inline void wide_nuts_transition(TeamT& tm, const Target& tgt, const WideMass& M, const double (&vard)[NS],
                                             const WideCtx& cx, RngState& rng, const WideVec<NS>& V, double e0, double logp0,
                                             double step_size, double emax, int max_depth, bool momentum_f32,
                                             TransitionOut& out) {
@@ -449,8 +454,8 @@ __device__ inline void wide_nuts_transition(WideTeam& tm, const Target& tgt, con
 }
 
 // ---- HMC transition (hmc.py:140-182); the accepted position lands in kWProp
-template <int NS, class Target>
-__device__ inline void wide_hmc_transition(WideTeam& tm, const Target& tgt, const WideMass& M, const double (&vard)[NS],
+template <int NS, class Target, class TeamT>
+__device__ inline void wide_hmc_transition(TeamT& tm, const Target& tgt, const WideMass& M, const double (&vard)[NS],
                                            const WideCtx& cx, RngState& rng, const WideVec<NS>& V, double e0, double logp0,
                                            double step_size, double emax, double path_length, int max_steps,
                                            TransitionOut& out) {
@@ -488,8 +493,8 @@ __device__ inline void wide_hmc_transition(WideTeam& tm, const Target& tgt, cons
 
 // the start of an iteration (base_hmc.py:141-148 / integration.py:52-66): momentum draw, start state -> both ends of the
 // trajectory, kWPsum, kWProp. Returns e0 (non-finite: base_hmc.py:145-148).
-template <int NS, class Target>
-__device__ inline double wide_start(WideTeam& tm, const Target& tgt, const WideMass& M, const DenseArrays& D, const double (&vard)[NS],
+template <int NS, class Target, class TeamT>
+__device__ inline double wide_start(TeamT& tm, const Target& tgt, const WideMass& M, const DenseArrays& D, const double (&vard)[NS],
                                     const double (&invd)[NS], const WideCtx& cx, RngState& rng, const WideVec<NS>& V, int d,
                                     bool momentum_f32, int sdot_mode, const double (&q)[NS], double& logp0) {
     const int t = tm.tid();
@@ -531,20 +536,20 @@ __device__ inline double wide_start(WideTeam& tm, const Target& tgt, const WideM
 }
 
 // ---- the iteration kernel -------------------------------------------------------------------------------------------
-template <int NS, template <int> class TargetT>
-__global__ __launch_bounds__(kWideThreads, 1) void run_wide_kernel(ChainArrays A, DenseArrays D, SamplerParams P, const double* tparams) {
+template <int NS, int W, template <int> class TargetT>
+__global__ __launch_bounds__(64 * W) void run_wide_kernel(ChainArrays A, DenseArrays D, SamplerParams P, const double* tparams) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int c = blockIdx.x + P.chain_begin;
     const int d = A.d, dpad = A.dpad;
     const long long row = static_cast<long long>(c) * dpad;
-    WideTeam tm;
+    Team<W> tm;
     const int stage_doubles = wide_stage_doubles(dpad);
     uint32_t* mt_lds = reinterpret_cast<uint32_t*>(lds + stage_doubles);
     tm.xbuf = lds + stage_doubles + kLdsMtDoubles;
     tm.parity = 0;
     double* bcast = tm.xbuf + 2 * kWideWaves * kTeamSlots;
     const int tid = tm.tid();
-    if (stop_at_entry<kWideWaves>(A.stop_dev, reinterpret_cast<int*>(bcast))) return;
+    if (stop_at_entry<W>(A.stop_dev, reinterpret_cast<int*>(bcast))) return;
     if (A.status[c] & kStatusBadInitialEnergy) return;
 
     TargetT<NS> tgt;
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(kWideThreads, 1) void run_wide_kernel(ChainArrays A
     vload<NS>(A.inv_std64 + row, invd);
     RngState rng;
     uint32_t* mt_glb = A.mt + static_cast<long long>(c) * kMtN;
-    for (int i = tid; i < kMtN; i += kWideThreads) mt_lds[i] = mt_glb[i];
+    for (int i = tid; i < kMtN; i += 64 * W) mt_lds[i] = mt_glb[i];
     tm.sync();
     rng.mt = mt_lds;
     rng.pos = first_i32(A.rng_pos[c]);
@@ -617,7 +622,7 @@ __global__ __launch_bounds__(kWideThreads, 1) void run_wide_kernel(ChainArrays A
     }
 
     tm.sync();
-    for (int i = tid; i < kMtN; i += kWideThreads) mt_glb[i] = rng.mt[i];
+    for (int i = tid; i < kMtN; i += 64 * W) mt_glb[i] = rng.mt[i];
     vstore<NS>(A.q + row, q);
     vstore<NS>(A.var64 + row, vard);
     vstore<NS>(A.inv_std64 + row, invd);
@@ -649,13 +654,13 @@ __global__ __launch_bounds__(kWideThreads, 1) void run_wide_kernel(ChainArrays A
 }
 
 // ---- unit entry points of the wide shapes (lmc_engine_logp_dlogp / _trajectory / _draw_momentum / _diag_update) ----------
-template <int NS, template <int> class TargetT>
-__global__ __launch_bounds__(kWideThreads, 1) void wide_logp_kernel(ChainArrays A, const double* tparams, const double* qin,
+template <int NS, int W, template <int> class TargetT>
+__global__ __launch_bounds__(64 * W) void wide_logp_kernel(ChainArrays A, const double* tparams, const double* qin,
                                                                      double* logp_out, double* grad_out) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int c = blockIdx.x;
     const int d = A.d;
-    WideTeam tm;
+    Team<W> tm;
     tm.xbuf = lds;
     tm.parity = 0;
     const int t = tm.tid();
@@ -677,8 +682,8 @@ __global__ __launch_bounds__(kWideThreads, 1) void wide_logp_kernel(ChainArrays 
 }
 
 // compute_state + n_fwd steps (+eps) + n_back steps (-eps); all states written out (integration.py:52-121)
-template <int NS, template <int> class TargetT>
-__global__ __launch_bounds__(kWideThreads, 1) void wide_trajectory_kernel(ChainArrays A, DenseArrays D, const double* tparams,
+template <int NS, int W, template <int> class TargetT>
+__global__ __launch_bounds__(64 * W) void wide_trajectory_kernel(ChainArrays A, DenseArrays D, const double* tparams,
                                                                            const double* q0, const double* p0in, int p0_is_f32,
                                                                            int sdot_mode, double eps, int n_fwd, int n_back,
                                                                            double* oq, double* op, double* ov, double* og,
@@ -687,7 +692,7 @@ __global__ __launch_bounds__(kWideThreads, 1) void wide_trajectory_kernel(ChainA
     const int c = blockIdx.x;
     const int d = A.d, dpad = A.dpad;
     const long long row = static_cast<long long>(c) * dpad;
-    WideTeam tm;
+    Team<W> tm;
     const int stage_doubles = wide_stage_doubles(dpad);
     tm.xbuf = lds + stage_doubles;
     tm.parity = 0;
@@ -740,13 +745,13 @@ __global__ __launch_bounds__(kWideThreads, 1) void wide_trajectory_kernel(ChainA
 }
 
 // potential.random() for every chain (quadpotential.py:221-224 / :374-376 / :411-414 / :450-453)
-template <int NS>
-__global__ __launch_bounds__(kWideThreads, 1) void wide_momentum_kernel(ChainArrays A, DenseArrays D, int momentum_f32, double* out) {
+template <int NS, int W>
+__global__ __launch_bounds__(64 * W) void wide_momentum_kernel(ChainArrays A, DenseArrays D, int momentum_f32, double* out) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int c = blockIdx.x;
     const int d = A.d, dpad = A.dpad;
     const long long row = static_cast<long long>(c) * dpad;
-    WideTeam tm;
+    Team<W> tm;
     const int stage_doubles = wide_stage_doubles(dpad);
     tm.xbuf = lds + stage_doubles;
     tm.parity = 0;
@@ -784,8 +789,8 @@ __global__ __launch_bounds__(kWideThreads, 1) void wide_momentum_kernel(ChainArr
 }
 
 // QuadPotentialDiagAdapt.update(sample = current position, grad, tune = True) for every chain
-template <int NS>
-__global__ __launch_bounds__(kWideThreads, 1) void wide_mass_update_kernel(ChainArrays A, SamplerParams P) {
+template <int NS, int W>
+__global__ __launch_bounds__(64 * W) void wide_mass_update_kernel(ChainArrays A, SamplerParams P) {
     const int c = blockIdx.x;
     const int tid = static_cast<int>(threadIdx.x);
     const long long row = static_cast<long long>(c) * A.dpad;

@@ -77,7 +77,7 @@ class Engine:
         self.capacity = 0
         self.keep_trace = False
         self.trace_begin = 0
-        self.wide = self.kernel_shape()[2] == 16   # the general kernels (include/lmc_hip.h: "Which kernels an engine runs")
+        self.wide = bool(self._lib.lmc_engine_uses_general_kernels(self._h))   # include/lmc_hip.h: "Which kernels an engine runs"
 
     def kernel_shape(self):
         """(unit_ns, run_ns, run_w) of this engine's kernels (lmc_engine_kernel_shape)."""

@@ -148,22 +148,22 @@ class UserTarget(DeviceTarget):
         h.update(extra.encode())
         return h.hexdigest()[:16]
 
-    def kernels_for(self, unit_ns, run_ns, run_w):
+    def kernels_for(self, unit_ns, run_ns, run_w, general=False):
         """(code object, run name, trajectory name, logp name) for one engine shape, compiled once and cached."""
-        key = (int(unit_ns), int(run_ns), int(run_w))
+        key = (int(unit_ns), int(run_ns), int(run_w), int(bool(general)))
         if key in self._code:
             return self._code[key]
-        if key[2] == 16:   # the general kernels (csrc/lmc_wide.hpp): model_ndim > 1024, dense mass matrices, float64 masses
-            names = ["lmc::run_wide_kernel<%d, lmc::UserTarget>" % key[1],
-                     "lmc::wide_trajectory_kernel<%d, lmc::UserTarget>" % key[0],
-                     "lmc::wide_logp_kernel<%d, lmc::UserTarget>" % key[0]]
+        if key[3]:   # the general kernels (csrc/lmc_wide.hpp): model_ndim > 1024, dense mass matrices, float64 masses
+            names = ["lmc::run_wide_kernel<%d, %d, lmc::UserTarget>" % (key[1], key[2]),
+                     "lmc::wide_trajectory_kernel<%d, %d, lmc::UserTarget>" % (key[0], key[2]),
+                     "lmc::wide_logp_kernel<%d, %d, lmc::UserTarget>" % (key[0], key[2])]
             tu = ('#include "lmc_wide.hpp"\n' + self.source +
                   "\nnamespace lmc {\n"
-                  "template __global__ void run_wide_kernel<%d, UserTarget>(ChainArrays, DenseArrays, SamplerParams, const double*);\n"
-                  "template __global__ void wide_trajectory_kernel<%d, UserTarget>(ChainArrays, DenseArrays, const double*, const double*, "
+                  "template __global__ void run_wide_kernel<%d, %d, UserTarget>(ChainArrays, DenseArrays, SamplerParams, const double*);\n"
+                  "template __global__ void wide_trajectory_kernel<%d, %d, UserTarget>(ChainArrays, DenseArrays, const double*, const double*, "
                   "const double*, int, int, double, int, int, double*, double*, double*, double*, double*, double*);\n"
-                  "template __global__ void wide_logp_kernel<%d, UserTarget>(ChainArrays, const double*, const double*, double*, double*);\n"
-                  "}\n" % (key[1], key[0], key[0]))
+                  "template __global__ void wide_logp_kernel<%d, %d, UserTarget>(ChainArrays, const double*, const double*, double*, double*);\n"
+                  "}\n" % (key[1], key[2], key[0], key[2], key[0], key[2]))
         else:
             names = ["lmc::run_kernel<%d, %d, lmc::UserTarget>" % (key[1], key[2]),
                      "lmc::trajectory_kernel<%d, lmc::UserTarget>" % key[0],
@@ -177,7 +177,7 @@ class UserTarget(DeviceTarget):
                   "}\n" % (key[1], key[2], key[0], key[0]))
         cache = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_user_targets")
         os.makedirs(cache, exist_ok=True)
-        path = os.path.join(cache, "user_%s_%d_%d_%d.hsaco" % (self._digest("hiprtc"), key[0], key[1], key[2]))
+        path = os.path.join(cache, "user_%s_%d_%d_%d%s.hsaco" % (self._digest("hiprtc"), key[0], key[1], key[2], "g" if key[3] else ""))
         lowered = None
         if os.path.exists(path) and os.path.exists(path + ".names"):
             with open(path, "rb") as fh:
@@ -204,7 +204,8 @@ class UserTarget(DeviceTarget):
 
         ns, rns, rw = C.c_int32(), C.c_int32(), C.c_int32()
         engine._check(engine._lib.lmc_engine_kernel_shape(engine._h, C.byref(ns), C.byref(rns), C.byref(rw)))
-        code, run, traj, logp = self.kernels_for(ns.value, rns.value, rw.value)
+        general = bool(engine._lib.lmc_engine_uses_general_kernels(engine._h))
+        code, run, traj, logp = self.kernels_for(ns.value, rns.value, rw.value, general)
         buf = C.create_string_buffer(code, len(code))
         engine._check(engine._lib.lmc_engine_load_user_kernels(engine._h, buf, run.encode(), traj.encode(), logp.encode()))
 

@@ -182,11 +182,14 @@ def test_fixed_diagonal_in_float64():
 GOLDENS_THROUGH_WIDE = ["e2e_hmc_c1", "e2e_nuts_std64", "e2e_nuts_ar1_16", "e2e_nuts_funnel8", "e2e_nuts_diag50", "e2e_nuts_normal1d"]
 
 
+@pytest.mark.parametrize("team", [1, 16])
 @pytest.mark.parametrize("name", GOLDENS_THROUGH_WIDE)
-def test_small_goldens_replay_through_the_general_kernel(golden_dir, name, monkeypatch):
+def test_small_goldens_replay_through_the_general_kernel(golden_dir, name, team, monkeypatch):
     """LMC_FORCE_WIDE=1: the captured reference chains of the fused kernels' own shapes -- window switches, divergences,
-    HMC, d = 1 -- every iteration through the general kernel."""
+    HMC, d = 1 -- every iteration through the general kernel, as one wavefront per chain (the shape dim <= 1024 takes) and as
+    the 16-wavefront team (LMC_WIDE_TEAM=16: the shape dim > 1024 takes)."""
     monkeypatch.setenv("LMC_FORCE_WIDE", "1")
+    monkeypatch.setenv("LMC_WIDE_TEAM", str(team))
     g = _load(golden_dir, name)
     d, chains, tune, draws = int(g["d"]), int(g["chains"]), int(g["tune"]), int(g["draws"])
     kw = kwargs_from(g)
@@ -203,7 +206,7 @@ def test_small_goldens_replay_through_the_general_kernel(golden_dir, name, monke
             _s2, step = lmc.init_nuts(tgt, d, random_seed=seeds, **kw)
         eng = step._make_engine(1)
         try:
-            assert eng.wide
+            assert eng.wide and eng.kernel_shape()[2] == team
         finally:
             eng.close()
         snaps, outs = oracle_chain_snapshots(ostep, g["start"], seeds[c], tune, draws)
@@ -212,11 +215,13 @@ def test_small_goldens_replay_through_the_general_kernel(golden_dir, name, monke
     assert total >= min(chains, 2) * (tune + draws) - 2
 
 
+@pytest.mark.parametrize("team", [1, 16])
 @pytest.mark.parametrize("name", ["e2e_nuts_full_ar1_12", "e2e_nuts_fullinv_ar1_12", "e2e_nuts_full64_ar1_12", "e2e_hmc_full_std10"])
-def test_dense_goldens_replay_through_the_general_kernel(golden_dir, name, monkeypatch):
+def test_dense_goldens_replay_through_the_general_kernel(golden_dir, name, team, monkeypatch):
     from tests.test_gpu_dense import _oracle_and_device_steps, _replay
 
     monkeypatch.setenv("LMC_FORCE_WIDE", "1")
+    monkeypatch.setenv("LMC_WIDE_TEAM", str(team))
     g = _load(golden_dir, name)
     ostep, dstep, start = _oracle_and_device_steps(g)
     f32_born = str(g["potential"]) not in ("inv", "full64")
