@@ -41,7 +41,7 @@ extern "C" {
  * tuning) / quadpotential.py:346 (QuadPotentialDiag, fixed diagonal, float64 momentum draw) */
 #define LMC_POT_DIAG_ADAPT 0
 #define LMC_POT_DIAG 1
-/* dense mass matrices (dim <= 256): quadpotential.py:428 (QuadPotentialFull: float32 covariance, float32
+/* dense mass matrices ("Which kernels an engine runs" below for the sizes): quadpotential.py:428 (QuadPotentialFull: float32 covariance, float32
  * momentum by a triangular solve), :388 (QuadPotentialFullInv: mass matrix A given, float64 momentum L n),
  * :471 (QuadPotentialFullAdapt: covariance + Cholesky factor re-estimated while tuning, one matrix per chain) */
 #define LMC_POT_FULL 2
@@ -153,10 +153,11 @@ typedef struct lmc_config {
 /* Which kernels an engine runs. The FUSED kernels (one chain = one wavefront or a team of 2 / 4, the tree in registers and
  * LDS) cover dim <= 1024 with diagonal and dim <= 256 with dense mass matrices, float32 adaptive masses. Everything else the
  * reference accepts -- dim up to 16 384 (base_hmc.py:102 has no limit), QuadPotentialFull / FullInv up to dim 2048
- * (quadpotential.py:388-468), QuadPotentialDiagAdapt(dtype="float64") -- runs in the GENERAL kernels (csrc/lmc_wide.hpp: one
- * chain = one wavefront up to dim 512, a workgroup of 16 wavefronts beyond, the tree in the chain's HBM row): the same
- * algorithm, statement for statement, several times slower per leapfrog. Not in the general kernels: FULL_ADAPT beyond dim
- * 256, LMC_RNG_PHILOX, and LMC_TARGET_EXTERNAL with anything but a float32 diagonal. */
+ * (quadpotential.py:388-468), QuadPotentialFullAdapt up to dim 1024 (:470-560; the refresh then factorises through HBM),
+ * QuadPotentialDiagAdapt(dtype="float64") -- runs in the GENERAL kernels (csrc/lmc_wide.hpp: one chain = one wavefront up
+ * to dim 512, a workgroup of 16 wavefronts beyond, the tree in the chain's HBM row): the same algorithm, statement for
+ * statement, several times slower per leapfrog. Not in the general kernels: LMC_RNG_PHILOX, and LMC_TARGET_EXTERNAL with
+ * anything but a float32 diagonal. */
 /* Fill *cfg with the reference's defaults for the given shape. */
 void lmc_config_defaults(lmc_config* cfg, int32_t chains, int32_t dim);
 

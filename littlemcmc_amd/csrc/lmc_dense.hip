@@ -2,6 +2,8 @@
 // Kept apart from lmc_engine.hip so that the two sets of kernel instantiations compile in parallel.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/lmc_hip.h"
 #include "lmc_dense.hpp"
 #include "lmc_tick_dense.hpp"
@@ -109,12 +111,18 @@ int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArra
     const int lds = dense_adapt_lds_bytes(A.d, A.dpad);
     const dim3 grid(n_chains > 0 ? n_chains : A.chains);
     (void)hipGetLastError();
-    if (dense_adapt_grid(A.d) == 8)
+    // LMC_CHOL_HBM=1 (a test knob): the factorisation through HBM at every size an engine allocated the work area for, so that
+    // the FullAdapt goldens of the small shapes check it against the register form (same factor bit for bit)
+    const char* env = std::getenv("LMC_CHOL_HBM");
+    const bool force_hbm = env && std::atoi(env) != 0 && D.chol_work != nullptr;
+    if (dense_adapt_grid(A.d) == 8 && !force_hbm)
         hipLaunchKernelGGL(dense_adapt_kernel<8>, grid, dim3(64), lds, stream, A, D, multiplier, update_window, mask, chain_begin, expect_iter);
-    else if (dense_adapt_grid(A.d) == 16)
+    else if (dense_adapt_grid(A.d) == 16 && !force_hbm)
         hipLaunchKernelGGL(dense_adapt_kernel<16>, grid, dim3(256), lds, stream, A, D, multiplier, update_window, mask, chain_begin, expect_iter);
-    else
+    else if (dense_adapt_grid(A.d) == 32 && !force_hbm)
         hipLaunchKernelGGL(dense_adapt_kernel<32>, grid, dim3(1024), lds, stream, A, D, multiplier, update_window, mask, chain_begin, expect_iter);
+    else   // the factorisation through HBM: d > 256 (or the test knob)
+        hipLaunchKernelGGL(dense_adapt_kernel<0>, grid, dim3(kCholHbmThreads), lds, stream, A, D, multiplier, update_window, mask, chain_begin, expect_iter);
     return static_cast<int>(hipGetLastError());
 }
 

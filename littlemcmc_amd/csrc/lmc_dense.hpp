@@ -837,10 +837,14 @@ __global__ __launch_bounds__(64) void dense_momentum_kernel(ChainArrays A, Dense
 // keeps the previous factor and is counted.
 constexpr int kCholLocals = 8;
 // T: one wavefront (8 x 8 threads) per chain up to d = 64, 256 threads up to d = 128, else 1024
-constexpr int dense_adapt_grid(int d) { return d <= 8 * kCholLocals ? 8 : d <= 16 * kCholLocals ? 16 : 32; }
+// (0: beyond 32 x 8 = 256 dimensions the matrix does not fit the register file -- cholesky_hbm below, 1024 threads)
+constexpr int dense_adapt_grid(int d) { return d <= 8 * kCholLocals ? 8 : d <= 16 * kCholLocals ? 16 : d <= 32 * kCholLocals ? 32 : 0; }
 constexpr int dense_adapt_lds_bytes(int d, int dpad) {
     return 4 * d * 8 + 16 + 2 * (d + 4) * 4 + dense_adapt_grid(d) * dpad * 4;
 }
+static_assert(32 * kCholLocals == kDenseAdaptRegisterMaxDim, "lmc_dense_types.hpp: kDenseAdaptRegisterMaxDim");
+constexpr int kCholHbmThreads = 1024;
+constexpr int kCholHbmMaxDim = 2 * kCholHbmThreads;   // two rows of a column per thread
 
 template <int T>
 __device__ inline bool cholesky_registers(const float* covT, float* fac, int d, int dpad, float* colbuf, float* rowbuf,
@@ -921,11 +925,71 @@ __device__ inline bool cholesky_registers(const float* covT, float* fac, int d, 
     return true;
 }
 
+// The same factorisation for a matrix that does not fit the register file (256 < d <= 2048), column by column
+// ("left-looking"): entry (i, j) starts from cov[i][j], takes a_ij = fma(-l_ik, l_jk, a_ij) for k = 0 .. j-1 in that order and is
+// divided by l_jj = sqrt(a_jj) -- per entry the very operation sequence of cholesky_registers() / host_cholesky(), hence the
+// same factor bit for bit. The factor under construction is kept TRANSPOSED in an HBM work area (wt[k][i] = L[i][k]): the
+// thread that owns row i reads its operands coalesced over i, the other operand wt[k][j] is one address for the whole
+// workgroup. Every thread also carries the pivot's own accumulation (one more fma on the operand it has already loaded),
+// so a column costs ONE barrier. A failed factorisation leaves `fac` untouched (the work area is scratch).
+template <int kThreads>
+__device__ inline bool cholesky_hbm(const float* covT, float* fac, float* wt, int d, int dpad, int tid) {
+    constexpr int R = kCholHbmMaxDim / kThreads;
+    for (int j = 0; j < d; ++j) {
+        int row[R];
+        float acc[R];
+        float ajj = covT[static_cast<long long>(j) * dpad + j];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = j + tid + r * kThreads;
+            row[r] = i < d ? i : j;                                       // (an idle slot recomputes the pivot's row)
+            acc[r] = covT[static_cast<long long>(j) * dpad + row[r]];     // cov[i][j]
+        }
+        const float* wk = wt;
+        int k = 0;
+        for (; k + 8 <= j; k += 8, wk += 8 * static_cast<long long>(dpad)) {
+            float wj[8], wi[R][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                wj[u] = wk[static_cast<long long>(u) * dpad + j];
+#pragma unroll
+                for (int r = 0; r < R; ++r) wi[r][u] = wk[static_cast<long long>(u) * dpad + row[r]];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ajj = __builtin_fmaf(-wj[u], wj[u], ajj);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = __builtin_fmaf(-wi[r][u], wj[u], acc[r]);
+            }
+        }
+        for (; k < j; ++k, wk += dpad) {
+            const float wjk = wk[j];
+            ajj = __builtin_fmaf(-wjk, wjk, ajj);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = __builtin_fmaf(-wk[row[r]], wjk, acc[r]);
+        }
+        if (!((ajj > 0.0f) && (ajj < __builtin_inf()))) return false;   // uniform: every thread holds the same pivot
+        const float ljj = sqrtf(ajj);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = j + tid + r * kThreads;
+            if (i < d) wt[static_cast<long long>(j) * dpad + i] = (i == j) ? ljj : acc[r] / ljj;
+        }
+        __threadfence_block();
+        __syncthreads();   // row j of the work area is complete before column j + 1 reads it
+    }
+    for (int idx = tid; idx < d * dpad; idx += kThreads) {   // L row-major, zero above the diagonal and in the padding columns
+        const int i = idx / dpad, jc = idx - i * dpad;
+        fac[idx] = jc <= i ? wt[static_cast<long long>(jc) * dpad + i] : 0.0f;
+    }
+    return true;
+}
+
 template <int T>
-__global__ __launch_bounds__(T * T) void dense_adapt_kernel(ChainArrays A, DenseArrays D, double multiplier,
+__global__ __launch_bounds__(T > 0 ? T * T : kCholHbmThreads) void dense_adapt_kernel(ChainArrays A, DenseArrays D, double multiplier,
                                                             int update_window, int* mask, int chain_begin, int expect_iter) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int kThreads = T * T;
+    constexpr int kThreads = T > 0 ? T * T : kCholHbmThreads;
     const int c = blockIdx.x + chain_begin, tid = threadIdx.x;
     // mask != nullptr (tick path): only the chains that finished a tuning iteration in the last tick take part
     if (mask != nullptr && mask[c] == 0) return;
@@ -993,7 +1057,12 @@ __global__ __launch_bounds__(T * T) void dense_adapt_kernel(ChainArrays A, Dense
     __syncthreads();     // covT of this chain is complete and visible to the whole workgroup
     if (refresh) {
         bool ok = (*flag == 0);
-        if (ok) ok = cholesky_registers<T>(covT, fac, d, dpad, colbuf, rowbuf, tid);
+        if constexpr (T > 0) {
+            if (ok) ok = cholesky_registers<T>(covT, fac, d, dpad, colbuf, rowbuf, tid);
+        } else {
+            (void)colbuf; (void)rowbuf;
+            if (ok) ok = cholesky_hbm<kThreads>(covT, fac, D.chol_work + static_cast<long long>(c) * D.mat_stride, d, dpad, tid);
+        }
         if (!ok && tid == 0) D.chol_failed[c] += 1;
     }
     __syncthreads();

@@ -27,7 +27,11 @@ struct DenseArrays {
     int* prev_update;       // [C]
     int* window;            // [C]
     int* chol_failed;       // [C]  number of refreshes whose factorisation failed (old factor kept)
+    float* chol_work;       // [C][sweep_rows(d)][dpad] scratch of cholesky_hbm (d > 256 only, else nullptr): the factor, transposed
 };
+
+// FullAdapt's refresh factorises in registers up to here, through HBM beyond (lmc_dense.hpp: cholesky_registers / cholesky_hbm)
+constexpr int kDenseAdaptRegisterMaxDim = 256;
 
 // rows of a stored (transposed) inverse mass matrix: dim rounded up to two sweep batches, extra rows zero
 constexpr int kSweepBatch = 8;

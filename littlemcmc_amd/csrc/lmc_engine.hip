@@ -656,7 +656,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     // goldens of the small shapes replay through them too
     bool forced = false;
     if (const char* env = std::getenv("LMC_FORCE_WIDE"))
-        forced = std::atoi(env) != 0 && cfg->potential != LMC_POT_FULL_ADAPT && cfg->rng_mode == LMC_RNG_NUMPY &&
+        forced = std::atoi(env) != 0 && cfg->rng_mode == LMC_RNG_NUMPY &&
                  (cfg->target_family != LMC_TARGET_EXTERNAL || cfg->potential < LMC_POT_FULL);
     const bool wide = cfg->dim > 1024 || (cfg->potential >= LMC_POT_FULL && cfg->dim > 256) || cfg->mass_f64 != 0 || rtc_dense || forced;
     if (wide) {
@@ -664,9 +664,9 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
             return fail(nullptr, LMC_ERR_INVALID, "dim %d is beyond the general kernels' %d", cfg->dim, kWideMaxDim);
         if (cfg->potential >= LMC_POT_FULL && cfg->dim > kWideMaxDenseDim)
             return fail(nullptr, LMC_ERR_INVALID, "dense mass matrices are supported up to dim %d (got %d)", kWideMaxDenseDim, cfg->dim);
-        if (cfg->potential == LMC_POT_FULL_ADAPT)
-            return fail(nullptr, LMC_ERR_INVALID, "per-chain adapted dense matrices (FULL_ADAPT) run in the fused kernels only: dim <= 256 "
-                                                  "(got %d), float32, built-in or compiled-in densities", cfg->dim);
+        if (cfg->potential == LMC_POT_FULL_ADAPT && cfg->dim > kWideMaxDenseAdaptDim)
+            return fail(nullptr, LMC_ERR_INVALID, "per-chain adapted dense matrices (FULL_ADAPT) are supported up to dim %d (got %d)",
+                        kWideMaxDenseAdaptDim, cfg->dim);
         if (cfg->target_family == LMC_TARGET_EXTERNAL && (cfg->potential >= LMC_POT_FULL || cfg->mass_f64))
             return fail(nullptr, LMC_ERR_INVALID, "an externally evaluated density runs with diagonal float32 mass matrices at any dim up to %d, "
                                                   "with dense ones up to dim 256; give the density as a device functor for the other shapes", kWideMaxDim);
@@ -903,6 +903,11 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
             if ((rc = dev_alloc(e, &e->fac1, static_cast<size_t>(e->d8) * dp)) != LMC_OK) return bail(rc);
             if ((rc = dev_alloc(e, &e->raw1T, d * dp)) != LMC_OK) return bail(rc);
             if ((rc = dev_alloc(e, &e->mean1, dp)) != LMC_OK) return bail(rc);
+            // beyond 256 dimensions the refresh factorises through HBM (lmc_dense.hpp: cholesky_hbm) and needs a work area per
+            // chain; LMC_CHOL_HBM=1 (a test knob) gives the small shapes one too, and dense_launch_adapt then takes that form
+            const char* hbm_env = std::getenv("LMC_CHOL_HBM");
+            if (cfg->dim > kDenseAdaptRegisterMaxDim || (hbm_env && std::atoi(hbm_env) != 0))
+                if ((rc = dev_alloc(e, &D.chol_work, C * drows * dp)) != LMC_OK) return bail(rc);
         }
     }
     // default potential of BaseHMC (base_hmc.py:109-113): QuadPotentialDiagAdapt(d, zeros, ones, 10); a dense
@@ -1672,12 +1677,32 @@ static int wide_run(lmc_engine* e, SamplerParams P) {
     P.chain_begin = 0;
     P.relay_mask = relay_mask_for(e->cfg.chains);
     hipStream_t st = main_stream(e);
-    if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledInDense) {
-        void* args[] = {&e->A, &e->D, &P, &e->tparams};
-        return user_launch(e, e->user_run, st, static_cast<unsigned>(e->cfg.chains), 64u * e->run_w, static_cast<unsigned>(e->lds_bytes), args);
+    const bool rtc = e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledInDense;
+    // while tuning, FullAdapt refreshes covariance and factor after EVERY iteration (quadpotential.py:528-552): one iteration
+    // per launch with the update kernel in between, like dense_run(); everything else is one launch
+    const long long end = P.iter_begin + P.n_iters;
+    long long it = P.iter_begin;
+    while (it < end) {
+        const bool adapt = e->cfg.potential == LMC_POT_FULL_ADAPT && it < P.n_tune;
+        SamplerParams Q = P;
+        Q.iter_begin = it;
+        Q.n_iters = static_cast<int>(adapt ? 1 : end - it);
+        int rc;
+        if (rtc) {
+            void* args[] = {&e->A, &e->D, &Q, &e->tparams};
+            rc = user_launch(e, e->user_run, st, static_cast<unsigned>(e->cfg.chains), 64u * e->run_w, static_cast<unsigned>(e->lds_bytes), args);
+            if (rc != LMC_OK) return rc;
+        } else {
+            rc = wide_launch_run(e->cfg.target_family, e->ns, e->run_w, st, e->A, e->D, Q, e->tparams, e->cfg.chains);
+            if (rc != 0) return dense_fail(e, rc, "run (general kernel)");
+        }
+        if (adapt) {
+            rc = dense_launch_adapt(st, e->A, e->D, e->dense_multiplier, e->dense_update_window, nullptr, 0, e->cfg.chains,
+                                    static_cast<int>(it + 1));
+            if (rc != 0) return dense_fail(e, rc, "dense update");
+        }
+        it += Q.n_iters;
     }
-    const int rc = wide_launch_run(e->cfg.target_family, e->ns, e->run_w, st, e->A, e->D, P, e->tparams, e->cfg.chains);
-    if (rc != 0) return dense_fail(e, rc, "run (general kernel)");
     return LMC_OK;
 }
 

@@ -51,6 +51,7 @@ __host__ __device__ constexpr int wide_lds_doubles(int dpad) { return wide_stage
 struct WideMass {
     int kind;            // 0 diagonal; 1 dense, float32 matrix; 2 dense, float64 matrix
     const void* covT;    // dense: [sweep_rows(d)][dpad], covT[j][i] = cov[i][j]
+    const void* fac;     // dense: the chain's factor for the momentum draw (DenseArrays::fac; per chain for FullAdapt)
     int d, dpad;
 };
 
@@ -506,9 +507,9 @@ __device__ inline double wide_start(TeamT& tm, const Target& tgt, const WideMass
         for (int s = 0; s < NS; ++s)
             p0[s] = momentum_f32 ? static_cast<double>(static_cast<float>(invd[s]) * static_cast<float>(z[s])) : z[s] * invd[s];
     } else if (D.kind == kDenseFullInv) {   // L n (FullInv) / solve_triangular(chol.T, n) as the sweep of L^-1 (Full float64)
-        wide_matvec<NS, double>(tm, static_cast<const double*>(D.fac), d, V.dpad, cx.xop, z, p0);
+        wide_matvec<NS, double>(tm, static_cast<const double*>(M.fac), d, V.dpad, cx.xop, z, p0);
     } else {
-        wide_momentum_strsv<NS>(tm, static_cast<const float*>(D.fac), d, V.dpad, z, cx.bcast + 4, p0);
+        wide_momentum_strsv<NS>(tm, static_cast<const float*>(M.fac), d, V.dpad, z, cx.bcast + 4, p0);
     }
     double g0[NS], v0[NS], v0s[NS];
     logp0 = first_f64(tgt.logp_grad(tm, q, g0));
@@ -557,6 +558,7 @@ __global__ __launch_bounds__(64 * W) void run_wide_kernel(ChainArrays A, DenseAr
     WideMass M;
     M.kind = D.covT == nullptr ? 0 : (D.kind == kDenseFullInv ? 2 : 1);
     M.covT = D.covT == nullptr ? nullptr : static_cast<const char*>(D.covT) + static_cast<long long>(c) * D.mat_stride * (M.kind == 2 ? 8 : 4);
+    M.fac = D.covT == nullptr ? nullptr : static_cast<const char*>(D.fac) + static_cast<long long>(c) * D.fac_stride * (M.kind == 2 ? 8 : 4);
     M.d = d; M.dpad = dpad;
     WideVec<NS> V{(glb_double*)(A.scratch + static_cast<long long>(c) * A.scratch_stride), dpad};
     WideCtx cx{(lds_double*)lds, lds, bcast};
@@ -702,6 +704,7 @@ __global__ __launch_bounds__(64 * W) void wide_trajectory_kernel(ChainArrays A, 
     WideMass M;
     M.kind = D.covT == nullptr ? 0 : (D.kind == kDenseFullInv ? 2 : 1);
     M.covT = D.covT == nullptr ? nullptr : static_cast<const char*>(D.covT) + static_cast<long long>(c) * D.mat_stride * (M.kind == 2 ? 8 : 4);
+    M.fac = D.covT == nullptr ? nullptr : static_cast<const char*>(D.fac) + static_cast<long long>(c) * D.fac_stride * (M.kind == 2 ? 8 : 4);
     M.d = d; M.dpad = dpad;
     double q[NS], p[NS], g[NS], v[NS], vard[NS];
     vload<NS>(A.var64 + row, vard);

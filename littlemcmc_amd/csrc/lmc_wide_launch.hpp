@@ -11,6 +11,7 @@ constexpr int kWideUnsupported = -1;
 constexpr int kWideBlock = 1024;        // threads per chain of the large team (16 wavefronts)
 constexpr int kWideMaxDim = 16384;      // 1024 threads x 16 elements
 constexpr int kWideOneWaveMaxDim = 512;  // one wavefront per chain up to here (8 elements per lane), the 16-wavefront team beyond
+constexpr int kWideMaxDenseAdaptDim = 1024;  // FullAdapt: two float64 estimators, covariance, factor and work area per chain (26 MB at 1024)
 constexpr int kWideMaxDenseDim = 2048;  // dense mass matrices: the operand vector is staged in LDS, the host factorises in O(d^3)
 
 int wide_scratch_slots(int max_levels);

@@ -7,9 +7,10 @@ numerics of their own: every method is a call into liblmc_hip.so (a one-chain en
 consumes the *global* legacy numpy stream exactly like the reference does -- the MT19937 state
 is handed to the device and back -- so ``np.random.seed(...)`` keeps its meaning.
 
-Dense potentials (QuadPotentialFull / FullInv / FullAdapt, quadpotential.py:390-615) run on the device for
-model_ndim <= 256: matrix sweeps inside the leapfrog, triangular-solve momentum draws, and for FullAdapt a
-batched covariance refresh + Cholesky kernel after every tuning iteration (littlemcmc_amd/csrc/lmc_dense.hpp).
+Dense potentials (QuadPotentialFull / FullInv / FullAdapt, quadpotential.py:390-615) run on the device: matrix
+sweeps inside the leapfrog, triangular-solve momentum draws, and for FullAdapt a batched covariance refresh + Cholesky
+kernel after every tuning iteration (littlemcmc_amd/csrc/lmc_dense.hpp) -- fused kernels up to model_ndim = 256, the
+general kernels beyond (Full / FullInv up to 2048, FullAdapt up to 1024; littlemcmc_amd/csrc/lmc_wide.hpp).
 Sparse scalings (QuadPotentialSparse needs scikit-sparse in the reference) are not implemented.
 """
 import numpy as np
@@ -249,7 +250,8 @@ class QuadPotentialDiag(QuadPotential):
 
 
 MAX_DENSE_NDIM = 2048        # QuadPotentialFull / FullInv: fused kernels up to 256, the general kernels beyond (include/lmc_hip.h)
-MAX_DENSE_ADAPT_NDIM = 256   # QuadPotentialFullAdapt: one matrix per chain, refreshed + factorised every tuning iteration
+MAX_DENSE_ADAPT_NDIM = 1024  # QuadPotentialFullAdapt: one matrix per chain, refreshed + factorised every tuning iteration (fused kernels
+                             # and a register-resident factorisation up to 256, the general kernels and one through HBM beyond)
 
 
 def _square(a, what):

@@ -127,7 +127,7 @@ def test_reference_argument_errors():
     start, step = lmc.init_nuts(tgt, 3, init="adapt_full")   # sampling.py:588-592 (host objects only: no GPU needed)
     assert isinstance(step.potential, lmc.QuadPotentialFullAdapt) and not start.any()
     with pytest.raises(NotImplementedError):          # per-chain adapted dense matrices: the fused kernels, up to 256 dimensions
-        lmc.QuadPotentialFullAdapt(257, np.zeros(257), np.eye(257), 1)
+        lmc.QuadPotentialFullAdapt(1025, np.zeros(1025), None, 1)
     with pytest.raises(NotImplementedError):          # shared dense matrices: the general kernels take over up to 2048
         lmc.QuadPotentialFull(np.eye(2049))
     assert lmc.QuadPotentialFull(np.eye(300))._n == 300

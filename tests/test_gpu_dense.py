@@ -115,8 +115,8 @@ def test_dense_rejects_what_the_reference_rejects():
         lmc.quad_potential(np.array([[1.0, 0.0], [0.0, -1.0]]), True)
     with pytest.raises(ValueError):
         lmc.QuadPotentialFullAdapt(3, np.zeros(3), np.eye(2), 1)
-    with pytest.raises(NotImplementedError):      # per-chain adapted matrices: the fused kernels' 256 dimensions
-        lmc.QuadPotentialFullAdapt(300, np.zeros(300), np.eye(300), 1)
+    with pytest.raises(NotImplementedError):      # per-chain adapted matrices: 26 MB per chain at 1024 (tests/test_gpu_wide.py)
+        lmc.QuadPotentialFullAdapt(1025, np.zeros(1025), None, 1)
     with pytest.raises(NotImplementedError):      # shared matrices: the general kernels' 2048 (tests/test_gpu_wide.py)
         lmc.QuadPotentialFull(np.eye(2049))
 

@@ -230,6 +230,105 @@ def test_dense_goldens_replay_through_the_general_kernel(golden_dir, name, team,
     assert n >= 0.97 * (tune + draws)
 
 
+# ---------------------------------------------------------------------------------------------------
+# QuadPotentialFullAdapt beyond the fused kernels' 256 dimensions (quadpotential.py:470-560): the general sampling kernel on
+# per-chain matrices, the refresh factorised through HBM (csrc/lmc_dense.hpp: cholesky_hbm)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,family", [(300, "ar1"), (520, "ar1"), (600, "std_normal")])
+def test_full_adapt_beyond_256_dimensions_replays_the_oracle(d, family):
+    """init='jitter+adapt_full' at d = 300 (one wavefront per chain) and d = 520 (the 16-wavefront team): every iteration from
+    the oracle's pre-iteration state -- estimators, covariance, factor, window bookkeeping after each tuning iteration."""
+    from tests.test_gpu_dense import _replay
+
+    of = OT.make(family, d)
+    tgt = device_target(family, d, of.params())
+    seed = 900 + d
+    start, ostep = orc.init_nuts(of, d, init="jitter+adapt_full", seeds=[seed])
+    start_d, dstep = lmc.init_nuts(tgt, d, init="jitter+adapt_full", random_seed=[seed])
+    np.testing.assert_array_equal(start, start_d)
+    eng = dstep._make_engine(1)
+    try:
+        assert eng.wide and eng.kernel_shape()[2] == (1 if d <= 512 else 16)
+    finally:
+        eng.close()
+    tune, draws = 12, 3
+    assert _replay(ostep, dstep, start, seed, tune, draws, True, "adapt_full d=%d" % d) >= tune + draws - 2
+
+
+@pytest.mark.parametrize("name", ["e2e_nuts_adaptfull_ar1_10_a", "e2e_nuts_adaptfull_ar1_10_b", "e2e_nuts_adaptfull_std70"])
+def test_full_adapt_goldens_replay_through_the_general_kernel_and_the_hbm_factorisation(golden_dir, name, monkeypatch):
+    """LMC_FORCE_WIDE=1 + LMC_CHOL_HBM=1: the reference's own FullAdapt chains (window switches included) through the general
+    sampling kernel and the factorisation that serves d > 256 -- same tolerances as the register form's test."""
+    from tests.test_gpu_dense import test_dense_transitions_replay_the_reference_chain as replay_reference_chain
+
+    monkeypatch.setenv("LMC_FORCE_WIDE", "1")
+    monkeypatch.setenv("LMC_CHOL_HBM", "1")
+    replay_reference_chain(golden_dir, name)
+
+
+def test_hbm_factorisation_equals_the_register_form(golden_dir, monkeypatch):
+    """The two factorisations apply the same operation sequence to every entry: covariance and factor after each update of
+    the reference's update sequence (tests/test_quadpotential.py:183-224) are equal bit for bit, and a d = 200 estimate too."""
+    from tests.test_gpu_dense import test_full_adapt_update_sequence_matches_reference as update_sequence
+
+    def factors(d, n_updates, hbm):
+        if hbm:
+            monkeypatch.setenv("LMC_CHOL_HBM", "1")
+        else:
+            monkeypatch.delenv("LMC_CHOL_HBM", raising=False)
+        rs = np.random.RandomState(7)
+        a = rs.randn(d, d) / np.sqrt(d)
+        root = np.linalg.cholesky(a @ a.T + 0.3 * np.eye(d))
+        out = []
+        with lmc.Engine(T.StdNormal(d), chains=2, potential="full_adapt") as eng:
+            eng.set_dense_potential(np.eye(d), np.zeros(d), 1, 50, 2.0, 1)
+            for i in range(n_updates):
+                eng.set_position((root @ rs.randn(d, 2)).T.copy())
+                eng.dense_update(True)
+            st = eng.get_dense_state()
+            assert (st["chol_failures"] == 0).all()
+            out = [st["cov"].copy(), st["chol"].copy()]
+        return out
+
+    for d in (24, 200):
+        cov_r, chol_r = factors(d, 12, False)
+        cov_h, chol_h = factors(d, 12, True)
+        np.testing.assert_array_equal(cov_r, cov_h)
+        np.testing.assert_array_equal(chol_r, chol_h)
+        assert np.abs(chol_r[0] - np.eye(d)).max() > 1e-3      # (it did learn something)
+    monkeypatch.setenv("LMC_CHOL_HBM", "1")
+    for name in ("w20", "w15u4"):
+        update_sequence(golden_dir, name)
+
+
+def test_full_adapt_sample_at_300_dimensions_learns_the_covariance():
+    """sample() with a QuadPotentialFullAdapt at d = 300 end to end (window 600: the estimate that takes over at the switch has
+    more samples than dimensions -- with fewer the reference itself stops on a singular matrix): the adapted matrices approach
+    the target's covariance and the trees get shallower than with the diagonal metric (tests/test_gpu_dense.py at d = 8)."""
+    d, chains, tune, draws = 300, 16, 1000, 50
+    tgt = T.AR1(d, 0.9)
+    pot = lmc.QuadPotentialFullAdapt(d, np.zeros(d), np.eye(d), 10, adaptation_window=600)
+    trace, stats, eng = lmc.sample(tgt, d, draws=draws, tune=tune, chains=chains, step=lmc.NUTS(tgt, d, potential=pot),
+                                   random_seed=5, return_engine=True, progressbar=False)
+    try:
+        assert eng.wide
+        st = eng.get_dense_state(fields=("cov", "chol_failures"))
+    finally:
+        eng.close()
+    assert (st["chol_failures"] == 0).all()
+    assert trace.shape == (chains, draws, d) and np.isfinite(trace).all()
+    cov = st["cov"].mean(axis=0)
+    sd = np.sqrt(np.diag(cov))
+    assert sd.min() > 0.5 and sd.max() < 1.3      # (the estimate still holds the warm-up's first, narrow samples)
+    corr = cov / np.outer(sd, sd)
+    near = np.abs(np.subtract.outer(np.arange(d), np.arange(d))) == 1
+    assert abs(corr[near].mean() - 0.9) < 0.05
+    far = np.abs(np.subtract.outer(np.arange(d), np.arange(d))) > 60
+    assert abs(corr[far].mean()) < 0.05
+    _, stats_diag = lmc.sample(tgt, d, draws=draws, tune=tune, chains=chains, random_seed=5, progressbar=False)
+    assert stats["tree_size"].mean() < 0.8 * stats_diag["tree_size"].mean()
+
+
 USER_AR1 = """
 namespace lmc {
 template <int NS>
