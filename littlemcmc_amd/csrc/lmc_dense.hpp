@@ -47,6 +47,9 @@ struct DenseCoop {
     lds_double* dout;                                     // [16][xs]: the products, same columns
     __attribute__((address_space(3))) int* n_active;      // chains of this workgroup still sampling
     int ct_stride, xs, k_rows, dpad, wave, n_waves;
+#ifdef LMC_COOP_TIMING   // diagnostic build (tools/coop_timing.py): clock ticks waiting / multiplying / on the chain's own work
+    unsigned long long* tk;
+#endif
 };
 
 template <class MatT>
@@ -141,7 +144,15 @@ __device__ __forceinline__ int coop_product(const DenseCoop& cc, const double (&
     lds_double* xp = cc.x + (2 * cc.wave) * cc.xs + lane * NS;
 #pragma unroll
     for (int s = 0; s < NS; ++s) { xp[s] = p[s]; xp[cc.xs + s] = g[s]; }
+#ifdef LMC_COOP_TIMING
+    const unsigned long long t_arrive = clock64();
+    cc.tk[3] += t_arrive - cc.tk[4];
+#endif
     __syncthreads();
+#ifdef LMC_COOP_TIMING
+    const unsigned long long t_go = clock64();
+    cc.tk[0] += t_go - t_arrive;
+#endif
     const int active = first_i32(*cc.n_active);
     const int kk = lane >> 4, jj = lane & 15;
     for (int t = cc.wave; t < cc.dpad / 16; t += cc.n_waves) {
@@ -149,6 +160,10 @@ __device__ __forceinline__ int coop_product(const DenseCoop& cc, const double (&
         __attribute__((address_space(3))) const float* a = cc.ct + kk * cc.ct_stride + 16 * t + jj;
         const lds_double* b = cc.x + jj * cc.xs + kk;
         const int nkb = cc.k_rows / 4;   // a multiple of 4: k_rows is a multiple of 16
+        // (requesting the next operands before issuing the current products -- a software pipeline over batches of 4 or 8
+        // k-blocks -- was measured and is SLOWER: 2.46e8 / 2.22e8 against 2.66e8 leapfrog-steps/s. The product phase is bound by
+        // the FP64 matrix pipe itself -- 32 products x 64 cycles per wave, two waves per SIMD -- and the extra live operands
+        // cost spills: DESIGN.md section 9)
         for (int kb = 0; kb < nkb; kb += 4) {   // the four tiles' operands are requested before the first product is issued
             float af[4];
             double bf[4];
@@ -163,10 +178,18 @@ __device__ __forceinline__ int coop_product(const DenseCoop& cc, const double (&
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[4 * r] = acc0[r] + acc1[r];
     }
+#ifdef LMC_COOP_TIMING
+    const unsigned long long t_done = clock64();
+    cc.tk[1] += t_done - t_go;
+#endif
     __syncthreads();
     const lds_double* dp = cc.dout + (2 * cc.wave) * cc.xs + lane * NS;
 #pragma unroll
     for (int s = 0; s < NS; ++s) { v[s] = dp[s]; w[s] = dp[cc.xs + s]; }
+#ifdef LMC_COOP_TIMING
+    cc.tk[4] = clock64();
+    cc.tk[2] += cc.tk[4] - t_done;
+#endif
     return active;
 }
 #endif
@@ -731,10 +754,21 @@ __global__ __launch_bounds__(64 * kCoopWaves, 2) void run_dense_coop_kernel(Chai
     cc.dout = (lds_double*)dout;
     cc.n_active = (__attribute__((address_space(3))) int*)n_active;
     cc.ct_stride = cts; cc.xs = xs; cc.k_rows = k_rows; cc.dpad = dpad; cc.wave = wave; cc.n_waves = kCoopWaves;
+#ifdef LMC_COOP_TIMING
+    unsigned long long tk[5] = {0, 0, 0, 0, static_cast<unsigned long long>(clock64())};
+    cc.tk = tk;
+#endif
     if (mine) {
         DenseMat<float> mm{M, nullptr, 0, d, dpad, &cc};
         dense_run_chain<NS, float, TargetT>(A, D, P, tparams, c, priv, mm, (lds_double*)(priv + dense_lds_doubles(dpad)), slots);
         if (lane_id() == 0) atomicSub(n_active, 1);
+#ifdef LMC_COOP_TIMING
+        if (lane_id() == 0) {   // [0] = waiting for the group | multiplying, [1] = waiting for the product | own work, [2] = after the last product
+            A.counters[c * kNumCounters + 0] += static_cast<long long>(((tk[0] & 0xffffffffull) << 32) | (tk[1] & 0xffffffffull));
+            A.counters[c * kNumCounters + 1] += static_cast<long long>(((tk[2] & 0xffffffffull) << 32) | (tk[3] & 0xffffffffull));
+            A.counters[c * kNumCounters + 2] += static_cast<long long>(clock64() - tk[4]);
+        }
+#endif
     }
     // drain: answer the group's barriers until every chain is done
     double z[NS], v[NS], w[NS];

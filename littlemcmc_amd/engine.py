@@ -58,6 +58,16 @@ class Engine:
         # QuadPotentialDiagAdapt(dtype=...) (quadpotential.py:159,175-184); float64 runs in the general kernels
         self.mass_f64 = np.dtype(mass_dtype) == np.float64 and potential in ("diag_adapt", "diag")
         cfg.mass_f64 = int(self.mass_f64)
+        if cfg.target_family == _abi.TARGET_EXTERNAL:
+            # a density evaluated by the caller (a torch / Python callable) is driven by the tick kernels, which exist for the
+            # fused shapes and for float32 diagonals beyond them (include/lmc_hip.h: "Which kernels an engine runs")
+            if potential not in ("diag_adapt", "diag") and self.dim > 256:
+                raise NotImplementedError("a density given as a torch / Python callable runs with dense mass matrices up to "
+                                          "model_ndim = 256 (got %d); give it as a device functor (targets.UserTarget) for "
+                                          "larger ones" % self.dim)
+            if self.mass_f64:
+                raise NotImplementedError("a density given as a torch / Python callable runs with float32 diagonal mass matrices; "
+                                          "give it as a device functor (targets.UserTarget) for dtype='float64'")
         if sdot is None:
             sdot = DEFAULT_SDOT
         if sdot == "auto":   # float32 start-energy rounding of the host's numpy (see _blas_probe.py)
