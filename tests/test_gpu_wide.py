@@ -234,7 +234,7 @@ def test_dense_goldens_replay_through_the_general_kernel(golden_dir, name, team,
 # QuadPotentialFullAdapt beyond the fused kernels' 256 dimensions (quadpotential.py:470-560): the general sampling kernel on
 # per-chain matrices, the refresh factorised through HBM (csrc/lmc_dense.hpp: cholesky_hbm)
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("d,family", [(300, "ar1"), (520, "ar1"), (600, "std_normal")])
+@pytest.mark.parametrize("d,family", [(300, "ar1"), (520, "ar1"), (600, "std_normal"), (1024, "std_normal")])
 def test_full_adapt_beyond_256_dimensions_replays_the_oracle(d, family):
     """init='jitter+adapt_full' at d = 300 (one wavefront per chain) and d = 520 (the 16-wavefront team): every iteration from
     the oracle's pre-iteration state -- estimators, covariance, factor, window bookkeeping after each tuning iteration."""
@@ -251,7 +251,7 @@ def test_full_adapt_beyond_256_dimensions_replays_the_oracle(d, family):
         assert eng.wide and eng.kernel_shape()[2] == (1 if d <= 512 else 16)
     finally:
         eng.close()
-    tune, draws = 12, 3
+    tune, draws = (12, 3) if d < 1024 else (5, 1)      # (1024: the largest size the potential accepts)
     assert _replay(ostep, dstep, start, seed, tune, draws, True, "adapt_full d=%d" % d) >= tune + draws - 2
 
 
