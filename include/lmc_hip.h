@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LMC_ABI_VERSION 5
+#define LMC_ABI_VERSION 6
 
 /* status codes */
 #define LMC_OK 0
@@ -147,16 +147,18 @@ typedef struct lmc_config {
     double adaptation_window_multiplier; /* 1.0: QuadPotentialDiagAdapt's window grows by this factor at every switch (quadpotential.py:243) */
     int32_t rng_mode;             /* LMC_RNG_*; 0 = the reference's stream */
     int32_t mass_f64;             /* QuadPotentialDiagAdapt(dtype="float64") (quadpotential.py:159,175-184): variance, standard deviations
-                                   * and the momentum draw stay float64; 0 = the reference's default float32. General kernels (below). */
+                                   * and the momentum draw stay float64; with LMC_POT_FULL_ADAPT: QuadPotentialFullAdapt(dtype="float64")
+                                   * (:484,497-509): float64 covariance, Cholesky factor and momentum solve. 0 = the reference's
+                                   * default float32. General kernels (below). */
 } lmc_config;
 
 /* Which kernels an engine runs. The FUSED kernels (one chain = one wavefront or a team of 2 / 4, the tree in registers and
  * LDS) cover dim <= 1024 with diagonal and dim <= 256 with dense mass matrices, float32 adaptive masses. Everything else the
  * reference accepts -- dim up to 16 384 (base_hmc.py:102 has no limit), QuadPotentialFull / FullInv up to dim 2048
  * (quadpotential.py:388-468), QuadPotentialFullAdapt up to dim 1024 (:470-560; the refresh then factorises through HBM),
- * QuadPotentialDiagAdapt(dtype="float64") -- runs in the GENERAL kernels (csrc/lmc_wide.hpp: one chain = one wavefront up
- * to dim 512, a workgroup of 16 wavefronts beyond, the tree in the chain's HBM row): the same algorithm, statement for
- * statement, several times slower per leapfrog. Not in the general kernels: LMC_RNG_PHILOX, and LMC_TARGET_EXTERNAL with
+ * QuadPotentialDiagAdapt / QuadPotentialFullAdapt(dtype="float64") -- runs in the GENERAL kernels (csrc/lmc_wide.hpp: one
+ * chain = one wavefront up to dim 512, a workgroup of 16 wavefronts beyond, the tree in the chain's HBM row): the same
+ * algorithm, statement for statement, several times slower per leapfrog. Not in the general kernels: LMC_RNG_PHILOX, and LMC_TARGET_EXTERNAL with
  * anything but a float32 diagonal. */
 /* Fill *cfg with the reference's defaults for the given shape. */
 void lmc_config_defaults(lmc_config* cfg, int32_t chains, int32_t dim);
@@ -335,11 +337,14 @@ typedef struct lmc_dense_state {
     int32_t* window;         /* potential._adaptation_window */
     int32_t* previous_update;/* potential._previous_update */
     int32_t* chol_failures;  /* refreshes whose factorisation failed: potential._chol_error is not None */
+    double* cov64;           /* cov / chol as float64: what QuadPotentialFullAdapt(dtype="float64") (cfg.mass_f64) holds; the */
+    double* chol64;          /* float32 potentials' values widened. set(): either form of a matrix, not both */
 } lmc_dense_state;
 int lmc_engine_get_dense_state(lmc_engine* e, const lmc_dense_state* dst);
 int lmc_engine_set_dense_state(lmc_engine* e, const lmc_dense_state* src);
 /* cov / chol [dim][dim] of ONE chain (the host mirror of step.potential after sample()). */
 int lmc_engine_get_dense_chain(lmc_engine* e, int32_t chain, float* cov, float* chol);
+int lmc_engine_get_dense_chain_f64(lmc_engine* e, int32_t chain, double* cov, double* chol);   /* (float64 potentials: unrounded) */
 /* The lower Cholesky factor [dim][dim] in float64 of the float64 potentials: QuadPotentialFull(cov, dtype="float64")._chol
  * (quadpotential.py:441-443) / QuadPotentialFullInv.L (:402), as the device holds it. */
 int lmc_engine_get_dense_factor_f64(lmc_engine* e, double* chol);

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LMC_HIP_LIB") or os.path.join(_HERE, "liblmc_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OK = 0
 
 KIND_NUTS, KIND_HMC = 0, 1
@@ -66,7 +66,8 @@ class DenseState(C.Structure):
     FIELDS = (("cov", np.float32, "m"), ("chol", np.float32, "m"), ("fore_mean", np.float64, "v"),
               ("fore_raw_cov", np.float64, "m"), ("fore_n", np.float64, "s"), ("back_mean", np.float64, "v"),
               ("back_raw_cov", np.float64, "m"), ("back_n", np.float64, "s"), ("window", np.int32, "s"),
-              ("previous_update", np.int32, "s"), ("chol_failures", np.int32, "s"))
+              ("previous_update", np.int32, "s"), ("chol_failures", np.int32, "s"),
+              ("cov64", np.float64, "m"), ("chol64", np.float64, "m"))
     _fields_ = [(name, C.c_void_p) for name, _dt, _k in FIELDS]
 
 
@@ -92,6 +93,7 @@ _SIGNATURES = {
     "lmc_engine_tick_positions": (_P, [_P]),
     "lmc_engine_tick": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int32)]),
     "lmc_engine_get_dense_chain": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "lmc_engine_get_dense_chain_f64": (C.c_int, [_P, C.c_int32, _P, _P]),
     "lmc_engine_get_dense_factor_f64": (C.c_int, [_P, _P]),
     "lmc_engine_seed": (C.c_int, [_P, _P]),
     "lmc_engine_set_rng_state": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_double]),

@@ -113,7 +113,7 @@ class BaseHMC:
             adaptation_window=getattr(self.potential, "_initial_adaptation_window", 101),
             adaptation_window_multiplier=getattr(self.potential, "adaptation_window_multiplier", 1.0),
             rng=getattr(self, "_momentum_rng", "numpy"),
-            mass_dtype=getattr(self.potential, "dtype", "float32") if self.potential._engine_kind in ("diag_adapt", "diag") else "float32",
+            mass_dtype=getattr(self.potential, "dtype", "float32") if self.potential._engine_kind in ("diag_adapt", "diag", "full_adapt") else "float32",
         )
 
     def _make_engine(self, chains, device=0):

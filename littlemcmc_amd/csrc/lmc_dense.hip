@@ -115,7 +115,9 @@ int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArra
     // the FullAdapt goldens of the small shapes check it against the register form (same factor bit for bit)
     const char* env = std::getenv("LMC_CHOL_HBM");
     const bool force_hbm = env && std::atoi(env) != 0 && D.chol_work != nullptr;
-    if (dense_adapt_grid(A.d) == 8 && !force_hbm)
+    if (D.mat_f64)   // QuadPotentialFullAdapt(dtype="float64"): covariance, factor and factorisation in float64 (general kernels)
+        hipLaunchKernelGGL((dense_adapt_kernel<0, double>), grid, dim3(kCholHbmThreads), lds, stream, A, D, multiplier, update_window, mask, chain_begin, expect_iter);
+    else if (dense_adapt_grid(A.d) == 8 && !force_hbm)
         hipLaunchKernelGGL(dense_adapt_kernel<8>, grid, dim3(64), lds, stream, A, D, multiplier, update_window, mask, chain_begin, expect_iter);
     else if (dense_adapt_grid(A.d) == 16 && !force_hbm)
         hipLaunchKernelGGL(dense_adapt_kernel<16>, grid, dim3(256), lds, stream, A, D, multiplier, update_window, mask, chain_begin, expect_iter);
@@ -136,12 +138,17 @@ int tick_dense_launch(int ns, bool mat_f64, hipStream_t stream, const ChainArray
     return static_cast<int>(hipGetLastError());
 }
 
-int dense_launch_reset(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, const float* cov1T,
-                       const float* fac1, const double* raw1T, const double* mean1, double weight, int window, int d8) {
+int dense_launch_reset(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, const void* cov1T,
+                       const void* fac1, const double* raw1T, const double* mean1, double weight, int window, int d8) {
     const int per_chain = (d8 * A.dpad + 255) / 256;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(dense_reset_kernel, dim3(A.chains, per_chain < 64 ? per_chain : 64), dim3(256), 0, stream, A, D,
-                       cov1T, fac1, raw1T, mean1, weight, window, d8);
+    const dim3 grid(A.chains, per_chain < 64 ? per_chain : 64);
+    if (D.mat_f64)
+        hipLaunchKernelGGL(dense_reset_kernel<double>, grid, dim3(256), 0, stream, A, D, static_cast<const double*>(cov1T),
+                           static_cast<const double*>(fac1), raw1T, mean1, weight, window, d8);
+    else
+        hipLaunchKernelGGL(dense_reset_kernel<float>, grid, dim3(256), 0, stream, A, D, static_cast<const float*>(cov1T),
+                           static_cast<const float*>(fac1), raw1T, mean1, weight, window, d8);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -966,23 +966,27 @@ __device__ inline bool cholesky_registers(const float* covT, float* fac, int d, 
 // thread that owns row i reads its operands coalesced over i, the other operand wt[k][j] is one address for the whole
 // workgroup. Every thread also carries the pivot's own accumulation (one more fma on the operand it has already loaded),
 // so a column costs ONE barrier. A failed factorisation leaves `fac` untouched (the work area is scratch).
-template <int kThreads>
-__device__ inline bool cholesky_hbm(const float* covT, float* fac, float* wt, int d, int dpad, int tid) {
+__device__ __forceinline__ float chol_fnma(float a, float b, float c) { return __builtin_fmaf(-a, b, c); }
+__device__ __forceinline__ double chol_fnma(double a, double b, double c) { return __builtin_fma(-a, b, c); }
+__device__ __forceinline__ float chol_sqrt(float a) { return sqrtf(a); }
+__device__ __forceinline__ double chol_sqrt(double a) { return sqrt(a); }
+template <int kThreads, class MatT>
+__device__ inline bool cholesky_hbm(const MatT* covT, MatT* fac, MatT* wt, int d, int dpad, int tid) {
     constexpr int R = kCholHbmMaxDim / kThreads;
     for (int j = 0; j < d; ++j) {
         int row[R];
-        float acc[R];
-        float ajj = covT[static_cast<long long>(j) * dpad + j];
+        MatT acc[R];
+        MatT ajj = covT[static_cast<long long>(j) * dpad + j];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = j + tid + r * kThreads;
             row[r] = i < d ? i : j;                                       // (an idle slot recomputes the pivot's row)
             acc[r] = covT[static_cast<long long>(j) * dpad + row[r]];     // cov[i][j]
         }
-        const float* wk = wt;
+        const MatT* wk = wt;
         int k = 0;
         for (; k + 8 <= j; k += 8, wk += 8 * static_cast<long long>(dpad)) {
-            float wj[8], wi[R][8];
+            MatT wj[8], wi[R][8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 wj[u] = wk[static_cast<long long>(u) * dpad + j];
@@ -991,19 +995,19 @@ __device__ inline bool cholesky_hbm(const float* covT, float* fac, float* wt, in
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                ajj = __builtin_fmaf(-wj[u], wj[u], ajj);
+                ajj = chol_fnma(wj[u], wj[u], ajj);
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[r] = __builtin_fmaf(-wi[r][u], wj[u], acc[r]);
+                for (int r = 0; r < R; ++r) acc[r] = chol_fnma(wi[r][u], wj[u], acc[r]);
             }
         }
         for (; k < j; ++k, wk += dpad) {
-            const float wjk = wk[j];
-            ajj = __builtin_fmaf(-wjk, wjk, ajj);
+            const MatT wjk = wk[j];
+            ajj = chol_fnma(wjk, wjk, ajj);
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = __builtin_fmaf(-wk[row[r]], wjk, acc[r]);
+            for (int r = 0; r < R; ++r) acc[r] = chol_fnma(wk[row[r]], wjk, acc[r]);
         }
-        if (!((ajj > 0.0f) && (ajj < __builtin_inf()))) return false;   // uniform: every thread holds the same pivot
-        const float ljj = sqrtf(ajj);
+        if (!((ajj > MatT(0)) && (ajj < static_cast<MatT>(__builtin_inf())))) return false;   // uniform: every thread holds the same pivot
+        const MatT ljj = chol_sqrt(ajj);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = j + tid + r * kThreads;
@@ -1014,12 +1018,12 @@ __device__ inline bool cholesky_hbm(const float* covT, float* fac, float* wt, in
     }
     for (int idx = tid; idx < d * dpad; idx += kThreads) {   // L row-major, zero above the diagonal and in the padding columns
         const int i = idx / dpad, jc = idx - i * dpad;
-        fac[idx] = jc <= i ? wt[static_cast<long long>(jc) * dpad + i] : 0.0f;
+        fac[idx] = jc <= i ? wt[static_cast<long long>(jc) * dpad + i] : MatT(0);
     }
     return true;
 }
 
-template <int T>
+template <int T, class MatT = float>
 __global__ __launch_bounds__(T > 0 ? T * T : kCholHbmThreads) void dense_adapt_kernel(ChainArrays A, DenseArrays D, double multiplier,
                                                             int update_window, int* mask, int chain_begin, int expect_iter) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1053,8 +1057,8 @@ __global__ __launch_bounds__(T > 0 ? T * T : kCholHbmThreads) void dense_adapt_k
     double* meanb = D.emean + (1 - sel) * plane + static_cast<long long>(c) * dpad;
     double* rawf = D.rawT + sel * mplane + static_cast<long long>(c) * d * dpad;
     double* rawb = D.rawT + (1 - sel) * mplane + static_cast<long long>(c) * d * dpad;
-    float* covT = static_cast<float*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
-    float* fac = static_cast<float*>(D.fac) + static_cast<long long>(c) * D.fac_stride;
+    MatT* covT = static_cast<MatT*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
+    MatT* fac = static_cast<MatT*>(D.fac) + static_cast<long long>(c) * D.fac_stride;
     if (tid == 0) *flag = 0;
     for (int i = tid; i < d; i += kThreads) {   // quadpotential.py:594-599
         const double x = A.q[static_cast<long long>(c) * dpad + i];
@@ -1081,7 +1085,7 @@ __global__ __launch_bounds__(T > 0 ? T * T : kCholHbmThreads) void dense_adapt_k
         rawf[idx] = rf;
         rawb[idx] = rawb[idx] + 1.0 * newb[i] * oldb[j];
         if (refresh) {
-            const float cv = static_cast<float>(rf / denom);   // np.divide(raw, n - 1, out=float32)
+            const MatT cv = static_cast<MatT>(rf / denom);   // np.divide(raw, n - 1, out=cov): the quotient in the potential's dtype
             covT[idx] = cv;
             bad |= !isfinite(cv);
         }
@@ -1092,10 +1096,11 @@ __global__ __launch_bounds__(T > 0 ? T * T : kCholHbmThreads) void dense_adapt_k
     if (refresh) {
         bool ok = (*flag == 0);
         if constexpr (T > 0) {
+            static_assert(sizeof(MatT) == 4, "the register-resident factorisation is float32");
             if (ok) ok = cholesky_registers<T>(covT, fac, d, dpad, colbuf, rowbuf, tid);
         } else {
             (void)colbuf; (void)rowbuf;
-            if (ok) ok = cholesky_hbm<kThreads>(covT, fac, D.chol_work + static_cast<long long>(c) * D.mat_stride, d, dpad, tid);
+            if (ok) ok = cholesky_hbm<kThreads, MatT>(covT, fac, static_cast<MatT*>(D.chol_work) + static_cast<long long>(c) * D.mat_stride, d, dpad, tid);
         }
         if (!ok && tid == 0) D.chol_failed[c] += 1;
     }
@@ -1123,15 +1128,16 @@ __global__ __launch_bounds__(T > 0 ? T * T : kCholHbmThreads) void dense_adapt_k
 
 // QuadPotentialFullAdapt.__init__ for every chain (quadpotential.py:474-519): replicate the initial covariance,
 // its factor and the foreground estimator (mean, raw = weight * cov, n = weight); empty background.
-static __global__ __launch_bounds__(256) void dense_reset_kernel(ChainArrays A, DenseArrays D, const float* cov1T,
-                                                          const float* fac1, const double* raw1T, const double* mean1,
+template <class MatT>
+static __global__ __launch_bounds__(256) void dense_reset_kernel(ChainArrays A, DenseArrays D, const MatT* cov1T,
+                                                          const MatT* fac1, const double* raw1T, const double* mean1,
                                                           double weight, int window, int d8) {
     const int c = blockIdx.x;
     const int d = A.d, dpad = A.dpad;
     const long long plane = static_cast<long long>(A.chains) * dpad;
     const long long mplane = static_cast<long long>(A.chains) * d * dpad;
-    float* covT = static_cast<float*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
-    float* fac = static_cast<float*>(D.fac) + static_cast<long long>(c) * D.fac_stride;
+    MatT* covT = static_cast<MatT*>(D.covT) + static_cast<long long>(c) * D.mat_stride;
+    MatT* fac = static_cast<MatT*>(D.fac) + static_cast<long long>(c) * D.fac_stride;
     double* raw0 = D.rawT + static_cast<long long>(c) * d * dpad;
     double* mean0 = D.emean + static_cast<long long>(c) * dpad;
     const int total = d8 * dpad;

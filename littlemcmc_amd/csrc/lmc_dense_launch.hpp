@@ -29,7 +29,7 @@ int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArra
 struct TickArrays;
 int tick_dense_launch(int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
                       const TickArrays& K, const SamplerParams& P, const double* logp, const double* grad, int* adapt_mask);
-int dense_launch_reset(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, const float* cov1T,
-                       const float* fac1, const double* raw1T, const double* mean1, double weight, int window, int d8);
+int dense_launch_reset(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, const void* cov1T,   // MatT per D.mat_f64
+                       const void* fac1, const double* raw1T, const double* mean1, double weight, int window, int d8);
 
 }  // namespace lmc

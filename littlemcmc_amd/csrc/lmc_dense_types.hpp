@@ -27,7 +27,8 @@ struct DenseArrays {
     int* prev_update;       // [C]
     int* window;            // [C]
     int* chol_failed;       // [C]  number of refreshes whose factorisation failed (old factor kept)
-    float* chol_work;       // [C][sweep_rows(d)][dpad] scratch of cholesky_hbm (d > 256 only, else nullptr): the factor, transposed
+    void* chol_work;        // MatT [C][sweep_rows(d)][dpad] scratch of cholesky_hbm (d > 256 or float64, else nullptr): the factor, transposed
+    int mat_f64;            // covT / fac / chol_work hold doubles (FullInv, Full float64, FullAdapt(dtype="float64")), else floats
 };
 
 // FullAdapt's refresh factorises in registers up to here, through HBM beyond (lmc_dense.hpp: cholesky_registers / cholesky_hbm)

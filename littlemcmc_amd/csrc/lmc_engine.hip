@@ -287,8 +287,8 @@ struct lmc_engine {
     // dense mass matrices (cfg.potential >= LMC_POT_FULL)
     DenseArrays D;
     int d8 = 0;                    // rows of the stored Cholesky factor (dim rounded up to 8)
-    float* cov1T = nullptr;        // FULL_ADAPT: initial matrices of ONE chain, replicated by reset
-    float* fac1 = nullptr;
+    void* cov1T = nullptr;         // FULL_ADAPT: initial matrices of ONE chain (floats, or doubles with mass_f64), replicated by reset
+    void* fac1 = nullptr;
     double* raw1T = nullptr;
     double* mean1 = nullptr;
     double dense_weight = 1.0, dense_multiplier = 2.0;
@@ -646,8 +646,9 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     if (cfg->chains < 1 || cfg->dim < 1) return fail(nullptr, LMC_ERR_INVALID, "chains and dim must be >= 1");
     if (cfg->potential < LMC_POT_DIAG_ADAPT || cfg->potential > LMC_POT_FULL_F64)
         return fail(nullptr, LMC_ERR_INVALID, "unknown potential %d", cfg->potential);
-    if (cfg->mass_f64 && cfg->potential > LMC_POT_DIAG)
-        return fail(nullptr, LMC_ERR_INVALID, "mass_f64 is the dtype of the diagonal potentials (LMC_POT_DIAG_ADAPT / LMC_POT_DIAG)");
+    if (cfg->mass_f64 && cfg->potential > LMC_POT_DIAG && cfg->potential != LMC_POT_FULL_ADAPT)
+        return fail(nullptr, LMC_ERR_INVALID, "mass_f64 is the dtype of the diagonal potentials and of LMC_POT_FULL_ADAPT "
+                                              "(float64 fixed matrices: LMC_POT_FULL_F64 / LMC_POT_FULL_INV)");
     // Shapes the fused kernels are not instantiated for run in the general kernels (lmc_wide.hpp: one chain = 16 wavefronts)
     // (... and a density compiled at run time meets a dense mass matrix there: hiprtc instantiates the general kernel for it)
     const bool rtc_dense = cfg->target_family == LMC_TARGET_USER && !kUserCompiledInDense && cfg->potential >= LMC_POT_FULL &&
@@ -874,12 +875,20 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         const size_t drows = sweep_rows(cfg->dim);
         D.mat_stride = per_chain ? static_cast<long long>(drows * dp) : 0;
         D.fac_stride = per_chain ? static_cast<long long>(e->d8) * static_cast<long long>(dp) : 0;
+        const bool adapt_f64 = per_chain && cfg->mass_f64 != 0;   // QuadPotentialFullAdapt(dtype="float64")
+        D.mat_f64 = (pot_f64(cfg->potential) || adapt_f64) ? 1 : 0;
         if (pot_f64(cfg->potential)) {
             double *m = nullptr, *f = nullptr;
             if ((rc = dev_alloc(e, &m, drows * dp)) != LMC_OK) return bail(rc);
             if ((rc = dev_alloc(e, &f, drows * dp)) != LMC_OK) return bail(rc);
             D.covT = m; D.fac = f;
             if (cfg->potential == LMC_POT_FULL_F64 && (rc = dev_alloc(e, &e->chol64T, drows * dp)) != LMC_OK) return bail(rc);
+        } else if (adapt_f64) {
+            double *m = nullptr, *f = nullptr, *w = nullptr;
+            if ((rc = dev_alloc(e, &m, P * drows * dp)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &f, P * e->d8 * dp)) != LMC_OK) return bail(rc);
+            if ((rc = dev_alloc(e, &w, P * drows * dp)) != LMC_OK) return bail(rc);   // the float64 refresh always factorises through HBM
+            D.covT = m; D.fac = f; D.chol_work = w;
         } else {
             float *m = nullptr, *f = nullptr;
             if ((rc = dev_alloc(e, &m, P * drows * dp)) != LMC_OK) return bail(rc);
@@ -899,15 +908,27 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
             if ((rc = dev_alloc(e, &D.prev_update, C)) != LMC_OK) return bail(rc);
             if ((rc = dev_alloc(e, &D.window, C)) != LMC_OK) return bail(rc);
             if ((rc = dev_alloc(e, &D.chol_failed, C)) != LMC_OK) return bail(rc);
-            if ((rc = dev_alloc(e, &e->cov1T, d * dp)) != LMC_OK) return bail(rc);
-            if ((rc = dev_alloc(e, &e->fac1, static_cast<size_t>(e->d8) * dp)) != LMC_OK) return bail(rc);
+            if (adapt_f64) {
+                double *c1 = nullptr, *f1 = nullptr;
+                if ((rc = dev_alloc(e, &c1, d * dp)) != LMC_OK) return bail(rc);
+                if ((rc = dev_alloc(e, &f1, static_cast<size_t>(e->d8) * dp)) != LMC_OK) return bail(rc);
+                e->cov1T = c1; e->fac1 = f1;
+            } else {
+                float *c1 = nullptr, *f1 = nullptr;
+                if ((rc = dev_alloc(e, &c1, d * dp)) != LMC_OK) return bail(rc);
+                if ((rc = dev_alloc(e, &f1, static_cast<size_t>(e->d8) * dp)) != LMC_OK) return bail(rc);
+                e->cov1T = c1; e->fac1 = f1;
+            }
             if ((rc = dev_alloc(e, &e->raw1T, d * dp)) != LMC_OK) return bail(rc);
             if ((rc = dev_alloc(e, &e->mean1, dp)) != LMC_OK) return bail(rc);
             // beyond 256 dimensions the refresh factorises through HBM (lmc_dense.hpp: cholesky_hbm) and needs a work area per
             // chain; LMC_CHOL_HBM=1 (a test knob) gives the small shapes one too, and dense_launch_adapt then takes that form
             const char* hbm_env = std::getenv("LMC_CHOL_HBM");
-            if (cfg->dim > kDenseAdaptRegisterMaxDim || (hbm_env && std::atoi(hbm_env) != 0))
-                if ((rc = dev_alloc(e, &D.chol_work, C * drows * dp)) != LMC_OK) return bail(rc);
+            if (!adapt_f64 && (cfg->dim > kDenseAdaptRegisterMaxDim || (hbm_env && std::atoi(hbm_env) != 0))) {
+                float* w = nullptr;
+                if ((rc = dev_alloc(e, &w, C * drows * dp)) != LMC_OK) return bail(rc);
+                D.chol_work = w;
+            }
         }
     }
     // default potential of BaseHMC (base_hmc.py:109-113): QuadPotentialDiagAdapt(d, zeros, ones, 10); a dense
@@ -1275,6 +1296,36 @@ int lmc_engine_set_dense_potential(lmc_engine* e, const double* matrix, const do
         HIP_TRY(e, hipMemcpy(e->chol64T, LT.data(), LT.size() * sizeof(double), hipMemcpyHostToDevice));
         return LMC_OK;
     }
+    if (e->cfg.potential == LMC_POT_FULL_ADAPT && e->D.mat_f64) {
+        // QuadPotentialFullAdapt(dtype="float64") (quadpotential.py:507-509): float64 covariance and factor
+        if (adaptation_window < 1 || update_window < 1 || !(adaptation_window_multiplier > 0.0) || initial_weight < 0.0)
+            return fail(e, LMC_ERR_INVALID, "bad FullAdapt parameters");
+        std::vector<double> L(m);
+        if (!host_cholesky(L, d)) return fail(e, LMC_ERR_INVALID, "matrix is not positive definite");
+        std::vector<double> covT(static_cast<size_t>(d) * dp, 0.0), fac(static_cast<size_t>(d8) * dp, 0.0);
+        std::vector<double> rawT(static_cast<size_t>(d) * dp, 0.0), mean_p(dp, 0.0);
+        for (int i = 0; i < d; ++i) {
+            mean_p[i] = mean[i];
+            for (int j = 0; j < d; ++j) {
+                covT[static_cast<size_t>(j) * dp + i] = m[static_cast<size_t>(i) * d + j];
+                rawT[static_cast<size_t>(j) * dp + i] = m[static_cast<size_t>(i) * d + j];
+                fac[static_cast<size_t>(i) * dp + j] = L[static_cast<size_t>(i) * d + j];
+            }
+        }
+        for (int i = d; i < d8; ++i) fac[static_cast<size_t>(i) * dp + i] = 1.0;
+        HIP_TRY(e, hipMemcpy(e->cov1T, covT.data(), covT.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(e->fac1, fac.data(), fac.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(e->raw1T, rawT.data(), rawT.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(e->mean1, mean_p.data(), mean_p.size() * sizeof(double), hipMemcpyHostToDevice));
+        e->dense_weight = initial_weight;
+        e->dense_window = adaptation_window;
+        e->dense_multiplier = adaptation_window_multiplier;
+        e->dense_update_window = update_window;
+        const int rc64 = dense_reset(e);
+        if (rc64 != LMC_OK) return rc64;
+        HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
+        return LMC_OK;
+    }
     // QuadPotentialFull / FullAdapt: float32 covariance and its lower Cholesky factor (quadpotential.py:441-443)
     std::vector<float> cov(dd);
     for (size_t i = 0; i < dd; ++i) cov[i] = static_cast<float>(m[i]);
@@ -1349,22 +1400,27 @@ static int dense_state_xfer(lmc_engine* e, const lmc_dense_state* st, bool to_us
                    st->window || st->previous_update || st->chol_failures))
         return fail(e, LMC_ERR_STATE, "estimator fields exist for FULL_ADAPT only");
     const size_t P = adapt ? C : 1;
-    // matrices: device [P][rows][dp] (transposed for cov) <-> user [C][d][d]
-    auto mat_to_user = [&](float* user, const void* dev, size_t rows, bool dev_f64, bool transpose) -> int {
-        std::vector<float> host_f(dev_f64 ? 0 : P * rows * dp);
-        std::vector<double> host_d(dev_f64 ? P * rows * dp : 0);
-        if (dev_f64) HIP_TRY(e, hipMemcpy(host_d.data(), dev, host_d.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const bool dev64 = D.mat_f64 != 0;   // the device matrices hold doubles (FullInv, Full float64, FullAdapt float64)
+    // matrices: device [P][rows][dp] (transposed for cov) <-> user [C][d][d], float or double on either side
+    auto mat_to_user = [&](void* user, bool user64, const void* dev, size_t rows, bool transpose) -> int {
+        std::vector<float> host_f(dev64 ? 0 : P * rows * dp);
+        std::vector<double> host_d(dev64 ? P * rows * dp : 0);
+        if (dev64) HIP_TRY(e, hipMemcpy(host_d.data(), dev, host_d.size() * sizeof(double), hipMemcpyDeviceToHost));
         else HIP_TRY(e, hipMemcpy(host_f.data(), dev, host_f.size() * sizeof(float), hipMemcpyDeviceToHost));
-        std::vector<float> out(C * d * d);
+        std::vector<float> out_f(user64 ? 0 : C * d * d);
+        std::vector<double> out_d(user64 ? C * d * d : 0);
         for (size_t c = 0; c < C; ++c) {
             const size_t pc = adapt ? c : 0;
             for (size_t i = 0; i < d; ++i)
                 for (size_t j = 0; j < d; ++j) {
                     const size_t src = pc * rows * dp + (transpose ? j * dp + i : i * dp + j);
-                    out[(c * d + i) * d + j] = dev_f64 ? static_cast<float>(host_d[src]) : host_f[src];
+                    const double v = dev64 ? host_d[src] : static_cast<double>(host_f[src]);
+                    if (user64) out_d[(c * d + i) * d + j] = v;
+                    else out_f[(c * d + i) * d + j] = static_cast<float>(v);
                 }
         }
-        HIP_TRY(e, hipMemcpy(user, out.data(), out.size() * sizeof(float), hipMemcpyDefault));
+        if (user64) HIP_TRY(e, hipMemcpy(user, out_d.data(), out_d.size() * sizeof(double), hipMemcpyDefault));
+        else HIP_TRY(e, hipMemcpy(user, out_f.data(), out_f.size() * sizeof(float), hipMemcpyDefault));
         return LMC_OK;
     };
     int rc;
@@ -1372,23 +1428,40 @@ static int dense_state_xfer(lmc_engine* e, const lmc_dense_state* st, bool to_us
     if (adapt) HIP_TRY(e, hipMemcpy(sel.data(), D.esel, C * sizeof(int), hipMemcpyDeviceToHost));
     if (to_user) {
         const size_t drows = sweep_rows(e->cfg.dim);
-        if (st->cov && (rc = mat_to_user(st->cov, D.covT, drows, inv, true)) != LMC_OK) return rc;
-        if (st->chol && (rc = mat_to_user(st->chol, fac_src, inv ? drows : d8, inv, inv)) != LMC_OK) return rc;
+        const size_t fac_rows = inv ? drows : d8;
+        if (st->cov && (rc = mat_to_user(st->cov, false, D.covT, drows, true)) != LMC_OK) return rc;
+        if (st->chol && (rc = mat_to_user(st->chol, false, fac_src, fac_rows, inv)) != LMC_OK) return rc;
+        if (st->cov64 && (rc = mat_to_user(st->cov64, true, D.covT, drows, true)) != LMC_OK) return rc;
+        if (st->chol64 && (rc = mat_to_user(st->chol64, true, fac_src, fac_rows, inv)) != LMC_OK) return rc;
     } else {
-        auto mat_from_user = [&](const float* user, float* dev, size_t rows, bool transpose, bool identity_pad) -> int {
-            std::vector<float> in(C * d * d), host(C * rows * dp, 0.0f);
-            HIP_TRY(e, hipMemcpy(in.data(), user, in.size() * sizeof(float), hipMemcpyDefault));
+        auto mat_from_user = [&](const void* user, bool user64, void* dev, size_t rows, bool transpose, bool identity_pad) -> int {
+            std::vector<float> in_f(user64 ? 0 : C * d * d);
+            std::vector<double> in_d(user64 ? C * d * d : 0);
+            if (user64) HIP_TRY(e, hipMemcpy(in_d.data(), user, in_d.size() * sizeof(double), hipMemcpyDefault));
+            else HIP_TRY(e, hipMemcpy(in_f.data(), user, in_f.size() * sizeof(float), hipMemcpyDefault));
+            std::vector<float> host_f(dev64 ? 0 : C * rows * dp, 0.0f);
+            std::vector<double> host_d(dev64 ? C * rows * dp : 0, 0.0);
             for (size_t c = 0; c < C; ++c) {
                 for (size_t i = 0; i < d; ++i)
-                    for (size_t j = 0; j < d; ++j)
-                        host[c * rows * dp + (transpose ? j * dp + i : i * dp + j)] = in[(c * d + i) * d + j];
-                for (size_t i = d; identity_pad && i < rows; ++i) host[c * rows * dp + i * dp + i] = 1.0f;
+                    for (size_t j = 0; j < d; ++j) {
+                        const double v = user64 ? in_d[(c * d + i) * d + j] : static_cast<double>(in_f[(c * d + i) * d + j]);
+                        const size_t dst = c * rows * dp + (transpose ? j * dp + i : i * dp + j);
+                        if (dev64) host_d[dst] = v; else host_f[dst] = static_cast<float>(v);
+                    }
+                for (size_t i = d; identity_pad && i < rows; ++i) {
+                    if (dev64) host_d[c * rows * dp + i * dp + i] = 1.0; else host_f[c * rows * dp + i * dp + i] = 1.0f;
+                }
             }
-            HIP_TRY(e, hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+            if (dev64) HIP_TRY(e, hipMemcpy(dev, host_d.data(), host_d.size() * sizeof(double), hipMemcpyHostToDevice));
+            else HIP_TRY(e, hipMemcpy(dev, host_f.data(), host_f.size() * sizeof(float), hipMemcpyHostToDevice));
             return LMC_OK;
         };
-        if (st->cov && (rc = mat_from_user(st->cov, static_cast<float*>(D.covT), sweep_rows(e->cfg.dim), true, false)) != LMC_OK) return rc;
-        if (st->chol && (rc = mat_from_user(st->chol, static_cast<float*>(D.fac), d8, false, true)) != LMC_OK) return rc;
+        if ((st->cov && st->cov64) || (st->chol && st->chol64))
+            return fail(e, LMC_ERR_INVALID, "set either the float32 or the float64 form of a matrix");
+        if (st->cov && (rc = mat_from_user(st->cov, false, D.covT, sweep_rows(e->cfg.dim), true, false)) != LMC_OK) return rc;
+        if (st->chol && (rc = mat_from_user(st->chol, false, D.fac, d8, false, true)) != LMC_OK) return rc;
+        if (st->cov64 && (rc = mat_from_user(st->cov64, true, D.covT, sweep_rows(e->cfg.dim), true, false)) != LMC_OK) return rc;
+        if (st->chol64 && (rc = mat_from_user(st->chol64, true, D.fac, d8, false, true)) != LMC_OK) return rc;
     }
     if (!adapt) return LMC_OK;
     const size_t mplane = C * d * dp, plane = C * dp;
@@ -1471,33 +1544,43 @@ static int dense_state_xfer(lmc_engine* e, const lmc_dense_state* st, bool to_us
     return LMC_OK;
 }
 
-int lmc_engine_get_dense_chain(lmc_engine* e, int32_t chain, float* cov, float* chol) {
+static int dense_chain_fetch(lmc_engine* e, int32_t chain, void* cov, void* chol, bool user64) {
     if (!e || chain < 0 || chain >= e->cfg.chains) return fail(e, LMC_ERR_INVALID, "bad chain index");
     if (e->cfg.potential < LMC_POT_FULL) return fail(e, LMC_ERR_STATE, "not a dense potential");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
     const size_t d = e->cfg.dim, dp = e->dpad;
-    const bool inv = pot_f64(e->cfg.potential);
+    const bool inv = pot_f64(e->cfg.potential), dev64 = e->D.mat_f64 != 0;
     const void* fac_src = e->cfg.potential == LMC_POT_FULL_F64 ? static_cast<const void*>(e->chol64T) : e->D.fac;
-    const size_t esz = inv ? sizeof(double) : sizeof(float);
-    auto fetch = [&](float* user, const void* dev, long long stride, bool transpose) -> int {
+    const size_t esz = dev64 ? sizeof(double) : sizeof(float);
+    auto fetch = [&](void* user, const void* dev, long long stride, bool transpose) -> int {
         std::vector<char> raw(d * dp * esz);
         const char* src = static_cast<const char*>(dev) + static_cast<size_t>(chain) * static_cast<size_t>(stride) * esz;
         HIP_TRY(e, hipMemcpy(raw.data(), src, raw.size(), hipMemcpyDeviceToHost));
-        std::vector<float> out(d * d);
+        std::vector<float> out_f(user64 ? 0 : d * d);
+        std::vector<double> out_d(user64 ? d * d : 0);
         for (size_t i = 0; i < d; ++i)
             for (size_t j = 0; j < d; ++j) {
                 const size_t k = transpose ? j * dp + i : i * dp + j;
-                out[i * d + j] = inv ? static_cast<float>(reinterpret_cast<const double*>(raw.data())[k])
-                                     : reinterpret_cast<const float*>(raw.data())[k];
+                const double v = dev64 ? reinterpret_cast<const double*>(raw.data())[k]
+                                       : static_cast<double>(reinterpret_cast<const float*>(raw.data())[k]);
+                if (user64) out_d[i * d + j] = v; else out_f[i * d + j] = static_cast<float>(v);
             }
-        HIP_TRY(e, hipMemcpy(user, out.data(), out.size() * sizeof(float), hipMemcpyDefault));
+        if (user64) HIP_TRY(e, hipMemcpy(user, out_d.data(), out_d.size() * sizeof(double), hipMemcpyDefault));
+        else HIP_TRY(e, hipMemcpy(user, out_f.data(), out_f.size() * sizeof(float), hipMemcpyDefault));
         return LMC_OK;
     };
     int rc;
     if (cov && (rc = fetch(cov, e->D.covT, e->D.mat_stride, true)) != LMC_OK) return rc;
     if (chol && (rc = fetch(chol, fac_src, e->D.fac_stride, inv)) != LMC_OK) return rc;
     return LMC_OK;
+}
+
+int lmc_engine_get_dense_chain(lmc_engine* e, int32_t chain, float* cov, float* chol) {
+    return dense_chain_fetch(e, chain, cov, chol, false);
+}
+int lmc_engine_get_dense_chain_f64(lmc_engine* e, int32_t chain, double* cov, double* chol) {
+    return dense_chain_fetch(e, chain, cov, chol, true);
 }
 
 int lmc_engine_get_dense_factor_f64(lmc_engine* e, double* chol) {
@@ -1672,7 +1755,7 @@ static SamplerParams make_params(const lmc_engine* e, int64_t n_tune, int64_t it
 
 // lmc_engine_run() for the shapes the fused kernels are not instantiated for (lmc_wide.hpp)
 static int wide_run(lmc_engine* e, SamplerParams P) {
-    if (e->cfg.potential >= LMC_POT_FULL) P.momentum_f32 = !pot_f64(e->cfg.potential);
+    if (e->cfg.potential >= LMC_POT_FULL) P.momentum_f32 = !e->D.mat_f64;
     if (e->cfg.potential != LMC_POT_DIAG_ADAPT) P.adapt_mass = 0;
     P.chain_begin = 0;
     P.relay_mask = relay_mask_for(e->cfg.chains);

@@ -189,28 +189,29 @@ __device__ inline void wide_normals_regs(TeamT& tm, RngState& r, int d, double* 
 
 // solve_triangular(chol.T, float32(z)) (quadpotential.py:450-453): the column sweep of the reference BLAS strsv over the
 // row-major float32 factor (x_j /= L_jj, then x_i -= L_ji x_j for i < j, j descending), one team barrier per column
-template <int NS, class TeamT>
-__device__ inline void wide_momentum_strsv(TeamT& tm, const float* L, int d, int dpad, const double (&z)[NS], double* bc,
+// (T = double: QuadPotentialFullAdapt(dtype="float64") -- the same sweep in float64 on a float64 factor)
+template <int NS, class T, class TeamT>
+__device__ inline void wide_momentum_strsv(TeamT& tm, const T* L, int d, int dpad, const double (&z)[NS], double* bc,
                                            double (&p0)[NS]) {
     const int t = tm.tid();
-    float x[NS];
+    T x[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) x[s] = (t * NS + s < d) ? static_cast<float>(z[s]) : 0.0f;
-    float* bcf = reinterpret_cast<float*>(bc);   // two broadcast slots, used alternately
+    for (int s = 0; s < NS; ++s) x[s] = (t * NS + s < d) ? static_cast<T>(z[s]) : T(0);
+    T* bcf = reinterpret_cast<T*>(bc);   // two broadcast slots, used alternately
     for (int j = d - 1; j >= 0; --j) {
         const int owner = j / NS, sj = j % NS;
         if (t == owner) {
-            float xs = 0.0f;
+            T xs = T(0);
 #pragma unroll
             for (int s = 0; s < NS; ++s) if (s == sj) xs = x[s];
-            const float xj = xs / L[static_cast<long long>(j) * dpad + j];
+            const T xj = xs / L[static_cast<long long>(j) * dpad + j];
 #pragma unroll
             for (int s = 0; s < NS; ++s) if (s == sj) x[s] = xj;
             bcf[j & 1] = xj;
         }
         tm.sync();
-        const float xj = bcf[j & 1];
-        const float* row = L + static_cast<long long>(j) * dpad + t * NS;
+        const T xj = bcf[j & 1];
+        const T* row = L + static_cast<long long>(j) * dpad + t * NS;
 #pragma unroll
         for (int s = 0; s < NS; ++s)
             if (t * NS + s < j) x[s] = x[s] - row[s] * xj;
@@ -508,8 +509,10 @@ __device__ inline double wide_start(TeamT& tm, const Target& tgt, const WideMass
             p0[s] = momentum_f32 ? static_cast<double>(static_cast<float>(invd[s]) * static_cast<float>(z[s])) : z[s] * invd[s];
     } else if (D.kind == kDenseFullInv) {   // L n (FullInv) / solve_triangular(chol.T, n) as the sweep of L^-1 (Full float64)
         wide_matvec<NS, double>(tm, static_cast<const double*>(M.fac), d, V.dpad, cx.xop, z, p0);
+    } else if (D.mat_f64) {                 // FullAdapt(dtype="float64"): the factor changes on the device, so the solve runs here
+        wide_momentum_strsv<NS, double>(tm, static_cast<const double*>(M.fac), d, V.dpad, z, cx.bcast + 4, p0);
     } else {
-        wide_momentum_strsv<NS>(tm, static_cast<const float*>(M.fac), d, V.dpad, z, cx.bcast + 4, p0);
+        wide_momentum_strsv<NS, float>(tm, static_cast<const float*>(M.fac), d, V.dpad, z, cx.bcast + 4, p0);
     }
     double g0[NS], v0[NS], v0s[NS];
     logp0 = first_f64(tgt.logp_grad(tm, q, g0));
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(64 * W) void run_wide_kernel(ChainArrays A, DenseAr
     TargetT<NS> tgt;
     tgt.init(tm, tparams, d);
     WideMass M;
-    M.kind = D.covT == nullptr ? 0 : (D.kind == kDenseFullInv ? 2 : 1);
+    M.kind = D.covT == nullptr ? 0 : (D.mat_f64 ? 2 : 1);
     M.covT = D.covT == nullptr ? nullptr : static_cast<const char*>(D.covT) + static_cast<long long>(c) * D.mat_stride * (M.kind == 2 ? 8 : 4);
     M.fac = D.covT == nullptr ? nullptr : static_cast<const char*>(D.fac) + static_cast<long long>(c) * D.fac_stride * (M.kind == 2 ? 8 : 4);
     M.d = d; M.dpad = dpad;
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(64 * W) void wide_trajectory_kernel(ChainArrays A, 
     TargetT<NS> tgt;
     tgt.init(tm, tparams, d);
     WideMass M;
-    M.kind = D.covT == nullptr ? 0 : (D.kind == kDenseFullInv ? 2 : 1);
+    M.kind = D.covT == nullptr ? 0 : (D.mat_f64 ? 2 : 1);
     M.covT = D.covT == nullptr ? nullptr : static_cast<const char*>(D.covT) + static_cast<long long>(c) * D.mat_stride * (M.kind == 2 ? 8 : 4);
     M.fac = D.covT == nullptr ? nullptr : static_cast<const char*>(D.fac) + static_cast<long long>(c) * D.fac_stride * (M.kind == 2 ? 8 : 4);
     M.d = d; M.dpad = dpad;
@@ -776,8 +779,10 @@ __global__ __launch_bounds__(64 * W) void wide_momentum_kernel(ChainArrays A, De
             p0[s] = momentum_f32 ? static_cast<double>(static_cast<float>(invd[s]) * static_cast<float>(z[s])) : z[s] * invd[s];
     } else if (D.kind == kDenseFullInv) {
         wide_matvec<NS, double>(tm, static_cast<const double*>(D.fac), d, dpad, (lds_double*)lds, z, p0);
+    } else if (D.mat_f64) {
+        wide_momentum_strsv<NS, double>(tm, static_cast<const double*>(D.fac) + static_cast<long long>(c) * D.fac_stride, d, dpad, z, bcast + 4, p0);
     } else {
-        wide_momentum_strsv<NS>(tm, static_cast<const float*>(D.fac) + static_cast<long long>(c) * D.fac_stride, d, dpad, z, bcast + 4, p0);
+        wide_momentum_strsv<NS, float>(tm, static_cast<const float*>(D.fac) + static_cast<long long>(c) * D.fac_stride, d, dpad, z, bcast + 4, p0);
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {

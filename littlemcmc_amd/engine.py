@@ -56,7 +56,8 @@ class Engine:
         cfg.lds_levels = int(lds_levels)
         cfg.rng_mode = {"numpy": _abi.RNG_NUMPY, "philox": _abi.RNG_PHILOX}[rng]   # include/lmc_hip.h: LMC_RNG_*
         # QuadPotentialDiagAdapt(dtype=...) (quadpotential.py:159,175-184); float64 runs in the general kernels
-        self.mass_f64 = np.dtype(mass_dtype) == np.float64 and potential in ("diag_adapt", "diag")
+        # QuadPotentialFullAdapt(dtype=...) (quadpotential.py:484,497-509) likewise: float64 covariance, factor and momentum
+        self.mass_f64 = np.dtype(mass_dtype) == np.float64 and potential in ("diag_adapt", "diag", "full_adapt")
         cfg.mass_f64 = int(self.mass_f64)
         if cfg.target_family == _abi.TARGET_EXTERNAL:
             # a density evaluated by the caller (a torch / Python callable) is driven by the tick kernels, which exist for the
@@ -394,11 +395,17 @@ class Engine:
     def _dense_shape(self, kind):
         return {"m": (self.chains, self.dim, self.dim), "v": (self.chains, self.dim), "s": (self.chains,)}[kind]
 
+    def _dense_f64(self):
+        """cov / chol travel as float64: QuadPotentialFullAdapt(dtype="float64")."""
+        return self.mass_f64 and self.potential == "full_adapt"
+
     def dense_chain(self, chain=0):
-        """(cov, chol) of one chain, float32 [dim, dim]."""
-        cov = np.empty((self.dim, self.dim), dtype=np.float32)
-        chol = np.empty((self.dim, self.dim), dtype=np.float32)
-        self._check(self._lib.lmc_engine_get_dense_chain(self._h, int(chain), _abi.ptr(cov), _abi.ptr(chol)))
+        """(cov, chol) of one chain [dim, dim], in the potential's dtype (float32; float64 for FullAdapt(dtype="float64"))."""
+        dt = np.float64 if self._dense_f64() else np.float32
+        cov = np.empty((self.dim, self.dim), dtype=dt)
+        chol = np.empty((self.dim, self.dim), dtype=dt)
+        get = self._lib.lmc_engine_get_dense_chain_f64 if self._dense_f64() else self._lib.lmc_engine_get_dense_chain
+        self._check(get(self._h, int(chain), _abi.ptr(cov), _abi.ptr(chol)))
         return cov, chol
 
     def dense_factor_f64(self):
@@ -412,24 +419,32 @@ class Engine:
         ``fields`` restricts the copy (the matrices are chains x dim x dim)."""
         st = _abi.DenseState()
         out = {}
+        f64 = self._dense_f64()
         for name, dt, kind in _abi.DenseState.FIELDS:
+            if name in ("cov64", "chol64"):   # "cov" / "chol" come in the potential's dtype
+                continue
             if self.potential != "full_adapt" and name not in ("cov", "chol"):
                 continue
             if fields is not None and name not in fields:
                 continue
-            out[name] = np.empty(self._dense_shape(kind), dtype=dt)
-            setattr(st, name, out[name].ctypes.data)
+            wide = f64 and name in ("cov", "chol")
+            out[name] = np.empty(self._dense_shape(kind), dtype=np.float64 if wide else dt)
+            setattr(st, name + "64" if wide else name, out[name].ctypes.data)
         self._check(self._lib.lmc_engine_get_dense_state(self._h, C.byref(st)))
         return out
 
     def set_dense_state(self, state):
         st = _abi.DenseState()
         keep = []
+        f64 = self._dense_f64()
         for name, dt, kind in _abi.DenseState.FIELDS:
+            if name in ("cov64", "chol64"):
+                continue
             if name in state and state[name] is not None:
-                a = np.ascontiguousarray(np.broadcast_to(np.asarray(state[name], dtype=dt), self._dense_shape(kind)))
+                wide = f64 and name in ("cov", "chol")
+                a = np.ascontiguousarray(np.broadcast_to(np.asarray(state[name], dtype=np.float64 if wide else dt), self._dense_shape(kind)))
                 keep.append(a)
-                setattr(st, name, a.ctypes.data)
+                setattr(st, name + "64" if wide else name, a.ctypes.data)
         self._check(self._lib.lmc_engine_set_dense_state(self._h, C.byref(st)))
 
     def dense_update(self, tune=True):

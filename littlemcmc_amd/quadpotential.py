@@ -91,7 +91,7 @@ class QuadPotential:
             from .engine import Engine
 
             self._engine = Engine(_targets.StdNormal(self._n), chains=1, potential=self._engine_kind,
-                                  mass_dtype=getattr(self, "dtype", "float32") if self._engine_kind in ("diag_adapt", "diag") else "float32",
+                                  mass_dtype=getattr(self, "dtype", "float32") if self._engine_kind in ("diag_adapt", "diag", "full_adapt") else "float32",
                                   adaptation_window=getattr(self, "_initial_adaptation_window", 101),
                                   adaptation_window_multiplier=getattr(self, "adaptation_window_multiplier", 1.0))
             self._own_engine = True
@@ -371,15 +371,19 @@ class QuadPotentialFullAdapt(_DensePotential):
             raise ValueError("Wrong shape for initial_cov: expected %s got %s" % (n, initial_cov.shape))
         if len(initial_mean) != n:
             raise ValueError("Wrong shape for initial_mean: expected %s got %s" % (n, len(initial_mean)))
-        if dtype not in (None, "float32", np.float32):
-            raise NotImplementedError("the device mass matrix is float32, like the reference's default")
+        if dtype is None:   # quadpotential.py:497-498
+            dtype = "float32"
+        dtype = np.dtype(dtype).name
+        if dtype not in ("float32", "float64"):
+            raise NotImplementedError("QuadPotentialFullAdapt runs on the device in float32 (the reference's default) or float64")
         if n > MAX_DENSE_ADAPT_NDIM:
             raise NotImplementedError("per-chain adapted dense mass matrices run on the device up to model_ndim = %d"
                                       % MAX_DENSE_ADAPT_NDIM)
         super().__init__(n)
-        self.dtype = "float32"
+        self.dtype = dtype
+        self._momentum_f32 = dtype == "float32"   # quadpotential.py:451: normal(size=n).astype(self.dtype)
         if initial_cov is None:  # quadpotential.py:501-503
-            initial_cov = np.eye(n, dtype="float32")
+            initial_cov = np.eye(n, dtype=dtype)
             initial_weight = 1
         self._initial_mean = np.array(initial_mean, dtype="d")
         self._matrix = np.array(initial_cov, dtype="d")
@@ -387,7 +391,7 @@ class QuadPotentialFullAdapt(_DensePotential):
         self._adaptation_window = int(adaptation_window)
         self._adaptation_window_multiplier = float(adaptation_window_multiplier)
         self._update_window = int(update_window)
-        self._cov = np.array(initial_cov, dtype="float32", copy=True)
+        self._cov = np.array(initial_cov, dtype=dtype, copy=True)
         self._chol = None
         self._chol_error = None
         self._previous_update = 0

@@ -161,6 +161,7 @@ class FullPotential:
         self.chol = scipy.linalg.cholesky(self.cov, lower=True)
         self.n = len(self.cov)
         self.n_samples = 0
+        self.momentum_f32 = self.cov.dtype == np.float32   # :451: normal(size=n).astype(self.dtype)
 
     def reset(self):
         pass
@@ -230,6 +231,7 @@ class FullAdaptPotential(FullPotential):
         n, mean, cov, weight, window, mult, upd, dtype = self._init
         self.n = n
         self.cov = np.array(cov, dtype=dtype, copy=True)
+        self.momentum_f32 = self.cov.dtype == np.float32
         self.chol = scipy.linalg.cholesky(self.cov, lower=True)
         self.chol_error = None
         self.fore = _WelfordCov(n, mean, cov, weight)
@@ -239,7 +241,7 @@ class FullAdaptPotential(FullPotential):
         self.previous_update = 0
 
     def _refresh(self, est):  # :521-526
-        np.divide(est.raw, est.n_samples - 1, out=self.cov)  # float64 quotient stored as float32
+        np.divide(est.raw, est.n_samples - 1, out=self.cov)  # float64 quotient stored in the potential's dtype
         try:
             self.chol = scipy.linalg.cholesky(self.cov, lower=True)
         except (scipy.linalg.LinAlgError, ValueError) as error:

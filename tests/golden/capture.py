@@ -587,6 +587,50 @@ def capture_diag_float64():
     save("e2e_nuts_diag64_ar1_12", **out)
 
 
+def capture_full_adapt_float64():
+    """QuadPotentialFullAdapt(dtype="float64") (quadpotential.py:484,497-509): unit values, an update sequence across a window
+    switch, one NUTS run with the potential handed to the step."""
+    from littlemcmc.quadpotential import QuadPotentialFullAdapt
+
+    fam, d, tune, draws = "ar1", 10, 230, 40
+    f = targets.make(fam, d)
+    rs = np.random.RandomState(15)
+    init_cov = _spd(rs, d)
+    pot = QuadPotentialFullAdapt(d, np.full(d, 0.25), init_cov, 10, adaptation_window=20, dtype="float64")
+    x = rs.randn(d)
+    np.random.seed(199)
+    rnd = np.array([pot.random() for _ in range(3)])
+    out = dict(unit_x=x, unit_velocity=np.asarray(pot.velocity(x)), unit_energy=np.array(pot.energy(x)), unit_random=rnd,
+               unit_random_dtype=np.array(str(rnd.dtype)), unit_random_seed=np.array(199), unit_initial_mean=np.full(d, 0.25),
+               unit_initial_cov=init_cov, unit_chol=np.array(pot._chol), unit_chol_dtype=np.array(str(pot._chol.dtype)))
+    samples = rs.randn(60, d) @ np.linalg.cholesky(_spd(rs, d)).T * 1.5 - 0.5
+    rows = {k: [] for k in ("cov", "chol", "fn", "bn", "window", "prev")}
+    for smp in samples:
+        pot.update(smp, None, True)
+        rows["cov"].append(np.array(pot._cov))
+        rows["chol"].append(np.array(pot._chol))
+        rows["fn"].append(pot._foreground_cov.n_samples)
+        rows["bn"].append(pot._background_cov.n_samples)
+        rows["window"].append(pot._adaptation_window)
+        rows["prev"].append(pot._previous_update)
+    out.update(seq_samples=samples, seq_cov_dtype=np.array(str(pot._cov.dtype)), seq_n_samples=np.array(pot._n_samples),
+               **{"seq_" + k: np.array(v) for k, v in rows.items()})
+    np.random.seed(SEED + 17)
+    seeds = np.array([np.random.randint(2 ** 30)])
+    np.random.seed(int(seeds[0]))
+    start = 2 * np.random.rand(d) - 1
+    pot2 = QuadPotentialFullAdapt(d, start, np.eye(d), 10, dtype="float64")
+    step = ref.NUTS(f, d, potential=pot2)
+    trace, stats = ref.sample(f, d, draws=draws, tune=tune, step=step, start=start, chains=1, cores=1,
+                              progressbar=False, random_seed=list(seeds), discard_tuned_samples=False)
+    out.update(family=np.array(fam), d=np.array(d), chains=np.array(1), tune=np.array(tune), draws=np.array(draws),
+               seeds=seeds, start=start, params=f.params(), trace=trace, final_cov=np.array(pot2._cov),
+               final_chol=np.array(pot2._chol), final_cov_dtype=np.array(str(pot2._cov.dtype)))
+    for k, v in stats.items():
+        out["stat_" + k] = v
+    save("e2e_nuts_adaptfull64_ar1_10", **out)
+
+
 def capture_step_rand_callable():
     shrink = lambda s: 0.9 * s   # noqa: E731
     f = targets.make("ar1", 12)
@@ -636,7 +680,7 @@ CAPTURES = {"leapfrog": capture_leapfrog, "transitions": capture_transitions, "a
             "e2e": capture_e2e, "seeds": capture_seeds, "dense_units": capture_dense_units,
             "dense_adapt": capture_dense_adapt, "dense_e2e": capture_dense_e2e, "dense_full64": capture_dense_full64,
             "diag_window_multiplier": capture_diag_window_multiplier, "step_rand": capture_step_rand,
-            "diag_float64": capture_diag_float64, "step_rand_callable": capture_step_rand_callable, "wide": capture_wide}
+            "diag_float64": capture_diag_float64, "full_adapt_float64": capture_full_adapt_float64, "step_rand_callable": capture_step_rand_callable, "wide": capture_wide}
 
 if __name__ == "__main__":
     # capture.py [group | e2e:<name>[,<name>...]] ...   (no argument: everything)

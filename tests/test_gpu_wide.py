@@ -167,6 +167,66 @@ def test_diag_adapt_float64_matches_the_reference(golden_dir):
     assert step.potential._var.dtype == np.float64 and str(g["final_var_dtype"]) == "float64"
 
 
+def test_full_adapt_float64_matches_the_reference(golden_dir):
+    """QuadPotentialFullAdapt(dtype="float64") (quadpotential.py:484,497-509): protocol values, the update() sequence across a
+    window switch -- covariance exact, factor to float64 rounding -- and every iteration of the captured reference run, with
+    estimators, covariance and factor compared after each tuning iteration."""
+    from tests.test_gpu_dense import _replay
+
+    g = _load(golden_dir, "e2e_nuts_adaptfull64_ar1_10")
+    d = int(g["d"])
+    pot = lmc.QuadPotentialFullAdapt(d, g["unit_initial_mean"], g["unit_initial_cov"], 10, adaptation_window=20, dtype="float64")
+    x = g["unit_x"]
+    np.testing.assert_allclose(pot.velocity(x), g["unit_velocity"], rtol=1e-14)
+    np.testing.assert_allclose(pot.energy(x), float(g["unit_energy"]), rtol=1e-13)
+    np.random.seed(int(g["unit_random_seed"]))
+    rnd = np.array([pot.random() for _ in range(3)])
+    assert str(rnd.dtype) == str(g["unit_random_dtype"]) == "float64"
+    np.testing.assert_allclose(rnd, g["unit_random"], rtol=1e-12, atol=1e-14)
+    assert pot._chol.dtype == np.float64
+    np.testing.assert_allclose(pot._chol, g["unit_chol"], rtol=1e-13, atol=1e-15)
+    for i, smp in enumerate(g["seq_samples"]):
+        pot.update(smp, None, True)
+        assert pot._cov.dtype == np.float64 and pot._chol.dtype == np.float64
+        np.testing.assert_array_equal(pot._cov, g["seq_cov"][i], err_msg="update %d" % i)
+        np.testing.assert_allclose(pot._chol, g["seq_chol"][i], rtol=1e-12, atol=1e-14, err_msg="update %d" % i)
+        assert pot._adaptation_window == int(g["seq_window"][i]) and pot._previous_update == int(g["seq_prev"][i])
+    assert pot._n_samples == int(g["seq_n_samples"])
+    # the captured run, iteration by iteration (float64 tolerances: nothing on this path is float32-born)
+    f = OT.make(str(g["family"]), d)
+    tgt = device_target(str(g["family"]), d, g["params"])
+    tune, draws = int(g["tune"]), int(g["draws"])
+    ostep = orc.Step(f, d, kind="nuts", potential=orc.FullAdaptPotential(d, g["start"], np.eye(d), 10, dtype="float64"))
+    dstep = lmc.NUTS(tgt, d, potential=lmc.QuadPotentialFullAdapt(d, g["start"], np.eye(d), 10, dtype="float64"))
+    eng = dstep._make_engine(1)
+    try:
+        assert eng.wide and eng.mass_f64
+    finally:
+        eng.close()
+    assert _replay(ostep, dstep, g["start"], int(g["seeds"][0]), tune, draws, False, "adapt_full float64") >= tune + draws - 2
+    # ... and through sample(): the potential the step object is left with carries the dtype
+    dstep = lmc.NUTS(tgt, d, potential=lmc.QuadPotentialFullAdapt(d, g["start"], np.eye(d), 10, dtype="float64"))
+    trace, stats = lmc.sample(tgt, d, draws=draws, tune=tune, step=dstep, start=g["start"], chains=1,
+                              random_seed=[int(s) for s in g["seeds"]], discard_tuned_samples=False, progressbar=False)
+    n = 12
+    np.testing.assert_array_equal(stats["tree_size"][:, :n], g["stat_tree_size"][:, :n])
+    np.testing.assert_allclose(trace[:, :n], g["trace"][:, :n], rtol=1e-7, atol=1e-9)
+    assert dstep.potential._cov.dtype == np.float64 and dstep.potential._chol.dtype == np.float64
+
+
+def test_full_adapt_float64_at_300_dimensions():
+    """The float64 form beyond the fused kernels' sizes too: an oracle chain at d = 300, every iteration."""
+    from tests.test_gpu_dense import _replay
+
+    d, seed = 300, 4321
+    f = OT.make("ar1", d)
+    tgt = device_target("ar1", d, f.params())
+    start = orc.jitter_start(seed, d)
+    ostep = orc.Step(f, d, kind="nuts", potential=orc.FullAdaptPotential(d, start, np.eye(d), 10, dtype="float64"))
+    dstep = lmc.NUTS(tgt, d, potential=lmc.QuadPotentialFullAdapt(d, start, np.eye(d), 10, dtype="float64"))
+    assert _replay(ostep, dstep, start, seed, 10, 2, False, "adapt_full float64 d=300") >= 10
+
+
 def test_fixed_diagonal_in_float64():
     """QuadPotentialDiag(v, dtype="float64") (quadpotential.py:349-365): the diagonal is not rounded to float32."""
     d = 9
