@@ -1357,8 +1357,22 @@ __device__ __forceinline__ void dual_average_update(const CA& A, const PT& P, do
     // reference's Python floats get); the device pow is only the fallback beyond the table
     double sq, mk;
     if (da.count < A.da_table_len) {
+#ifndef LMC_DA_TABLE_SLOAD
+#define LMC_DA_TABLE_SLOAD 1
+#endif
+#if LMC_DA_TABLE_SLOAD
+        // The tables are written once by the host before any launch and count is wave-uniform: read them through the scalar
+        // cache (s_load_dwordx2, no vector-memory round trip and no vmcnt wait behind the reload of q; round 4).
+        typedef const __attribute__((address_space(4))) double cst_double;
+        cst_double* ts = (cst_double*)A.da_sqrt;
+        cst_double* tk = (cst_double*)A.da_mk;
+        asm volatile("" : "+s"(ts), "+s"(tk));
+        sq = ts[da.count];
+        mk = tk[da.count];
+#else
         sq = first_f64(A.da_sqrt[da.count]);
         mk = first_f64(A.da_mk[da.count]);
+#endif
     } else {
         sq = sqrt(static_cast<double>(da.count));
         mk = pow(static_cast<double>(da.count), -P.k);
@@ -1389,9 +1403,23 @@ __device__ __forceinline__ void moments_update(const CA& A, TeamT& tm, int c, lo
 }
 
 // draw row + per-draw statistics of iteration `git`
+// The record's value for this lane (lane k < 7: statistic k; lane 7: the integers), pure register arithmetic.
+__device__ __forceinline__ double stat_record_value(int tid, const TransitionOut& out, double step_now, double step_bar_now, bool tune) {
+    double v = step_now;
+    v = (tid == kSfStepSizeBar) ? step_bar_now : v;
+    v = (tid == kSfAccept) ? out.accept : v;
+    v = (tid == kSfEnergyError) ? out.energy_error : v;
+    v = (tid == kSfEnergy) ? out.energy : v;
+    v = (tid == kSfMaxEnergyError) ? out.max_energy_error : v;
+    v = (tid == kSfModelLogp) ? out.model_logp : v;
+    const unsigned flags = (static_cast<unsigned>(out.depth) & 0xffffu) | (out.diverging ? kRecDiverging : 0u) |
+                           (tune ? kRecTune : 0u) | (out.accepted ? kRecAccepted : 0u);
+    const double ints = __hiloint2double(static_cast<int>(flags), out.n_leapfrog);
+    return (tid == 7) ? ints : v;
+}
+// the two stores of a draw: the trace row and the 64-byte record (eight lanes, ONE store)
 template <int NS, class CA>
-__device__ __forceinline__ void write_outputs(const CA& A, int c, int tid, long long git, const double (&q)[NS],
-                                              const TransitionOut& out, double step_now, double step_bar_now, bool tune) {
+__device__ __forceinline__ void store_outputs(const CA& A, int c, int tid, long long git, const double (&q)[NS], double rec) {
     const int d = A.d;
     const long long orow = static_cast<long long>(c) * A.cap + git;
     if (A.trace != nullptr && git >= A.trace_begin) {
@@ -1402,20 +1430,12 @@ __device__ __forceinline__ void write_outputs(const CA& A, int c, int tid, long 
             if (e < d) tr[e] = q[s];
         }
     }
-    if (tid < 8) {   // lane k < 7: statistic k; lane 7: the integers. ONE 64-byte store.
-        double v = step_now;
-        v = (tid == kSfStepSizeBar) ? step_bar_now : v;
-        v = (tid == kSfAccept) ? out.accept : v;
-        v = (tid == kSfEnergyError) ? out.energy_error : v;
-        v = (tid == kSfEnergy) ? out.energy : v;
-        v = (tid == kSfMaxEnergyError) ? out.max_energy_error : v;
-        v = (tid == kSfModelLogp) ? out.model_logp : v;
-        const unsigned flags = (static_cast<unsigned>(out.depth) & 0xffffu) | (out.diverging ? kRecDiverging : 0u) |
-                               (tune ? kRecTune : 0u) | (out.accepted ? kRecAccepted : 0u);
-        const double ints = __hiloint2double(static_cast<int>(flags), out.n_leapfrog);
-        v = (tid == 7) ? ints : v;
-        reinterpret_cast<double*>(A.stat_rec + orow)[tid] = v;
-    }
+    if (tid < 8) reinterpret_cast<double*>(A.stat_rec + orow)[tid] = rec;
+}
+template <int NS, class CA>
+__device__ __forceinline__ void write_outputs(const CA& A, int c, int tid, long long git, const double (&q)[NS],
+                                              const TransitionOut& out, double step_now, double step_bar_now, bool tune) {
+    store_outputs<NS>(A, c, tid, git, q, stat_record_value(tid, out, step_now, step_bar_now, tune));
 }
 
 // diagonal mass adaptation (quadpotential.py:231-245, :324-340): both Welford estimators take the draw, the
@@ -1651,9 +1671,32 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         if (adapt_step) dual_average_update(A, P2, out.accept, da);
         LMC_PHASE(3)
 
+        // ---- the stop word, looked at HERE (round 4): it was requested when the iteration started, so the wait in front of its
+        // first use is a wait for whatever vector-memory operation is still outstanding. At the very end of the iteration
+        // (where it used to be looked at) that was the acknowledgement of the stores just issued -- the estimator rows, the
+        // trace row, the statistics record: a store round trip per iteration spent doing nothing. Here the only thing
+        // outstanding is the reload of q above (needed for the stores below anyway; while tuning the dual-averaging update
+        // has already waited for it), and the record's value is formed first so that its arithmetic runs under that wait.
+        // The stores of the iteration then drain under the next iteration's momentum draw. Measured, alternating runs on one
+        // box (profiles/r04_iteration_tail_ab.txt), together with the dual-averaging tables read through the scalar cache:
+        // north_star shape +0.4 ... +1.0 %, C2 +1 ... +1.5 %, C4 +0.4 ... +1.1 %, C3 equal (its iteration is 25 times longer).
+#ifndef LMC_EARLY_STOP_CHECK
+#define LMC_EARLY_STOP_CHECK 1
+#endif
+        double rec_value = 0.0;
+        bool stop_now = false;
+        if constexpr (LMC_EARLY_STOP_CHECK != 0) {
+            rec_value = stat_record_value(tid, out, da.step_now, da.step_bar_now, tune);
+            int sw = stop_word;
+            asm volatile("" : "+v"(rec_value), "+v"(sw));   // the record's value is complete before the word is waited for
+            stop_now = stop_requested(tm, sw, rng_bcast);
+        }
+
         // ---- diagonal mass adaptation (quadpotential.py:231-245, :324-340). (Requesting the estimator rows before the
         // dual-averaging update, to take their HBM round trip off the critical path, measured -12 % at d = 128: sixteen
-        // more live registers across the update spill other state.)
+        // more live registers across the update spill other state. Requesting them in front of the record's arithmetic and
+        // the stop word above -- only ~50 instructions under the round trip -- still loses: north_star shape -1.4 %, C3
+        // -1.5 %, C4 -5 %, profiles/r04_iteration_tail_ab.txt.)
         if (tune && P2.adapt_mass) {
             double wm[NS], wr[NS], wmb[NS], wrb[NS];
             diag_mass_prefetch<NS>(A, row, ms, wm, wr, wmb, wrb);
@@ -1667,8 +1710,13 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
         if (!tune) ++ct_after;
 
         if (A.mom_mean != nullptr && !tune) moments_update<NS>(A, tm, c, row, q);
-        write_outputs<NS>(A, c, tid, git, q, out, da.step_now, da.step_bar_now, tune);
-        if (stop_requested(tm, stop_word, rng_bcast)) break;
+        if constexpr (LMC_EARLY_STOP_CHECK != 0) {
+            store_outputs<NS>(A, c, tid, git, q, rec_value);
+            if (stop_now) break;
+        } else {
+            write_outputs<NS>(A, c, tid, git, q, out, da.step_now, da.step_bar_now, tune);
+            if (stop_requested(tm, stop_word, rng_bcast)) break;
+        }
     }
 
     // ---- store persistent chain state (region 3 of the arguments)
