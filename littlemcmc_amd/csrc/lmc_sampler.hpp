@@ -1162,13 +1162,29 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                     if (qsrc == -1) vcopy(tqv, cq);
                     else if (qsrc == -2) vcopy(tqv, eq);
                     else level_load_q<NS, W>(cx, qsrc, tqv);
+#ifndef LMC_PARK_REORDER_MIN_NS
+#define LMC_PARK_REORDER_MIN_NS 4
+#endif
+                    // Four-element slices (C4, C5: trees that live in the scratch row from level 2 on, and in C5 single chains
+                    // whose 4 095-leapfrog trees are what a launch ends with): the node's scalars (LDS) go first and both loaded
+                    // vectors are in registers before the node's FIRST scratch-row store. Left to itself the compiler waits for
+                    // tqv's load right before the fourth store and again at the scalars, and at those joins of LDS / scratch-row
+                    // paths the wait is "everything outstanding" -- the acknowledgement of the stores just issued (found reading
+                    // the ISA, round 4). Measured, alternating runs on one box (profiles/r04_iteration_tail_ab.txt, box 3): C5
+                    // +1 ... +2 %, C4 equal; C3 (two-element slices) -0.1 ... -0.4 %, hence the condition.
+                    constexpr bool kParkReorder = NS >= LMC_PARK_REORDER_MIN_NS;
+                    if constexpr (kParkReorder) level_scal_park<NS, W>(cx, m + 1, tw, ta, qsrc, elane, en_last, lp_last);
                     if (m == 0) {
                         level1_store<NS, W>(cx, tl, cp, tqv);
                     } else {
+                        if constexpr (kParkReorder) {
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(tl[s]), "+v"(tqv[s]));
+                        }
                         levelN_store<NS, W>(cx, m + 1, 0, tl); levelN_store<NS, W>(cx, m + 1, 1, cp);
                         levelN_store<NS, W>(cx, m + 1, 2, tps); levelN_store<NS, W>(cx, m + 1, 3, tqv);
                     }
-                    level_scal_park<NS, W>(cx, m + 1, tw, ta, qsrc, elane, en_last, lp_last);
+                    if constexpr (!kParkReorder) level_scal_park<NS, W>(cx, m + 1, tw, ta, qsrc, elane, en_last, lp_last);
                 }
             }
         }
