@@ -23,7 +23,10 @@ roofline         = the bound that binds the kernel: FP64 vector issue. achieved 
                    so they are not a bound. Counter-derived fields (HBM traffic, VALU instructions per leapfrog) are
                    quoted from profiles/pmc_counters.json ONLY if that profile was taken on this very build
                    (source hash match); otherwise they are null.
-secondary        = north_star's named shape (standard normal, d = 128, same chains / recipe) timed the same way.
+secondary        = north_star's named shape (standard normal, d = 128, same chains / recipe) in both RNG modes and, on the
+                   default command line, the other BASELINE.json configurations -- C2 (4 096 x 64), C4 (8 192 x 1000),
+                   C5 (16 384 x 256 funnel, treedepth 12; as K launches and as ONE launch) -- each timed the same way with
+                   its own roofline and tail block.
 cpu_baseline     = the numpy oracle (a port of the reference, oracle/lmc_oracle.py) on this box's host cores, one chain
                    per core, same recipe, bounded sample.
 """
@@ -196,7 +199,9 @@ def main():
     ap.add_argument("--no-trace", action="store_true", help="do not store draws (statistics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the standard-normal d=128 secondary workload")
+    ap.add_argument("--no-secondary", action="store_true", help="skip every secondary workload")
+    ap.add_argument("--no-baseline-configs", action="store_true",
+                    help="skip the C2 / C4 / C5 lines the default command line appends to `secondary` (keeps the north_star shape)")
     ap.add_argument("--cpu-iters", type=int, default=2000, help="iterations per oracle chain in the CPU baseline")
     ap.add_argument("--lds-levels", type=int, default=0)
     ap.add_argument("--rng", default="numpy", choices=["numpy", "philox"],
@@ -320,28 +325,38 @@ def main():
     n_units = args.gpus if inproc else world          # GPUs (chain blocks) of the job
     chains_total = args.chains if args.scaling == "strong" else args.chains * n_units
 
-    def unit_block(u):
-        return chain_block(chains_total, u, n_units) if args.scaling == "strong" else (u * args.chains, (u + 1) * args.chains)
-
-    # the chain blocks THIS process drives: one (its rank's) under the process-per-GPU launcher, all of them in-process
     n_dev = torch.cuda.device_count()
-    if inproc:
-        parts = [{"unit": u, "dev": u % n_dev, "lo": unit_block(u)[0], "hi": unit_block(u)[1]} for u in range(n_units)]
-    else:
-        parts = [{"unit": rank, "dev": local_rank, "lo": unit_block(rank)[0], "hi": unit_block(rank)[1]}]
-    for p_ in parts:
-        if p_["hi"] - p_["lo"] < 1:
-            raise SystemExit("GPU %d owns no chain (%d chains over %d GPUs)" % (p_["unit"], chains_total, n_units))
+
+    def job_parts(job_chains):
+        """The chain blocks THIS process drives for a job of `job_chains` chains (per GPU under weak scaling): one (its
+        rank's) under the process-per-GPU launcher, all of them in-process. -> (parts, chains_total)"""
+        total = job_chains if args.scaling == "strong" else job_chains * n_units
+
+        def unit_block(u):
+            return chain_block(total, u, n_units) if args.scaling == "strong" else (u * job_chains, (u + 1) * job_chains)
+
+        if inproc:
+            parts_ = [{"unit": u, "dev": u % n_dev, "lo": unit_block(u)[0], "hi": unit_block(u)[1]} for u in range(n_units)]
+        else:
+            parts_ = [{"unit": rank, "dev": local_rank, "lo": unit_block(rank)[0], "hi": unit_block(rank)[1]}]
+        for p_ in parts_:
+            if p_["hi"] - p_["lo"] < 1:
+                raise SystemExit("GPU %d owns no chain (%d chains over %d GPUs)" % (p_["unit"], total, n_units))
+        return parts_, total
+
+    parts, _ct = job_parts(args.chains)
     chains = parts[0]["hi"] - parts[0]["lo"]          # the first block: the GPU the roofline / tail figures are taken on
-    devs_here = sorted({p_["dev"] for p_ in parts})
+    all_devs = sorted({u % n_dev for u in range(n_units)}) if inproc else [local_rank]
 
     def sync_all():
-        for dv in devs_here:
+        for dv in all_devs:
             torch.cuda.synchronize(dv)
 
-    # seeds: sample()'s own derivation over the GLOBAL chain index space (prefix stable), block per GPU
+    # seeds: sample()'s own derivation over the GLOBAL chain index space (prefix stable: a job of fewer chains uses the
+    # first of them), block per GPU
+    most_chains = max(chains_total, 65536 if args.scaling == "strong" else 65536 * n_units)
     np.random.seed(SEED)
-    seeds_all = np.array([np.random.randint(2 ** 30) for _ in range(chains_total)], dtype=np.uint32)
+    seeds_all = np.array([np.random.randint(2 ** 30) for _ in range(most_chains)], dtype=np.uint32)
 
     def all_reduce(vals, op):
         t = torch.tensor(vals, dtype=torch.float64, device=red_dev)
@@ -361,8 +376,17 @@ def main():
     RNG_LABEL = {"numpy": "MT19937 (numpy legacy stream, same-seed parity mode)",
                  "philox": "Philox4x32-10 momentum stream (throughput mode: NOT the reference's draws), tree uniforms MT19937"}
 
-    def run_job(target_name, dim, with_ess, rng="numpy"):
-        """The timed job on this process's chain block(s) -> dict of measurements (wall / leapfrogs reduced over ranks)."""
+    def run_job(target_name, dim, with_ess, rng="numpy", job_chains=None, max_treedepth=None, K=K, ips=ips, tag=""):
+        """The timed job on this process's chain block(s) -> dict of measurements (wall / leapfrogs reduced over ranks).
+        Defaults = the primary workload of the command line; the BASELINE configurations that ride along as `secondary`
+        lines name their own chains / tree depth / launch split."""
+        parts, chains_total = job_parts(args.chains if job_chains is None else job_chains)
+        chains = parts[0]["hi"] - parts[0]["lo"]
+        devs_here = sorted({p_["dev"] for p_ in parts})
+        md = args.max_treedepth if max_treedepth is None else max_treedepth
+        n_total = K * ips
+        n_tune = n_total // 2
+        w_ips = min(ips, 100)                              # warm-up launches stay short whatever the timed split is
         target, target_desc = make_target(lmc, target_name, dim)
         np.random.seed(int(seeds_all[0]))
         start = 2 * np.random.rand(dim) - 1            # init_nuts jitter (sampling.py:574-584)
@@ -379,7 +403,7 @@ def main():
             pot = lmc.QuadPotentialFull(cov)
             mass_desc = "fixed dense mass (the target's covariance, one float32 matrix shared by all chains)"
         if args.kind == "nuts":
-            step = lmc.NUTS(target, dim, potential=pot, max_treedepth=args.max_treedepth)
+            step = lmc.NUTS(target, dim, potential=pot, max_treedepth=md)
         else:
             step = lmc.HamiltonianMC(target, dim, potential=pot, path_length=2.0)
         kw = step._engine_kwargs()
@@ -419,7 +443,7 @@ def main():
             lone.seed(seeds_all[:1])
             lone.set_position(start)
             lone.reset_tuning()
-            n_l = 2 * ips
+            n_l = 2 * w_ips
             lone.reserve(n_l, keep_trace=False)
             lone.run(n_l // 2, 0, n_l // 2)
             lone.synchronize()
@@ -449,10 +473,10 @@ def main():
             }
 
         if W > 0:   # warm-up: W launches of a throw-away copy of the job
-            warm = [new_job(p_, W * ips, (W * ips) // 2, keep_trace=False) for p_ in parts]
+            warm = [new_job(p_, W * w_ips, (W * w_ips) // 2, keep_trace=False) for p_ in parts]
             for s_ in range(W):
                 for w_ in warm:
-                    w_.run((W * ips) // 2, s_ * ips, ips)
+                    w_.run((W * w_ips) // 2, s_ * w_ips, w_ips)
             for w_ in warm:
                 w_.synchronize()
                 w_.close()
@@ -557,13 +581,14 @@ def main():
         if ess is not None:   # post-warm-up time of the slowest rank
             ess["draw_seconds"], ess["diagnostics_seconds"] = all_reduce([ess["draw_seconds"], ess["diagnostics_seconds"]],
                                                                          dist.ReduceOp.MAX)
-        method = ("NUTS max_treedepth=%d" % args.max_treedepth) if args.kind == "nuts" else "HMC path_length=2"
-        label = config_label(target_name, dim, chains_total, args.max_treedepth, args.kind, args.mass)
+        method = ("NUTS max_treedepth=%d" % md) if args.kind == "nuts" else "HMC path_length=2"
+        label = config_label(target_name, dim, chains_total if args.scaling == "strong" else chains_total // n_units, md, args.kind, args.mass) + tag
         part = ("%d chains on this GPU" % chains) if n_units == 1 else ("%d chains in blocks of ~%d per GPU" % (chains_total, chains))
         return {
             "label": label, "target": target_name, "dim": dim, "start": start, "mass_desc": mass_desc, "rng": RNG_LABEL[rng], "rng_mode": rng,
             "workload": "%s: %d chains x dim %d %s, %s, %s, tune %d + draws %d in %d launches of %d iterations; %s" % (
                 label, chains_total, dim, target_desc, method, mass_desc, n_tune, n_total - n_tune, K, ips, part),
+            "K": K, "ips": ips, "chains_total": chains_total, "chains_this_gpu": chains, "n_tune": n_tune, "n_total": n_total,
             "wall": wall_max, "leap_all": leap_all, "leap_local": leap_local, "kernel_ms": kernel_ms,
             "dispatch_ms_avg": float(np.mean(dispatch_ms)), "dispatches_per_step": nst,
             "depth_mean": depth_mean, "div_after": int(div_all), "ess": ess, "tail": tail,
@@ -585,7 +610,7 @@ def main():
         prof = pmc_profile(key, src_hash)
         r = {
             "kernel": ("lmc::run_kernel<NS=%d>" if args.mass == "diag" else "lmc::run_dense_kernel<NS=%d>") % max(1, (dim + 63) // 64),
-            "kernel_ms_avg": sum(job["kernel_ms"]) / K, "leapfrogs_per_launch": job["leap_local"] / K,
+            "kernel_ms_avg": sum(job["kernel_ms"]) / job["K"], "leapfrogs_per_launch": job["leap_local"] / job["K"],
             "dispatches_per_step": job["dispatches_per_step"], "dispatch_ms_avg": job["dispatch_ms_avg"],
             "launch_note": "a step (launch) is %d concurrent dispatches of the kernel, one per sub-block of chains on its own "
                            "stream; kernel_ms_avg = HIP-event span of the timed region / steps, dispatch_ms_avg = mean event "
@@ -621,19 +646,31 @@ def main():
                       "note": "a matrix shared by all chains is read from L2; the kernel is vector-issue bound "
                               "(DESIGN.md section 9); the HBM contract figures above are not a bound here"})
         if prof:   # measured on this very build (source hash match)
-            r["traffic"] = prof["hbm_bytes_per_leapfrog"] * job["leap_local"] / K
+            r["traffic"] = prof["hbm_bytes_per_leapfrog"] * job["leap_local"] / job["K"]
             r["valu_inst_per_leapfrog"] = prof.get("valu_inst_per_leapfrog")
             r["simd_valu_busy"] = prof.get("simd_valu_busy")
             r["pmc_source"] = prof.get("source")
         return r
 
     primary = run_job(args.target, args.dim, with_ess=True, rng=args.rng)
-    secondary = None
-    philox_line = None
-    if not args.no_secondary and args.mass == "diag" and args.kind == "nuts" and (args.target, args.dim) != ("std_normal", 128):
-        secondary = run_job("std_normal", 128, with_ess=False)
-        if not args.no_philox_line and args.rng == "numpy":
-            philox_line = run_job("std_normal", 128, with_ess=False, rng="philox")
+    # The other BASELINE.json configurations ride along as `secondary` lines, each timed exactly like the primary (barrier,
+    # HIP events on the launch streams, max over ranks) with its own roofline and tail block: north_star's named shape in
+    # both RNG modes, C2, C4, and C5 both as K launches and as ONE launch (what sample() does; C5 is tail-bound, so the
+    # launch split is part of the result). Only on the default command line (the primary IS C3): a custom primary
+    # workload keeps the north_star lines only.
+    secondaries = []
+    default_primary = (args.target, args.dim, args.chains, args.max_treedepth) == ("ar1", 128, 65536, 10)
+    if not args.no_secondary and args.mass == "diag" and args.kind == "nuts":
+        if (args.target, args.dim) != ("std_normal", 128):
+            secondaries.append(run_job("std_normal", 128, with_ess=False))
+            if not args.no_philox_line and args.rng == "numpy":
+                secondaries.append(run_job("std_normal", 128, with_ess=False, rng="philox"))
+        if default_primary and not args.no_baseline_configs:
+            secondaries.append(run_job("std_normal", 64, with_ess=False, job_chains=4096, max_treedepth=10))
+            secondaries.append(run_job("diag", 1000, with_ess=False, job_chains=8192, max_treedepth=10))
+            secondaries.append(run_job("funnel", 256, with_ess=False, job_chains=16384, max_treedepth=12))
+            secondaries.append(run_job("funnel", 256, with_ess=False, job_chains=16384, max_treedepth=12, K=1, ips=K * ips,
+                                       tag=" (one launch)"))
 
     if rank == 0:
         value = primary["leap_all"] / primary["wall"]
@@ -674,20 +711,17 @@ def main():
             "launcher_fallback": launcher_fallback,
             "source_hash": src_hash, "source_tree_hash": _build.source_hash(),
         }
-        if secondary is not None:
-            out["secondary"] = [{
-                "workload": secondary["workload"], "value": secondary["leap_all"] / secondary["wall"],
-                "unit": "leapfrog-steps/s", "ms_per_step": secondary["wall"] * 1e3 / K, "leapfrogs": secondary["leap_all"],
-                "wall_s": secondary["wall"], "mean_depth_draws": secondary["depth_mean"],
-                "divergences_after_tune": secondary["div_after"], "roofline": roofline(secondary),
-                "tail": secondary["tail"], "per_rank": secondary["per_rank"], "rng": secondary["rng"]}]
-        if philox_line is not None:   # separately labelled, never the headline: not the reference's random stream
-            out["secondary"].append({
-                "workload": philox_line["workload"] + "; COUNTER-BASED MOMENTUM STREAM", "rng": philox_line["rng"],
-                "value": philox_line["leap_all"] / philox_line["wall"], "unit": "leapfrog-steps/s",
-                "ms_per_step": philox_line["wall"] * 1e3 / K, "leapfrogs": philox_line["leap_all"], "wall_s": philox_line["wall"],
-                "mean_depth_draws": philox_line["depth_mean"], "divergences_after_tune": philox_line["div_after"],
-                "roofline": roofline(philox_line), "tail": philox_line["tail"], "per_rank": philox_line["per_rank"]})
+        if secondaries:
+            out["secondary"] = []
+            for job in secondaries:   # (a counter-based line is separately labelled, never the headline: not the reference's random stream)
+                out["secondary"].append({
+                    "workload": job["workload"] + ("; COUNTER-BASED MOMENTUM STREAM" if job["rng_mode"] == "philox" else ""),
+                    "rng": job["rng"], "value": job["leap_all"] / job["wall"], "unit": "leapfrog-steps/s",
+                    "steps": job["K"], "iters_per_step": job["ips"], "ms_per_step": job["wall"] * 1e3 / job["K"],
+                    "chains_total": job["chains_total"], "chains_this_gpu": job["chains_this_gpu"], "dim": job["dim"],
+                    "leapfrogs": job["leap_all"], "wall_s": job["wall"], "mean_depth_draws": job["depth_mean"],
+                    "divergences_after_tune": job["div_after"], "roofline": roofline(job), "tail": job["tail"],
+                    "per_rank": job["per_rank"]})
         if not args.no_cpu_baseline and n_units == 1:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.target, args.dim, seeds_all[:64], primary["start"], args.cpu_iters, args.mass)
         sys.stdout.flush()

@@ -247,7 +247,8 @@ int lmc_engine_set_step_jitter(lmc_engine* e, int32_t enable, double lo, double 
 /* step_rand as an ARBITRARY host function (base_hmc.py:46,123,154-155: `step_size = self._step_rand(step_size)` once per
  * iteration): the caller evaluates it for every chain and hands the results over; the next lmc_engine_run() integrates
  * with step_sizes[chain] (HOST or DEVICE pointer, [chains]) instead of exp(log_step) / exp(log_bar) -- run ONE iteration
- * per call and refresh the values in between. NULL switches back. Dual averaging is untouched (the reference adapts the
+ * per call and refresh the values in between. NULL switches back -- to the adapted step sizes, or to the device's own jitter if
+ * lmc_engine_set_step_jitter() enabled one (before or while the override was in force). Dual averaging is untouched (the reference adapts the
  * un-jittered step size too). */
 int lmc_engine_set_step_sizes(lmc_engine* e, const double* step_sizes);
 /* potential.update(sample = the chain's current position, grad, tune) of QuadPotentialDiagAdapt for every chain as a call

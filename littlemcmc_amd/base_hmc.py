@@ -171,8 +171,9 @@ class BaseHMC:
         self.step_size = float(np.exp(self.step_adapt._log_step if (self.tune and self.adapt_step_size)
                                       else self.step_adapt._log_bar))
         if self._host_step_rand() is not None:   # base_hmc.py:154-155 (evaluated before the launch: see StepRandUniform)
-            self.step_size = float(self._step_rand(self.step_size))
-            eng.set_step_sizes([self.step_size])
+            # the reference keeps the ADAPTED value on the object (base_hmc.py:151-153) and integrates with the jittered one
+            # (a local, :154-155): only the engine sees step_rand's result
+            eng.set_step_sizes([float(self._step_rand(self.step_size))])
             eng.set_rng_state(0, np.random.get_state())   # the callable may have drawn from the global stream
         eng.run(1 if self.tune else 0, 0, 1)
         np.random.set_state(eng.get_rng_state(0))

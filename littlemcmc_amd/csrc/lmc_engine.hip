@@ -271,6 +271,7 @@ struct lmc_engine {
     int* stop_host = nullptr;   // pinned, device-mapped host word the sampling kernels poll (lmc_engine_request_stop): the host
                                 // sets it with a plain store -- no stream, no copy engine, no command processor in the way
     int step_jitter = 0;        // step_rand as step * uniform(lo, hi) (lmc_engine_set_step_jitter); 2: values from the host (lmc_engine_set_step_sizes)
+    int step_jitter_device = 0; // what lmc_engine_set_step_jitter last asked for (0 / 1): what set_step_sizes(NULL) goes back to
     double* step_override = nullptr;   // [C] the host's step sizes for the next iteration
     double jitter_lo = 1.0, jitter_hi = 1.0;
     bool sub_pending = false;   // sub-block kernels in flight that the main stream has not been ordered after
@@ -464,10 +465,13 @@ static int dense_reset(lmc_engine* e) {   // FULL_ADAPT: constructor state for e
 
 // potentials whose matrices live in float64 on the device (and whose momentum draw is float64)
 // stop word: one chain in (mask + 1) of a launch of n chains relays the host's word (lmc_sampler.hpp: stop_request_load);
-// mask + 1 = the power of two >= n, at most 256, so that a launch of any size has a relay within 16 * (mask + 1) iterations
+// mask + 1 = the largest power of two <= n, at most 256: every residue of (chain + git / 16) mod (mask + 1) is then owned by a
+// chain that exists, so SOME chain relays at every 16th iteration whatever the launch size. (Rounded UP -- round 4 -- the
+// residues n .. mask had no chain: a 130-chain launch could pass ~126 consecutive marks, ~2 000 iterations, without reading the
+// host's word or writing the progress hint; found by review, tests/test_gpu_scale.py::test_interrupt_latency_of_a_130_chain_job.)
 static int relay_mask_for(long long n) {
     int m = 1;
-    while (m < n && m < 256) m *= 2;
+    while (2LL * m <= n && m < 256) m *= 2;
     return m - 1;
 }
 
@@ -1086,7 +1090,7 @@ int lmc_engine_set_step_sizes(lmc_engine* e, const double* step_sizes) {
     if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     if (!step_sizes) {   // back to the adapted step sizes (or the device's own jitter, if that was set before)
-        if (e->step_jitter == 2) e->step_jitter = 0;
+        if (e->step_jitter == 2) e->step_jitter = e->step_jitter_device;
         return LMC_OK;
     }
     if (!e->step_override) {
@@ -1124,7 +1128,8 @@ int lmc_engine_diag_update(lmc_engine* e, int32_t tune) {
 int lmc_engine_set_step_jitter(lmc_engine* e, int32_t enable, double lo, double hi) {
     if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
     if (enable && !(std::isfinite(lo) && std::isfinite(hi))) return fail(e, LMC_ERR_INVALID, "step jitter bounds must be finite");
-    e->step_jitter = enable ? 1 : 0;
+    e->step_jitter_device = enable ? 1 : 0;
+    if (e->step_jitter != 2) e->step_jitter = e->step_jitter_device;   // (a host override in force stays in force until set_step_sizes(NULL))
     e->jitter_lo = lo;
     e->jitter_hi = hi;
     return LMC_OK;

@@ -29,7 +29,7 @@ class HipLeapfrogIntegrator:
 
             kind = self._potential._engine_kind
             self._engine = Engine(self._logp_dlogp_func, chains=1, potential=kind,
-                                  mass_dtype=getattr(self._potential, "dtype", "float32") if kind in ("diag_adapt", "diag") else "float32")
+                                  mass_dtype=getattr(self._potential, "dtype", "float32") if kind in ("diag_adapt", "diag", "full_adapt") else "float32")
             self._potential._bind(self._engine)
         return self._engine
 

@@ -159,10 +159,12 @@ def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None):
         return n_done, True
 
 
-def _run_job_host_step_rand(eng, step, tune, n_total, progressbar):
+def _run_job_host_step_rand(eng, step, tune, n_total, progressbar, callback=None):
     """The job loop when ``step_rand`` is an arbitrary Python callable (base_hmc.py:154-155): it has to be evaluated
     between iterations, so every iteration is a launch of its own -- adaptation state down, the callable once per chain,
-    step sizes up (lmc_engine_set_step_sizes). The compatibility path; StepRandUniform runs inside the kernel."""
+    step sizes up (lmc_engine_set_step_sizes). The compatibility path; StepRandUniform runs inside the kernel.
+    ``callback`` is called once per iteration (= per launch: the host is in the loop anyway, so ``iteration`` is exact
+    here, not a device hint) and may raise KeyboardInterrupt like in _run_job."""
     import time
 
     t0 = time.perf_counter()
@@ -171,16 +173,21 @@ def _run_job_host_step_rand(eng, step, tune, n_total, progressbar):
         for it in range(n_total):
             eng.set_step_sizes(step._host_step_sizes(eng, it < tune))
             eng.run(tune, it, 1)
+            if callback is not None:
+                callback(trace=None, draw=JobProgress(it, n_total, it < tune, eng.chains, it))
             if progressbar and (it + 1) % 100 == 0:
                 _log.info("Sampling %d chains: %d/%d iterations, %.1f s" % (eng.chains, it + 1, n_total, time.perf_counter() - t0))
         eng.synchronize()
-        eng.set_step_sizes(None)
         return n_total, False
     except KeyboardInterrupt:
         eng.synchronize()
         n_done = min(eng.completed_iterations(), n_total)
         _log.warning("Sampling interrupted after %d of %d iterations; returning the draws so far." % (n_done, n_total))
         return n_done, True
+    finally:
+        # whoever keeps the engine (return_engine=True) gets it back without the per-chain override, interrupted or not
+        eng.synchronize()
+        eng.set_step_sizes(None)
 
 
 def visible_devices():
@@ -331,7 +338,7 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
         if target.family == _abi.TARGET_EXTERNAL and not launch_iters:
             per_launch = max(n_total, 1)   # ticks: chains never wait for each other inside one request
         if getattr(step, "_host_step_rand", lambda: None)() is not None:
-            n_done, interrupted = _run_job_host_step_rand(eng, step, int(tune), n_total, progressbar)
+            n_done, interrupted = _run_job_host_step_rand(eng, step, int(tune), n_total, progressbar, callback)
         else:
             n_done, interrupted = _run_job(eng, int(tune), n_total, per_launch, progressbar, callback)
         raise_for_status(eng.status())

@@ -605,12 +605,17 @@ class Step:
         self.samples_after_tune = 0
         self.num_divs_sample = 0
         self.last_margins = None
+        # True: the reference's SEQUENTIAL driver to the letter -- one step object for all chains (sampling.py:370-383) whose
+        # FullAdapt potential is never reset, so chain k starts from chain k-1's matrix, estimators and grown window.
+        # False (default, what the device does and what the reference's multi-process driver computes): every chain fresh.
+        self.sequential_carry_over = False
         self.stats_dtypes = NUTS_STATS if kind == "nuts" else HMC_STATS
 
     def reset_tuning(self):  # base_hmc.py:192-200
         self.adapt.reset()
         self.tune = True
-        self.pot.reset()
+        if not (self.sequential_carry_over and isinstance(self.pot, FullAdaptPotential)):
+            self.pot.reset()   # (QuadPotentialFullAdapt inherits the base class's no-op reset, quadpotential.py:137-139)
 
     def astep(self, q0, rng):
         """base_hmc.py:140-190."""
@@ -691,8 +696,9 @@ def init_nuts(f, d, init="auto", seeds=None, **kwargs):
 
 
 def sample(f, d, draws=1000, tune=1000, step=None, init="auto", chains=2, start=None,
-           random_seed=None, discard_tuned_samples=True, record_margins=False, **kwargs):
-    """sampling.py:35-222 sequential path (cores=1): returns (trace[chains,draws,d], stats)."""
+           random_seed=None, discard_tuned_samples=True, record_margins=False, sequential_carry_over=False, **kwargs):
+    """sampling.py:35-222 sequential path (cores=1): returns (trace[chains,draws,d], stats).
+    ``sequential_carry_over``: see Step.sequential_carry_over (pinned by tests/golden/e2e_adaptfull_two_chains.npz)."""
     if isinstance(random_seed, (int, np.integer)):
         seeds = derive_seeds(int(random_seed), chains)
     else:
@@ -702,6 +708,7 @@ def sample(f, d, draws=1000, tune=1000, step=None, init="auto", chains=2, start=
         step = step_ if step is None else step
         start = start_ if start is None else start
     starts = [start] * chains if isinstance(start, np.ndarray) and start.ndim == 1 else list(start)
+    step.sequential_carry_over = bool(sequential_carry_over)
     n = tune + draws
     trace = np.zeros((chains, n, d))
     stats = {k: np.zeros((chains, n, 1), dtype=dt) for k, dt in step.stats_dtypes.items()}

@@ -676,7 +676,35 @@ def capture_wide():
     save("e2e_nuts_full_ar1_384", **out)
 
 
-CAPTURES = {"leapfrog": capture_leapfrog, "transitions": capture_transitions, "adapt": capture_adapt,
+# ---------------------------------------------------------------------------------------
+# 13. init="adapt_full" with TWO chains through the sequential driver (cores=1): the reference reuses one step object
+#     (sampling.py:370-383) and QuadPotentialFullAdapt.reset() is the base class's no-op (quadpotential.py:137-139), so
+#     chain 1 starts from the matrix, estimators and grown window chain 0 ended with. Captured next to it: the reference's
+#     ONE-chain run with chain 1's seed -- what its multi-process driver would compute for chain 1, and what the device
+#     computes (every chain fresh). The pair pins the difference instead of describing it.
+# ---------------------------------------------------------------------------------------
+def capture_full_adapt_two_chains():
+    fam, d, tune, draws = "ar1", 6, 150, 50
+    f = targets.make(fam, d)
+    np.random.seed(SEED + 77)
+    seeds = [int(np.random.randint(2 ** 30)) for _ in range(2)]
+    out = dict(family=np.array(fam), d=np.array(d), chains=np.array(2), tune=np.array(tune), draws=np.array(draws),
+               seeds=np.array(seeds), init=np.array("adapt_full"), params=f.params())
+    trace, stats = ref.sample(f, d, draws=draws, tune=tune, chains=2, cores=1, init="adapt_full", progressbar=False,
+                              random_seed=list(seeds), discard_tuned_samples=False)
+    out["trace"] = trace
+    for k, v in stats.items():
+        out["stat_" + k] = v
+    trace1, stats1 = ref.sample(f, d, draws=draws, tune=tune, chains=1, cores=1, init="adapt_full", progressbar=False,
+                                random_seed=[seeds[1]], discard_tuned_samples=False)
+    out["solo1_trace"] = trace1
+    for k, v in stats1.items():
+        out["solo1_stat_" + k] = v
+    assert not np.allclose(trace[1], trace1[0]), "the carry-over should show"
+    save("e2e_adaptfull_two_chains", **out)
+
+
+CAPTURES = {"full_adapt_two_chains": capture_full_adapt_two_chains, "leapfrog": capture_leapfrog, "transitions": capture_transitions, "adapt": capture_adapt,
             "e2e": capture_e2e, "seeds": capture_seeds, "dense_units": capture_dense_units,
             "dense_adapt": capture_dense_adapt, "dense_e2e": capture_dense_e2e, "dense_full64": capture_dense_full64,
             "diag_window_multiplier": capture_diag_window_multiplier, "step_rand": capture_step_rand,

@@ -398,6 +398,30 @@ def test_dense_fixed_wide_vectors(d, kind):
     assert n >= 12
 
 
+def test_full_adapt_two_chains_are_independent_not_carried_over(golden_dir):
+    """init="adapt_full", chains=2, cores=1: the ONE place where this engine and the reference's sequential driver
+    knowingly differ (missing item 4). The reference reuses one step object for all chains
+    (/root/reference/littlemcmc/sampling.py:370-383) and QuadPotentialFullAdapt.reset() is the inherited no-op
+    (quadpotential.py:137-139), so its chain 1 starts from chain 0's final matrix and grown window. Here every chain is
+    fresh: chain 0 is the reference's chain 0, and chain 1 is the reference's ONE-chain run with chain 1's seed (captured
+    next to the two-chain run, tests/golden/capture.py group full_adapt_two_chains; the oracle reproduces both behaviours
+    bit for bit, tests/test_oracle_dense_golden.py) -- what the reference's own multi-process driver computes."""
+    g = _load(golden_dir, "e2e_adaptfull_two_chains")
+    d, tune, draws = int(g["d"]), int(g["tune"]), int(g["draws"])
+    tgt = device_target(g["family"], d, g["params"])
+    seeds = [int(s) for s in g["seeds"]]
+    trace, stats = lmc.sample(tgt, d, draws=draws, tune=tune, chains=2, cores=1, init="adapt_full", random_seed=seeds,
+                              discard_tuned_samples=False, progressbar=False)
+    n = 8   # a prefix, as for every tuned chain (float32-born momentum: REPLAY_F32 per iteration)
+    for c, (want_q, want_ts) in enumerate([(g["trace"][0], g["stat_tree_size"][0]),
+                                           (g["solo1_trace"][0], g["solo1_stat_tree_size"][0])]):
+        np.testing.assert_array_equal(stats["tree_size"][c, :n, 0], want_ts[:n, 0], err_msg="chain %d" % c)
+        np.testing.assert_allclose(trace[c, :n], want_q[:n], rtol=20 * REPLAY_F32, atol=1e-6, err_msg="chain %d" % c)
+    # ... and NOT the sequential driver's chain 1 (it integrates with another matrix from its first iteration on)
+    assert np.abs(trace[1, :n] - g["trace"][1, :n]).max() > 1e-3
+    assert np.abs(g["solo1_trace"][0, :n] - g["trace"][1, :n]).max() > 1e-3
+
+
 # ---------------------------------------------------------------------------------------------------
 # size-independent properties at scale: chains are independent, so chain c of a large run IS chain c of a small one
 # ---------------------------------------------------------------------------------------------------

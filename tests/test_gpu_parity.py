@@ -119,7 +119,7 @@ def test_e2e_golden_through_sample_api(golden_dir, name):
     for c in range(chains):
         got = {n_: stats[n_][c, :, 0] for n_ in stats}
         want = {n_: g["stat_" + n_][c, :, 0] for n_ in stats}
-        verified += assert_chain_matches(trace[c], got, g["trace"][c], want, margins[c, :, 0],
+        verified += assert_chain_matches(trace[c], got, g["trace"][c], want, margins[c],
                                          label="%s chain %d" % (name, c))
     # whole tuned chains are chaotic (see test_every_iteration_of_the_golden_runs, which checks EVERY iteration from
     # the oracle's own state): require a solid prefix. Deep trees at d = 128 amplify the float32 start-energy

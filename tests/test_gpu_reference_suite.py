@@ -190,7 +190,7 @@ def test_plain_python_callable_reproduces_the_reference_chain(golden_dir):
     for c in range(chains):
         got = {n_: stats[n_][c, :, 0] for n_ in stats}
         want = {n_: g["stat_" + n_][c, :, 0] for n_ in stats}
-        verified += assert_chain_matches(trace[c], got, g["trace"][c], want, margins[c, :, 0], label="callable chain %d" % c)
+        verified += assert_chain_matches(trace[c], got, g["trace"][c], want, margins[c], label="callable chain %d" % c)
     assert verified >= chains * 15
     # the step-method protocol with a plain callable, and a callable returning CPU torch tensors
     import torch

@@ -127,3 +127,33 @@ def test_full_potential_float64_units(golden_dir):
     draws = np.array([pot.random(rng) for _ in range(3)])
     assert str(draws.dtype) == str(g["unit_random_dtype"]) == "float64"
     np.testing.assert_allclose(draws, g["unit_random"], rtol=RTOL)
+
+
+def test_full_adapt_two_chains_sequential_carry_over(golden_dir):
+    """init="adapt_full", chains=2, cores=1 (missing item 4). The reference's sequential driver reuses ONE
+    step object (/root/reference/littlemcmc/sampling.py:370-383) and QuadPotentialFullAdapt.reset() is the inherited no-op
+    (quadpotential.py:137-139): chain 1 starts from the covariance, estimators and grown window chain 0 ended with. The
+    oracle reproduces that run bit for bit when told to (sequential_carry_over=True) and, by default, gives every chain
+    a fresh potential -- in which case chain 1 is the reference's ONE-chain run with chain 1's seed (what the reference's
+    multi-process driver computes, and what the device computes: tests/test_gpu_dense.py pins the device side)."""
+    g = _load(golden_dir, "e2e_adaptfull_two_chains")
+    d, tune, draws = int(g["d"]), int(g["tune"]), int(g["draws"])
+    f = targets.make(str(g["family"]), d)
+    seeds = [int(s) for s in g["seeds"]]
+    with np.errstate(all="ignore"):
+        carried, cstats = orc.sample(f, d, draws=draws, tune=tune, chains=2, init="adapt_full", random_seed=seeds,
+                                     discard_tuned_samples=False, sequential_carry_over=True)
+        fresh, fstats = orc.sample(f, d, draws=draws, tune=tune, chains=2, init="adapt_full", random_seed=seeds,
+                                   discard_tuned_samples=False)
+    np.testing.assert_allclose(carried, g["trace"], rtol=RTOL, atol=1e-300)
+    for name_ in cstats:
+        if name_ in INT_STATS:
+            np.testing.assert_array_equal(cstats[name_], g["stat_" + name_], err_msg=name_)
+    # chain 0 is the same either way; chain 1 fresh == the reference's one-chain run with chain 1's seed
+    np.testing.assert_allclose(fresh[0], g["trace"][0], rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(fresh[1], g["solo1_trace"][0], rtol=RTOL, atol=1e-300)
+    for name_ in fstats:
+        if name_ in INT_STATS:
+            np.testing.assert_array_equal(fstats[name_][1], g["solo1_stat_" + name_][0], err_msg=name_)
+    # ... and the two behaviours do differ, from chain 1's first iteration on (another starting matrix)
+    assert not np.allclose(g["trace"][1, :5], g["solo1_trace"][0, :5])
