@@ -6,7 +6,7 @@
 
 #include "../../include/lmc_hip.h"
 #include "lmc_dense.hpp"
-#include "lmc_tick_dense.hpp"
+#include "lmc_tick.hpp"
 #include "lmc_dense_launch.hpp"
 #ifdef LMC_USER_TARGET_HEADER
 #include LMC_USER_TARGET_HEADER
@@ -126,6 +126,52 @@ int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArra
     else   // the factorisation through HBM: d > 256 (or the test knob)
         hipLaunchKernelGGL(dense_adapt_kernel<0>, grid, dim3(kCholHbmThreads), lds, stream, A, D, multiplier, update_window, mask, chain_begin, expect_iter);
     return static_cast<int>(hipGetLastError());
+}
+
+// ---- the tick state machine (lmc_tick.hpp: tick_step) with a dense mass matrix: densities evaluated by the caller
+// (targets.TorchTarget) sampled with QuadPotentialFull / FullInv / FullAdapt. The differences from the diagonal policy are
+// the ones between lmc_sampler.hpp and lmc_dense.hpp: velocities are matrix sweeps and therefore stored with the trajectory
+// ends and tree nodes, one sweep per leapfrog forms v = C p and w = C g, the momentum is a triangular solve (or L n), and
+// FullAdapt's update of a chain that finished a tuning iteration in this tick runs in dense_adapt_kernel, launched masked
+// by the host between two ticks.
+// per-chain HBM row: 0-4 left end {q, p, g, v, w}, 5-9 right end, p_sum, proposal q, half-stepped momentum, the start
+// state's stored velocity, then 6 vectors per subtree level {lp, lv, rp, rv, psum, proposal q} (tick_dense_scratch_vectors)
+template <int NS, class MatT>
+struct TickDenseMass {
+    static constexpr bool kDense = true;
+    static constexpr int kEndVecs = 5, kLevelVecs = 6, kPsum = kSlotPsum, kProp = kSlotProp, kHalf = kSlotHalf, kV0s = kSlotV0s,
+                         kFixed = kTickDenseFixedSlots;
+    static constexpr int kLp = 0, kLv = 1, kRp = 2, kRv = 3, kPs = 4, kQ = 5;
+    const DenseArrays& D;
+    int c;
+    DenseMat<MatT> mm;
+    __device__ __forceinline__ TickDenseMass(const ChainArrays& A, const DenseArrays& D_, int c_)
+        : D(D_), c(c_), mm{static_cast<const MatT*>(D_.covT) + static_cast<long long>(c_) * D_.mat_stride, nullptr, 0, A.d, A.dpad} {}
+    __device__ __forceinline__ void momentum(Team<1>&, int d, double* lds, bool, const double (&)[NS], double (&p0)[NS]) {
+        lds_double* xop = (lds_double*)lds;   // the normals lie in lds[0, d) (TickWaveShape::normals)
+        if (D.kind == kDenseFullInv)
+            dense_momentum_inv<NS>(static_cast<const double*>(D.fac), d, mm.dpad, xop, p0);
+        else
+            dense_momentum_full<NS>(static_cast<const float*>(D.fac) + static_cast<long long>(c) * D.fac_stride, d, mm.dpad, xop, p0);
+    }
+    __device__ __forceinline__ double start_state(Team<1>& tm, double* lds, int, int, bool momentum_f32, int sdot_mode,
+                                                  const double (&p0)[NS], const double (&g0)[NS], double logp0, double (&v0)[NS],
+                                                  double (&w0)[NS], double (&v0s)[NS]) {
+        return dense_start_state<NS, MatT>(tm, mm, lds, momentum_f32, sdot_mode, p0, g0, logp0, v0, w0, v0s);
+    }
+    __device__ __forceinline__ void velocity(double* lds, const double (&p)[NS], const double (&g)[NS], double (&v)[NS], double (&w)[NS]) {
+        velocity2<NS, MatT>(mm, (lds_double*)lds, p, g, v, w);
+    }
+};
+
+template <int NS, class MatT>
+__global__ __launch_bounds__(64, dense_waves_per_simd(NS)) void tick_dense_kernel(ChainArrays A, DenseArrays D, TickArrays K,
+                                                                                  SamplerParams P, const double* logp_in,
+                                                                                  const double* grad_in, int* adapt_mask) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // 2 * dpad doubles: normals / sweep operands / sdot staging
+    TickWaveShape shape(lds, A.dpad);
+    TickDenseMass<NS, MatT> mass(A, D, static_cast<int>(blockIdx.x));
+    tick_step<NS>(A, K, P, logp_in, grad_in, lds, shape, mass, D.kind == kDenseFullAdapt ? adapt_mask : nullptr);
 }
 
 int tick_dense_launch(int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,

@@ -25,7 +25,7 @@ int dense_launch_trajectory(int family, int ns, bool mat_f64, hipStream_t stream
 int dense_launch_momentum(int ns, hipStream_t stream, const ChainArrays& A, const DenseArrays& D, double* out);
 int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArrays& D, double multiplier,
                        int update_window, int* mask = nullptr, int chain_begin = 0, int n_chains = 0, int expect_iter = -1);
-// the tick kernel with a dense mass matrix (lmc_tick_dense.hpp)
+// the tick kernel with a dense mass matrix (lmc_dense.hip: TickDenseMass + tick_step of lmc_tick.hpp)
 struct TickArrays;
 int tick_dense_launch(int ns, bool mat_f64, hipStream_t stream, const ChainArrays& A, const DenseArrays& D,
                       const TickArrays& K, const SamplerParams& P, const double* logp, const double* grad, int* adapt_mask);

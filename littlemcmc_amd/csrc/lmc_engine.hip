@@ -393,6 +393,13 @@ static void dev_free(lmc_engine* e, void* p) {
         default: return fail(e, LMC_ERR_INVALID, "unsupported vector width ns=%d", ns); \
     }
 
+// M(NS, W, T) for every sampling-kernel shape of this build (LMC_PAIR_SHAPES, lmc_sampler.hpp)
+#ifdef LMC_EXPERIMENTAL_SHAPES
+#define LMC_FOR_EACH_SHAPE(M, T) M(1, 1, T) M(2, 1, T) M(4, 1, T) M(4, 2, T) M(4, 4, T) M(2, 8, T) M(2, 2, T) M(1, 4, T)
+#else
+#define LMC_FOR_EACH_SHAPE(M, T) M(1, 1, T) M(2, 1, T) M(4, 1, T) M(4, 2, T) M(4, 4, T)
+#endif
+
 #ifdef LMC_USER_TARGET_HEADER
 #define LMC_USER_CASE(KERNEL_CALL) \
     case LMC_TARGET_USER: { KERNEL_CALL(UserTarget); } break;
@@ -711,7 +718,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     e->dpad = 64 * e->ns;
     if (wide) {   // thread t of the chain's team owns elements t*ns .. t*ns+ns-1
         // one wavefront per chain up to 8 elements per lane (dim <= 512: 2-6x the team's rate there, tools/wide_team_ab.py),
-        // else 16 wavefronts; an externally evaluated density always takes the large team (lmc_tick_wide.hpp is instantiated
+        // else 16 wavefronts; an externally evaluated density always takes the large team (tick_wide_kernel, lmc_wide.hip, is instantiated
         // for it only). LMC_WIDE_TEAM=16 is a test knob: the large team at every shape, so the small goldens replay through it too
         const char* team_env = std::getenv("LMC_WIDE_TEAM");
         const bool large_team = cfg->dim > kWideOneWaveMaxDim || cfg->target_family == LMC_TARGET_EXTERNAL || (team_env && std::atoi(team_env) == 16);
@@ -771,7 +778,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         e->nlds = 1;
         e->lds_bytes = wide_lds_bytes(e->dpad);
     } else {
-        const int waves_per_cu = 4 * run_waves_per_simd(e->run_ns);
+        const int waves_per_cu = 4 * run_waves_per_simd(e->run_ns, e->run_w);
         const int blocks_per_cu = waves_per_cu / e->run_w > 0 ? waves_per_cu / e->run_w : 1;
         const long budget = (163840L / blocks_per_cu) / 1280 * 1280 - lds_tail_doubles(e->run_w) * 8L;
         if (pair_min_doubles(e->run_ns, e->run_w) * 8L > budget)
@@ -1019,7 +1026,8 @@ int lmc_engine_occupancy(lmc_engine* e, int32_t* resident_chains, int32_t* waves
     }
     // (the very instantiation run() launches: the counter-based momentum stream is its own kernel with its own registers)
 #define OCC_ONE(NSV, WV, T)                                                                                    \
-    {                                                                                                          \
+    if (!found && e->run_ns == NSV && e->run_w == WV) {                                                        \
+        found = true;                                                                                          \
         if (e->cfg.rng_mode == LMC_RNG_PHILOX) {                                                               \
             if (run_lds > 64 * 1024)                                                                           \
                 HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NSV, WV, T, 1>),      \
@@ -1034,15 +1042,12 @@ int lmc_engine_occupancy(lmc_engine* e, int32_t* resident_chains, int32_t* waves
                                                                     static_cast<size_t>(run_lds)));            \
         }                                                                                                      \
     }
+    // every shape of LMC_PAIR_SHAPES (lmc_sampler.hpp), the experimental ones of a variant build included
 #define OCC_CALL(T)                                                                                            \
     {                                                                                                          \
-        const int shape = e->run_ns * 10 + e->run_w;                                                           \
-        if (shape == 11) OCC_ONE(1, 1, T)                                                                      \
-        else if (shape == 21) OCC_ONE(2, 1, T)                                                                 \
-        else if (shape == 41) OCC_ONE(4, 1, T)                                                                 \
-        else if (shape == 42) OCC_ONE(4, 2, T)                                                                 \
-        else if (shape == 44) OCC_ONE(4, 4, T)                                                                 \
-        else return fail(e, LMC_ERR_INVALID, "unsupported kernel shape ns=%d w=%d", e->run_ns, e->run_w);      \
+        bool found = false;                                                                                    \
+        LMC_FOR_EACH_SHAPE(OCC_ONE, T)                                                                         \
+        if (!found) return fail(e, LMC_ERR_INVALID, "unsupported kernel shape ns=%d w=%d", e->run_ns, e->run_w); \
     }
     LMC_FAMILY_SWITCH(e, e->cfg.target_family, OCC_CALL)
 #undef OCC_CALL
@@ -1812,37 +1817,25 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
     const int n_sub = e->n_sub;
     HIP_TRY(e, order_sub_blocks_after_main(e));
 #define RUN_ONE(NSV, WV, T)                                                                                    \
-    {                                                                                                          \
-        if (run_lds > 64 * 1024)                                                                               \
-            HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NSV, WV, T>),             \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));              \
-        LMC_LAUNCH((run_kernel<NSV, WV, T>), grid, block, run_lds, st, e->A, P, e->tparams);                   \
-    }
-#define RUN_PHILOX(NSV, T) LMC_LAUNCH((run_kernel<NSV, 1, T, 1>), grid, block, run_lds, st, e->A, P, e->tparams);
-#define RUN_PHILOX_TEAM(WV, T)                                                                                 \
-    {                                                                                                          \
-        if (run_lds > 64 * 1024)                                                                               \
-            HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<4, WV, T, 1>),            \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));              \
-        LMC_LAUNCH((run_kernel<4, WV, T, 1>), grid, block, run_lds, st, e->A, P, e->tparams);                  \
+    if (!found && e->run_ns == NSV && e->run_w == WV) {                                                        \
+        found = true;                                                                                          \
+        if (e->cfg.rng_mode == LMC_RNG_PHILOX) {                                                               \
+            if (run_lds > 64 * 1024)                                                                           \
+                HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NSV, WV, T, 1>),      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));          \
+            LMC_LAUNCH((run_kernel<NSV, WV, T, 1>), grid, block, run_lds, st, e->A, P, e->tparams);            \
+        } else {                                                                                               \
+            if (run_lds > 64 * 1024)                                                                           \
+                HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NSV, WV, T>),         \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));          \
+            LMC_LAUNCH((run_kernel<NSV, WV, T>), grid, block, run_lds, st, e->A, P, e->tparams);               \
+        }                                                                                                      \
     }
 #define RUN_CALL(T)                                                                                            \
     {                                                                                                          \
-        const int shape = e->run_ns * 10 + e->run_w;                                                           \
-        if (e->cfg.rng_mode == LMC_RNG_PHILOX) {                                                               \
-            if (shape == 11) RUN_PHILOX(1, T)                                                                  \
-            else if (shape == 21) RUN_PHILOX(2, T)                                                             \
-            else if (shape == 41) RUN_PHILOX(4, T)                                                             \
-            else if (shape == 42) RUN_PHILOX_TEAM(2, T)                                                        \
-            else if (shape == 44) RUN_PHILOX_TEAM(4, T)                                                        \
-            else return fail(e, LMC_ERR_INVALID, "LMC_RNG_PHILOX: unsupported kernel shape ns=%d w=%d", e->run_ns, e->run_w); \
-        } else                                                                                                 \
-        if (shape == 11) RUN_ONE(1, 1, T)                                                                      \
-        else if (shape == 21) RUN_ONE(2, 1, T)                                                                 \
-        else if (shape == 41) RUN_ONE(4, 1, T)                                                                 \
-        else if (shape == 42) RUN_ONE(4, 2, T)                                                                 \
-        else if (shape == 44) RUN_ONE(4, 4, T)                                                                 \
-        else return fail(e, LMC_ERR_INVALID, "unsupported kernel shape ns=%d w=%d", e->run_ns, e->run_w);      \
+        bool found = false;                                                                                    \
+        LMC_FOR_EACH_SHAPE(RUN_ONE, T)                                                                         \
+        if (!found) return fail(e, LMC_ERR_INVALID, "unsupported kernel shape ns=%d w=%d", e->run_ns, e->run_w); \
     }
     for (int b = 0; b < n_sub; ++b) {
         const long long lo = static_cast<long long>(e->cfg.chains) * b / n_sub, hi = static_cast<long long>(e->cfg.chains) * (b + 1) / n_sub;
@@ -1861,8 +1854,6 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
     }
 #undef RUN_CALL
 #undef RUN_ONE
-#undef RUN_PHILOX
-#undef RUN_PHILOX_TEAM
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, order_external_stream_after_sub_blocks(e));
     return LMC_OK;

@@ -354,7 +354,8 @@ template <class TeamT>
 __device__ inline void team_normals_parallel(TeamT& tm, RngState& r, int d, double* out, double* stage, uint32_t* buf_a,
                                              uint32_t* buf_b) {
     constexpr int W = TeamT::kWaves;
-    static_assert(W == 4, "three attempt waves cover a generation's 156 attempts, the fourth twists");
+    static_assert(W >= 4, "three attempt waves cover a generation's 156 attempts, 227 threads twist");
+    constexpr int AW = 3;   // waves that evaluate attempts (a generation of 624 words holds 156: three waves cover it)
     const int tid = tm.tid(), lane = lane_id(), wave = tm.wave();
     int produced = 0;
     tm.sync();   // earlier readers of out / stage / the stream state are done
@@ -378,12 +379,12 @@ __device__ inline void team_normals_parallel(TeamT& tm, RngState& r, int d, doub
         uint32_t* alt = (cur == buf_a) ? buf_b : buf_a;
         const bool twisting = !next_ready;
         if (twisting && tid < 227) mt_twist_strand(cur, alt, tid);
-        // attempts of this round: whole attempts in carry ++ cur[pos, 624), one per thread of waves 0 .. W-2
+        // attempts of this round: whole attempts in carry ++ cur[pos, 624), one per thread of waves 0 .. AW-1
         const int navail = (ncarry + kMtN - pos) >> 2;
-        const int n_att = navail < 64 * (W - 1) ? navail : 64 * (W - 1);
+        const int n_att = navail < 64 * AW ? navail : 64 * AW;
         double x1 = 0.0, x2 = 0.0;
         unsigned long long mask = 0ull;
-        if (wave < W - 1 && n_att > 0) {
+        if (wave < AW && n_att > 0) {
             const int at = tid < n_att ? tid : n_att - 1;   // a thread beyond n_att re-reads the last whole attempt and is masked out
             const int base = pos + 4 * at - ncarry;          // -2 for the attempt that starts in the carried words
             const bool in_carry = base < pos;
@@ -398,22 +399,22 @@ __device__ inline void team_normals_parallel(TeamT& tm, RngState& r, int d, doub
         }
         // the words no whole attempt of this generation can use (read before the barrier: the buffer is twisted over after it)
         const uint32_t tail0 = first_u32(cur[kMtN - 2]), tail1 = have623 ? gen623 : first_u32(cur[kMtN - 1]);
-        double v[2 * (W - 1)];
+        double v[2 * AW];
 #pragma unroll
-        for (int k = 0; k < W - 1; ++k) {   // exact: a 32-bit integer in a double, the other waves' slots contribute 0
+        for (int k = 0; k < AW; ++k) {   // exact: a 32-bit integer in a double, the other waves' slots contribute 0
             v[2 * k] = (k == wave) ? static_cast<double>(static_cast<uint32_t>(mask)) : 0.0;
             v[2 * k + 1] = (k == wave) ? static_cast<double>(static_cast<uint32_t>(mask >> 32)) : 0.0;
         }
-        tm.template exchange<2 * (W - 1)>(v);   // the round's one barrier: all reads of cur and the strands of the twist are behind it
+        tm.template exchange<2 * AW>(v);   // the round's one barrier: all reads of cur and the strands of the twist are behind it
         if (twisting) {   // the generation's last word: every wave forms it for itself, thread 0 stores it
             next623 = first_u32(mt_twist(tail1, alt[0], alt[396]));
             if (tid == 0) alt[kMtN - 1] = next623;
             next_ready = true;
         }
         int before = 0, total = 0;
-        unsigned long long m[W - 1];
+        unsigned long long m[AW];
 #pragma unroll
-        for (int k = 0; k < W - 1; ++k) {
+        for (int k = 0; k < AW; ++k) {
             m[k] = static_cast<unsigned long long>(static_cast<uint32_t>(v[2 * k])) |
                    (static_cast<unsigned long long>(static_cast<uint32_t>(v[2 * k + 1])) << 32);
             const int cnt = __popcll(m[k]);
@@ -425,7 +426,7 @@ __device__ inline void team_normals_parallel(TeamT& tm, RngState& r, int d, doub
         if (total >= want) {   // the want-th accepted attempt of the round ends the call
             int run = 0;
 #pragma unroll
-            for (int k = 0; k < W - 1; ++k) {
+            for (int k = 0; k < AW; ++k) {
                 const int cnt = __popcll(m[k]);
                 if (run < want && run + cnt >= want) {
                     unsigned long long mm = m[k];
@@ -436,7 +437,7 @@ __device__ inline void team_normals_parallel(TeamT& tm, RngState& r, int d, doub
             }
             taken = want;
         }
-        if (wave < W - 1) {
+        if (wave < AW) {
             const int rank = before + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
                                                        __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u)));
             const bool acc = ((mask >> lane) & 1ull) != 0ull;
@@ -488,8 +489,8 @@ __device__ inline void team_normals(TeamT& tm, RngState& r, int d, double* out, 
                                     uint32_t* mt_a, uint32_t* mt_b) {
     if constexpr (TeamT::kWaves == 1) {
         rng_normals(r, d, out, stage);
-    } else if (TeamT::kWaves == 4 && (first_i32(r.pos) & 1) == 0) {   // (an odd position -- a state handed over from the host after a
-        if constexpr (TeamT::kWaves == 4) team_normals_parallel(tm, r, d, out, stage, mt_a, mt_b);   // 32-bit draw -- takes wave 0's word-granular path)
+    } else if (TeamT::kWaves >= 4 && (first_i32(r.pos) & 1) == 0) {   // (an odd position -- a state handed over from the host after a
+        if constexpr (TeamT::kWaves >= 4) team_normals_parallel(tm, r, d, out, stage, mt_a, mt_b);   // 32-bit draw -- takes wave 0's word-granular path)
     } else {
         tm.sync();
         if (tm.wave() == 0) {
@@ -678,7 +679,9 @@ struct PairLds {   // offsets in doubles from the start of the block's dynamic L
     static constexpr int kXsumSize = W > 1 ? 2 * 8 * W : 0;
     static constexpr int kScal = kXsum + kXsumSize;               // per-level scalars, one copy per wave
     static constexpr int kCold = kScal + W * kLevelScalDoubles;
-    static constexpr int kColdLds = LMC_PAIR_COLD_LDS;           // cold slots in LDS; the others head the scratch row
+    // cold slots in LDS; the others head the scratch row. Eight waves per chain (NS = 2, d <= 1024): eight reduction buffers
+    // and eight copies of the level scalars leave room for two (79 KB of the 80 KB a team may use at two teams per CU)
+    static constexpr int kColdLds = W >= 8 ? (LMC_PAIR_COLD_LDS < 2 ? LMC_PAIR_COLD_LDS : 2) : LMC_PAIR_COLD_LDS;
     static constexpr int kL1 = kCold + kColdLds * DP;             // level 1: {lp, rp, q}
     static constexpr int kL2 = kL1 + 3 * DP;                      // levels 2..nlds: {lp, rp, psum, q}
     static constexpr int kMinDoubles = kL2;                       // head + cold + level 1: what the form needs at least
@@ -686,7 +689,15 @@ struct PairLds {   // offsets in doubles from the start of the block's dynamic L
     __host__ __device__ static constexpr int total_doubles(int nlds) { return kL2 + (nlds > 1 ? (nlds - 1) * 4 * DP : 0); }
 };
 // (ns, w) -> plan sizes for the host (every shape run_kernel is instantiated for)
+// LMC_EXPERIMENTAL_SHAPES (a variant build, tools/c4_shape_ab.sh / tools/c5_team_latency.sh): shapes that were measured and
+// lost -- eight waves of two elements (C4: 1.48e8 against <4,4>'s 2.11e8, profiles/r05_c4_shape_ab.txt), and the d = 256
+// teams <2,2> / <1,4> (a lone chain's leapfrog is slower on them than on <4,1>, profiles/r05_c5_team_latency.txt). Selected
+// per engine with LMC_RUN_SHAPE="ns,w".
+#ifdef LMC_EXPERIMENTAL_SHAPES
+#define LMC_PAIR_SHAPES(X) X(1, 1) X(2, 1) X(4, 1) X(4, 2) X(4, 4) X(2, 8) X(2, 2) X(1, 4)
+#else
 #define LMC_PAIR_SHAPES(X) X(1, 1) X(2, 1) X(4, 1) X(4, 2) X(4, 4)
+#endif
 constexpr int pair_min_doubles(int ns, int w) {
 #define X(NSV, WV) if (ns == NSV && w == WV) return PairLds<NSV, WV>::kMinDoubles;
     LMC_PAIR_SHAPES(X)
@@ -1284,8 +1295,11 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
 #ifndef LMC_WAVES_NS4
 #define LMC_WAVES_NS4 2
 #endif
-constexpr int run_waves_per_simd(int ns) {
-    return ns <= 1 ? LMC_WAVES_NS1 : ns == 2 ? LMC_WAVES_NS2 : ns == 4 ? LMC_WAVES_NS4 : 1;
+#ifndef LMC_WAVES_NS2_W8
+#define LMC_WAVES_NS2_W8 4   // eight waves per chain = two per SIMD: two chains per CU need four waves per SIMD (128 VGPRs)
+#endif
+constexpr int run_waves_per_simd(int ns, int w = 1) {
+    return (ns == 2 && w == 8) ? LMC_WAVES_NS2_W8 : ns <= 1 ? LMC_WAVES_NS1 : ns == 2 ? LMC_WAVES_NS2 : ns == 4 ? LMC_WAVES_NS4 : 1;
 }
 // LDS carve (doubles) behind the subtree stack: MT19937 state (624 words), team exchange area, RNG re-broadcast
 constexpr int kLdsMtDoubles = 320;
@@ -1293,8 +1307,8 @@ constexpr int kLdsMtDoubles = 320;
 #define LMC_MT_IN_LDS_W1 1   // one-wave kernels: 1 keeps the MT19937 state in LDS for the launch, 0 uses it in place (L2)
 #endif
 constexpr bool run_mt_in_lds(int w) { return w > 1 || LMC_MT_IN_LDS_W1; }
-constexpr int lds_tail_doubles(int w) {   // W == 4: a second MT19937 buffer behind everything (team_normals_parallel)
-    return w == 1 ? (run_mt_in_lds(1) ? kLdsMtDoubles : 0) : kLdsMtDoubles + 2 * w * kTeamSlots + 4 + (w == 4 ? kLdsMtDoubles : 0);
+constexpr int lds_tail_doubles(int w) {   // W >= 4: a second MT19937 buffer behind everything (team_normals_parallel)
+    return w == 1 ? (run_mt_in_lds(1) ? kLdsMtDoubles : 0) : kLdsMtDoubles + 2 * w * kTeamSlots + 4 + (w >= 4 ? kLdsMtDoubles : 0);
 }
 
 // ---- pieces of the iteration body shared by the diagonal and the dense-mass kernels ---------------------------
@@ -1521,7 +1535,7 @@ __device__ __forceinline__ void diag_mass_update(const CA& A, const PT& P, long 
 // RNG = 0: the reference's stream (numpy legacy MT19937 + polar method, same-seed parity); 1: momentum from Philox
 // (philox_normals: the throughput mode, its own kernel instantiation so that the parity kernels are untouched by it)
 template <int NS, int W, template <int> class TargetT, int RNG = 0>
-__global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(ChainArrays, SamplerParams, const double* tparams) {
+__global__ __launch_bounds__(64 * W, run_waves_per_simd(NS, W)) void run_kernel(ChainArrays, SamplerParams, const double* tparams) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const long long t_resident = wall_clock64();   // constant-rate clock: the chain's residence time (kCtWaveTicks)
     // the two argument structs are read from the kernarg segment region by region (KernArgs above), never held by value
@@ -1561,7 +1575,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS)) void run_kernel(Cha
     RngState rng;
     uint32_t* mt_glb = A0.mt + static_cast<long long>(c) * kMtN;
     uint32_t* mt_lds = reinterpret_cast<uint32_t*>(lds + lds_doubles);
-    uint32_t* mt_lds2 = reinterpret_cast<uint32_t*>(rng_bcast + 4);   // W == 4 only: the generation being twisted out of place
+    uint32_t* mt_lds2 = reinterpret_cast<uint32_t*>(rng_bcast + 4);   // W >= 4 only: the generation being twisted out of place
     constexpr bool kMtInLds = run_mt_in_lds(W);
     if constexpr (kMtInLds) {
         for (int i = tid; i < kMtN; i += 64 * W) mt_lds[i] = mt_glb[i];

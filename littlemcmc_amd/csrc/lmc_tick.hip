@@ -5,6 +5,21 @@
 
 namespace lmc {
 
+// chains that still want evaluations (only launched when the host asks: one atomic per 256 chains, not per chain
+// per tick -- 65 536 atomics on one address cost more than the rest of the tick)
+__global__ __launch_bounds__(256) void tick_count_kernel(TickArrays K, int chains) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const bool active = c < chains && K.phase[c] != kTickDone;
+    const unsigned long long m = ballot64(active);
+    __shared__ int part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int n = part[0] + part[1] + part[2] + part[3];
+        if (n) atomicAdd(K.n_active, n);
+    }
+}
+
 int tick_launch(int ns, hipStream_t stream, const ChainArrays& A, const TickArrays& K, const SamplerParams& P,
                 const double* logp, const double* grad) {
     const dim3 grid(A.chains), block(64);

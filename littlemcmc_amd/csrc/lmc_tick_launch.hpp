@@ -51,7 +51,7 @@ int tick_launch(int ns, hipStream_t stream, const ChainArrays& A, const TickArra
 int tick_launch_begin(int ns, hipStream_t stream, const ChainArrays& A, const TickArrays& K, long long iter_begin);
 int tick_launch_count(hipStream_t stream, const TickArrays& K, int chains);   // K.n_active += chains not yet done
 
-// per-chain HBM row of the dense tick kernel (lmc_tick_dense.hpp): 0-4 left end {q, p, g, v, w}, 5-9 right end, p_sum,
+// per-chain HBM row of the dense tick kernel (lmc_dense.hip: TickDenseMass): 0-4 left end {q, p, g, v, w}, 5-9 right end, p_sum,
 // proposal q, half-stepped momentum, the start state's stored velocity, then 6 vectors per subtree level
 constexpr int kSlotPsum = 10, kSlotProp = 11, kSlotHalf = 12, kSlotV0s = 13, kTickDenseFixedSlots = 14;
 constexpr int tick_dense_scratch_vectors(int max_levels) { return kTickDenseFixedSlots + 6 * max_levels; }

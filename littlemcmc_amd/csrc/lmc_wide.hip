@@ -5,7 +5,7 @@
 
 #include "../../include/lmc_hip.h"
 #include "lmc_wide.hpp"
-#include "lmc_tick_wide.hpp"
+#include "lmc_tick.hpp"
 #include "lmc_wide_launch.hpp"
 #ifdef LMC_USER_TARGET_HEADER
 #include LMC_USER_TARGET_HEADER
@@ -121,7 +121,35 @@ int wide_launch_momentum(int ns, int w, hipStream_t stream, const ChainArrays& A
     return static_cast<int>(hipGetLastError());
 }
 
-// the tick kernels of the wide shapes (lmc_tick_wide.hpp, generated from lmc_tick.hpp): externally evaluated densities
+// ---- the tick state machine (lmc_tick.hpp: tick_step) for the shapes of the general kernels: externally evaluated densities
+// (a Python callable, a batched torch callable) beyond 1024 dimensions. One chain = a workgroup of 16 wavefronts, model_ndim
+// up to 16 384, diagonal mass matrices. What differs from the one-wavefront shape: the team's reductions and barriers, the
+// normals drawn 1024 at a time by wave 0 (numpy's stream is sequential), the uniform stream shared by the team.
+struct TickWideShape {
+    typedef WideTeam TeamT;
+    static constexpr int kThreads = kWideThreads;
+    TeamT tm;
+    double* bcast;
+    __device__ __forceinline__ TickWideShape(double* lds, int dpad) {
+        tm.xbuf = lds + wide_stage_doubles(dpad);
+        tm.parity = 0;
+        bcast = tm.xbuf + 2 * kWideWaves * kTeamSlots;
+    }
+    template <int NS>
+    __device__ __forceinline__ void normals(RngState& rng, int d, int, double* lds, double (&z)[NS]) {
+        wide_normals_regs<NS>(tm, rng, d, lds, bcast, z);
+    }
+};
+
+template <int NS>
+__global__ __launch_bounds__(kWideThreads, 1) void tick_wide_kernel(ChainArrays A, TickArrays K, SamplerParams P, const double* logp_in,
+                                                                     const double* grad_in) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // wide_stage_doubles(dpad): normals chunk + staging / sdot staging; team exchange; broadcast words
+    TickWideShape shape(lds, A.dpad);
+    TickDiagMass<NS> mass(A, static_cast<long long>(blockIdx.x) * A.dpad, static_cast<int>(threadIdx.x));
+    tick_step<NS>(A, K, P, logp_in, grad_in, lds, shape, mass, nullptr);
+}
+
 int tick_wide_launch(int ns, hipStream_t stream, const ChainArrays& A, const TickArrays& K, const SamplerParams& P,
                      const double* logp, const double* grad) {
     const dim3 grid(A.chains), block(kWideThreads);
@@ -134,7 +162,7 @@ int tick_wide_launch(int ns, hipStream_t stream, const ChainArrays& A, const Tic
 int tick_wide_launch_begin(int ns, hipStream_t stream, const ChainArrays& A, const TickArrays& K, long long iter_begin) {
     const dim3 grid(A.chains), block(kWideThreads);
     (void)hipGetLastError();
-    WIDE_NS_SWITCH(ns, hipLaunchKernelGGL((tick_wide_begin_kernel<NS>), grid, block, 0, stream, A, K, iter_begin))
+    WIDE_NS_SWITCH(ns, hipLaunchKernelGGL((tick_begin_kernel<NS, kWideThreads>), grid, block, 0, stream, A, K, iter_begin))
     return static_cast<int>(hipGetLastError());
 }
 

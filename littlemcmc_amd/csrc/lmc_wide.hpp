@@ -29,7 +29,7 @@ namespace lmc {
 constexpr int kWideWaves = 16;
 constexpr int kWideThreads = 64 * kWideWaves;
 constexpr int kWideChunk = 1024;   // normals per rng_normals() call (the stream semantics do not depend on the chunking)
-typedef Team<kWideWaves> WideTeam;   // the tick kernel of the wide shapes (lmc_tick_wide.hpp) always uses the large team
+typedef Team<kWideWaves> WideTeam;   // the tick kernel of the wide shapes (lmc_wide.hip: TickWideShape) always uses the large team
 
 // vectors of the chain's scratch row (dpad doubles each)
 enum WideSlot : int {

@@ -297,7 +297,7 @@ class TorchTarget(DeviceTarget):
 
     ``TorchTarget.from_logp(d, logp_fn)`` builds the gradient with autograd from ``logp_fn(q) -> [chains]``.
     Limits: d <= 16 384 with diagonal mass matrices (beyond 1 024 the chain is a workgroup of 16 wavefronts:
-    csrc/lmc_tick_wide.hpp); dense mass matrices (QuadPotentialFull*, init="adapt_full") as for
+    csrc/lmc_tick.hpp: tick_step with TickWideShape, lmc_wide.hip); dense mass matrices (QuadPotentialFull*, init="adapt_full") as for
     the fused kernels up to d = 256. A fused ``UserTarget`` is several times faster (no HBM round trip of
     the chain state per leapfrog); this is the path for "cannot write device code".
     """

@@ -224,27 +224,25 @@ def test_torch_target_host_contract_without_a_gpu():
     assert torch.allclose(lp, torch.full((2,), -1.5, dtype=torch.float64)) and torch.allclose(g, -torch.ones(2, 3, dtype=torch.float64))
 
 
-def test_generated_dense_tick_kernel_is_current():
-    """csrc/lmc_tick_dense.hpp is generated from csrc/lmc_tick.hpp (tools/gen_tick_dense.py): the committed file must be
-    what the generator produces from the committed source."""
-    import importlib.util
+def test_the_tick_state_machine_has_one_statement():
+    """Round 5: the tick state machine (externally evaluated densities) exists ONCE -- csrc/lmc_tick.hpp: tick_step,
+    parameterised by a Shape policy (one wavefront / the 16-wavefront team) and a Mass policy (diagonal / dense). Until
+    round 4 lmc_tick_dense.hpp and lmc_tick_wide.hpp were text-substituted copies produced by tools/gen_tick_*.py; they
+    must not come back, and the three kernels must be instantiations of the one function."""
     import os
+    import re
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("gen_tick_dense", os.path.join(root, "tools", "gen_tick_dense.py"))
-    gen = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(gen)
-    assert open(gen.OUT).read() == gen.TEXT
-
-
-def test_generated_wide_tick_kernel_is_current():
-    """csrc/lmc_tick_wide.hpp (the tick state machine for model_ndim > 1024, one chain = 16 wavefronts) is generated from
-    csrc/lmc_tick.hpp by tools/gen_tick_wide.py: the committed file must be what the generator produces."""
-    import importlib.util
-    import os
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("gen_tick_wide", os.path.join(root, "tools", "gen_tick_wide.py"))
-    gen = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(gen)
-    assert open(gen.OUT).read() == gen.TEXT
+    csrc = os.path.join(root, "littlemcmc_amd", "csrc")
+    for gone in ("lmc_tick_dense.hpp", "lmc_tick_wide.hpp"):
+        assert not os.path.exists(os.path.join(csrc, gone)), gone
+    for gone in ("gen_tick_dense.py", "gen_tick_wide.py"):
+        assert not os.path.exists(os.path.join(root, "tools", gone)), gone
+    text = {f: open(os.path.join(csrc, f)).read() for f in ("lmc_tick.hpp", "lmc_dense.hip", "lmc_wide.hip")}
+    assert len(re.findall(r"void tick_step\(", text["lmc_tick.hpp"])) == 1
+    for f, kernel in (("lmc_tick.hpp", "tick_kernel"), ("lmc_dense.hip", "tick_dense_kernel"), ("lmc_wide.hip", "tick_wide_kernel")):
+        body = text[f][text[f].index("void %s(" % kernel):]
+        assert "tick_step<NS>(" in body[:1200], kernel
+    # the NUTS statements of the machine live in lmc_tick.hpp only
+    for f in ("lmc_dense.hip", "lmc_wide.hip"):
+        assert "subtree_done" not in text[f] and "begin_doubling" not in text[f]

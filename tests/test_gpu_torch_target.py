@@ -207,7 +207,7 @@ def test_graph_replay_of_the_callable_gives_the_same_chains():
 
 
 # ---------------------------------------------------------------------------------------------------
-# torch-callable density x dense mass matrix: csrc/lmc_tick_dense.hpp (generated from lmc_tick.hpp)
+# torch-callable density x dense mass matrix: tick_step of csrc/lmc_tick.hpp with the dense Mass policy (lmc_dense.hip)
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["e2e_nuts_full_ar1_12", "e2e_nuts_fullinv_ar1_12", "e2e_hmc_full_std10",
                                   "e2e_nuts_adaptfull_ar1_10_b", "e2e_nuts_adaptfull_std70"])

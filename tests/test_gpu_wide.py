@@ -461,11 +461,11 @@ def test_wide_engines_on_several_devices_and_interrupts():
     np.testing.assert_array_equal(tr, full)
 
 
-# ---- externally evaluated densities (Python / torch callables) beyond 1024 dimensions: csrc/lmc_tick_wide.hpp ----------
+# ---- externally evaluated densities (Python / torch callables) beyond 1024 dimensions: tick_step with TickWideShape (lmc_wide.hip) ----------
 @pytest.mark.parametrize("name", ["e2e_nuts_ar1_16", "e2e_hmc_c1", "e2e_nuts_std64"])
 def test_goldens_replay_through_the_wide_tick_kernel(golden_dir, name, monkeypatch):
     """LMC_FORCE_WIDE=1 with a torch callable: every iteration of the captured reference chains through the tick state
-    machine of the general kernels (generated from the one-wavefront tick kernel by tools/gen_tick_wide.py)."""
+    machine of the general kernels (tick_step of lmc_tick.hpp instantiated on the 16-wavefront team)."""
     from tests.test_gpu_torch_target import torch_ar1, torch_std_normal
 
     monkeypatch.setenv("LMC_FORCE_WIDE", "1")

@@ -31,9 +31,30 @@ def ar1(q):
     return -0.5 * (q * pq).sum(dim=1), -pq
 
 
-ar1_compiled = None
-for name, tgt in (("fused AR1Target", lmc.targets.AR1(d, rho)), ("TorchTarget (eager, 7 torch kernels / tick)", TorchTarget(d, ar1)),
-                  ("TorchTarget (graph=True: fn replayed as a HIP graph)", TorchTarget(d, ar1, graph=True))):
+# The same density written for the GPU instead of transcribed from the formula: g = -P q as ONE float64 GEMM with the
+# (negated) tridiagonal precision matrix as a dense d x d operand (rocBLAS: matrix cores), logp = 0.5 q.g as a product and a
+# row sum -- three kernels and ~4 passes over the (chains x d) arrays instead of nine kernels and ~20 passes. What a user's
+# callable costs is the user's; this line shows how much of the tick is the callable (the tick kernel itself: profiles/r05_tick_*).
+negP = torch.zeros((d, d), dtype=torch.float64, device="cuda")
+idx = torch.arange(d, device="cuda")
+negP[idx, idx] = -diag
+negP[idx[1:], idx[:-1]] = -off
+negP[idx[:-1], idx[1:]] = -off
+
+
+def ar1_gemm(q):
+    g = q @ negP
+    return 0.5 * (q * g).sum(dim=1), g
+
+
+only = os.environ.get("LMC_TICK_BENCH_ONLY")   # substring filter (profiling runs)
+variants = (("fused AR1Target", lmc.targets.AR1(d, rho)), ("TorchTarget (eager, 9 torch kernels / tick)", TorchTarget(d, ar1)),
+            ("TorchTarget (graph=True: fn replayed as a HIP graph)", TorchTarget(d, ar1, graph=True)),
+            ("TorchTarget (GEMM form, 4 torch kernels / tick)", TorchTarget(d, ar1_gemm)),
+            ("TorchTarget (GEMM form, graph=True)", TorchTarget(d, ar1_gemm, graph=True)))
+for name, tgt in variants:
+    if only and only not in name:
+        continue
     step = lmc.NUTS(tgt, d)
     eng = step._make_engine(chains)
     eng.seed(np.arange(chains, dtype=np.uint32) + 1)
