@@ -115,16 +115,17 @@ def test_e2e_golden_through_sample_api(golden_dir, name):
     _t, _s, margins = orc.sample(f, d, draws=draws, tune=tune, step=ostep, chains=chains,
                                  random_seed=int(g["random_seed"]), discard_tuned_samples=False,
                                  record_margins=True, **okw)
-    verified = 0
+    verified, per_chain = 0, []
     for c in range(chains):
         got = {n_: stats[n_][c, :, 0] for n_ in stats}
         want = {n_: g["stat_" + n_][c, :, 0] for n_ in stats}
-        verified += assert_chain_matches(trace[c], got, g["trace"][c], want, margins[c],
-                                         label="%s chain %d" % (name, c))
+        per_chain.append(assert_chain_matches(trace[c], got, g["trace"][c], want, margins[c],
+                                              label="%s chain %d" % (name, c)))
+        verified += per_chain[-1]
     # whole tuned chains are chaotic (see test_every_iteration_of_the_golden_runs, which checks EVERY iteration from
     # the oracle's own state): require a solid prefix. Deep trees at d = 128 amplify the float32 start-energy
     # rounding faster (60+ leapfrogs per iteration feeding dual averaging), so their prefix is shorter.
-    print("%s: %d of %d iterations verified as one chain" % (name, verified, chains * (tune + draws)))
+    print("%s: %d of %d iterations verified as one chain (per chain: %s of %d)" % (name, verified, chains * (tune + draws), per_chain, tune + draws))
     # Floors = what this build measures on MI355X (round 3: 1637, 71, 39, 149, 159, 105, 400, 32 iterations summed over the
     # captured chains) minus ~20 % for hosts whose float32 BLAS dot rounds differently from the capture host's.
     floors = {"e2e_hmc_c1": 1300, "e2e_nuts_std64": 56, "e2e_nuts_std128": 30, "e2e_nuts_ar1_16": 120,

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """How long do two same-seed chains stay together when ONE float32 rounding differs? (CPU only; writes
-profiles/r04_same_seed_decorrelation.json)
+profiles/r04_same_seed_decorrelation.json; with --strict-order-ceiling also the ceiling of a strict-summation-order device
+build, profiles/r05_same_seed_decorrelation.json)
 
 north_star asks for draws whose per-chain moments "match the reference CPU sampler on identical RNG seeds". Whole tuned
 chains cannot agree bit for bit across machines: dual averaging feeds the acceptance statistic back into the step size
@@ -74,6 +75,45 @@ def one_ulp_experiment():
     return rows
 
 
+def strict_order_ceiling():
+    """Review item (round 4, N3): would a device build that evaluates every dot product in the host BLAS's summation order
+    ("strict order") track a golden chain for all its iterations? Here is its CEILING, measured on the CPU: the oracle
+    against itself with EVERY sum bit-identical (it is the same numpy) and the only difference the one a strict-order device
+    build cannot remove -- its exp / log differ from glibc's by up to an ulp, so the acceptance statistic of an iteration
+    (nuts.py:421-425: an exp of a difference of logaddexp chains) lands on a neighbouring double about every other time.
+    Every iteration's statistic is moved by -1 / 0 / +1 ulp at random (seeded); everything else is identical. The chains
+    part at the same distance as with the float32 start-energy difference above, i.e. where device chains part today:
+    bit-identical sums would not lengthen the prefix; bit-identical transcendentals would be needed as well (numpy's exp /
+    log, glibc's exp / log1p / log with their tables and FMA contraction patterns)."""
+    rows = []
+    for name, fam, d, chains, tune, draws in RUNS:
+        f = OT.make(fam, d)
+        base = orc.sample(f, d, draws=draws, tune=tune, chains=1, random_seed=SEED, discard_tuned_samples=False)[1]
+        real_update = orc.DualAverage.update
+        firsts = []
+        for trial in range(3):
+            rs = np.random.RandomState(1000 + trial)
+
+            def perturbed(self, accept, tune_flag, _real=real_update, _rs=rs):
+                k = _rs.randint(-1, 2)
+                if k:
+                    accept = np.nextafter(accept, 2.0 if k > 0 else -1.0)
+                return _real(self, accept, tune_flag)
+
+            orc.DualAverage.update = perturbed
+            try:
+                pert = orc.sample(f, d, draws=draws, tune=tune, chains=1, random_seed=SEED, discard_tuned_samples=False)[1]
+            finally:
+                orc.DualAverage.update = real_update
+            a = {k: base[k][0, :, 0] for k in base}
+            b = {k: pert[k][0, :, 0] for k in pert}
+            firsts.append(first_difference(a, b))
+        rows.append({"golden": name, "dim": d, "iterations": tune + draws,
+                     "first_iteration_with_a_different_tree_3_trials": firsts})
+        print("%-20s +-1 ulp in every accept statistic: trees differ from iteration %s (of %d)" % (name, firsts, tune + draws))
+    return rows
+
+
 def main():
     host = detect_sdot_mode()
     other = _abi.SDOT_OPENBLAS_HASWELL if host == _abi.SDOT_OPENBLAS_SKYLAKEX else _abi.SDOT_OPENBLAS_SKYLAKEX
@@ -107,7 +147,9 @@ def main():
            "summary": {"median_first_different_tree": float(np.median([r["first_iteration_with_a_different_tree"] for r in rows
                                                                        if r["first_iteration_with_a_different_tree"] is not None])),
                        "chains_never_differing": sum(r["first_iteration_with_a_different_tree"] is None for r in rows)}}
-    path = os.path.join(ROOT, "profiles", "r04_same_seed_decorrelation.json")
+    if "--strict-order-ceiling" in sys.argv:
+        doc["strict_order_ceiling"] = {"what": strict_order_ceiling.__doc__.replace("\n", " "), "rows": strict_order_ceiling()}
+    path = os.path.join(ROOT, "profiles", "r05_same_seed_decorrelation.json" if "strict_order_ceiling" in doc else "r04_same_seed_decorrelation.json")
     with open(path, "w") as fh:
         json.dump(doc, fh, indent=1)
     print("wrote", path, doc["summary"])
