@@ -508,7 +508,14 @@ def main():
             dist.barrier()
         sync_all()
         t0 = time.perf_counter()
+        # Two steps are kept in flight per engine, not all K: the engine picks the LDS plan of a launch when it is ENQUEUED from
+        # the tree sizes the running chains report (results do not depend on it), so the queue must not run ahead of the job;
+        # the wait is for the step before last, while the last one still runs -- the device never idles.
         for s_ in range(K):          # every launch goes out on all GPUs before anything is waited for
+            if s_ >= 2:
+                for k_ in range(len(engs)):
+                    for b_ in range(len(run_streams[k_])):
+                        ev[s_ - 2][k_][b_][1].synchronize()
             for k_, e_ in enumerate(engs):
                 for b_, st_ in enumerate(run_streams[k_]):
                     ev[s_][k_][b_][0].record(st_)

@@ -254,6 +254,8 @@ static thread_local std::string g_last_error;
 struct lmc_engine {
     lmc_config cfg;
     int ns = 0, dpad = 0, nlds = 1, lds_bytes = 0;   // ns: vector width of the W = 1 unit kernels (dpad = 64 * ns)
+    int nlds1 = 1, lds_bytes1 = 0, lds_plan = 0;      // one-wave sampling kernels: the deep-tree LDS plan (PairLds<NS, 1, 1>) and who chooses (0 / 1 pinned, 2 = per launch from the chains' reports)
+    int plan_now = 0;                                 // the plan of the launches being enqueued (lds_plan == 2: follows the tree-size hint with hysteresis)
     bool wide = false;          // the general kernels (lmc_wide.hpp): one chain = 16 wavefronts, dpad = 1024 * ns -- model_ndim > 1024,
                                 // dense matrices beyond 256 dimensions, float64 adaptive diagonals
     double* init_diag64 = nullptr;   // [C][dpad] wide: the initial diagonal in float64
@@ -480,6 +482,32 @@ static int relay_mask_for(long long n) {
     int m = 1;
     while (2LL * m <= n && m < 256) m *= 2;
     return m - 1;
+}
+
+#ifdef LMC_USER_TARGET_HEADER
+static const bool kUserCompiledIn = true;
+#else
+static const bool kUserCompiledIn = false;
+#endif
+// dynamic LDS of a sampling-kernel workgroup under plan 0 (stack + tail: MT19937, team exchange) / plan 1 (stack only)
+static int sampling_lds_bytes(const lmc_engine* e, int plan = 0) {
+    return plan == 1 ? e->lds_bytes1 : e->lds_bytes + lds_tail_doubles(e->run_w) * 8;
+}
+// Which LDS plan the launches enqueued NOW run under (lmc_sampler.hpp: run_kernel<.., PL>; results do not depend on it). Relay
+// chains leave their own mean tree size of the running launch in a pinned host word as they go (stop_request_load), so
+// this costs a host load -- no stream is touched, and a caller that enqueues far ahead of execution simply keeps the plan it
+// started with (sample() and bench.py keep two launches in flight, so the choice follows the job). Hysteresis: up at kPlanUp
+// leapfrogs per iteration, down at kPlanDown.
+static int choose_lds_plan(lmc_engine* e, long long iter_begin) {
+    if (e->lds_plan != 2 || e->cfg.kind != LMC_KIND_NUTS) return e->lds_plan == 1 ? 1 : 0;
+    // The first 200 iterations are the regime the reference itself treats as special (early_max_treedepth, nuts.py:205-208):
+    // step sizes still settle and trees are deeper than the job's own -- a launch that starts there takes plan 0 whatever is
+    // reported (measured: C2 otherwise spends its third and fourth launch in the deep-tree plan, -2.4 %).
+    if (iter_begin < 200) return 0;
+    const int hint = e->stop_host ? __atomic_load_n(e->stop_host + 24, __ATOMIC_ACQUIRE) : 0;
+    if (hint >= kPlanUp) e->plan_now = 1;
+    else if (hint > 0 && hint <= kPlanDown) e->plan_now = 0;
+    return e->plan_now;
 }
 
 static bool pot_f64(int potential) { return potential == LMC_POT_FULL_INV || potential == LMC_POT_FULL_F64; }
@@ -790,6 +818,30 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         if (nlds < 1) nlds = 1;
         e->nlds = nlds;
         e->lds_bytes = pair_total_doubles(e->run_ns, e->run_w, nlds) * 8;
+        // The deep-tree plan of the one-wave kernels (lmc_sampler.hpp: PairLds<NS, 1, 1>, run_kernel's kDynPlan): MT19937 used in
+        // place, one cold slot (none at NS = 4) in LDS, and the room that frees holds stack level 2. Same budget per wave (the
+        // generator's 2.5 KB included, since it is not in LDS under this plan). By default the engine picks the plan of every
+        // launch it enqueues from the tree sizes the running chains report (choose_lds_plan); LMC_LDS_PLAN=0 / 1 pins it (A/B
+        // runs, the bit-identity test), and an explicit cfg.lds_levels (a test knob for plan 0's level count) pins plan 0.
+        e->nlds1 = nlds;
+        e->lds_bytes1 = 0;
+        e->lds_plan = 0;
+        const long budget1 = (163840L / blocks_per_cu) / 1280 * 1280;
+        if (e->run_w == 1 && run_mt_in_lds(1) && cfg->lds_levels <= 0 && pair_min_doubles(e->run_ns, 1, 1) * 8L <= budget1) {
+            int n1 = 1;
+            while (n1 < max_levels && pair_total_doubles(e->run_ns, 1, n1 + 1, 1) * 8L <= budget1) ++n1;
+            e->nlds1 = n1;
+            e->lds_bytes1 = pair_total_doubles(e->run_ns, 1, n1, 1) * 8;
+            e->lds_plan = 2;
+            if (const char* env = std::getenv("LMC_LDS_PLAN")) {
+                if (env[0] == '0') e->lds_plan = 0;
+                else if (env[0] == '1') e->lds_plan = 1;
+            }
+            if (e->nlds1 <= e->nlds) e->lds_plan = 0;   // nothing gained: the plan would only move the generator out
+            if (cfg->rng_mode == LMC_RNG_PHILOX || (cfg->target_family == LMC_TARGET_USER && !kUserCompiledIn))
+                e->lds_plan = 0;                         // (instantiated for the built-in densities on the parity stream)
+            e->plan_now = e->lds_plan == 1 ? 1 : 0;
+        }
     }
     if (e->lds_bytes > 160 * 1024) return bail(fail(nullptr, LMC_ERR_INVALID, "lds_levels too large"));
 
@@ -829,6 +881,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         std::memset(e->stop_host, 0, 128);
         A.stop = static_cast<const int*>(dev_view);
         A.progress = static_cast<int*>(dev_view) + 16;
+        A.tree_hint = static_cast<int*>(dev_view) + 24;   // mean tree size a relay chain reports (choose_lds_plan); 0 = nothing yet
     }
     TRY_ALLOC(dev_alloc(e, &A.stop_dev, 1));   // what the relay chains set and every chain reads (zeroed)
     TRY_ALLOC(dev_alloc(e, &e->seeds, C));
@@ -985,11 +1038,6 @@ void lmc_engine_destroy(lmc_engine* e) {
 }
 
 // ---- run-time compiled user density ------------------------------------------------------------------------------
-#ifdef LMC_USER_TARGET_HEADER
-static const bool kUserCompiledIn = true;
-#else
-static const bool kUserCompiledIn = false;
-#endif
 
 int lmc_engine_kernel_shape(lmc_engine* e, int32_t* unit_ns, int32_t* run_ns, int32_t* run_w) {
     if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
@@ -1015,7 +1063,7 @@ int lmc_engine_occupancy(lmc_engine* e, int32_t* resident_chains, int32_t* waves
     if (e->cfg.target_family == LMC_TARGET_EXTERNAL || e->cfg.potential >= LMC_POT_FULL || e->wide) return LMC_OK;
     int cus = 0;
     HIP_TRY(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device));
-    const int run_lds = e->lds_bytes + lds_tail_doubles(e->run_w) * 8;
+    const int run_lds = sampling_lds_bytes(e);
     const int block = 64 * e->run_w;
     int per_cu = 0;
     if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledIn) {
@@ -1059,7 +1107,7 @@ int lmc_engine_occupancy(lmc_engine* e, int32_t* resident_chains, int32_t* waves
 int32_t lmc_engine_run_lds_bytes(lmc_engine* e) {
     if (!e || e->cfg.target_family == LMC_TARGET_EXTERNAL || (e->cfg.potential >= LMC_POT_FULL && !e->wide)) return -1;
     if (e->wide) return e->lds_bytes;
-    return e->lds_bytes + lds_tail_doubles(e->run_w) * 8;
+    return sampling_lds_bytes(e, e->plan_now);
 }
 
 int lmc_engine_load_user_kernels(lmc_engine* e, const void* code_object, const char* run_name, const char* trajectory_name,
@@ -1693,6 +1741,8 @@ int lmc_engine_reset_tuning(lmc_engine* e) {
     if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     if (e->stop_host) __atomic_store_n(e->stop_host + 16, 0, __ATOMIC_RELEASE);   // progress hint: iteration 0 again
+    if (e->stop_host) __atomic_store_n(e->stop_host + 24, 0, __ATOMIC_RELEASE);   // tree-size hint: nothing reported yet
+    if (e->lds_plan == 2) e->plan_now = 0;
     // QuadPotentialDiag.reset() is a no-op (quadpotential.py:138-140): only the adaptive potential resets
     int rc = launch_reset(e, 1, e->cfg.potential == LMC_POT_DIAG_ADAPT ? 1 : 0);
     if (rc != LMC_OK) return rc;
@@ -1812,10 +1862,19 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
     SamplerParams P = make_params(e, n_tune, iter_begin, n_iters);
     if (e->wide) return wide_run(e, P);
     if (e->cfg.potential >= LMC_POT_FULL) return dense_run(e, P);
-    const int run_lds = e->lds_bytes + lds_tail_doubles(e->run_w) * 8;   // subtree stack + MT19937 + team exchange
+    const int plan = choose_lds_plan(e, iter_begin);
+    if (plan == 1) {   // the deep-tree plan: its own level count, no generator behind the stack
+        P.nlds = e->nlds1;
+        P.lds_doubles = e->lds_bytes1 / 8;
+    }
+    const int run_lds = sampling_lds_bytes(e, plan);   // subtree stack (+ MT19937 + team exchange under plan 0)
     const dim3 block(64 * e->run_w);
     const int n_sub = e->n_sub;
     HIP_TRY(e, order_sub_blocks_after_main(e));
+#define RUN_PLAN1(NSV, WV, T)                                                                                  \
+    if constexpr (WV == 1) {                                                                                   \
+        LMC_LAUNCH((run_kernel<NSV, 1, T, 0, 1>), grid, block, run_lds, st, e->A, P, e->tparams);              \
+    }
 #define RUN_ONE(NSV, WV, T)                                                                                    \
     if (!found && e->run_ns == NSV && e->run_w == WV) {                                                        \
         found = true;                                                                                          \
@@ -1824,6 +1883,8 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
                 HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NSV, WV, T, 1>),      \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, run_lds));          \
             LMC_LAUNCH((run_kernel<NSV, WV, T, 1>), grid, block, run_lds, st, e->A, P, e->tparams);            \
+        } else if (plan == 1) {                                                                                \
+            RUN_PLAN1(NSV, WV, T)                                                                              \
         } else {                                                                                               \
             if (run_lds > 64 * 1024)                                                                           \
                 HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&run_kernel<NSV, WV, T>),         \
@@ -1854,6 +1915,7 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
     }
 #undef RUN_CALL
 #undef RUN_ONE
+#undef RUN_PLAN1
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, order_external_stream_after_sub_blocks(e));
     return LMC_OK;

@@ -85,6 +85,7 @@ struct ChainArrays {
     const double* step_override;   // [C] step sizes chosen by the host for the next iteration (P.step_jitter == 2), else nullptr
     int* progress;        // [1] pinned host word: the iteration index a relay chain last started (lmc_engine_progress: a hint the
                           //     host reads without touching a stream)
+    int* tree_hint;       // [1] pinned host word (or nullptr): a relay chain's mean tree size in its launch so far (the LDS plan choice)
     const uint32_t* seed; // [C] the seeds of lmc_engine_seed (key of the counter-based momentum stream, LMC_RNG_PHILOX)
     double* mom_mean;     // [C][dpad] running mean of the post-warm-up draws (nullptr = not kept)
     double* mom_m2;       // [C][dpad] running sum of squared deviations (Welford)
@@ -669,7 +670,7 @@ constexpr int kLevelScalDoubles = 96;   // 4 per parked level, levels < 24 (max_
 enum ColdSlot : int { kColdAold = 0, kColdPsum = 1, kColdOp = 2, kColdOq = 3, kColdOg = 4, kNumCold = 5 };
 constexpr int kNumColdSlots = kNumCold;
 
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 struct PairLds {   // offsets in doubles from the start of the block's dynamic LDS; W waves share one plan
     static constexpr int DP = 64 * NS * W;
     static constexpr int kRedWave = 64 * kRedValues;              // one reduction buffer per wave
@@ -681,7 +682,13 @@ struct PairLds {   // offsets in doubles from the start of the block's dynamic L
     static constexpr int kCold = kScal + W * kLevelScalDoubles;
     // cold slots in LDS; the others head the scratch row. Eight waves per chain (NS = 2, d <= 1024): eight reduction buffers
     // and eight copies of the level scalars leave room for two (79 KB of the 80 KB a team may use at two teams per CU)
-    static constexpr int kColdLds = W >= 8 ? (LMC_PAIR_COLD_LDS < 2 ? LMC_PAIR_COLD_LDS : 2) : LMC_PAIR_COLD_LDS;
+    // PL = 1 (one-wave kernels only): the DEEP-TREE plan -- the MT19937 state is used in place (L2) and only the first cold slot
+    // (NS <= 2; none at NS = 4) stays in LDS, which makes room for stack level 2. Measured (profiles/r05_c3_level2_lds_ab.txt,
+    // r05_level2_lds_ab_others.txt): C3 +7.5 %, C5 +2.4 %, but depth-3 trees -8 ... -11 % (the momentum draw reads the
+    // generator through L2) -- so the engine picks the plan per launch from the tree sizes the chains report (run_kernel<.., PL>).
+    static_assert(PL == 0 || W == 1, "the deep-tree plan exists for one-wave kernels");
+    static constexpr int kColdLds = PL == 1 ? (NS >= 4 ? 0 : (LMC_PAIR_COLD_LDS < 1 ? LMC_PAIR_COLD_LDS : 1))
+                                            : (W >= 8 ? (LMC_PAIR_COLD_LDS < 2 ? LMC_PAIR_COLD_LDS : 2) : LMC_PAIR_COLD_LDS);
     static constexpr int kL1 = kCold + kColdLds * DP;             // level 1: {lp, rp, q}
     static constexpr int kL2 = kL1 + 3 * DP;                      // levels 2..nlds: {lp, rp, psum, q}
     static constexpr int kMinDoubles = kL2;                       // head + cold + level 1: what the form needs at least
@@ -698,14 +705,14 @@ struct PairLds {   // offsets in doubles from the start of the block's dynamic L
 #else
 #define LMC_PAIR_SHAPES(X) X(1, 1) X(2, 1) X(4, 1) X(4, 2) X(4, 4)
 #endif
-constexpr int pair_min_doubles(int ns, int w) {
-#define X(NSV, WV) if (ns == NSV && w == WV) return PairLds<NSV, WV>::kMinDoubles;
+constexpr int pair_min_doubles(int ns, int w, int plan = 0) {
+#define X(NSV, WV) if (ns == NSV && w == WV) return (plan == 1 && WV == 1) ? PairLds<NSV, 1, 1>::kMinDoubles : PairLds<NSV, WV, 0>::kMinDoubles;
     LMC_PAIR_SHAPES(X)
 #undef X
     return 1 << 30;
 }
-constexpr int pair_total_doubles(int ns, int w, int nlds) {
-#define X(NSV, WV) if (ns == NSV && w == WV) return PairLds<NSV, WV>::total_doubles(nlds);
+constexpr int pair_total_doubles(int ns, int w, int nlds, int plan = 0) {
+#define X(NSV, WV) if (ns == NSV && w == WV) return (plan == 1 && WV == 1) ? PairLds<NSV, 1, 1>::total_doubles(nlds) : PairLds<NSV, WV, 0>::total_doubles(nlds);
     LMC_PAIR_SHAPES(X)
 #undef X
     return 1 << 30;
@@ -723,7 +730,7 @@ struct PairCtx {
 };
 
 // ---- batched lane reductions through LDS ("transposed" reduction)
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ void red_put(const PairCtx& cx, int v, double x) {
     if constexpr (W == 1) ((lds_double*)cx.lds)[v * 64 + lane_id()] = x;
     else ((lds_double*)cx.lds)[v * 64 + lane_id() + cx.wave_red] = x;
@@ -733,7 +740,7 @@ __device__ __forceinline__ void red_put(const PairCtx& cx, int v, double x) {
 // Team (W > 1): every wave reduces its own buffer, lanes 8k+7 drop the wave's six sums into a double-buffered combine
 // area, ONE barrier, every wave adds the W partials in wave order (the same value in every wave). A wave can reach
 // the next-but-one reduction (same buffer) only after every wave has passed the barrier in between.
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ double red_gather(PairCtx& cx) {
     typedef double d2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) d2 lds_d2;
@@ -754,7 +761,7 @@ __device__ __forceinline__ double red_gather(PairCtx& cx) {
     s += dpp_f64<0x114>(s);
     if constexpr (W > 1) {
         const int lane = lane_id();
-        lds_double* xs = L + (PairLds<NS, W>::kXsum + cx.xpar * (8 * W)) + (lane >> 3) * W;
+        lds_double* xs = L + (PairLds<NS, W, PL>::kXsum + cx.xpar * (8 * W)) + (lane >> 3) * W;
         if ((lane & 7) == 7) xs[cx.wave] = s;
         __syncthreads();
         double t = xs[0];
@@ -807,13 +814,13 @@ __device__ __forceinline__ ExpLanesConst exp_lanes_const() {
 #endif
     return c;
 }
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ double exp_lanes(const PairCtx& cx, const ExpLanesConst& c, double x) {
     const double kf = rint(x * c.inv);
     double r = __builtin_fma(-kf, c.hi, x);
     r = __builtin_fma(-kf, c.lo, r);
     const int ki = static_cast<int>(kf);
-    const double t = ((const lds_double*)cx.lds)[PairLds<NS, W>::kExp + (ki & 31)];
+    const double t = ((const lds_double*)cx.lds)[PairLds<NS, W, PL>::kExp + (ki & 31)];
     double p = fma_sgpr_addend(r, c.c6, c.c5);
     p = fma_sgpr_addend(p, r, c.c4);
     p = fma_sgpr_addend(p, r, c.c3);
@@ -824,101 +831,101 @@ __device__ __forceinline__ double exp_lanes(const PairCtx& cx, const ExpLanesCon
 }
 
 // ---- cold slots and subtree-stack levels: LDS offsets are immediates, the scratch row takes what does not fit
-template <int NS, int W, int SLOT>
+template <int NS, int W, int PL, int SLOT>
 __device__ __forceinline__ void cold_load(const PairCtx& cx, double (&x)[NS]) {
-    using L = PairLds<NS, W>;
+    using L = PairLds<NS, W, PL>;
     if constexpr (SLOT < L::kColdLds) vload_as<NS>((lds_double*)cx.lds + (L::kCold + SLOT * L::DP), x);
     else vload_as<NS>((glb_double*)cx.glb + (SLOT - L::kColdLds) * L::DP, x);
 }
-template <int NS, int W, int SLOT>
+template <int NS, int W, int PL, int SLOT>
 __device__ __forceinline__ void cold_store(const PairCtx& cx, const double (&x)[NS]) {
-    using L = PairLds<NS, W>;
+    using L = PairLds<NS, W, PL>;
     if constexpr (SLOT < L::kColdLds) vstore_as<NS>((lds_double*)cx.lds + (L::kCold + SLOT * L::DP), x);
     else vstore_as<NS>((glb_double*)cx.glb + (SLOT - L::kColdLds) * L::DP, x);
 }
 // level 1 (always LDS): {lp, rp, q}
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ void level1_load(const PairCtx& cx, double (&lp)[NS], double (&rp)[NS], double (&ps)[NS]) {
-    using L = PairLds<NS, W>;
+    using L = PairLds<NS, W, PL>;
     lds_double* b = (lds_double*)cx.lds + L::kL1;
     vload_as<NS>(b, lp); vload_as<NS>(b + L::DP, rp);
 #pragma unroll
     for (int s = 0; s < NS; ++s) ps[s] = lp[s] + rp[s];   // the very sum the pair formed (nuts.py:386)
 }
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ void level1_store(const PairCtx& cx, const double (&lp)[NS], const double (&rp)[NS], const double (&pq)[NS]) {
-    using L = PairLds<NS, W>;
+    using L = PairLds<NS, W, PL>;
     lds_double* b = (lds_double*)cx.lds + L::kL1;
     vstore_as<NS>(b, lp); vstore_as<NS>(b + L::DP, rp); vstore_as<NS>(b + 2 * L::DP, pq);
 }
 // offset (doubles) of vector v of level j > nlds in the scratch row. Opaque to the optimiser on purpose: a
 // loop-invariant level (the peeled j = 2) would otherwise get its per-lane 64-bit address precomputed outside the pair
 // loop and kept in (spilled) registers; this way the access is scalar base + uniform offset + the lane-offset register
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ unsigned glb_level_offset(const PairCtx& cx, int j, int v) {
-    using L = PairLds<NS, W>;
+    using L = PairLds<NS, W, PL>;
     unsigned off = L::kGlbLevels + static_cast<unsigned>(j - cx.nlds - 1) * (4u * L::DP) + static_cast<unsigned>(v) * L::DP;
     asm volatile("" : "+s"(off));
     return off;
 }
 // levels j >= 2: {lp, rp, psum, q}; vector index v in 0..3
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ void levelN_load(const PairCtx& cx, int j, int v, double (&x)[NS]) {
-    using L = PairLds<NS, W>;
+    using L = PairLds<NS, W, PL>;
     int nl = cx.nlds;
     asm volatile("" : "+s"(nl));   // compared afresh (one s_cmp): hoisted, the loop-invariant test lives in a spilled lane mask
     if (j <= nl) vload_as<NS>((lds_double*)cx.lds + (L::kL2 + (j - 2) * 4 * L::DP + v * L::DP), x);
-    else vload_as<NS>((glb_double*)cx.glb + glb_level_offset<NS, W>(cx, j, v), x);
+    else vload_as<NS>((glb_double*)cx.glb + glb_level_offset<NS, W, PL>(cx, j, v), x);
 }
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ void levelN_store(const PairCtx& cx, int j, int v, const double (&x)[NS]) {
-    using L = PairLds<NS, W>;
+    using L = PairLds<NS, W, PL>;
     int nl = cx.nlds;
     asm volatile("" : "+s"(nl));
     if (j <= nl) vstore_as<NS>((lds_double*)cx.lds + (L::kL2 + (j - 2) * 4 * L::DP + v * L::DP), x);
-    else vstore_as<NS>((glb_double*)cx.glb + glb_level_offset<NS, W>(cx, j, v), x);
+    else vstore_as<NS>((glb_double*)cx.glb + glb_level_offset<NS, W, PL>(cx, j, v), x);
 }
 // left-end momentum / proposal position of any level j >= 1
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ void level_load_lp(const PairCtx& cx, int j, double (&x)[NS]) {
-    if (j == 1) vload_as<NS>((lds_double*)cx.lds + PairLds<NS, W>::kL1, x); else levelN_load<NS, W>(cx, j, 0, x);
+    if (j == 1) vload_as<NS>((lds_double*)cx.lds + PairLds<NS, W, PL>::kL1, x); else levelN_load<NS, W, PL>(cx, j, 0, x);
 }
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ void level_load_q(const PairCtx& cx, int j, double (&x)[NS]) {
-    if (j == 1) vload_as<NS>((lds_double*)cx.lds + (PairLds<NS, W>::kL1 + 2 * PairLds<NS, W>::DP), x); else levelN_load<NS, W>(cx, j, 3, x);
+    if (j == 1) vload_as<NS>((lds_double*)cx.lds + (PairLds<NS, W, PL>::kL1 + 2 * PairLds<NS, W, PL>::DP), x); else levelN_load<NS, W, PL>(cx, j, 3, x);
 }
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ void level_scal_put(const PairCtx& cx, int j, double w, double a, double pe, double plogp) {
     if (lane_id() == 0) {
-        lds_double* s = (lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * j) + (W > 1 ? cx.wave_scal : 0);
+        lds_double* s = (lds_double*)cx.lds + (PairLds<NS, W, PL>::kScal + 4 * j) + (W > 1 ? cx.wave_scal : 0);
         s[0] = w; s[1] = a; s[2] = pe; s[3] = plogp;
     }
 }
 // weights of level j only (the proposal's energy / log-density stay where they are until a node is parked or accepted)
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ void level_scal_get_wa(const PairCtx& cx, int j, double& w, double& a) {
-    const lds_double* s = (const lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * j) + (W > 1 ? cx.wave_scal : 0);
+    const lds_double* s = (const lds_double*)cx.lds + (PairLds<NS, W, PL>::kScal + 4 * j) + (W > 1 ? cx.wave_scal : 0);
     w = s[0]; a = s[1];
 }
 // scalars of a node parked at level j: weights from the caller; the proposal's {energy, log-density} from their source --
 // lane `elane` of (en, lp) when the proposal is a leaf of the current pair (src < 0: that lane stores them itself, no
 // cross-lane read), else copied from level src
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ void level_scal_park(const PairCtx& cx, int j, double w, double a, int src, int elane, double en, double lp) {
-    lds_double* s = (lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * j) + (W > 1 ? cx.wave_scal : 0);
+    lds_double* s = (lds_double*)cx.lds + (PairLds<NS, W, PL>::kScal + 4 * j) + (W > 1 ? cx.wave_scal : 0);
     const int lane = lane_id();
     if (src < 0) {
         if (lane == elane) { s[2] = en; s[3] = lp; }
     } else {
-        const lds_double* f = (const lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * src) + (W > 1 ? cx.wave_scal : 0);
+        const lds_double* f = (const lds_double*)cx.lds + (PairLds<NS, W, PL>::kScal + 4 * src) + (W > 1 ? cx.wave_scal : 0);
         const double pe = f[2], pl = f[3];
         if (lane == 0) { s[2] = pe; s[3] = pl; }
     }
     if (lane == 0) { s[0] = w; s[1] = a; }
 }
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ void level_scal_get(const PairCtx& cx, int j, double& w, double& a, double& pe, double& plogp) {
-    const lds_double* s = (const lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * j) + (W > 1 ? cx.wave_scal : 0);   // same address in every lane: LDS broadcast
+    const lds_double* s = (const lds_double*)cx.lds + (PairLds<NS, W, PL>::kScal + 4 * j) + (W > 1 ? cx.wave_scal : 0);   // same address in every lane: LDS broadcast
     w = s[0]; a = s[1]; pe = s[2]; plogp = s[3];
 }
 
@@ -953,7 +960,7 @@ __device__ __forceinline__ void leapfrog_partial(TeamT& tm, const Target& tgt, c
 }
 
 // one cascade level: node a = {alp, arp, aps} (earlier), in-flight node {tl (left end), tps, right end velocity v}
-template <int NS, int W = 1>
+template <int NS, int W = 1, int PL = 0>
 __device__ __forceinline__ double cascade_dots(PairCtx& cx, const double (&var)[NS], const double (&alp)[NS],
                                                const double (&arp)[NS], const double (&aps)[NS], const double (&tl)[NS],
                                                double (&tps)[NS], const double (&v)[NS]) {
@@ -969,13 +976,13 @@ __device__ __forceinline__ double cascade_dots(PairCtx& cx, const double (&var)[
         d4 = __builtin_fma(p2, varp, d4); d5 = __builtin_fma(p2, v[s], d5);
         tps[s] = ps;
     }
-    red_put<NS, W>(cx, 0, d0); red_put<NS, W>(cx, 1, d1); red_put<NS, W>(cx, 2, d2);
-    red_put<NS, W>(cx, 3, d3); red_put<NS, W>(cx, 4, d4); red_put<NS, W>(cx, 5, d5);
-    return red_gather<NS, W>(cx);
+    red_put<NS, W, PL>(cx, 0, d0); red_put<NS, W, PL>(cx, 1, d1); red_put<NS, W, PL>(cx, 2, d2);
+    red_put<NS, W, PL>(cx, 3, d3); red_put<NS, W, PL>(cx, 4, d4); red_put<NS, W, PL>(cx, 5, d5);
+    return red_gather<NS, W, PL>(cx);
 }
 
 // On return the chain's row of A.q (qrow) holds the proposal; q is NOT updated (the caller reloads it).
-template <int NS, class Target, class TeamT>
+template <int NS, int PL, class Target, class TeamT>
 __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const double (&var)[NS], RngState& rng,
                                         PairCtx& cx, double* qrow, const double (&q)[NS],
                                         const double (&p0)[NS], const double (&g0)[NS], double e0, double logp0,
@@ -986,8 +993,8 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
     // momentum sum and the extended end's momentum before the doubling are cold slots
     double cq[NS], cp[NS], cg[NS];
     vcopy(cq, q); vcopy(cp, p0); vcopy(cg, g0);
-    cold_store<NS, W, kColdOq>(cx, q); cold_store<NS, W, kColdOp>(cx, p0); cold_store<NS, W, kColdOg>(cx, g0);
-    cold_store<NS, W, kColdPsum>(cx, p0);
+    cold_store<NS, W, PL, kColdOq>(cx, q); cold_store<NS, W, PL, kColdOp>(cx, p0); cold_store<NS, W, PL, kColdOg>(cx, g0);
+    cold_store<NS, W, PL, kColdPsum>(cx, p0);
     bool c_right = true;                                    // which end {c*} is
     bool c_start = momentum_f32, o_start = momentum_f32;    // end still is the float32 start state
     double prop_e = e0, prop_logp = logp0;
@@ -999,7 +1006,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
     // c_tot of the moment they were last merged and are brought to the current one only when a subtree is ACCEPTED: a
     // rejected subtree whose leaf moved the offset by more than ~745 would otherwise flush them to zero and the
     // acceptance statistic with them (0/0).
-    lds_double* tot = (lds_double*)cx.lds + PairLds<NS, W>::kScal + (W > 1 ? cx.wave_scal : 0);
+    lds_double* tot = (lds_double*)cx.lds + PairLds<NS, W, PL>::kScal + (W > 1 ? cx.wave_scal : 0);
     if (lane_id() == 0) { tot[0] = 0.0; tot[1] = 0.0; tot[2] = 1.0; tot[3] = 0.0; }
     int depth = 0, n_leap = 0;
     bool diverging = false, turning = false, exhausted = true;
@@ -1048,7 +1055,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                     const double f = exp_uniform(coff - x);
                     const int lane = lane_id();
                     if (lane >= 1 && lane < kLevelScalDoubles / 4) {   // the parked levels {w, a, ..}; slot 0 (totals) keeps its own offset
-                        lds_double* sc = (lds_double*)cx.lds + (PairLds<NS, W>::kScal + 4 * lane) + (W > 1 ? cx.wave_scal : 0);
+                        lds_double* sc = (lds_double*)cx.lds + (PairLds<NS, W, PL>::kScal + 4 * lane) + (W > 1 ? cx.wave_scal : 0);
                         sc[0] = sc[0] * f; sc[1] = sc[1] * f;
                     }
                     coff = x;
@@ -1066,7 +1073,7 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         const double x = -de;
         const double xn = dpp_f64<0x101>(x);                   // row_shl:1: lane l <- lane l+1
         const double arg = odd_lane ? (x - coff) : ((xn - coff) + fmin(xn, 0.0));
-        ev = exp_lanes<NS, W>(cx, ec, arg);
+        ev = exp_lanes<NS, W, PL>(cx, ec, arg);
         return ok;
     };
 
@@ -1075,13 +1082,13 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         const double eps = right ? step_size : -step_size;
         if (right != c_right) {   // the other end becomes the one that is extended
             double t[NS];
-            cold_load<NS, W, kColdOq>(cx, t); cold_store<NS, W, kColdOq>(cx, cq); vcopy(cq, t);
-            cold_load<NS, W, kColdOp>(cx, t); cold_store<NS, W, kColdOp>(cx, cp); vcopy(cp, t);
-            cold_load<NS, W, kColdOg>(cx, t); cold_store<NS, W, kColdOg>(cx, cg); vcopy(cg, t);
+            cold_load<NS, W, PL, kColdOq>(cx, t); cold_store<NS, W, PL, kColdOq>(cx, cq); vcopy(cq, t);
+            cold_load<NS, W, PL, kColdOp>(cx, t); cold_store<NS, W, PL, kColdOp>(cx, cp); vcopy(cp, t);
+            cold_load<NS, W, PL, kColdOg>(cx, t); cold_store<NS, W, PL, kColdOg>(cx, cg); vcopy(cg, t);
             const bool tb = c_start; c_start = o_start; o_start = tb;
             c_right = right;
         }
-        cold_store<NS, W, kColdAold>(cx, cp);   // momentum of the extended end before this doubling (nuts.py:332-338 operands)
+        cold_store<NS, W, PL, kColdAold>(cx, cp);   // momentum of the extended end before this doubling (nuts.py:332-338 operands)
         const bool aold_start = c_start;
 
         // subtree node under construction: momentum sum tps, weights; its right-end momentum is always the current cp,
@@ -1099,8 +1106,8 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         if (D == 0) {
             double v[NS], kinp, lp, en, ev;
             leapfrog_partial<NS>(tm, tgt, var, eps, cq, cp, cg, v, kinp, lp);
-            red_put<NS, W>(cx, 0, kinp); red_put<NS, W>(cx, 1, lp);   // (DPP butterflies for the lone leaf and the trajectory-level
-            const double s0 = red_gather<NS, W>(cx);                   //  test measured 1 % slower on depth-3 trees, equal on C3)
+            red_put<NS, W, PL>(cx, 0, kinp); red_put<NS, W, PL>(cx, 1, lp);   // (DPP butterflies for the lone leaf and the trajectory-level
+            const double s0 = red_gather<NS, W, PL>(cx);                   //  test measured 1 % slower on depth-3 trees, equal on C3)
             if (leaf_scalars(s0, 1, en, ev) == 1) {
                 tw = readlane_f64(ev, 15); ta = readlane_f64(ev, 14);
                 en_last = en; lp_last = s0;
@@ -1111,15 +1118,15 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
             for (int k = 0; k < n_pairs; ++k) {
                 double v[NS], kinA, lpA, kinB, lpB;
                 leapfrog_partial<NS>(tm, tgt, var, eps, cq, cp, cg, v, kinA, lpA);
-                red_put<NS, W>(cx, 0, kinA); red_put<NS, W>(cx, 1, lpA);
+                red_put<NS, W, PL>(cx, 0, kinA); red_put<NS, W, PL>(cx, 1, lpA);
                 vcopy(eq, cq); vcopy(ep, cp);
                 leapfrog_partial<NS>(tm, tgt, var, eps, cq, cp, cg, v, kinB, lpB);   // speculative w.r.t. the first leaf's divergence test
-                red_put<NS, W>(cx, 2, kinB); red_put<NS, W>(cx, 3, lpB);
+                red_put<NS, W, PL>(cx, 2, kinB); red_put<NS, W, PL>(cx, 3, lpB);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) tps[s] = ep[s] + cp[s];
-                red_put<NS, W>(cx, 4, pdot_v<NS>(tps, var, ep));   // var (.) ep is the first leaf's velocity, re-formed (same rounded product)
-                red_put<NS, W>(cx, 5, pdot<NS>(tps, v));
-                const double s0 = red_gather<NS, W>(cx);
+                red_put<NS, W, PL>(cx, 4, pdot_v<NS>(tps, var, ep));   // var (.) ep is the first leaf's velocity, re-formed (same rounded product)
+                red_put<NS, W, PL>(cx, 5, pdot<NS>(tps, v));
+                const double s0 = red_gather<NS, W, PL>(cx);
                 // this pair closes m right children (levels 1..m)
                 const int m = __builtin_ctz(~static_cast<unsigned>(k) | (1u << (D - 1)));
                 double en, ev;
@@ -1141,9 +1148,9 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                 if (m >= 1) {
                     double alp[NS], arp[NS], aps[NS];
                     double aw, aa;
-                    level1_load<NS, W>(cx, alp, arp, aps);   // (requesting it before the leaf scalars measured -8 %: one more live address)
-                    level_scal_get_wa<NS, W>(cx, 1, aw, aa);
-                    const double sj = cascade_dots<NS, W>(cx, var, alp, arp, aps, ep, tps, v);
+                    level1_load<NS, W, PL>(cx, alp, arp, aps);   // (requesting it before the leaf scalars measured -8 %: one more live address)
+                    level_scal_get_wa<NS, W, PL>(cx, 1, aw, aa);
+                    const double sj = cascade_dots<NS, W, PL>(cx, var, alp, arp, aps, ep, tps, v);
                     const bool turn = red_any_nonpositive(sj, 0, 6);
                     const double wsum = aw + tw;
                     const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < tw);
@@ -1154,11 +1161,11 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                 // ---- cascade levels 2..m: node a = stack[j]; the in-flight node's left end is stack[j-1]'s
                 for (int j = 2; j <= m; ++j) {
                     double blp[NS], brp[NS], bps[NS], tl[NS];
-                    levelN_load<NS, W>(cx, j, 0, blp); levelN_load<NS, W>(cx, j, 1, brp); levelN_load<NS, W>(cx, j, 2, bps);
-                    level_load_lp<NS, W>(cx, j - 1, tl);
+                    levelN_load<NS, W, PL>(cx, j, 0, blp); levelN_load<NS, W, PL>(cx, j, 1, brp); levelN_load<NS, W, PL>(cx, j, 2, bps);
+                    level_load_lp<NS, W, PL>(cx, j - 1, tl);
                     double bw, ba;
-                    level_scal_get_wa<NS, W>(cx, j, bw, ba);
-                    const double sj = cascade_dots<NS, W>(cx, var, blp, brp, bps, tl, tps, v);
+                    level_scal_get_wa<NS, W, PL>(cx, j, bw, ba);
+                    const double sj = cascade_dots<NS, W, PL>(cx, var, blp, brp, bps, tl, tps, v);
                     const bool turn = red_any_nonpositive(sj, 0, 6);
                     const double wsum = bw + tw;
                     const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < tw);
@@ -1169,10 +1176,10 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                 if (turning) break;
                 if (k + 1 < n_pairs) {   // park the node at level m + 1 (the last pair's cascade result stays in flight)
                     double tl[NS], tqv[NS];
-                    if (m == 0) vcopy(tl, ep); else level_load_lp<NS, W>(cx, m, tl);
+                    if (m == 0) vcopy(tl, ep); else level_load_lp<NS, W, PL>(cx, m, tl);
                     if (qsrc == -1) vcopy(tqv, cq);
                     else if (qsrc == -2) vcopy(tqv, eq);
-                    else level_load_q<NS, W>(cx, qsrc, tqv);
+                    else level_load_q<NS, W, PL>(cx, qsrc, tqv);
 #ifndef LMC_PARK_REORDER_MIN_NS
 #define LMC_PARK_REORDER_MIN_NS 4
 #endif
@@ -1184,18 +1191,18 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
                     // the ISA, round 4). Measured, alternating runs on one box (profiles/r04_iteration_tail_ab.txt, box 3): C5
                     // +1 ... +2 %, C4 equal; C3 (two-element slices) -0.1 ... -0.4 %, hence the condition.
                     constexpr bool kParkReorder = NS >= LMC_PARK_REORDER_MIN_NS;
-                    if constexpr (kParkReorder) level_scal_park<NS, W>(cx, m + 1, tw, ta, qsrc, elane, en_last, lp_last);
+                    if constexpr (kParkReorder) level_scal_park<NS, W, PL>(cx, m + 1, tw, ta, qsrc, elane, en_last, lp_last);
                     if (m == 0) {
-                        level1_store<NS, W>(cx, tl, cp, tqv);
+                        level1_store<NS, W, PL>(cx, tl, cp, tqv);
                     } else {
                         if constexpr (kParkReorder) {
 #pragma unroll
                             for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(tl[s]), "+v"(tqv[s]));
                         }
-                        levelN_store<NS, W>(cx, m + 1, 0, tl); levelN_store<NS, W>(cx, m + 1, 1, cp);
-                        levelN_store<NS, W>(cx, m + 1, 2, tps); levelN_store<NS, W>(cx, m + 1, 3, tqv);
+                        levelN_store<NS, W, PL>(cx, m + 1, 0, tl); levelN_store<NS, W, PL>(cx, m + 1, 1, cp);
+                        levelN_store<NS, W, PL>(cx, m + 1, 2, tps); levelN_store<NS, W, PL>(cx, m + 1, 3, tqv);
                     }
-                    if constexpr (!kParkReorder) level_scal_park<NS, W>(cx, m + 1, tw, ta, qsrc, elane, en_last, lp_last);
+                    if constexpr (!kParkReorder) level_scal_park<NS, W, PL>(cx, m + 1, tw, ta, qsrc, elane, en_last, lp_last);
                 }
             }
         }
@@ -1214,13 +1221,13 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
             double tqv[NS];
             if (qsrc == -1) vcopy(tqv, cq);
             else if (qsrc == -2) vcopy(tqv, eq);
-            else level_load_q<NS, W>(cx, qsrc, tqv);
+            else level_load_q<NS, W, PL>(cx, qsrc, tqv);
             vstore_as<NS>((glb_double*)qrow, tqv);
             if (qsrc < 0) {
                 prop_e = readlane_f64(en_last, elane); prop_logp = readlane_f64(lp_last, elane);
             } else {
                 double w_, a_;
-                level_scal_get<NS, W>(cx, qsrc, w_, a_, prop_e, prop_logp);
+                level_scal_get<NS, W, PL>(cx, qsrc, w_, a_, prop_e, prop_logp);
                 prop_e = first_f64(prop_e); prop_logp = first_f64(prop_logp);
             }
         }
@@ -1228,14 +1235,14 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
         double tlp[NS], psum[NS], op[NS], aold[NS];
         if (D == 0) vcopy(tlp, cp);
         else if (D == 1) vcopy(tlp, ep);
-        else level_load_lp<NS, W>(cx, D - 1, tlp);
-        cold_load<NS, W, kColdPsum>(cx, psum); cold_load<NS, W, kColdOp>(cx, op); cold_load<NS, W, kColdAold>(cx, aold);
+        else level_load_lp<NS, W, PL>(cx, D - 1, tlp);
+        cold_load<NS, W, PL, kColdPsum>(cx, psum); cold_load<NS, W, PL, kColdOp>(cx, op); cold_load<NS, W, PL, kColdAold>(cx, aold);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {   // in place; float32 storage when the start momentum is float32
             const double t = psum[s] + tps[s];
             psum[s] = momentum_f32 ? static_cast<double>(static_cast<float>(t)) : t;
         }
-        cold_store<NS, W, kColdPsum>(cx, psum);
+        cold_store<NS, W, PL, kColdPsum>(cx, psum);
         double ov[NS], av[NS];   // velocities of the untouched end and of the extended end as it was before this doubling
         end_velocity<NS>(ov, var, op, o_start);
         end_velocity<NS>(av, var, aold, aold_start);
@@ -1260,9 +1267,9 @@ __device__ inline void nuts_transition2(TeamT& tm, const Target& tgt, const doub
             }
         }
         c_start = false;
-        red_put<NS, W>(cx, 0, d0); red_put<NS, W>(cx, 1, d1); red_put<NS, W>(cx, 2, d2);
-        red_put<NS, W>(cx, 3, d3); red_put<NS, W>(cx, 4, d4); red_put<NS, W>(cx, 5, d5);
-        if (red_any_nonpositive(red_gather<NS, W>(cx), 0, 6)) { turning = true; exhausted = false; break; }
+        red_put<NS, W, PL>(cx, 0, d0); red_put<NS, W, PL>(cx, 1, d1); red_put<NS, W, PL>(cx, 2, d2);
+        red_put<NS, W, PL>(cx, 3, d3); red_put<NS, W, PL>(cx, 4, d4); red_put<NS, W, PL>(cx, 5, d5);
+        if (red_any_nonpositive(red_gather<NS, W, PL>(cx), 0, 6)) { turning = true; exhausted = false; break; }
     }
 
     const double wn_end = first_f64(tot[0]), an_end = first_f64(tot[1]);
@@ -1310,6 +1317,10 @@ constexpr bool run_mt_in_lds(int w) { return w > 1 || LMC_MT_IN_LDS_W1; }
 constexpr int lds_tail_doubles(int w) {   // W >= 4: a second MT19937 buffer behind everything (team_normals_parallel)
     return w == 1 ? (run_mt_in_lds(1) ? kLdsMtDoubles : 0) : kLdsMtDoubles + 2 * w * kTeamSlots + 4 + (w >= 4 ? kLdsMtDoubles : 0);
 }
+// The engine switches a launch to the deep-tree LDS plan when the chains report at least kPlanUp leapfrogs per iteration and back
+// when they report at most kPlanDown (hysteresis; the measured break-even is ~20: the plan costs ~2 800 cycles per iteration --
+// the momentum draw reads MT19937 through L2 -- and saves ~150 per leapfrog of a deep tree).
+constexpr int kPlanUp = 24, kPlanDown = 14;
 
 // ---- pieces of the iteration body shared by the diagonal and the dense-mass kernels ---------------------------
 // lmc_engine_request_stop(): the host's Ctrl-C (sampling.py:324-328, :470-471 in the reference: keep what has been drawn).
@@ -1324,8 +1335,11 @@ constexpr int lds_tail_doubles(int w) {   // W >= 4: a second MT19937 buffer beh
 // relay with it). A team agrees on ONE value (thread 0's) so that no wave leaves a barrier behind.
 // A launch that STARTS under a request does nothing at all (stop_at_entry): sample() enqueues all launches of a job up
 // front, and the ones still queued when Ctrl-C arrives must neither run an iteration nor touch iter_count.
+// The relay also leaves ITS OWN mean tree size of this launch so far (`leaps` leapfrogs in `it` iterations; leaps < 0: nothing to
+// report) in A.tree_hint, a pinned host word: what the engine picks the next launch's LDS plan from, without touching a stream.
+// Computed inside the relay branch only -- no chain pays for it per iteration.
 template <class CA, class PT>
-__device__ __forceinline__ int stop_request_load(const CA& A, const PT& P, int chain_in_launch, int it, long long git) {
+__device__ __forceinline__ int stop_request_load(const CA& A, const PT& P, int chain_in_launch, int it, long long git, long long leaps = -1) {
     int* dev = A.stop_dev;
     const int mask = P.relay_mask;
     const bool relay = (it == 0) ? ((chain_in_launch & mask) == 0)
@@ -1335,6 +1349,10 @@ __device__ __forceinline__ int stop_request_load(const CA& A, const PT& P, int c
             __hip_atomic_store(dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ... and leaves word of where the job is (a posted store into the same pinned block)
         __hip_atomic_store(A.progress, static_cast<int>(git), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (leaps >= 0 && it >= 8 && A.tree_hint != nullptr) {
+            const int mean = static_cast<int>(static_cast<float>(leaps) / static_cast<float>(it));
+            __hip_atomic_store(A.tree_hint, mean > 0 ? mean : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     return __hip_atomic_load(dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1534,7 +1552,14 @@ __device__ __forceinline__ void diag_mass_update(const CA& A, const PT& P, long 
 
 // RNG = 0: the reference's stream (numpy legacy MT19937 + polar method, same-seed parity); 1: momentum from Philox
 // (philox_normals: the throughput mode, its own kernel instantiation so that the parity kernels are untouched by it)
-template <int NS, int W, template <int> class TargetT, int RNG = 0>
+// PL: the LDS plan (PairLds<NS, W, PL>). 0 keeps the MT19937 state and three cold slots in LDS -- best for shallow trees, where the
+// momentum draw is a fifth of an iteration; 1 (one-wave kernels) uses the generator in place and keeps stack level 2 in LDS
+// instead -- best for deep trees, where every other pair cascades through it. The plans differ in WHERE a chain's private data
+// lives, never in arithmetic: results are bit-identical (tests/test_gpu_round5.py::test_lds_plans_are_bit_identical), so the
+// engine is free to pick per launch from the tree sizes the chains report (A.tree_hint; lmc_engine.hip: choose_lds_plan).
+// (Both plans as two bodies of ONE kernel with every chain choosing for itself were built first and lose 7-20 % under
+// either plan -- profiles/r05_lds_plan_dual_body_ab.txt -- the kernel per plan keeps each plan's code as it was measured.)
+template <int NS, int W, template <int> class TargetT, int RNG = 0, int PL = 0>
 __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS, W)) void run_kernel(ChainArrays, SamplerParams, const double* tparams) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const long long t_resident = wall_clock64();   // constant-rate clock: the chain's residence time (kCtWaveTicks)
@@ -1576,7 +1601,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS, W)) void run_kernel(
     uint32_t* mt_glb = A0.mt + static_cast<long long>(c) * kMtN;
     uint32_t* mt_lds = reinterpret_cast<uint32_t*>(lds + lds_doubles);
     uint32_t* mt_lds2 = reinterpret_cast<uint32_t*>(rng_bcast + 4);   // W >= 4 only: the generation being twisted out of place
-    constexpr bool kMtInLds = run_mt_in_lds(W);
+    constexpr bool kMtInLds = run_mt_in_lds(W) && PL == 0;
     if constexpr (kMtInLds) {
         for (int i = tid; i < kMtN; i += 64 * W) mt_lds[i] = mt_glb[i];
         tm.sync();
@@ -1600,7 +1625,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS, W)) void run_kernel(
     long long ct_maxdepth = 0, ct_divs = 0, ct_after = 0, ct_leap = 0;
     int status = 0;
 
-    // compile-time LDS plan (PairLds<NS, W>), the chain's scratch row for what does not fit
+    // compile-time LDS plan (PairLds<NS, W, PL>), the chain's scratch row for what does not fit
     static_assert(NS <= 4, "sampling kernels hold at most four elements per lane");
     PairCtx cx;
     cx.lds = lds;
@@ -1629,7 +1654,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS, W)) void run_kernel(
         const bool tune = git < P.n_tune;
         const bool momentum_f32 = P.momentum_f32 != 0;
         LMC_PHASE(5)
-        const int stop_word = stop_request_load(ka.A(), P, static_cast<int>(blockIdx.x), it, git);
+        const int stop_word = stop_request_load(ka.A(), P, static_cast<int>(blockIdx.x), it, git, P.kind == 0 ? ct_leap : -1);
 
         // ---- momentum draw (quadpotential.py:221-224 / :374-376)
         double p0[NS];
@@ -1682,7 +1707,7 @@ __global__ __launch_bounds__(64 * W, run_waves_per_simd(NS, W)) void run_kernel(
         TransitionOut out;
         if (P.kind == 0) {
             const int md = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
-            nuts_transition2<NS>(tm, tgt, vard, rng, cx, qrow, q, p0, g0, e0, logp0, step_size, P.emax, md,
+            nuts_transition2<NS, PL>(tm, tgt, vard, rng, cx, qrow, q, p0, g0, e0, logp0, step_size, P.emax, md,
                                  momentum_f32, out);
             vload<NS>(qrow, q);   // the proposal was written to the chain's row of A.q
             // (handing it over in registers when the last doubling accepted it measured -4 % on depth-3 trees)

@@ -91,7 +91,7 @@ def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None):
     reference: a KeyboardInterrupt ends sampling and what has been drawn so far is returned).
 
     The launches are asynchronous and back to back (the engine's sub-block streams keep the chip full across launch
-    boundaries), so the host does not step in between them: it polls the completion events of the launches it queued,
+    boundaries); the host keeps three of them queued, polls the completion events of the launches it queued,
     logs progress as they complete (``progressbar=True``; the reference's per-draw bar, sampling.py:455-459, at launch
     granularity) and, on Ctrl-C, asks the device to stop -- every chain leaves its launch at its next iteration
     boundary and the launches still queued do nothing (lmc_engine_request_stop). With several GPUs (an EngineGroup)
@@ -111,21 +111,37 @@ def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None):
         except Exception:   # no torch: plain blocking wait (no progress lines, Ctrl-C acts when the job ends)
             torch = None
     t0 = time.perf_counter()
+    # The launches are enqueued a few ahead of execution, not all up front: the engine picks the LDS plan of a launch when it
+    # is ENQUEUED, from the tree sizes the running chains report (lmc_engine.hip: choose_lds_plan; results do not depend on
+    # it), so the queue must not run far ahead of the job. Three in flight per stream keep the device busy across launch
+    # boundaries whatever the host's polling granularity.
+    sizes = list(per_launch) if isinstance(per_launch, (list, tuple)) else [int(per_launch)]   # (the last size repeats)
+    pending = []
+    it = 0
+    while it < n_total:
+        n = min(sizes[min(len(pending), len(sizes) - 1)], n_total - it)
+        pending.append((it, n))
+        it += n
+
+    def enqueue_next():
+        first, n = pending.pop(0)
+        eng.run(tune, first, n)
+        if torch is not None:
+            evs = []
+            for s_ in streams:
+                with torch.cuda.device(s_.device):
+                    ev_ = torch.cuda.Event()
+                    ev_.record(s_)
+                evs.append(ev_)
+            marks.append((first + n, evs))
+
     try:
-        it = 0
-        while it < n_total:
-            n = min(per_launch, n_total - it)
-            eng.run(tune, it, n)
-            it += n
-            if torch is not None:
-                evs = []
-                for s_ in streams:
-                    with torch.cuda.device(s_.device):
-                        ev_ = torch.cuda.Event()
-                        ev_.record(s_)
-                    evs.append(ev_)
-                marks.append((it, evs))
+        depth = 3 if torch is not None else len(pending)
+        while pending and len(marks) < depth:
+            enqueue_next()
         if torch is None:
+            while pending:
+                enqueue_next()
             eng.synchronize()
         else:
             reported = 0
@@ -140,12 +156,14 @@ def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None):
                 if all(e_.query() for e_ in marks[0][1]):
                     done = marks.pop(0)[0]
                     launches_done += 1
+                    if pending:
+                        enqueue_next()
                     if progressbar and done != reported:
                         reported = done
                         _log.info("Sampling %d chains: %d/%d iterations (%s), %.1f s" % (
                             eng.chains, done, n_total, "tuning" if done <= tune else "drawing", time.perf_counter() - t0))
                     continue
-                time.sleep(0.002)
+                time.sleep(0.0005)
             eng.synchronize()
         return n_total, False
     except KeyboardInterrupt:
@@ -332,7 +350,10 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
             if slots and slots < per_dev < 6 * slots:
                 per_launch = min(per_launch, 100)
             elif slots and per_dev >= 6 * slots:
-                per_launch = min(per_launch, 500)
+                # (round 5) the engine chooses the LDS plan of a launch when it is enqueued, from iteration 200 on and from what
+                # the running chains report: a 200-iteration launch and two short ones let the choice settle early, the rest of
+                # the job runs in launches of 500
+                per_launch = [200, 100, 100, 500] if per_launch >= 500 else per_launch
             elif not slots and getattr(getattr(eng, "engines", [eng])[0], "wide", False):
                 per_launch = min(per_launch, 200)   # general kernels (one workgroup per chain, a few hundred resident): same reason
         if target.family == _abi.TARGET_EXTERNAL and not launch_iters:

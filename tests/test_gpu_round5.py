@@ -171,3 +171,55 @@ def test_standalone_integrator_keeps_full_adapt_float64():
     assert st.v.dtype == np.float64
     np.testing.assert_allclose(st.v, cov.dot(p), rtol=1e-14)
     np.testing.assert_allclose(float(np.ravel(st.energy)[0]), 0.5 * p.dot(cov.dot(p)) + 0.5 * q.dot(q), rtol=1e-14)
+
+
+# ---- LDS plans of the one-wave sampling kernels (lmc_sampler.hpp: run_kernel<.., PL>; lmc_engine.hip: choose_lds_plan) ------------
+def _plan_job(monkeypatch, plan, tgt, d, chains, n, kw=None):
+    if plan is None:
+        monkeypatch.delenv("LMC_LDS_PLAN", raising=False)
+    else:
+        monkeypatch.setenv("LMC_LDS_PLAN", plan)
+    eng, step = _engine(tgt, d, chains, **(kw or {}))
+    try:
+        eng.reserve(n, keep_trace=True)
+        for first in range(0, n, 52):          # launches enqueued one by one, each after the one before has reported tree sizes
+            eng.run(n // 2, first, min(52, n - first))   # (the engine considers the deep-tree plan from iteration 200 on)
+            eng.synchronize()
+        assert not eng.status().any()
+        out = (eng.trace().copy(), eng.stat_i32(_abi.STAT_TREE_SIZE, 0, n).copy(), eng.stat_f64(_abi.STAT_ENERGY, 0, n).copy(),
+               [eng.get_rng_state(c)[2] for c in range(min(chains, 4))])
+        return out, eng.run_lds_bytes()
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("family,d,kw", [("ar1", 128, {}), ("funnel", 256, {"max_treedepth": 12}), ("std_normal", 64, {}),
+                                           ("ar1", 40, {})])
+def test_lds_plans_are_bit_identical(monkeypatch, family, d, kw):
+    """The two LDS plans of the one-wave sampling kernels differ in WHERE a chain's private data lives -- plan 0: MT19937
+    state and three cold slots in LDS, stack level 2 in the scratch row; plan 1: the generator used in place, stack level 2
+    in LDS -- never in arithmetic. Pinned to plan 0, pinned to plan 1, or chosen per launch by the engine from the tree
+    sizes the chains report: the same draws, statistics and generator positions, bit for bit."""
+    tgt = {"ar1": lambda: T.AR1(d, 0.9), "funnel": lambda: T.Funnel(d), "std_normal": lambda: T.StdNormal(d)}[family]()
+    chains, n = 96, 260
+    ref, lds0 = _plan_job(monkeypatch, "0", tgt, d, chains, n, kw)
+    one, lds1 = _plan_job(monkeypatch, "1", tgt, d, chains, n, kw)
+    auto, _ldsa = _plan_job(monkeypatch, None, tgt, d, chains, n, kw)
+    assert lds1 != lds0                      # the pinned plan really is another LDS layout
+    for other in (one, auto):
+        np.testing.assert_array_equal(ref[0], other[0])
+        np.testing.assert_array_equal(ref[1], other[1])
+        np.testing.assert_array_equal(ref[2], other[2])
+        assert ref[3] == other[3]
+
+
+def test_engine_follows_the_tree_sizes_the_chains_report(monkeypatch):
+    """choose_lds_plan: deep trees (AR(1) d = 128 settles at 60-130 leapfrogs per iteration) move the launches that are
+    enqueued after the chains have reported to the deep-tree plan -- from iteration 200 on, past the early-treedepth regime
+    -- and shallow trees (standard normal, 7 per iteration) stay."""
+    monkeypatch.delenv("LMC_LDS_PLAN", raising=False)
+    _out, lds_deep = _plan_job(monkeypatch, None, T.AR1(128, 0.9), 128, 256, 260)
+    _out, lds_shallow = _plan_job(monkeypatch, None, T.StdNormal(128), 128, 256, 260)
+    _out, lds_plan1 = _plan_job(monkeypatch, "1", T.StdNormal(128), 128, 256, 60)
+    _out, lds_plan0 = _plan_job(monkeypatch, "0", T.StdNormal(128), 128, 256, 60)
+    assert lds_deep == lds_plan1 and lds_shallow == lds_plan0 and lds_plan0 != lds_plan1
