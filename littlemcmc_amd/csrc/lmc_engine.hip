@@ -504,9 +504,11 @@ static int choose_lds_plan(lmc_engine* e, long long iter_begin) {
     // step sizes still settle and trees are deeper than the job's own -- a launch that starts there takes plan 0 whatever is
     // reported (measured: C2 otherwise spends its third and fourth launch in the deep-tree plan, -2.4 %).
     if (iter_begin < 200) return 0;
-    const int hint = e->stop_host ? __atomic_load_n(e->stop_host + 24, __ATOMIC_ACQUIRE) : 0;
+    const int word = e->stop_host ? __atomic_load_n(e->stop_host + 24, __ATOMIC_ACQUIRE) : 0;
+    const int at = word >> 12, hint = word & 4095;   // reporting iteration, mean leapfrogs per iteration of that chain's launch so far
+    if (hint == 0 || at < 100) return e->plan_now;   // nothing yet / a report from inside the settling phase: keep the plan
     if (hint >= kPlanUp) e->plan_now = 1;
-    else if (hint > 0 && hint <= kPlanDown) e->plan_now = 0;
+    else if (hint <= kPlanDown) e->plan_now = 0;
     return e->plan_now;
 }
 

@@ -85,7 +85,7 @@ struct ChainArrays {
     const double* step_override;   // [C] step sizes chosen by the host for the next iteration (P.step_jitter == 2), else nullptr
     int* progress;        // [1] pinned host word: the iteration index a relay chain last started (lmc_engine_progress: a hint the
                           //     host reads without touching a stream)
-    int* tree_hint;       // [1] pinned host word (or nullptr): a relay chain's mean tree size in its launch so far (the LDS plan choice)
+    int* tree_hint;       // [1] pinned host word (or nullptr): (iteration << 12) | a relay chain's mean tree size in its launch so far (LDS plan choice)
     const uint32_t* seed; // [C] the seeds of lmc_engine_seed (key of the counter-based momentum stream, LMC_RNG_PHILOX)
     double* mom_mean;     // [C][dpad] running mean of the post-warm-up draws (nullptr = not kept)
     double* mom_m2;       // [C][dpad] running sum of squared deviations (Welford)
@@ -1350,8 +1350,10 @@ __device__ __forceinline__ int stop_request_load(const CA& A, const PT& P, int c
         // ... and leaves word of where the job is (a posted store into the same pinned block)
         __hip_atomic_store(A.progress, static_cast<int>(git), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (leaps >= 0 && it >= 8 && A.tree_hint != nullptr) {
-            const int mean = static_cast<int>(static_cast<float>(leaps) / static_cast<float>(it));
-            __hip_atomic_store(A.tree_hint, mean > 0 ? mean : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            int mean = static_cast<int>(static_cast<float>(leaps) / static_cast<float>(it));
+            mean = mean < 1 ? 1 : (mean > 4095 ? 4095 : mean);
+            const int at = git > 0x7ffff ? 0x7ffff : static_cast<int>(git);   // which iteration reports (the engine ignores the first 100)
+            __hip_atomic_store(A.tree_hint, (at << 12) | mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     return __hip_atomic_load(dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

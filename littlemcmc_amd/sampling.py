@@ -91,7 +91,7 @@ def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None):
     reference: a KeyboardInterrupt ends sampling and what has been drawn so far is returned).
 
     The launches are asynchronous and back to back (the engine's sub-block streams keep the chip full across launch
-    boundaries); the host keeps three of them queued, polls the completion events of the launches it queued,
+    boundaries); the host keeps two of them queued, polls the completion events of the launches it queued,
     logs progress as they complete (``progressbar=True``; the reference's per-draw bar, sampling.py:455-459, at launch
     granularity) and, on Ctrl-C, asks the device to stop -- every chain leaves its launch at its next iteration
     boundary and the launches still queued do nothing (lmc_engine_request_stop). With several GPUs (an EngineGroup)
@@ -113,8 +113,8 @@ def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None):
     t0 = time.perf_counter()
     # The launches are enqueued a few ahead of execution, not all up front: the engine picks the LDS plan of a launch when it
     # is ENQUEUED, from the tree sizes the running chains report (lmc_engine.hip: choose_lds_plan; results do not depend on
-    # it), so the queue must not run far ahead of the job. Three in flight per stream keep the device busy across launch
-    # boundaries whatever the host's polling granularity.
+    # it), so the queue must not run far ahead of the job. Two in flight per stream keep the device busy across launch
+    # boundaries (the next one is enqueued while the last one runs).
     sizes = list(per_launch) if isinstance(per_launch, (list, tuple)) else [int(per_launch)]   # (the last size repeats)
     pending = []
     it = 0
@@ -136,7 +136,7 @@ def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None):
             marks.append((first + n, evs))
 
     try:
-        depth = 3 if torch is not None else len(pending)
+        depth = 2 if torch is not None else len(pending)
         while pending and len(marks) < depth:
             enqueue_next()
         if torch is None:
@@ -351,9 +351,9 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
                 per_launch = min(per_launch, 100)
             elif slots and per_dev >= 6 * slots:
                 # (round 5) the engine chooses the LDS plan of a launch when it is enqueued, from iteration 200 on and from what
-                # the running chains report: a 200-iteration launch and two short ones let the choice settle early, the rest of
-                # the job runs in launches of 500
-                per_launch = [200, 100, 100, 500] if per_launch >= 500 else per_launch
+                # the running chains report (it ignores reports from the first 100): four launches of 100 let the choice settle
+                # by iteration 300, the rest of the job runs in launches of 500
+                per_launch = [100, 100, 100, 100, 500] if per_launch >= 500 else per_launch
             elif not slots and getattr(getattr(eng, "engines", [eng])[0], "wide", False):
                 per_launch = min(per_launch, 200)   # general kernels (one workgroup per chain, a few hundred resident): same reason
         if target.family == _abi.TARGET_EXTERNAL and not launch_iters:
