@@ -223,3 +223,29 @@ def test_engine_follows_the_tree_sizes_the_chains_report(monkeypatch):
     _out, lds_plan1 = _plan_job(monkeypatch, "1", T.StdNormal(128), 128, 256, 60)
     _out, lds_plan0 = _plan_job(monkeypatch, "0", T.StdNormal(128), 128, 256, 60)
     assert lds_deep == lds_plan1 and lds_shallow == lds_plan0 and lds_plan0 != lds_plan1
+
+
+def test_sample_is_the_same_job_whatever_plan_the_engine_picks(monkeypatch):
+    """lmc.sample() on a job big enough for its launch schedule (4 x 100 iterations, then 500s, two launches in flight) with
+    the engine free to move launches to the deep-tree LDS plan, against the same call pinned to plan 0: the same draws and
+    statistics, bit for bit -- the choice (and the pacing that feeds it) is invisible in the results."""
+    d, chains, tune, draws = 128, 20000, 350, 250
+    tgt = T.AR1(d, 0.9)
+    out = []
+    for plan in ("0", None):
+        if plan is None:
+            monkeypatch.delenv("LMC_LDS_PLAN", raising=False)
+        else:
+            monkeypatch.setenv("LMC_LDS_PLAN", plan)
+        trace, stats, eng = lmc.sample(tgt, d, draws=draws, tune=tune, chains=chains, random_seed=99, progressbar=False,
+                                       return_engine=True)
+        try:
+            lds = eng.run_lds_bytes()
+        finally:
+            eng.close()
+        out.append((trace[::97].copy(), stats["tree_size"].copy(), stats["energy"][::97].copy(), lds))
+        del trace, stats
+    assert out[0][3] != out[1][3]            # the free engine did end up in the other plan (deep trees: AR(1) d = 128)
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
