@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LMC_ABI_VERSION 6
+#define LMC_ABI_VERSION 7
 
 /* status codes */
 #define LMC_OK 0
@@ -413,6 +413,11 @@ int lmc_engine_occupancy(lmc_engine* e, int32_t* resident_chains, int32_t* waves
 int32_t lmc_engine_run_lds_bytes(lmc_engine* e);
 int lmc_engine_load_user_kernels(lmc_engine* e, const void* code_object, const char* run_name, const char* trajectory_name,
                                  const char* logp_name);
+/* Optional, after lmc_engine_load_user_kernels(): the name of run_kernel<NS, 1, UserTarget, 0, 1> in the same code object -- the
+ * one-wave sampling kernel under the deep-tree LDS plan (stack level 2 in LDS, MT19937 used in place; csrc/lmc_sampler.hpp).
+ * With it the engine chooses the plan of every launch from the tree sizes the running chains report, as it does for the
+ * built-in densities (results do not depend on the choice); without it a run-time compiled density runs under plan 0. */
+int lmc_engine_load_user_run_plan1(lmc_engine* e, const char* run_name_plan1);
 
 /* ---- cross-chain diagnostics on the draws in HBM (the reference has none: ArviZ recipe only,
  * docs/tutorials/framework_cookbook.rst:201-213) -------------------------------------------------------------------

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LMC_HIP_LIB") or os.path.join(_HERE, "liblmc_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 OK = 0
 
 KIND_NUTS, KIND_HMC = 0, 1
@@ -136,6 +136,7 @@ _SIGNATURES = {
     "lmc_engine_progress": (C.c_int64, [_P]),
     "lmc_engine_run_lds_bytes": (C.c_int32, [_P]),
     "lmc_engine_load_user_kernels": (C.c_int, [_P, _P, C.c_char_p, C.c_char_p, C.c_char_p]),
+    "lmc_engine_load_user_run_plan1": (C.c_int, [_P, C.c_char_p]),
     "lmc_diag_lags_per_pass": (C.c_int, []),
     "lmc_diag_chain_stats": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _P, _P]),
 }

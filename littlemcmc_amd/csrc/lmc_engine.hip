@@ -255,6 +255,7 @@ struct lmc_engine {
     lmc_config cfg;
     int ns = 0, dpad = 0, nlds = 1, lds_bytes = 0;   // ns: vector width of the W = 1 unit kernels (dpad = 64 * ns)
     int nlds1 = 1, lds_bytes1 = 0, lds_plan = 0;      // one-wave sampling kernels: the deep-tree LDS plan (PairLds<NS, 1, 1>) and who chooses (0 / 1 pinned, 2 = per launch from the chains' reports)
+    int lds_plan_wanted = 0;                          // lds_plan once a run-time compiled density has handed over its plan-1 kernel
     int plan_now = 0;                                 // the plan of the launches being enqueued (lds_plan == 2: follows the tree-size hint with hysteresis)
     bool wide = false;          // the general kernels (lmc_wide.hpp): one chain = 16 wavefronts, dpad = 1024 * ns -- model_ndim > 1024,
                                 // dense matrices beyond 256 dimensions, float64 adaptive diagonals
@@ -304,6 +305,7 @@ struct lmc_engine {
     // depend on the density functor come from a code object the caller compiled with hiprtc
     hipModule_t user_module = nullptr;
     hipFunction_t user_run = nullptr, user_trajectory = nullptr, user_logp = nullptr;
+    hipFunction_t user_run1 = nullptr;               // run_kernel<NS, 1, UserTarget, 0, 1>: the sampling kernel under LDS plan 1 (optional)
     std::vector<void*> allocs;
     std::string err;
 };
@@ -840,8 +842,10 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
                 else if (env[0] == '1') e->lds_plan = 1;
             }
             if (e->nlds1 <= e->nlds) e->lds_plan = 0;   // nothing gained: the plan would only move the generator out
-            if (cfg->rng_mode == LMC_RNG_PHILOX || (cfg->target_family == LMC_TARGET_USER && !kUserCompiledIn))
-                e->lds_plan = 0;                         // (instantiated for the built-in densities on the parity stream)
+            if (cfg->rng_mode == LMC_RNG_PHILOX) e->lds_plan = 0;   // (instantiated on the parity stream)
+            e->lds_plan_wanted = e->lds_plan;
+            if (cfg->target_family == LMC_TARGET_USER && !kUserCompiledIn)
+                e->lds_plan = 0;                         // until lmc_engine_load_user_run_plan1() hands the plan-1 kernel over
             e->plan_now = e->lds_plan == 1 ? 1 : 0;
         }
     }
@@ -1121,10 +1125,23 @@ int lmc_engine_load_user_kernels(lmc_engine* e, const void* code_object, const c
     HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
     if (e->user_module) { (void)hipModuleUnload(e->user_module); e->user_module = nullptr; }
     e->user_run = e->user_trajectory = e->user_logp = nullptr;
+    e->user_run1 = nullptr;
+    if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledIn) { e->lds_plan = 0; e->plan_now = 0; }   // plan 0 until the plan-1 kernel is handed over
     HIP_TRY(e, hipModuleLoadData(&e->user_module, code_object));
     HIP_TRY(e, hipModuleGetFunction(&e->user_run, e->user_module, run_name));
     HIP_TRY(e, hipModuleGetFunction(&e->user_trajectory, e->user_module, trajectory_name));
     HIP_TRY(e, hipModuleGetFunction(&e->user_logp, e->user_module, logp_name));
+    return LMC_OK;
+}
+
+int lmc_engine_load_user_run_plan1(lmc_engine* e, const char* run_name_plan1) {
+    if (!e || !run_name_plan1) return fail(e, LMC_ERR_INVALID, "null argument");
+    if (!e->user_module) return fail(e, LMC_ERR_STATE, "lmc_engine_load_user_kernels() first");
+    if (e->wide || e->run_w != 1) return fail(e, LMC_ERR_INVALID, "the deep-tree LDS plan exists for the one-wave sampling kernels");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipModuleGetFunction(&e->user_run1, e->user_module, run_name_plan1));
+    e->lds_plan = e->lds_plan_wanted;
+    e->plan_now = e->lds_plan == 1 ? 1 : 0;
     return LMC_OK;
 }
 
@@ -1909,7 +1926,7 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
         if (n_sub > 1) e->sub_pending = true;
         if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledIn) {
             void* args[] = {&e->A, &P, &e->tparams};
-            const int rc = user_launch(e, e->user_run, st, grid.x, block.x, static_cast<unsigned>(run_lds), args);
+            const int rc = user_launch(e, (plan == 1 && e->user_run1) ? e->user_run1 : e->user_run, st, grid.x, block.x, static_cast<unsigned>(run_lds), args);
             if (rc != LMC_OK) return rc;
             continue;
         }

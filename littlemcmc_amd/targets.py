@@ -149,7 +149,8 @@ class UserTarget(DeviceTarget):
         return h.hexdigest()[:16]
 
     def kernels_for(self, unit_ns, run_ns, run_w, general=False):
-        """(code object, run name, trajectory name, logp name) for one engine shape, compiled once and cached."""
+        """(code object, run name, trajectory name, logp name, run name under LDS plan 1 or None) for one engine shape,
+        compiled once and cached."""
         key = (int(unit_ns), int(run_ns), int(run_w), int(bool(general)))
         if key in self._code:
             return self._code[key]
@@ -175,6 +176,10 @@ class UserTarget(DeviceTarget):
                   "int, int, double, int, int, double*, double*, double*, double*, double*, double*);\n"
                   "template __global__ void logp_kernel<%d, UserTarget>(ChainArrays, const double*, const double*, double*, double*);\n"
                   "}\n" % (key[1], key[2], key[0], key[0]))
+            if key[2] == 1:   # one-wave kernels: also the deep-tree LDS plan (csrc/lmc_sampler.hpp: run_kernel<.., PL = 1>)
+                names.append("lmc::run_kernel<%d, 1, lmc::UserTarget, 0, 1>" % key[1])
+                tu += ("namespace lmc {\ntemplate __global__ void run_kernel<%d, 1, UserTarget, 0, 1>(ChainArrays, SamplerParams, "
+                       "const double*);\n}\n" % key[1])
         cache = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_user_targets")
         os.makedirs(cache, exist_ok=True)
         path = os.path.join(cache, "user_%s_%d_%d_%d%s.hsaco" % (self._digest("hiprtc"), key[0], key[1], key[2], "g" if key[3] else ""))
@@ -183,7 +188,7 @@ class UserTarget(DeviceTarget):
             with open(path, "rb") as fh:
                 code = fh.read()
             with open(path + ".names") as fh:
-                lowered = fh.read().split("\n")[:3]
+                lowered = [ln for ln in fh.read().split("\n") if ln]
         else:
             code, lowered = _hiprtc_compile(tu, names)
             tmp = "%s.%d.tmp" % (path, os.getpid())     # several ranks may compile the same target at once
@@ -193,7 +198,7 @@ class UserTarget(DeviceTarget):
             with open(tmp, "w") as fh:
                 fh.write("\n".join(lowered))
             os.replace(tmp, path + ".names")
-        self._code[key] = (code, lowered[0], lowered[1], lowered[2])
+        self._code[key] = (code, lowered[0], lowered[1], lowered[2], lowered[3] if len(lowered) > 3 else None)
         return self._code[key]
 
     def _attach(self, engine):
@@ -205,9 +210,11 @@ class UserTarget(DeviceTarget):
         ns, rns, rw = C.c_int32(), C.c_int32(), C.c_int32()
         engine._check(engine._lib.lmc_engine_kernel_shape(engine._h, C.byref(ns), C.byref(rns), C.byref(rw)))
         general = bool(engine._lib.lmc_engine_uses_general_kernels(engine._h))
-        code, run, traj, logp = self.kernels_for(ns.value, rns.value, rw.value, general)
+        code, run, traj, logp, run1 = self.kernels_for(ns.value, rns.value, rw.value, general)
         buf = C.create_string_buffer(code, len(code))
         engine._check(engine._lib.lmc_engine_load_user_kernels(engine._h, buf, run.encode(), traj.encode(), logp.encode()))
+        if run1 is not None:   # the sampling kernel under the deep-tree LDS plan: the engine may now choose per launch
+            engine._check(engine._lib.lmc_engine_load_user_run_plan1(engine._h, run1.encode()))
 
     def __getstate__(self):
         st = super().__getstate__()

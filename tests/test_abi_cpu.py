@@ -62,15 +62,17 @@ def test_built_in_targets_and_the_run_time_user_family():
 
 
 def test_user_target_compiles_with_hiprtc_without_a_gpu():
-    """The run-time compiler needs no device: the three functor-dependent kernels of an engine shape come out of
+    """The run-time compiler needs no device: the functor-dependent kernels of an engine shape (three, and the sampling kernel's second LDS plan) come out of
     hiprtc as a gfx950 code object with the lowered names the engine looks up; the result is cached by content."""
     from littlemcmc_amd.targets import UserTarget
 
     t = UserTarget.separable(70, logp="-0.5*q*q", grad="-q")
     assert t.jit == "hiprtc" and t.lib_path is None
-    code, run, traj, logp = t.kernels_for(2, 2, 1)
+    code, run, traj, logp, run1 = t.kernels_for(2, 2, 1)
     assert code[:4] == b"\x7fELF" and len(code) > 10000
     assert "run_kernel" in run and "UserTarget" in run and "trajectory_kernel" in traj and "logp_kernel" in logp
+    assert run1 is not None and "run_kernel" in run1 and run1 != run   # one-wave shape: also the deep-tree LDS plan (ABI 7)
+    assert UserTarget.separable(600, logp="-0.5*q*q", grad="-q").kernels_for(4, 4, 4)[4] is None   # teams: plan 0 only
     assert t.kernels_for(2, 2, 1)[0] is code                      # in-memory cache
     assert UserTarget.separable(70, logp="-0.5*q*q", grad="-q").kernels_for(2, 2, 1)[0] == code   # disk cache
     with pytest.raises(RuntimeError, match="hiprtc compile failed"):

@@ -249,3 +249,22 @@ def test_sample_is_the_same_job_whatever_plan_the_engine_picks(monkeypatch):
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
     np.testing.assert_array_equal(out[0][2], out[1][2])
+
+
+def test_runtime_compiled_density_gets_the_deep_tree_plan_too(monkeypatch):
+    """A user's density compiled at run time (hiprtc: the plug-in path north_star describes) hands the engine BOTH
+    instantiations of the one-wave sampling kernel -- lmc_engine_load_user_kernels + lmc_engine_load_user_run_plan1 (ABI 7)
+    -- so its deep trees move to the deep-tree LDS plan like the built-in densities': same chains as pinned to plan 0."""
+    from tests.test_gpu_wide import USER_AR1
+
+    d, chains, n = 128, 96, 260
+    out = []
+    for plan in ("0", None):
+        user = T.UserTarget(d, USER_AR1, params=T.AR1(d, 0.9).params)
+        res, lds = _plan_job(monkeypatch, plan, user, d, chains, n)
+        out.append((res, lds))
+    builtin, _lds = _plan_job(monkeypatch, "0", T.AR1(d, 0.9), d, chains, n)
+    assert out[0][1] != out[1][1]                      # the free engine ended in plan 1
+    np.testing.assert_array_equal(out[0][0][0], out[1][0][0])
+    np.testing.assert_array_equal(out[0][0][1], out[1][0][1])
+    np.testing.assert_array_equal(out[0][0][1], builtin[1])   # ... and the user's AR(1) builds the built-in AR(1)'s trees
