@@ -264,10 +264,18 @@ struct lmc_engine {
     hipStream_t own_stream = nullptr, stream_ = nullptr;   // stream_: use main_stream(e), which orders sub-block launches first
     // run() deals the chains to n_sub contiguous sub-blocks, each launched on its own stream: the tail of one sub-block's
     // launch is filled by the other's, and consecutive run() calls only chain up per sub-block (chains are independent)
-    static constexpr int kMaxSub = 2;
+    // (four since round 5 -- profiles/r05_sub_blocks_ab.txt: against two, C3 equal, north_star shape -0.5 %, C2 +2.4 %, C4 +1 %,
+    // C5 +2.8 %; eight lose 35-40 % on C2 / C5: more streams than the hardware queues take)
+#ifndef LMC_MAX_SUB
+#define LMC_MAX_SUB 8
+#endif
+#ifndef LMC_DEFAULT_SUB
+#define LMC_DEFAULT_SUB 4
+#endif
+    static constexpr int kMaxSub = LMC_MAX_SUB;
     int n_sub = 1;
-    hipStream_t sub_stream[kMaxSub] = {nullptr, nullptr};
-    hipEvent_t sub_done[kMaxSub] = {nullptr, nullptr};
+    hipStream_t sub_stream[kMaxSub] = {};
+    hipEvent_t sub_done[kMaxSub] = {};
     hipEvent_t main_done = nullptr;
     double* chol64T = nullptr;  // FULL_F64: LT[j][i] = L[i][j] of the covariance's factor (what the state getters hand out; D.fac holds L^-1)
     uint32_t* seeds = nullptr;  // [C] the seeds of lmc_engine_seed (key of LMC_RNG_PHILOX's momentum stream)
@@ -783,7 +791,10 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     e->stream_ = e->own_stream;
     // sub-blocks: two halves of the chains on two streams (measured on C3's kernel: +2 % at 65 536 chains, +11 % at
     // 16 384, +22 % at 8 192, +36 % at 4 096 -- the per-launch tail of one half is covered by the other half's next launch)
-    e->n_sub = (cfg->chains >= 128 && !wide) ? lmc_engine::kMaxSub : 1;
+    e->n_sub = (cfg->chains >= 128 && !wide) ? (LMC_DEFAULT_SUB < lmc_engine::kMaxSub ? LMC_DEFAULT_SUB : lmc_engine::kMaxSub) : 1;
+    // (the dense-mass kernels keep two: their workgroups are large -- the shared-matrix kernel holds one per CU -- and a third
+    //  and fourth stream's dispatch starts late enough for an interrupt to find chains that have not begun)
+    if (e->n_sub > 2 && cfg->potential >= LMC_POT_FULL) e->n_sub = 2;
     if (const char* env = std::getenv("LMC_SUB_BLOCKS")) {
         const int v = std::atoi(env);
         if (v >= 1 && v <= lmc_engine::kMaxSub && v <= cfg->chains) e->n_sub = v;

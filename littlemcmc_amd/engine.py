@@ -233,8 +233,8 @@ class Engine:
 
     def run_streams(self):
         """Raw HIP stream handles run() launches its kernels on (one per sub-block of chains)."""
-        arr = (C.c_void_p * 4)()
-        n = self._lib.lmc_engine_run_streams(self._h, arr, 4)
+        arr = (C.c_void_p * 16)()
+        n = min(self._lib.lmc_engine_run_streams(self._h, arr, 16), 16)
         if n < 0:
             self._check(n)
         return [int(arr[i] or 0) for i in range(n)]

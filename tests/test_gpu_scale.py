@@ -71,8 +71,9 @@ def test_chain_block_prefix_stability_and_launch_slicing():
 
 
 def test_sub_block_streams_do_not_change_a_bit(monkeypatch):
-    """lmc_engine_run launches the chains as two halves on two internal streams (tails of one half's launch are
-    covered by the other's next launch). Same job, launched as ONE block: identical draws, statistics and adaptation
+    """lmc_engine_run launches the chains as four contiguous sub-blocks on four internal streams (two until round 5; the
+    tail of one sub-block's launch is covered by the others' next launches). Same job, launched as ONE block and as TWO:
+    identical draws, statistics and adaptation
     state -- with reads, position pushes and other entry points interleaved between the launches."""
     d, tune, draws, chains = 48, 70, 30, 513
     tgt = T.AR1(d, 0.9)
@@ -85,7 +86,7 @@ def test_sub_block_streams_do_not_change_a_bit(monkeypatch):
             monkeypatch.setenv("LMC_SUB_BLOCKS", str(sub_blocks))
         start, step = lmc.init_nuts(tgt, d, random_seed=seeds)
         eng = step._make_engine(chains)
-        assert len(eng.run_streams()) == (1 if sub_blocks == 1 else 2)
+        assert len(eng.run_streams()) == (4 if sub_blocks is None else sub_blocks)
         eng.seed(seeds); eng.set_position(start); eng.reset_tuning()
         eng.reserve(tune + draws, keep_trace=True, trace_begin=0)
         eng.run(tune, 0, 13)
@@ -98,11 +99,12 @@ def test_sub_block_streams_do_not_change_a_bit(monkeypatch):
         eng.close()
         return out
 
-    a, b = job(None), job(1)
-    for x, y in zip(a, b):
-        if x.ndim == 2 and x.shape[1] == _abi.NUM_COUNTERS:     # the residency clock (CT_WAVE_TICKS) is a timing, not a result
-            x, y = x[:, :_abi.CT_WAVE_TICKS], y[:, :_abi.CT_WAVE_TICKS]
-        np.testing.assert_array_equal(x, y)
+    a = job(None)
+    for b in (job(1), job(2)):
+        for x, y in zip(a, b):
+            if x.ndim == 2 and x.shape[1] == _abi.NUM_COUNTERS:     # the residency clock (CT_WAVE_TICKS) is a timing, not a result
+                x, y = x[:, :_abi.CT_WAVE_TICKS], y[:, :_abi.CT_WAVE_TICKS]
+            np.testing.assert_array_equal(x, y)
     np.testing.assert_array_equal(a[4], a[0][:, 20:30])
 
 
