@@ -211,3 +211,55 @@ def test_the_build_hash_is_compiled_into_the_binary(tmp_path):
     fake.write_bytes(b"\x7fELF no stamp at all")
     assert _build.binary_hash(str(fake)) is None and _build.needs_build(str(fake))
     assert _build.source_hash(("-DX",)) != _build.source_hash()          # private builds carry their own identity
+
+
+def test_a_chain_may_only_part_from_its_oracle_twin_for_a_reason():
+    """tests/_gpu_util.py: explain_first_difference / assert_chain_matches (round 5). The rule the -m gpu parity tests apply to
+    a device chain's first difference from the oracle, pinned on synthetic chains: a jump out of nowhere has no reason and
+    fails; geometric growth, a fragile decision, a U-turn at reduction noise and a float32-ulp energy difference are reasons."""
+    import pytest
+
+    from tests._gpu_util import FRAGILE, RTOL_Q, assert_chain_matches
+
+    n, d = 30, 4
+    rs = np.random.RandomState(0)
+    want_q = rs.randn(n, d) + 3.0
+    stats = {"depth": np.full(n, 3), "tree_size": np.full(n, 7), "step_size": np.full(n, 0.5), "energy": np.full(n, 10.0)}
+    calm = np.full((n, 3), 0.3)                      # no decision anywhere near its threshold
+
+    def chain(err_from, err_rel, step_rel=None):
+        got_q = want_q.copy()
+        got_q[err_from:] *= 1.0 + err_rel
+        got = {k: v.copy() for k, v in stats.items()}
+        if step_rel is not None:
+            got["step_size"][step_rel[0]:] *= 1.0 + step_rel[1]
+        return got_q, got
+
+    # identical chains: all iterations verified
+    assert assert_chain_matches(want_q.copy(), dict(stats), want_q, stats, calm) == n
+    # positions 1e-6 apart from iteration 12 on, nothing before: no reason -> fails
+    got_q, got = chain(12, 1e-6)
+    with pytest.raises(AssertionError, match="no reason"):
+        assert_chain_matches(got_q, got, want_q, stats, calm)
+    # the same jump with the step size already 1e-9 apart the iteration before: geometric growth -> accepted, prefix 12
+    got_q, got = chain(12, 1e-6, step_rel=(11, 1e-9))
+    assert assert_chain_matches(got_q, got, want_q, stats, calm) == 12
+    # ... or with a multinomial decision within FRAGILE of its threshold at iteration 5
+    fragile = calm.copy()
+    fragile[5, 0] = 0.1 * FRAGILE
+    got_q, got = chain(12, 1e-6)
+    assert assert_chain_matches(got_q, got, want_q, stats, fragile) == 12
+    # ... or a U-turn dot product at reduction-order noise
+    turn = calm.copy()
+    turn[9, 1] = 1e-12
+    assert assert_chain_matches(got_q, got, want_q, stats, turn) == 12
+    # ... or the energy of that very iteration a float32 ulp apart (another host's sdot)
+    got_e = {k: v.copy() for k, v in got.items()}
+    got_e["energy"][12] *= 1.0 + 5e-7
+    assert assert_chain_matches(got_q, got_e, want_q, stats, calm) == 12
+    # an integer statistic that differs out of nowhere fails too
+    got_i = {k: v.copy() for k, v in stats.items()}
+    got_i["tree_size"][20] = 15
+    with pytest.raises(AssertionError, match="no reason"):
+        assert_chain_matches(want_q.copy(), got_i, want_q, stats, calm)
+    assert RTOL_Q == 1e-7
