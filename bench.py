@@ -492,8 +492,8 @@ def main():
                 if n_total - trace_begin > fit:
                     trace_begin = n_total - max(fit, 1)
         engs = [new_job(p_, n_total, trace_begin, keep_trace=keep_trace) for p_ in parts]
-        # HIP events on the streams the kernel is launched on: an engine launches its chains as sub-blocks (two halves on
-        # two internal streams, lmc_engine_run_streams), so a step is `len(run_streams)` concurrent dispatches per GPU
+        # HIP events on the streams the kernel is launched on: an engine launches its chains as sub-blocks (contiguous quarters on
+        # four internal streams, lmc_engine_run_streams), so a step is `len(run_streams)` concurrent dispatches per GPU
         run_streams = [[torch.cuda.ExternalStream(h, device=torch.device("cuda", p_["dev"])) for h in e_.run_streams()]
                        for e_, p_ in zip(engs, parts)]
         nst = len(run_streams[0])

@@ -340,7 +340,7 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
         if not launch_iters:
             # ...except when the chains outnumber the resident wavefront slots. Only a few times over: whole-job launches
             # would run in a few job-long rounds with the last one part empty, while in segments of 100 iterations the
-            # engine's two sub-block streams keep the slots filled across segment boundaries (+22 % at 8 192 x d=128).
+            # engine's sub-block streams keep the slots filled across segment boundaries (+22 % at 8 192 x d=128).
             # Many times over: a launch is also the granularity of Ctrl-C for the chains whose wavefronts have not started
             # yet (a workgroup that starts under a stop request does nothing: interrupting ONE job-long launch of 20 rounds of
             # residency would return no draw at all), so the job is cut into launches of 500 iterations -- few enough that
