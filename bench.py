@@ -27,6 +27,9 @@ secondary        = north_star's named shape (standard normal, d = 128, same chai
                    default command line, the other BASELINE.json configurations -- C2 (4 096 x 64), C4 (8 192 x 1000),
                    C5 (16 384 x 256 funnel, treedepth 12; as K launches and as ONE launch) -- each timed the same way with
                    its own roofline and tail block.
+stdout           = ONE compact JSON line (compact_line(): <= 8192 bytes -- headline fields, config, roofline, cpu_baseline, ESS
+                   numbers, a short block per secondary workload); the verbose object (every note, full secondary blocks)
+                   is written to bench_detail.json (--detail-out), not to stderr.
 cpu_baseline     = the numpy oracle (a port of the reference, oracle/lmc_oracle.py) on this box's host cores, one chain
                    per core, same recipe, bounded sample.
 """
@@ -48,6 +51,106 @@ FLOP_PER_LEAPFROG_PER_DIM = 26   # SURVEY.md 8d "Bound": ~26*d FP64 flop per lea
 SEED = 20260928
 
 
+LINE_LIMIT = 8192   # bytes: the driver's record keeps a bounded tail of stdout; round 5's 24 KB line left BENCH_r05.parsed null
+
+
+def _short(text, n):
+    text = "" if text is None else str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def _pick(d, keys):
+    return {k: d.get(k) for k in keys if k in d}
+
+
+def compact_line(out, detail_path=None, limit=LINE_LIMIT):
+    """The ONE stdout line of a run: the contract's headline fields, `config`, `roofline`, `cpu_baseline`, the ESS numbers
+    and a few figures per secondary workload -- numbers and short labels only, every explanatory string stays in the
+    verbose object (`bench_detail.json`). Guaranteed <= `limit` bytes: if an unusual run (many ranks, long error texts)
+    still overshoots, per-rank rows and then secondary extras are dropped, never the headline / roofline / cpu_baseline."""
+    ROOF = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "kernel", "kernel_ms_avg",
+            "leapfrogs_per_launch", "dispatches_per_step", "dispatch_ms_avg", "flop_per_leapfrog", "bytes_per_leapfrog",
+            "valu_inst_per_leapfrog", "simd_valu_busy")
+    TAIL = ("busiest_chain_leapfrogs", "mean_chain_leapfrogs", "launch_max_over_mean", "critical_path_leapfrogs",
+            "lone_wave_us_per_leapfrog", "implied_wall_lower_bound_s", "kernel_s", "resident_chains", "waves_per_chain",
+            "lds_bytes_per_workgroup", "mean_wave_slot_occupancy")
+
+    def roof(r):
+        c = _pick(r, ROOF)
+        for k in ("hbm_contract_60d", "hbm_contract_28d_read_only"):
+            if isinstance(r.get(k), dict):
+                c[k + "_frac_of_8TBps"] = r[k].get("frac_of_8TBps")
+        if r.get("pmc_source"):
+            c["pmc_source"] = _short(str(r["pmc_source"]).split(" ")[0], 60)
+        return c
+
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data"))
+    cfg = dict(out.get("config", {}))
+    cfg["workload"] = _short(cfg.get("workload_short") or cfg.get("workload"), 120)
+    cfg.pop("workload_short", None)
+    cfg["rng"] = _short(cfg.get("rng"), 40)
+    line["config"] = cfg
+    line.update(_pick(out, ("leapfrogs", "wall_s", "mean_depth_draws", "divergences_after_tune")))
+    if out.get("ess_per_sec"):
+        line["ess_per_sec"] = {k: v for k, v in out["ess_per_sec"].items() if not isinstance(v, str)}
+        line["ess_per_sec"]["parity"] = "unpinned (the reference has no ESS)"
+    else:
+        line["ess_per_sec"] = None
+    line["roofline"] = roof(out.get("roofline", {}))
+    if out.get("cpu_baseline"):
+        cb = dict(out["cpu_baseline"])
+        cb["sample"] = _short(cb.get("sample_short") or cb.get("sample"), 160)
+        cb.pop("sample_short", None)
+        line["cpu_baseline"] = cb
+    line["tail"] = _pick(out.get("tail", {}), TAIL)
+    line["per_rank"] = [_pick(r, ("rank", "chains", "leapfrogs", "kernel_s", "wall_s")) for r in out.get("per_rank", [])]
+    line.update(_pick(out, ("rccl_ranks", "backend", "source_hash")))
+    line["rccl_error"] = None if out.get("rccl_error") is None else _short(out["rccl_error"], 160)
+    line["launcher"] = _short(str(out.get("launcher", "")).split(":")[0], 16)
+    line["launcher_fallback"] = None if out.get("launcher_fallback") is None else _short(out["launcher_fallback"], 160)
+    sec = []
+    for s_ in out.get("secondary", []):
+        r = s_.get("roofline", {})
+        t = s_.get("tail", {})
+        sec.append({"workload": _short(s_.get("workload_short") or s_.get("workload"), 80), "value": s_.get("value"),
+                    "ms_per_step": s_.get("ms_per_step"), "steps": s_.get("steps"),
+                    "roofline": _pick(r, ("kernel", "frac", "bound")),
+                    "tail": _pick(t, ("mean_wave_slot_occupancy", "implied_wall_lower_bound_s", "lone_wave_us_per_leapfrog"))})
+    if sec:
+        line["secondary"] = sec
+    if detail_path:
+        line["detail"] = detail_path
+
+    def trim(x):   # six significant digits for non-integral floats (integral ones -- leapfrog counts -- stay exact)
+        if isinstance(x, float) and x == x and abs(x) != float("inf") and x != int(x):
+            return float("%.6g" % x)
+        if isinstance(x, dict):
+            return {k: trim(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [trim(v) for v in x]
+        return x
+
+    for k_ in list(line):
+        if k_ not in ("value", "ms_per_step"):
+            line[k_] = trim(line[k_])
+    sec = line.get("secondary", [])
+
+    def size():
+        return len(json.dumps(line)) + 1
+
+    if size() > limit:
+        line["per_rank"] = "dropped (line limit): see detail"
+    if size() > limit and sec:
+        for s_ in sec:
+            s_.pop("tail", None)
+    if size() > limit:
+        line["tail"] = _pick(line["tail"], ("mean_wave_slot_occupancy", "implied_wall_lower_bound_s"))
+        line.pop("secondary", None)
+    assert size() <= limit, size()
+    return line
+
+
 def make_target(lmc, name, dim):
     if name == "ar1":
         return lmc.targets.AR1(dim, 0.9), "AR(1) rho=0.9 correlated Gaussian"
@@ -58,6 +161,20 @@ def make_target(lmc, name, dim):
     if name == "diag":
         return lmc.targets.DiagGaussian.ill_conditioned(dim, 1e4), "ill-conditioned diagonal Gaussian kappa=1e4"
     raise SystemExit("unknown target %s" % name)
+
+
+def kernel_name(dim, mass):
+    """The sampling kernel lmc_engine_run dispatches for a fused shape (lmc_engine.hip:773-776): NS elements per lane,
+    W wavefronts per chain -- one wavefront up to d = 256, teams of 2 / 4 above."""
+    if mass != "diag":
+        return "lmc::run_dense_coop_kernel<NS=%d>" % max(1, (dim + 63) // 64) if mass == "full" else \
+               "lmc::run_dense_kernel<NS=%d>" % max(1, (dim + 63) // 64)
+    if dim <= 256:
+        ns = 1 if dim <= 64 else (2 if dim <= 128 else 4)
+        return "lmc::run_kernel<NS=%d,W=1>" % ns
+    if dim <= 1024:
+        return "lmc::run_kernel<NS=4,W=%d>" % (2 if dim <= 512 else 4)
+    return "lmc::run_wide_kernel"
 
 
 def config_label(target, dim, chains_total, max_treedepth, kind, mass):
@@ -140,6 +257,8 @@ def cpu_baseline(name, dim, seeds, start, budget_iters, mass="diag"):
         "sample": "%d chains on %d worker processes (1 per usable core) x (tune %d + draws %d), %s d=%d, %s mass, numpy "
                   "oracle (port of the reference's sequential path); %.0f leapfrogs in %.1f s"
                   % (n_chains, cores, tune, draws, name, dim, mass, leap, wall),
+        "sample_short": "%d oracle chains (numpy port of the reference) on %d procs x (tune %d + draws %d), %s d=%d %s mass; "
+                        "%.0f leapfrogs in %.1f s" % (n_chains, cores, tune, draws, name, dim, mass, leap, wall),
         "per_core": leap / wall / cores,
     }
 
@@ -210,6 +329,8 @@ def main():
     ap.add_argument("--no-philox-line", action="store_true", help="skip the separately labelled counter-based-RNG line of the north_star shape")
     ap.add_argument("--no-tail", action="store_true", help="skip the lone-chain latency measurement of the tail block (profiling "
                                                            "runs: keeps every run_kernel dispatch the same size)")
+    ap.add_argument("--detail-out", default=None, help="where the verbose result object goes (default: bench_detail.json next to "
+                                                       "bench.py); stdout carries one compact line of at most %d bytes" % LINE_LIMIT)
     ap.add_argument("--no-rccl-check", action="store_true", help="N = 1: do not bring up the one-rank RCCL group")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (nccl = RCCL; gloo only to exercise the multi-rank path on one GPU)")
@@ -595,6 +716,8 @@ def main():
             "label": label, "target": target_name, "dim": dim, "start": start, "mass_desc": mass_desc, "rng": RNG_LABEL[rng], "rng_mode": rng,
             "workload": "%s: %d chains x dim %d %s, %s, %s, tune %d + draws %d in %d launches of %d iterations; %s" % (
                 label, chains_total, dim, target_desc, method, mass_desc, n_tune, n_total - n_tune, K, ips, part),
+            "workload_short": "%s: %d x %d %s, %s, %d x %d it" % (label, chains_total, dim, target_name,
+                                                                  ("NUTS td%d" % md) if args.kind == "nuts" else "HMC", K, ips),
             "K": K, "ips": ips, "chains_total": chains_total, "chains_this_gpu": chains, "n_tune": n_tune, "n_total": n_total,
             "wall": wall_max, "leap_all": leap_all, "leap_local": leap_local, "kernel_ms": kernel_ms,
             "dispatch_ms_avg": float(np.mean(dispatch_ms)), "dispatches_per_step": nst,
@@ -616,7 +739,7 @@ def main():
         key = ("%s:%d" % (job["target"], dim)) + ("" if args.mass == "diag" else ":" + args.mass) + ("" if job["rng_mode"] == "numpy" else ":" + job["rng_mode"])
         prof = pmc_profile(key, src_hash)
         r = {
-            "kernel": ("lmc::run_kernel<NS=%d>" if args.mass == "diag" else "lmc::run_dense_kernel<NS=%d>") % max(1, (dim + 63) // 64),
+            "kernel": kernel_name(dim, args.mass),
             "kernel_ms_avg": sum(job["kernel_ms"]) / job["K"], "leapfrogs_per_launch": job["leap_local"] / job["K"],
             "dispatches_per_step": job["dispatches_per_step"], "dispatch_ms_avg": job["dispatch_ms_avg"],
             "launch_note": "a step (launch) is %d concurrent dispatches of the kernel, one per sub-block of chains on its own "
@@ -688,7 +811,8 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": primary["workload"], "chains_total": chains_total, "chains_this_gpu": chains,
+                "workload": primary["workload"], "workload_short": primary["workload_short"] + (", %s mass" % args.mass),
+                "chains_total": chains_total, "chains_this_gpu": chains,
                 "dim": args.dim, "target": args.target, "tune": n_tune, "draws": n_total - n_tune,
                 "rng": primary["rng"],
                 "trace_in_hbm": not args.no_trace, "parallelism": "chain-block x%d (%s scaling)" % (n_units, args.scaling),
@@ -723,6 +847,7 @@ def main():
             for job in secondaries:   # (a counter-based line is separately labelled, never the headline: not the reference's random stream)
                 out["secondary"].append({
                     "workload": job["workload"] + ("; COUNTER-BASED MOMENTUM STREAM" if job["rng_mode"] == "philox" else ""),
+                    "workload_short": job["workload_short"] + (" [PHILOX momentum stream]" if job["rng_mode"] == "philox" else ""),
                     "rng": job["rng"], "value": job["leap_all"] / job["wall"], "unit": "leapfrog-steps/s",
                     "steps": job["K"], "iters_per_step": job["ips"], "ms_per_step": job["wall"] * 1e3 / job["K"],
                     "chains_total": job["chains_total"], "chains_this_gpu": job["chains_this_gpu"], "dim": job["dim"],
@@ -731,8 +856,17 @@ def main():
                     "per_rank": job["per_rank"]})
         if not args.no_cpu_baseline and n_units == 1:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.target, args.dim, seeds_all[:64], primary["start"], args.cpu_iters, args.mass)
+        # stdout carries ONE compact line (<= LINE_LIMIT bytes); the verbose object -- every note, the full secondary blocks --
+        # goes to a side file, never to stderr (the driver's record tails stdout and stderr together)
+        detail_path = args.detail_out or os.path.join(ROOT, "bench_detail.json")
+        try:
+            with open(detail_path, "w") as fh:
+                json.dump(out, fh, indent=1)
+            detail_rel = os.path.relpath(detail_path, ROOT)
+        except OSError as err:
+            detail_rel = "not written: %s" % err
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        os.write(real_stdout, (json.dumps(compact_line(out, detail_rel)) + "\n").encode())
     if group_up:
         if world > 1:
             dist.barrier()

@@ -263,3 +263,42 @@ def test_a_chain_may_only_part_from_its_oracle_twin_for_a_reason():
     with pytest.raises(AssertionError, match="no reason"):
         assert_chain_matches(want_q.copy(), got_i, want_q, stats, calm)
     assert RTOL_Q == 1e-7
+
+
+def test_bench_line_is_compact_on_a_default_shaped_result():
+    """Round 5's default run printed a 24 KB line and the driver's record lost it (BENCH_r05.parsed = null). The line
+    bench.py prints now is built by compact_line(): at most 8192 bytes on that very result object (kept under profiles/),
+    with the headline, `roofline`, `cpu_baseline` and a short block per secondary workload."""
+    import importlib
+    import json
+
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    verbose = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_driver_form.json")))
+    assert len(json.dumps(verbose)) > 20000
+    line = bench.compact_line(verbose, "bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) + 1 <= 8192 and len(text) < 6000, len(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["value"] == verbose["value"] and line["config"]["workload"].startswith("C3")
+    r = line["roofline"]
+    assert r["bound"] == "fp64_valu" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and r["traffic"] is not None
+    assert line["cpu_baseline"]["cores"] == verbose["cpu_baseline"]["cores"] and line["cpu_baseline"]["kind"] == "port"
+    assert len(line["secondary"]) == len(verbose["secondary"]) == 6
+    labels = [s_["workload"] for s_ in line["secondary"]]
+    assert [lb.split(":")[0] for lb in labels] == ["north_star shape", "north_star shape", "C2", "C4", "C5", "C5 (one launch)"]
+    for s_ in line["secondary"]:
+        assert s_["value"] > 0 and 0 < s_["roofline"]["frac"] < 1 and "mean_wave_slot_occupancy" in s_["tail"]
+    assert not any(isinstance(v, str) and len(v) > 170 for v in json.loads(text).values())
+
+    # eight ranks with long error texts still fit; the headline blocks are never what gets dropped
+    verbose["per_rank"] = [dict(verbose["per_rank"][0], rank=r_) for r_ in range(8)]
+    verbose["rccl_error"] = "x" * 2000
+    verbose["launcher_fallback"] = "y" * 2000
+    line8 = bench.compact_line(verbose, "bench_detail.json")
+    assert len(json.dumps(line8)) + 1 <= 8192 and len(line8["per_rank"]) == 8
+    assert "roofline" in line8 and "cpu_baseline" in line8
+    tiny = bench.compact_line(verbose, "bench_detail.json", limit=3000)
+    assert len(json.dumps(tiny)) + 1 <= 3000 and tiny["roofline"]["frac"] == line["roofline"]["frac"] and "cpu_baseline" in tiny
