@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LMC_ABI_VERSION 7
+#define LMC_ABI_VERSION 8
 
 /* status codes */
 #define LMC_OK 0
@@ -81,6 +81,17 @@ extern "C" {
  * elements: the draw needs no barrier, where the parity stream is produced by wave 0 alone). */
 #define LMC_RNG_NUMPY 0
 #define LMC_RNG_PHILOX 1
+
+/* LDS plan of the one-wave fused sampling kernels (csrc/lmc_sampler.hpp: PairLds<NS, 1, PL>). SHALLOW keeps the chain's
+ * MT19937 state and the cold slots of the trajectory in LDS and subtree-stack level 1; DEEP uses the generator in place
+ * (HBM/L2), one cold slot, and the room that frees holds stack level 2 -- faster once trees are deep (C3: +6 %). AUTO (the
+ * default): the engine picks the plan of every launch when it is enqueued, from the mean tree size the running chains report
+ * (plan SHALLOW for launches that start before iteration 200). Same statements, same results bit for bit under either plan
+ * (tests/test_gpu_round5.py); the pinned values exist for A/B runs and for putting either kernel under the oracle. Ignored
+ * by team (dim > 256), dense, general and tick kernels. */
+#define LMC_LDS_PLAN_AUTO 0
+#define LMC_LDS_PLAN_SHALLOW 1
+#define LMC_LDS_PLAN_DEEP 2
 
 /* per-chain status bits (lmc_engine_get_status) */
 #define LMC_STATUS_BAD_INITIAL_ENERGY 1   /* base_hmc.py:145-148 (ValueError in the reference) */
@@ -150,6 +161,9 @@ typedef struct lmc_config {
                                    * and the momentum draw stay float64; with LMC_POT_FULL_ADAPT: QuadPotentialFullAdapt(dtype="float64")
                                    * (:484,497-509): float64 covariance, Cholesky factor and momentum solve. 0 = the reference's
                                    * default float32. General kernels (below). */
+    int32_t lds_plan;             /* LMC_LDS_PLAN_*: which LDS plan the one-wave sampling kernels run under (results do not
+                                   * depend on it). 0 = the engine chooses per launch. */
+    int32_t reserved0;            /* must be 0 */
 } lmc_config;
 
 /* Which kernels an engine runs. The FUSED kernels (one chain = one wavefront or a team of 2 / 4, the tree in registers and
@@ -234,8 +248,10 @@ int lmc_engine_set_dual_average(lmc_engine* e, double log_step, double log_bar, 
  * run(): iterations [iter_begin, iter_begin + n_iters) of every chain; iterations with global index
  *        < n_tune are tuning iterations (stop_tuning happens at index n_tune, sampling.py:510-511).
  *        Asynchronous. Chains are independent (sampling.py:131-136: one process per chain in the reference), so
- *        the engine launches them as two contiguous sub-blocks on two internal streams: consecutive run() calls chain
- *        up per sub-block, and the tail of one sub-block's launch is covered by the other's next launch. Every other
+ *        the engine launches them as contiguous sub-blocks on internal streams of their own (FOUR for the fused diagonal-mass
+ *        kernels, two for the dense ones, one for the general kernels; lmc_engine_run_streams() returns the number --
+ *        size the array for LMC_MAX_RUN_STREAMS): consecutive run() calls chain up per sub-block, and the tail of one
+ *        sub-block's launch is covered by the others' next launch. Every other
  *        entry point (and lmc_engine_synchronize) is ordered after all launched sub-blocks; work on the engine's
  *        stream that precedes a run() is ordered before it.
  * run_streams(): the streams run() launches its kernels on (returns their number, at most `capacity` written) -- for
@@ -275,13 +291,55 @@ int lmc_engine_request_stop(lmc_engine* e, int32_t stop);
  * completed is lmc_chain_state.iter_count. */
 int64_t lmc_engine_progress(lmc_engine* e);
 int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_iters);
+#define LMC_MAX_RUN_STREAMS 8
 int lmc_engine_run_streams(lmc_engine* e, void** streams, int32_t capacity);
+/* The LDS plan (LMC_LDS_PLAN_SHALLOW / _DEEP) of the most recent lmc_engine_run() launch; 0 before the first launch and for
+ * engines whose kernels have one plan only. lmc_engine_run_lds_bytes() reports the bytes of that launch. */
+int32_t lmc_engine_last_run_plan(lmc_engine* e);
 
 /* ---- results (synchronise the stream). dst shapes: trace [chains][n_iters][dim]; stats [chains][n_iters] */
 int lmc_engine_get_trace(lmc_engine* e, double* dst, int64_t iter_begin, int64_t n_iters);
 int lmc_engine_get_stat_f64(lmc_engine* e, int32_t stat, double* dst, int64_t iter_begin, int64_t n_iters);
 int lmc_engine_get_stat_i32(lmc_engine* e, int32_t stat, int32_t* dst, int64_t iter_begin, int64_t n_iters);
 int lmc_engine_get_stat_u8(lmc_engine* e, int32_t stat, uint8_t* dst, int64_t iter_begin, int64_t n_iters);
+/* ---- results, streamed: sampling.py:207-222 hands the caller host arrays; a job's draws are tens of GiB (C3: 64 GiB), so the
+ * copy must not wait for the job. copy_window_async() enqueues, on a copy stream of the engine's own, the device->host copy of
+ * iterations [iter_begin, iter_begin + n_iters) of EVERY chain into the caller's final arrays, ordered after every
+ * lmc_engine_run() enqueued so far and asynchronous to the host and to later launches (the D2H of launch k runs under launch
+ * k + 1). Destinations are laid out like the reference's results -- trace [chains][n_out][dim], planes [chains][n_out] --
+ * and iteration `first` lands in row 0; a plane is one statistic out of the per-draw records, converted on the device to the
+ * dtype the reference's stats dict carries (nuts.py:87-101, hmc.py:36-50). For the copy to be asynchronous the
+ * destinations must be pinned host memory (lmc_host_alloc) or device memory; pageable memory works but blocks.
+ * copy_wait() waits for the copies enqueued so far (and nothing else). */
+#define LMC_PLANE_F64 0      /* idx = LMC_STAT_* f64 slot */
+#define LMC_PLANE_I32 1      /* idx = LMC_STAT_DEPTH / LMC_STAT_TREE_SIZE */
+#define LMC_PLANE_U8 2       /* idx = LMC_STAT_DIVERGING / _TUNE / _ACCEPTED */
+#define LMC_AS_NATIVE 0      /* float64 / int32 / uint8 as stored */
+#define LMC_AS_F64 1         /* written as float64 (the reference's "tree_size" is float64) */
+#define LMC_AS_I64 2         /* written as int64 (the reference's "depth", HMC's "n_steps") */
+#define LMC_MAX_PLANES 16
+typedef struct lmc_window_plane {
+    void* dst;               /* [chains][n_out] of the output dtype */
+    int32_t kind;            /* LMC_PLANE_* */
+    int32_t idx;
+    int32_t as;              /* LMC_AS_* */
+    int32_t reserved;
+} lmc_window_plane;
+typedef struct lmc_window_dst {
+    int64_t n_out;           /* iterations per chain the destination arrays hold */
+    int64_t first;           /* iteration index that lands in destination row 0 */
+    double* trace;           /* [chains][n_out][dim], or NULL */
+    int32_t n_planes;
+    int32_t reserved;
+    lmc_window_plane plane[LMC_MAX_PLANES];
+} lmc_window_dst;
+int lmc_engine_copy_window_async(lmc_engine* e, const lmc_window_dst* dst, int64_t iter_begin, int64_t n_iters);
+int lmc_engine_copy_wait(lmc_engine* e);
+/* Page-locked host memory every visible GPU can copy into (hipHostMalloc, portable): what the arrays sample() returns live
+ * in. NULL on failure (lmc_last_error(NULL)); free with lmc_host_free. */
+void* lmc_host_alloc(uint64_t bytes);
+void lmc_host_free(void* p);
+
 /* Device pointers of the engine-owned outputs for zero-copy consumers; valid until the next reserve()/destroy().
  * Trace: [chains][capacity - trace_begin][dim] float64. Statistics: [chains][capacity] records of LMC_STAT_RECORD_BYTES
  * = 64 bytes, one per draw, written by the sampling kernel in one coalesced store:

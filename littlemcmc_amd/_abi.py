@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LMC_HIP_LIB") or os.path.join(_HERE, "liblmc_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 OK = 0
 
 KIND_NUTS, KIND_HMC = 0, 1
@@ -20,6 +20,11 @@ TARGET_STD_NORMAL, TARGET_DIAG_GAUSSIAN, TARGET_AR1, TARGET_FUNNEL, TARGET_NORMA
 STATUS_BAD_INITIAL_ENERGY = 1
 SDOT_NATIVE, SDOT_OPENBLAS_SKYLAKEX, SDOT_OPENBLAS_HASWELL = 0, 1, 2
 RNG_NUMPY, RNG_PHILOX = 0, 1
+LDS_PLAN_AUTO, LDS_PLAN_SHALLOW, LDS_PLAN_DEEP = 0, 1, 2
+PLANE_F64, PLANE_I32, PLANE_U8 = 0, 1, 2
+AS_NATIVE, AS_F64, AS_I64 = 0, 1, 2
+MAX_PLANES = 16
+MAX_RUN_STREAMS = 8
 (STAT_STEP_SIZE, STAT_STEP_SIZE_BAR, STAT_ACCEPT, STAT_ENERGY_ERROR, STAT_ENERGY, STAT_MAX_ENERGY_ERROR,
  STAT_MODEL_LOGP) = range(7)
 STAT_DEPTH, STAT_TREE_SIZE = 0, 1
@@ -41,8 +46,21 @@ class Config(C.Structure):
         ("max_treedepth", C.c_int32), ("early_max_treedepth", C.c_int32),
         ("path_length", C.c_double), ("max_steps", C.c_int32), ("adaptation_window", C.c_int32),
         ("lds_levels", C.c_int32), ("start_energy_sdot", C.c_int32), ("adaptation_window_multiplier", C.c_double),
-        ("rng_mode", C.c_int32), ("mass_f64", C.c_int32),
+        ("rng_mode", C.c_int32), ("mass_f64", C.c_int32), ("lds_plan", C.c_int32), ("reserved0", C.c_int32),
     ]
+
+
+class WindowPlane(C.Structure):
+    """struct lmc_window_plane (include/lmc_hip.h)."""
+
+    _fields_ = [("dst", C.c_void_p), ("kind", C.c_int32), ("idx", C.c_int32), ("as_", C.c_int32), ("reserved", C.c_int32)]
+
+
+class WindowDst(C.Structure):
+    """struct lmc_window_dst (include/lmc_hip.h): where lmc_engine_copy_window_async() puts a window of iterations."""
+
+    _fields_ = [("n_out", C.c_int64), ("first", C.c_int64), ("trace", C.c_void_p), ("n_planes", C.c_int32),
+                ("reserved", C.c_int32), ("plane", WindowPlane * MAX_PLANES)]
 
 
 _P = C.c_void_p
@@ -106,6 +124,11 @@ _SIGNATURES = {
     "lmc_engine_reserve": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "lmc_engine_run": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32]),
     "lmc_engine_run_streams": (C.c_int, [_P, _P, C.c_int32]),
+    "lmc_engine_last_run_plan": (C.c_int32, [_P]),
+    "lmc_engine_copy_window_async": (C.c_int, [_P, C.POINTER(WindowDst), C.c_int64, C.c_int64]),
+    "lmc_engine_copy_wait": (C.c_int, [_P]),
+    "lmc_host_alloc": (_P, [C.c_uint64]),
+    "lmc_host_free": (None, [_P]),
     "lmc_engine_set_step_jitter": (C.c_int, [_P, C.c_int32, C.c_double, C.c_double]),
     "lmc_engine_set_step_sizes": (C.c_int, [_P, _P]),
     "lmc_engine_diag_update": (C.c_int, [_P, C.c_int32]),

@@ -223,6 +223,35 @@ __global__ void stat_gather_kernel(const StatRecord* rec, long long cap, int cha
     else static_cast<unsigned char*>(out)[k] = static_cast<unsigned char>((r.depth_flags >> (16 + idx)) & 1u);
 }
 
+// All statistics planes of the draws [iter_begin, iter_begin + n) of every chain in ONE pass over the 64-byte records
+// (lmc_engine_copy_window_async): thread k = (chain, draw) reads its record once and writes every plane's element in the
+// dtype the reference's stats dict carries; plane p is a dense [chains][n] array at stage + offset[p].
+struct WindowPlanes {
+    int n_planes;
+    int kind[LMC_MAX_PLANES], idx[LMC_MAX_PLANES], as[LMC_MAX_PLANES];
+    long long offset[LMC_MAX_PLANES];   // bytes from the staging area's base
+};
+__global__ void window_gather_kernel(const StatRecord* rec, long long cap, int chains, long long iter_begin, long long n, int hmc,
+                                     WindowPlanes W, char* stage) {
+    const long long k = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= static_cast<long long>(chains) * n) return;
+    const long long c = k / n, i = k - c * n;
+    const StatRecord r = rec[c * cap + iter_begin + i];
+    for (int p = 0; p < W.n_planes; ++p) {
+        char* out = stage + W.offset[p];
+        if (W.kind[p] == LMC_PLANE_F64) {
+            reinterpret_cast<double*>(out)[k] = r.f64[W.idx[p]];
+        } else if (W.kind[p] == LMC_PLANE_I32) {
+            const int v = (W.idx[p] == kSiTreeSize || hmc) ? r.tree_size : static_cast<int>(r.depth_flags & 0xffffu);
+            if (W.as[p] == LMC_AS_F64) reinterpret_cast<double*>(out)[k] = static_cast<double>(v);
+            else if (W.as[p] == LMC_AS_I64) reinterpret_cast<long long*>(out)[k] = static_cast<long long>(v);
+            else reinterpret_cast<int*>(out)[k] = v;
+        } else {
+            reinterpret_cast<unsigned char*>(out)[k] = static_cast<unsigned char>((r.depth_flags >> (16 + W.idx[p])) & 1u);
+        }
+    }
+}
+
 // After lmc_engine_set_chain_state(): inv_std = 1 / sqrt(var) in float32 (quadpotential.py:226-229).
 // from64: the float64 diagonal was set (QuadPotentialDiagAdapt(dtype="float64")), the float32 views follow it.
 __global__ void derive_inv_std_kernel(ChainArrays A, int from64) {
@@ -257,6 +286,7 @@ struct lmc_engine {
     int nlds1 = 1, lds_bytes1 = 0, lds_plan = 0;      // one-wave sampling kernels: the deep-tree LDS plan (PairLds<NS, 1, 1>) and who chooses (0 / 1 pinned, 2 = per launch from the chains' reports)
     int lds_plan_wanted = 0;                          // lds_plan once a run-time compiled density has handed over its plan-1 kernel
     int plan_now = 0;                                 // the plan of the launches being enqueued (lds_plan == 2: follows the tree-size hint with hysteresis)
+    int plan_last = -1;                               // the plan the most recent lmc_engine_run() actually launched with (-1: nothing launched yet)
     bool wide = false;          // the general kernels (lmc_wide.hpp): one chain = 16 wavefronts, dpad = 1024 * ns -- model_ndim > 1024,
                                 // dense matrices beyond 256 dimensions, float64 adaptive diagonals
     double* init_diag64 = nullptr;   // [C][dpad] wide: the initial diagonal in float64
@@ -267,7 +297,7 @@ struct lmc_engine {
     // (four since round 5 -- profiles/r05_sub_blocks_ab.txt: against two, C3 equal, north_star shape -0.5 %, C2 +2.4 %, C4 +1 %,
     // C5 +2.8 %; eight lose 35-40 % on C2 / C5: more streams than the hardware queues take)
 #ifndef LMC_MAX_SUB
-#define LMC_MAX_SUB 8
+#define LMC_MAX_SUB 4      // (eight lose 35-40 %: variant builds for A/B runs pass -DLMC_MAX_SUB=8)
 #endif
 #ifndef LMC_DEFAULT_SUB
 #define LMC_DEFAULT_SUB 4
@@ -277,6 +307,12 @@ struct lmc_engine {
     hipStream_t sub_stream[kMaxSub] = {};
     hipEvent_t sub_done[kMaxSub] = {};
     hipEvent_t main_done = nullptr;
+    // streamed results (lmc_engine_copy_window_async): a copy stream of the engine's own, ordered after the launches enqueued so
+    // far by events, and a device staging area the statistics planes of one window are gathered into
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_dep[kMaxSub + 1] = {};
+    char* copy_stage = nullptr;
+    size_t copy_stage_bytes = 0;
     double* chol64T = nullptr;  // FULL_F64: LT[j][i] = L[i][j] of the covariance's factor (what the state getters hand out; D.fac holds L^-1)
     uint32_t* seeds = nullptr;  // [C] the seeds of lmc_engine_seed (key of LMC_RNG_PHILOX's momentum stream)
     int* stop_host = nullptr;   // pinned, device-mapped host word the sampling kernels poll (lmc_engine_request_stop): the host
@@ -672,6 +708,7 @@ void lmc_config_defaults(lmc_config* cfg, int32_t chains, int32_t dim) {
     cfg->rng_mode = LMC_RNG_NUMPY;
     cfg->mass_f64 = 0;
     cfg->lds_levels = 0;
+    cfg->lds_plan = LMC_LDS_PLAN_AUTO;
     cfg->start_energy_sdot = LMC_SDOT_OPENBLAS_SKYLAKEX;
 }
 
@@ -695,6 +732,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         return fail(nullptr, LMC_ERR_INVALID, "ABI version mismatch: header %d, library %d", cfg->abi_version,
                     LMC_ABI_VERSION);
     if (cfg->chains < 1 || cfg->dim < 1) return fail(nullptr, LMC_ERR_INVALID, "chains and dim must be >= 1");
+    if (cfg->lds_plan < LMC_LDS_PLAN_AUTO || cfg->lds_plan > LMC_LDS_PLAN_DEEP)
+        return fail(nullptr, LMC_ERR_INVALID, "unknown lds_plan %d", cfg->lds_plan);
     if (cfg->potential < LMC_POT_DIAG_ADAPT || cfg->potential > LMC_POT_FULL_F64)
         return fail(nullptr, LMC_ERR_INVALID, "unknown potential %d", cfg->potential);
     if (cfg->mass_f64 && cfg->potential > LMC_POT_DIAG && cfg->potential != LMC_POT_FULL_ADAPT)
@@ -836,8 +875,9 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
         // The deep-tree plan of the one-wave kernels (lmc_sampler.hpp: PairLds<NS, 1, 1>, run_kernel's kDynPlan): MT19937 used in
         // place, one cold slot (none at NS = 4) in LDS, and the room that frees holds stack level 2. Same budget per wave (the
         // generator's 2.5 KB included, since it is not in LDS under this plan). By default the engine picks the plan of every
-        // launch it enqueues from the tree sizes the running chains report (choose_lds_plan); LMC_LDS_PLAN=0 / 1 pins it (A/B
-        // runs, the bit-identity test), and an explicit cfg.lds_levels (a test knob for plan 0's level count) pins plan 0.
+        // launch it enqueues from the tree sizes the running chains report (choose_lds_plan); cfg.lds_plan pins it (A/B runs, the
+        // bit-identity test, either kernel under the oracle), and an explicit cfg.lds_levels (a test knob for plan 0's level
+        // count) pins plan 0.
         e->nlds1 = nlds;
         e->lds_bytes1 = 0;
         e->lds_plan = 0;
@@ -847,11 +887,7 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
             while (n1 < max_levels && pair_total_doubles(e->run_ns, 1, n1 + 1, 1) * 8L <= budget1) ++n1;
             e->nlds1 = n1;
             e->lds_bytes1 = pair_total_doubles(e->run_ns, 1, n1, 1) * 8;
-            e->lds_plan = 2;
-            if (const char* env = std::getenv("LMC_LDS_PLAN")) {
-                if (env[0] == '0') e->lds_plan = 0;
-                else if (env[0] == '1') e->lds_plan = 1;
-            }
+            e->lds_plan = cfg->lds_plan == LMC_LDS_PLAN_SHALLOW ? 0 : cfg->lds_plan == LMC_LDS_PLAN_DEEP ? 1 : 2;
             if (e->nlds1 <= e->nlds) e->lds_plan = 0;   // nothing gained: the plan would only move the generator out
             if (cfg->rng_mode == LMC_RNG_PHILOX) e->lds_plan = 0;   // (instantiated on the parity stream)
             e->lds_plan_wanted = e->lds_plan;
@@ -1046,6 +1082,10 @@ void lmc_engine_destroy(lmc_engine* e) {
         if (e->sub_done[b]) (void)hipEventDestroy(e->sub_done[b]);
     }
     if (e->main_done) (void)hipEventDestroy(e->main_done);
+    if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
+    for (hipEvent_t ev : e->copy_dep)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->copy_stage) (void)hipFree(e->copy_stage);
     if (e->stop_host) (void)hipHostFree(e->stop_host);
     for (void* p : e->allocs)
         if (p) (void)hipFree(p);
@@ -1124,7 +1164,12 @@ int lmc_engine_occupancy(lmc_engine* e, int32_t* resident_chains, int32_t* waves
 int32_t lmc_engine_run_lds_bytes(lmc_engine* e) {
     if (!e || e->cfg.target_family == LMC_TARGET_EXTERNAL || (e->cfg.potential >= LMC_POT_FULL && !e->wide)) return -1;
     if (e->wide) return e->lds_bytes;
-    return sampling_lds_bytes(e, e->plan_now);
+    return sampling_lds_bytes(e, e->plan_last >= 0 ? e->plan_last : e->plan_now);   // the launch that ran, not the one that may come
+}
+
+int32_t lmc_engine_last_run_plan(lmc_engine* e) {
+    if (!e || e->plan_last < 0 || e->wide || e->cfg.potential >= LMC_POT_FULL || e->cfg.target_family == LMC_TARGET_EXTERNAL) return 0;
+    return e->plan_last == 1 ? LMC_LDS_PLAN_DEEP : LMC_LDS_PLAN_SHALLOW;
 }
 
 int lmc_engine_load_user_kernels(lmc_engine* e, const void* code_object, const char* run_name, const char* trajectory_name,
@@ -1704,6 +1749,9 @@ int lmc_engine_seed(lmc_engine* e, const uint32_t* seeds) {
     if (err == hipSuccess) err = hipStreamSynchronize(main_stream(e));
     (void)hipFree(dseeds);
     if (err != hipSuccess) return fail(e, LMC_ERR_HIP, "seed: %s", hipGetErrorString(err));
+    // new seeds = a new job: what the chains of the previous one reported about their tree sizes says nothing about it
+    if (e->stop_host) __atomic_store_n(e->stop_host + 24, 0, __ATOMIC_RELEASE);
+    if (e->lds_plan == 2) e->plan_now = 0;
     return LMC_OK;
 }
 
@@ -1773,6 +1821,7 @@ int lmc_engine_reset_tuning(lmc_engine* e) {
     if (e->stop_host) __atomic_store_n(e->stop_host + 16, 0, __ATOMIC_RELEASE);   // progress hint: iteration 0 again
     if (e->stop_host) __atomic_store_n(e->stop_host + 24, 0, __ATOMIC_RELEASE);   // tree-size hint: nothing reported yet
     if (e->lds_plan == 2) e->plan_now = 0;
+    e->plan_last = -1;
     // QuadPotentialDiag.reset() is a no-op (quadpotential.py:138-140): only the adaptive potential resets
     int rc = launch_reset(e, 1, e->cfg.potential == LMC_POT_DIAG_ADAPT ? 1 : 0);
     if (rc != LMC_OK) return rc;
@@ -1892,7 +1941,13 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
     SamplerParams P = make_params(e, n_tune, iter_begin, n_iters);
     if (e->wide) return wide_run(e, P);
     if (e->cfg.potential >= LMC_POT_FULL) return dense_run(e, P);
-    const int plan = choose_lds_plan(e, iter_begin);
+    int plan = choose_lds_plan(e, iter_begin);
+    // the deep-tree plan exists for the one-wave kernels, and for a run-time compiled density only once its plan-1 kernel has
+    // been handed over: anything else launches under plan 0 whatever was chosen (LDS layout and kernel must agree)
+    if (e->run_w != 1 || e->lds_bytes1 <= 0 ||
+        (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledIn && !e->user_run1))
+        plan = 0;
+    e->plan_last = plan;
     if (plan == 1) {   // the deep-tree plan: its own level count, no generator behind the stack
         P.nlds = e->nlds1;
         P.lds_doubles = e->lds_bytes1 / 8;
@@ -1937,7 +1992,7 @@ int lmc_engine_run(lmc_engine* e, int64_t n_tune, int64_t iter_begin, int32_t n_
         if (n_sub > 1) e->sub_pending = true;
         if (e->cfg.target_family == LMC_TARGET_USER && !kUserCompiledIn) {
             void* args[] = {&e->A, &P, &e->tparams};
-            const int rc = user_launch(e, (plan == 1 && e->user_run1) ? e->user_run1 : e->user_run, st, grid.x, block.x, static_cast<unsigned>(run_lds), args);
+            const int rc = user_launch(e, plan == 1 ? e->user_run1 : e->user_run, st, grid.x, block.x, static_cast<unsigned>(run_lds), args);
             if (rc != LMC_OK) return rc;
             continue;
         }
@@ -2081,6 +2136,113 @@ int lmc_engine_get_stat_u8(lmc_engine* e, int32_t stat, uint8_t* dst, int64_t it
     if (rc != LMC_OK) return rc;
     if (stat < 0 || stat >= kNumStatU8) return fail(e, LMC_ERR_INVALID, "unknown u8 stat %d", stat);
     return gather_stat(e, dst, sizeof(uint8_t), 2, stat, iter_begin, n_iters);
+}
+
+// ---- streamed results ------------------------------------------------------------------------------------------------------
+static size_t plane_elem_bytes(const lmc_window_plane& pl) {
+    if (pl.kind == LMC_PLANE_F64) return sizeof(double);
+    if (pl.kind == LMC_PLANE_U8) return 1;
+    return pl.as == LMC_AS_NATIVE ? sizeof(int32_t) : 8;
+}
+
+int lmc_engine_copy_window_async(lmc_engine* e, const lmc_window_dst* dst, int64_t iter_begin, int64_t n_iters) {
+    if (!e || !dst) return fail(e, LMC_ERR_INVALID, "null argument");
+    if (n_iters == 0) return LMC_OK;
+    if (iter_begin < 0 || n_iters < 0 || iter_begin + n_iters > e->A.cap || !e->A.stat_rec)
+        return fail(e, LMC_ERR_INVALID, "window [%lld, %lld) outside reserved capacity %lld", (long long)iter_begin,
+                    (long long)(iter_begin + n_iters), (long long)e->A.cap);
+    if (iter_begin < dst->first || iter_begin + n_iters > dst->first + dst->n_out)
+        return fail(e, LMC_ERR_INVALID, "window [%lld, %lld) outside the destination's iterations [%lld, %lld)", (long long)iter_begin,
+                    (long long)(iter_begin + n_iters), (long long)dst->first, (long long)(dst->first + dst->n_out));
+    if (dst->n_planes < 0 || dst->n_planes > LMC_MAX_PLANES) return fail(e, LMC_ERR_INVALID, "n_planes %d", dst->n_planes);
+    if (dst->trace && (!e->A.trace || iter_begin < e->A.trace_begin))
+        return fail(e, LMC_ERR_INVALID, "draws before iteration %lld were not stored", (long long)e->A.trace_begin);
+    for (int p = 0; p < dst->n_planes; ++p) {
+        const lmc_window_plane& pl = dst->plane[p];
+        const int lim = pl.kind == LMC_PLANE_F64 ? kNumStatF64 : pl.kind == LMC_PLANE_I32 ? kNumStatI32 : pl.kind == LMC_PLANE_U8 ? kNumStatU8 : -1;
+        if (!pl.dst || lim < 0 || pl.idx < 0 || pl.idx >= lim || pl.as < LMC_AS_NATIVE || pl.as > LMC_AS_I64 ||
+            (pl.kind != LMC_PLANE_I32 && pl.as != LMC_AS_NATIVE))
+            return fail(e, LMC_ERR_INVALID, "plane %d: kind %d idx %d as %d", p, pl.kind, pl.idx, pl.as);
+    }
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (!e->copy_stream) {
+        HIP_TRY(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        for (hipEvent_t& ev : e->copy_dep) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    // ordered after every launch enqueued so far: one event per sub-block stream (and the main stream), waited for on the
+    // device -- the host does not block, later launches are not held up
+    hipStream_t cs = e->copy_stream;
+    if (e->n_sub > 1)
+        for (int b = 0; b < e->n_sub; ++b) {
+            HIP_TRY(e, hipEventRecord(e->copy_dep[b], e->sub_stream[b]));
+            HIP_TRY(e, hipStreamWaitEvent(cs, e->copy_dep[b], 0));
+        }
+    HIP_TRY(e, hipEventRecord(e->copy_dep[lmc_engine::kMaxSub], e->stream_));
+    HIP_TRY(e, hipStreamWaitEvent(cs, e->copy_dep[lmc_engine::kMaxSub], 0));
+
+    const size_t C = e->cfg.chains, d = e->cfg.dim, n = static_cast<size_t>(n_iters), n_out = static_cast<size_t>(dst->n_out);
+    const size_t row0 = static_cast<size_t>(iter_begin - dst->first);
+    if (dst->trace) {
+        const size_t rows = static_cast<size_t>(e->A.cap - e->A.trace_begin);
+        const double* src = e->A.trace + static_cast<size_t>(iter_begin - e->A.trace_begin) * d;
+        HIP_TRY(e, hipMemcpy2DAsync(dst->trace + row0 * d, n_out * d * sizeof(double), src, rows * d * sizeof(double),
+                                    n * d * sizeof(double), C, hipMemcpyDefault, cs));
+    }
+    if (dst->n_planes > 0) {
+        WindowPlanes W;
+        std::memset(&W, 0, sizeof(W));
+        W.n_planes = dst->n_planes;
+        size_t need = 0;
+        for (int p = 0; p < dst->n_planes; ++p) {
+            W.kind[p] = dst->plane[p].kind; W.idx[p] = dst->plane[p].idx; W.as[p] = dst->plane[p].as;
+            W.offset[p] = static_cast<long long>(need);
+            need += (C * n * plane_elem_bytes(dst->plane[p]) + 255) / 256 * 256;
+        }
+        if (need > e->copy_stage_bytes) {   // (grown between windows only: copies of earlier windows still read the old area)
+            HIP_TRY(e, hipStreamSynchronize(cs));
+            if (e->copy_stage) (void)hipFree(e->copy_stage);
+            e->copy_stage = nullptr; e->copy_stage_bytes = 0;
+            HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->copy_stage), need));
+            e->copy_stage_bytes = need;
+            // (the synchronize above dropped the dependencies of this call: establish them again)
+            if (e->n_sub > 1)
+                for (int b = 0; b < e->n_sub; ++b) HIP_TRY(e, hipStreamWaitEvent(cs, e->copy_dep[b], 0));
+            HIP_TRY(e, hipStreamWaitEvent(cs, e->copy_dep[lmc_engine::kMaxSub], 0));
+        }
+        const size_t total = C * n;
+        LMC_LAUNCH(window_gather_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, cs, e->A.stat_rec, e->A.cap,
+                   e->cfg.chains, iter_begin, n_iters, e->cfg.kind == LMC_KIND_HMC ? 1 : 0, W, e->copy_stage);
+        HIP_TRY(e, hipGetLastError());
+        for (int p = 0; p < dst->n_planes; ++p) {
+            const size_t eb = plane_elem_bytes(dst->plane[p]);
+            HIP_TRY(e, hipMemcpy2DAsync(static_cast<char*>(dst->plane[p].dst) + row0 * eb, n_out * eb, e->copy_stage + W.offset[p], n * eb,
+                                        n * eb, C, hipMemcpyDefault, cs));
+        }
+    }
+    return LMC_OK;
+}
+
+int lmc_engine_copy_wait(lmc_engine* e) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    if (!e->copy_stream) return LMC_OK;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->copy_stream));
+    return LMC_OK;
+}
+
+void* lmc_host_alloc(uint64_t bytes) {
+    void* p = nullptr;
+    const hipError_t err = hipHostMalloc(&p, bytes > 0 ? static_cast<size_t>(bytes) : 1, hipHostMallocPortable);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        fail(nullptr, LMC_ERR_HIP, "hipHostMalloc(%llu bytes): %s", (unsigned long long)bytes, hipGetErrorString(err));
+        return nullptr;
+    }
+    return p;
+}
+
+void lmc_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 void* lmc_engine_trace_device_ptr(lmc_engine* e) { return e ? e->A.trace : nullptr; }

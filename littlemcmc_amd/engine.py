@@ -20,12 +20,73 @@ class _TickView:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
 
 
+class _PinnedBlock:
+    """Owner of one lmc_host_alloc() block; frees it when the last numpy view is gone."""
+
+    def __init__(self, lib, ptr):
+        self._lib, self._ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                self._lib.lmc_host_free(C.c_void_p(self._ptr))
+                self._ptr = 0
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype, lib=None):
+    """A C-contiguous numpy array in page-locked host memory (lmc_host_alloc: hipHostMalloc, portable across GPUs), freed
+    when the array and every view of it are gone. Device->host copies into it are asynchronous and run at link speed. Raises
+    HipLibraryError if the memory cannot be pinned."""
+    lib = lib or _abi.load()
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if nbytes == 0:
+        return np.empty(shape, dtype=dtype)
+    p = lib.lmc_host_alloc(nbytes)
+    if not p:
+        raise _abi.HipLibraryError("cannot pin %d bytes of host memory: %s" % (nbytes, (lib.lmc_last_error(None) or b"?").decode()))
+    buf = (C.c_char * nbytes).from_address(p)
+    buf._owner = _PinnedBlock(lib, p)          # (numpy keeps `buf` alive as the array's base)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+class StreamedResults:
+    """The arrays ``sample()`` returns, allocated up front and filled while the job runs (sampling.py:207-222 of the
+    reference returns host arrays; Engine.copy_window_async streams every launch's window of iterations into them under the
+    next launch): ``trace[chains, n_out, dim]`` float64 and one ``[chains, n_out]`` array per statistic, already in the
+    dtype of the reference's stats dict (the device converts), iteration ``first`` in row 0.
+
+    ``planes``: (name, kind, idx, as_, numpy dtype) with kind / as_ the LMC_PLANE_* / LMC_AS_* of include/lmc_hip.h."""
+
+    def __init__(self, chains, n_out, first, dim, planes, keep_trace=True, pinned=True, lib=None):
+        self.chains, self.n_out, self.first, self.dim = int(chains), int(n_out), int(first), int(dim)
+        self.planes = list(planes)
+        assert len(self.planes) <= _abi.MAX_PLANES
+        alloc = (lambda sh, dt: pinned_empty(sh, dt, lib)) if pinned else (lambda sh, dt: np.empty(sh, dtype=dt))
+        self.pinned = bool(pinned)
+        self.trace = alloc((self.chains, self.n_out, self.dim), np.float64) if keep_trace else None
+        self.stats = {name: alloc((self.chains, self.n_out), dt) for name, _k, _i, _a, dt in self.planes}
+
+    def window_dst(self, eng, chain_lo=0):
+        """struct lmc_window_dst for the engine that owns chains [chain_lo, chain_lo + eng.chains) of these arrays."""
+        w = _abi.WindowDst()
+        w.n_out, w.first = self.n_out, self.first
+        w.trace = None if self.trace is None else self.trace[chain_lo:].ctypes.data
+        w.n_planes = len(self.planes)
+        for p, (name, kind, idx, as_, _dt) in enumerate(self.planes):
+            w.plane[p].dst = self.stats[name][chain_lo:].ctypes.data
+            w.plane[p].kind, w.plane[p].idx, w.plane[p].as_ = int(kind), int(idx), int(as_)
+        return w
+
+
 class Engine:
     def __init__(self, target, chains, kind="nuts", potential="diag_adapt", device=0, lib_path=None,
                  target_accept=0.8, Emax=1000.0, adapt_step_size=True, step_scale=0.25, gamma=0.05, k=0.75,
                  t0=10, path_length=2.0, max_treedepth=10, early_max_treedepth=8, max_steps=1024,
                  adaptation_window=101, adaptation_window_multiplier=1.0, lds_levels=0, sdot=None, rng="numpy",
-                 mass_dtype="float32"):
+                 mass_dtype="float32", lds_plan="auto"):
         self._lib = _abi.load(lib_path or getattr(target, "lib_path", None))
         self._h = C.c_void_p()
         self.target = target
@@ -54,6 +115,9 @@ class Engine:
         cfg.adaptation_window = int(adaptation_window)
         cfg.adaptation_window_multiplier = float(adaptation_window_multiplier)
         cfg.lds_levels = int(lds_levels)
+        # include/lmc_hip.h: LMC_LDS_PLAN_* (results do not depend on it; pinned values are for A/B runs and parity tests)
+        cfg.lds_plan = {"auto": _abi.LDS_PLAN_AUTO, None: _abi.LDS_PLAN_AUTO, 0: _abi.LDS_PLAN_SHALLOW, "shallow": _abi.LDS_PLAN_SHALLOW,
+                        1: _abi.LDS_PLAN_DEEP, "deep": _abi.LDS_PLAN_DEEP}[lds_plan]
         cfg.rng_mode = {"numpy": _abi.RNG_NUMPY, "philox": _abi.RNG_PHILOX}[rng]   # include/lmc_hip.h: LMC_RNG_*
         # QuadPotentialDiagAdapt(dtype=...) (quadpotential.py:159,175-184); float64 runs in the general kernels
         # QuadPotentialFullAdapt(dtype=...) (quadpotential.py:484,497-509) likewise: float64 covariance, factor and momentum
@@ -231,10 +295,14 @@ class Engine:
             return None
         return self.occupancy()[0] or None
 
+    def last_run_plan(self):
+        """LDS plan of the most recent run() launch: "shallow" / "deep" (None: nothing launched, or a kernel with one plan)."""
+        return {_abi.LDS_PLAN_SHALLOW: "shallow", _abi.LDS_PLAN_DEEP: "deep"}.get(int(self._lib.lmc_engine_last_run_plan(self._h)))
+
     def run_streams(self):
         """Raw HIP stream handles run() launches its kernels on (one per sub-block of chains)."""
-        arr = (C.c_void_p * 16)()
-        n = min(self._lib.lmc_engine_run_streams(self._h, arr, 16), 16)
+        arr = (C.c_void_p * _abi.MAX_RUN_STREAMS)()
+        n = min(self._lib.lmc_engine_run_streams(self._h, arr, _abi.MAX_RUN_STREAMS), _abi.MAX_RUN_STREAMS)
         if n < 0:
             self._check(n)
         return [int(arr[i] or 0) for i in range(n)]
@@ -322,6 +390,16 @@ class Engine:
         out = np.empty((self.chains, n), dtype=np.uint8)
         self._check(self._lib.lmc_engine_get_stat_u8(self._h, int(stat), _abi.ptr(out), int(iter_begin), int(n)))
         return out
+
+    # ---- streamed results (include/lmc_hip.h: lmc_engine_copy_window_async) ---------------------------------
+    def copy_window_async(self, out, iter_begin, n_iters, chain_lo=0):
+        """Enqueue the device->host copy of iterations [iter_begin, iter_begin + n_iters) of every chain into the final
+        arrays of ``out`` (a StreamedResults; this engine's chains start at its row ``chain_lo``), ordered after the launches
+        enqueued so far, asynchronous to the host."""
+        self._check(self._lib.lmc_engine_copy_window_async(self._h, C.byref(out.window_dst(self, chain_lo)), int(iter_begin), int(n_iters)))
+
+    def copy_wait(self):
+        self._check(self._lib.lmc_engine_copy_wait(self._h))
 
     def trace_device_ptr(self):
         return self._lib.lmc_engine_trace_device_ptr(self._h)
@@ -556,6 +634,13 @@ class EngineGroup:
 
     def synchronize(self):
         self._each("synchronize")
+
+    def copy_window_async(self, out, iter_begin, n_iters):
+        for e, (lo, _hi) in zip(self.engines, self.blocks):
+            e.copy_window_async(out, iter_begin, n_iters, chain_lo=lo)
+
+    def copy_wait(self):
+        self._each("copy_wait")
 
     # ---- state ----------------------------------------------------------------------------------------------------
     def seed(self, seeds):

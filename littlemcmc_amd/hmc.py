@@ -49,6 +49,24 @@ class HamiltonianMC(BaseHMC):
         kw.update(path_length=self.path_length, max_steps=self.max_steps)
         return kw
 
+    def _result_planes(self):
+        """(name, LMC_PLANE_*, index, LMC_AS_*, dtype) per entry of stats_dtypes: what the device writes into sample()'s arrays."""
+        f = lambda name, slot: (name, _abi.PLANE_F64, slot, _abi.AS_NATIVE, np.float64)   # noqa: E731
+        b = lambda name, bit: (name, _abi.PLANE_U8, bit, _abi.AS_NATIVE, np.bool_)       # noqa: E731
+        return [
+            f("step_size", _abi.STAT_STEP_SIZE),
+            ("n_steps", _abi.PLANE_I32, _abi.STAT_DEPTH, _abi.AS_I64, np.int64),
+            b("tune", _abi.STAT_TUNE),
+            f("step_size_bar", _abi.STAT_STEP_SIZE_BAR),
+            f("accept", _abi.STAT_ACCEPT),
+            b("diverging", _abi.STAT_DIVERGING),
+            f("energy_error", _abi.STAT_ENERGY_ERROR),
+            f("energy", _abi.STAT_ENERGY),
+            f("path_length", _abi.STAT_MAX_ENERGY_ERROR),
+            b("accepted", _abi.STAT_ACCEPTED),
+            f("model_logp", _abi.STAT_MODEL_LOGP),
+        ]
+
     def _stats_from_engine(self, eng, iter_begin, n):
         f = lambda s: eng.stat_f64(s, iter_begin, n)   # noqa: E731
         return {

@@ -86,7 +86,54 @@ class JobProgress:
         return "JobProgress(iteration=%d, total=%d, tuning=%s, chains=%d)" % (self.iteration, self.total, self.tuning, self.chains)
 
 
-def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None):
+class _ResultStreamer:
+    """Fills the arrays sample() returns while the job runs. The arrays are page-locked host memory, and pinning tens of GiB
+    takes seconds, so they are allocated by a helper thread while the first launches run; the window of every launch is
+    handed to Engine.copy_window_async() as soon as both the launch is enqueued and the arrays exist (windows that come
+    earlier wait in a list -- the draws stay in HBM until the job is over, nothing is lost by copying late)."""
+
+    def __init__(self, eng, chains, n_out, first, dim, planes):
+        import threading
+
+        self.eng, self.first, self.out, self.err, self.waiting = eng, int(first), None, None, []
+
+        def alloc():
+            from .engine import StreamedResults
+
+            try:
+                self.out = StreamedResults(chains, n_out, first, dim, planes)
+            except BaseException as err:     # the host cannot pin that much: the draws are copied after the job instead
+                self.err = err
+
+        self._thread = threading.Thread(target=alloc, name="lmc-pin-results", daemon=True)
+        self._thread.start()
+
+    def window(self, first, n):
+        """on_enqueued(first, n) of _run_job: iterations [first, first + n) have been launched."""
+        a, b = max(int(first), self.first), int(first) + int(n)
+        if b > a:
+            self.waiting.append((a, b - a))
+        self._flush()
+
+    def _flush(self):
+        if self._thread.is_alive() or self.out is None:
+            return
+        for a, n in self.waiting:
+            self.eng.copy_window_async(self.out, a, n)
+        self.waiting = []
+
+    def finish(self):
+        """Wait for the arrays and for every copy; returns the StreamedResults (None if the memory could not be pinned)."""
+        self._thread.join()
+        if self.out is None:
+            _log.warning("results were not streamed (%s); copying them now that the job is over" % (self.err,))
+            return None
+        self._flush()
+        self.eng.copy_wait()
+        return self.out
+
+
+def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None, on_enqueued=None):
     """Enqueue the job's launches, then wait for them in a way Ctrl-C can reach (sampling.py:324-328, :470-471 in the
     reference: a KeyboardInterrupt ends sampling and what has been drawn so far is returned).
 
@@ -96,7 +143,9 @@ def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None):
     granularity) and, on Ctrl-C, asks the device to stop -- every chain leaves its launch at its next iteration
     boundary and the launches still queued do nothing (lmc_engine_request_stop). With several GPUs (an EngineGroup)
     every launch is enqueued on all devices before anything is waited for, and a launch counts as complete when it is
-    complete everywhere. Returns (iterations completed by EVERY chain, interrupted)."""
+    complete everywhere. ``on_enqueued(first, n)`` is called right after the launch of iterations [first, first + n) has
+    been enqueued (sample() enqueues the copy of that window into the result arrays there, so the copy of launch k runs under
+    launch k + 1). Returns (iterations completed by EVERY chain, interrupted)."""
     import time
 
     engines = getattr(eng, "engines", [eng])
@@ -115,7 +164,9 @@ def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None):
     # is ENQUEUED, from the tree sizes the running chains report (lmc_engine.hip: choose_lds_plan; results do not depend on
     # it), so the queue must not run far ahead of the job. Two in flight per stream keep the device busy across launch
     # boundaries (the next one is enqueued while the last one runs).
-    sizes = list(per_launch) if isinstance(per_launch, (list, tuple)) else [int(per_launch)]   # (the last size repeats)
+    sizes = [int(x) for x in per_launch] if isinstance(per_launch, (list, tuple)) else [int(per_launch)]   # (the last size repeats)
+    if not sizes or min(sizes) < 1:
+        raise ValueError("launch sizes must be >= 1 iteration (got %r)" % (per_launch,))
     pending = []
     it = 0
     while it < n_total:
@@ -126,6 +177,8 @@ def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None):
     def enqueue_next():
         first, n = pending.pop(0)
         eng.run(tune, first, n)
+        if on_enqueued is not None:
+            on_enqueued(first, n)
         if torch is not None:
             evs = []
             for s_ in streams:
@@ -181,8 +234,9 @@ def _run_job_host_step_rand(eng, step, tune, n_total, progressbar, callback=None
     """The job loop when ``step_rand`` is an arbitrary Python callable (base_hmc.py:154-155): it has to be evaluated
     between iterations, so every iteration is a launch of its own -- adaptation state down, the callable once per chain,
     step sizes up (lmc_engine_set_step_sizes). The compatibility path; StepRandUniform runs inside the kernel.
-    ``callback`` is called once per iteration (= per launch: the host is in the loop anyway, so ``iteration`` is exact
-    here, not a device hint) and may raise KeyboardInterrupt like in _run_job."""
+    ``callback`` is called once per iteration, right after that iteration's launch has been ENQUEUED (the launch is
+    asynchronous: ``iteration`` counts launches handed to the device, which runs at most one iteration behind, since the next
+    set_step_sizes() reads the adaptation state back) and may raise KeyboardInterrupt like in _run_job."""
     import time
 
     t0 = time.perf_counter()
@@ -203,9 +257,13 @@ def _run_job_host_step_rand(eng, step, tune, n_total, progressbar, callback=None
         _log.warning("Sampling interrupted after %d of %d iterations; returning the draws so far." % (n_done, n_total))
         return n_done, True
     finally:
-        # whoever keeps the engine (return_engine=True) gets it back without the per-chain override, interrupted or not
-        eng.synchronize()
-        eng.set_step_sizes(None)
+        # whoever keeps the engine (return_engine=True) gets it back without the per-chain override, interrupted or not;
+        # a failure in here must not mask the error that brought us here (a HIP error usually makes synchronize() fail too)
+        try:
+            eng.synchronize()
+            eng.set_step_sizes(None)
+        except Exception as cleanup_err:
+            _log.warning("cleanup after the per-iteration job failed: %s" % cleanup_err)
 
 
 def visible_devices():
@@ -247,7 +305,7 @@ def _resolve_devices(devices, device, cores, chains, probe):
 def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, init="auto", chains=None,
            cores=None, start=None, progressbar=True, random_seed=None, discard_tuned_samples=True,
            chain_idx=0, callback=None, mp_ctx=None, pickle_backend="pickle", size=None, device=None, devices=None,
-           launch_iters=None, return_engine=False, keep_moments=False, **kwargs):
+           launch_iters=None, return_engine=False, keep_moments=False, stream_results=True, **kwargs):
     """Draw samples with many chains on the MI355X(s) of this node (reference signature: sampling.py:35-53).
 
     Where the reference fans its chains out over ``cores`` worker processes (sampling.py:124-129,186-201), this fans
@@ -262,7 +320,10 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
     ``keep_moments`` (the kernel also keeps every chain's running mean / M2 of the post-warm-up draws:
     ``Engine.moments()``). ``callback(trace=None, draw=JobProgress)`` is called from the wait loop as the job advances
     and may raise KeyboardInterrupt to stop it (sampling.py:272-277 of the reference); ``mp_ctx`` and
-    ``pickle_backend`` are accepted and ignored (no worker processes).
+    ``pickle_backend`` are accepted and ignored (no worker processes). ``stream_results`` (default True): the returned
+    arrays are allocated up front in page-locked host memory and every launch's draws and statistics are copied into them
+    while the next launch runs (lmc_engine_copy_window_async), instead of in one blocking copy after the job; False keeps
+    the draws on the device until the job is over (the same arrays bit for bit, tests/test_gpu_round6.py).
     """
     if model_ndim is None:
         model_ndim = size if size is not None else getattr(logp_dlogp_func, "d", None)
@@ -358,14 +419,29 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
                 per_launch = min(per_launch, 200)   # general kernels (one workgroup per chain, a few hundred resident): same reason
         if target.family == _abi.TARGET_EXTERNAL and not launch_iters:
             per_launch = max(n_total, 1)   # ticks: chains never wait for each other inside one request
-        if getattr(step, "_host_step_rand", lambda: None)() is not None:
-            n_done, interrupted = _run_job_host_step_rand(eng, step, int(tune), n_total, progressbar, callback)
-        else:
-            n_done, interrupted = _run_job(eng, int(tune), n_total, per_launch, progressbar, callback)
+        host_rand = getattr(step, "_host_step_rand", lambda: None)() is not None
+        # Streamed results: the arrays the caller gets are allocated now (pinned), and the window of every launch is copied into
+        # them as soon as the launch is over, under the launches that follow (lmc_engine_copy_window_async). Not for jobs that
+        # launch per iteration (a host step_rand) or per tick (a torch / Python callable): their draws are copied at the end.
+        streamer = None
+        if stream_results and not host_rand and target.family != _abi.TARGET_EXTERNAL and n_total - lo > 0 and hasattr(step, "_result_planes"):
+            streamer = _ResultStreamer(eng, chains, n_total - lo, lo, model_ndim, step._result_planes())
+        try:
+            if host_rand:
+                n_done, interrupted = _run_job_host_step_rand(eng, step, int(tune), n_total, progressbar, callback)
+            else:
+                n_done, interrupted = _run_job(eng, int(tune), n_total, per_launch, progressbar, callback,
+                                               on_enqueued=streamer.window if streamer is not None else None)
+        finally:
+            streamed = streamer.finish() if streamer is not None else None
         raise_for_status(eng.status())
 
         n_out = max(n_done - lo, 0)
-        if n_out > 0:
+        if n_out > 0 and streamed is not None:
+            # (an interrupted job returns the iterations every chain completed: a prefix of the arrays)
+            trace = streamed.trace if n_out == streamed.n_out else streamed.trace[:, :n_out]
+            stats = {name: streamed.stats[name][:, :n_out, None].astype(dtype, copy=False) for name, dtype in step.stats_dtypes[0].items()}
+        elif n_out > 0:
             trace = eng.trace(lo, n_out)
             raw = step._stats_from_engine(eng, lo, n_out)
             stats = {name: raw[name][:, :, None].astype(dtype) for name, dtype in step.stats_dtypes[0].items()}

@@ -170,8 +170,9 @@ def oracle_chain_snapshots(ostep, start, seed, tune, draws):
     return snaps, outs
 
 
-def replay_iterations_on_device(step, snaps, outs, label=""):
+def replay_iterations_on_device(step, snaps, outs, label="", expect_plan=None):
     """One engine, one wavefront per snapshot; run ONE iteration everywhere; compare with the oracle.
+    ``expect_plan``: the LDS plan ("shallow" / "deep") the launch must have run under (Engine.last_run_plan()).
     Returns (n_checked, n_fragile)."""
     from littlemcmc_amd import _abi
 
@@ -197,6 +198,8 @@ def replay_iterations_on_device(step, snaps, outs, label=""):
             eng.reserve(1, keep_trace=True)
             eng.run(1 if tune_flag else 0, 0, 1)
             assert not eng.status().any()
+            if expect_plan is not None:
+                assert eng.last_run_plan() == expect_plan, (label, eng.last_run_plan(), eng.kernel_shape())
             q = eng.trace()[:, 0]
             stats = {k: v[:, 0] for k, v in step._stats_from_engine(eng, 0, 1).items()}
             after = eng.get_chain_state()
@@ -257,3 +260,47 @@ def assert_selected_chains_match_oracle(family, d, seeds, start, sel, n_it, trac
         out.append(assert_chain_matches(np.asarray(trace)[c, :n_it], got, ot[k], want, margins[k],
                                         label="%s chain %d" % (label, c)))
     return out
+
+
+def replay_golden_run(golden_dir, name, lds_plan="auto"):
+    """Every iteration of every chain of the reference-captured run ``tests/golden/<name>.npz``, replayed on the device from the
+    oracle's exact pre-iteration state (integer statistics exact, positions / energies / adaptation state to 1e-10).
+    ``lds_plan`` pins the LDS plan of the one-wave sampling kernels ("shallow" / "deep": lmc_config.lds_plan).
+    Returns (checked, fragile, total)."""
+    import os
+
+    from oracle import lmc_oracle as orc
+    from oracle import targets as OT
+
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    d, chains, tune, draws = int(g["d"]), int(g["chains"]), int(g["tune"]), int(g["draws"])
+    kw = kwargs_from(g)
+    fam = str(g["family"])
+    f = OT.DiagGaussian(g["params"]) if fam == "diag_gaussian" else OT.make(fam, d)
+    tgt = device_target(fam, d, g["params"])
+    seeds = [int(s) for s in g["seeds"]]
+    start = g["start"]
+    dkw = dict(kw)
+    if lds_plan != "auto":
+        dkw["lds_plan"] = lds_plan
+    total_checked = total_fragile = 0
+    for c in range(chains):   # every captured chain
+        if str(g["kind"]) == "hmc":
+            ostep = orc.Step(f, d, kind="hmc", **kw)
+            step = lmc.HamiltonianMC(tgt, d, **kw)
+        else:
+            _s, ostep = orc.init_nuts(f, d, seeds=seeds, **kw)
+            _s2, step = lmc.init_nuts(tgt, d, random_seed=seeds, **dkw)
+            np.testing.assert_array_equal(_s, _s2)
+            np.testing.assert_array_equal(_s, start)
+        snaps, outs = oracle_chain_snapshots(ostep, start, seeds[c], tune, draws)
+        # the oracle chain IS the golden chain on the capture host; elsewhere (other BLAS) allow drift
+        same = np.allclose(np.array([o["q"] for o in outs]), g["trace"][c], rtol=1e-9, atol=1e-12)
+        checked, fragile = replay_iterations_on_device(step, snaps, outs, label="%s chain %d" % (name, c),
+                                                       expect_plan=None if lds_plan == "auto" else lds_plan)
+        total_checked += checked
+        total_fragile += fragile
+        if same:
+            np.testing.assert_array_equal(np.array([o["stats"]["diverging"] for o in outs]),
+                                          g["stat_diverging"][c, :, 0])
+    return total_checked, total_fragile, chains * (tune + draws)

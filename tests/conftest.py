@@ -31,3 +31,25 @@ def _hip_library_built():
         except Exception as err:   # no hipcc on this box: the tests that need the library will say so themselves
             print("could not build liblmc_hip.so: %s" % err)
     yield
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _cold_user_target_cache():
+    """On a GPU box every run-time compiled density is compiled THERE: the on-disk cache of hiprtc code objects
+    (littlemcmc_amd/_user_targets, git-ignored and .gpurunignore'd) is emptied before the first test, so a -m gpu session
+    shows hiprtc working on the MI355X box instead of loading objects the build container happened to leave behind."""
+    try:
+        import torch
+
+        on_gpu = torch.cuda.is_available()
+    except Exception:
+        on_gpu = False
+    if on_gpu:
+        import glob
+
+        for path in glob.glob(os.path.join(ROOT, "littlemcmc_amd", "_user_targets", "*.hsaco")):
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+    yield

@@ -217,6 +217,10 @@ def capture_e2e(only=None):
         ("e2e_nuts_normal1d", "normal1d", 1, "nuts", 2, 120, 80, {}),
         # the benchmarked instantiation (BASELINE config C3's shape: AR(1) at d = 128, two elements per lane)
         ("e2e_nuts_ar1_128", "ar1", 128, "nuts", 2, 250, 50, {}),
+        # round 6: the exact instantiations of BASELINE configs C5 and C4 -- run_kernel<4, 1, FunnelTarget> (d = 256, depth 12)
+        # and run_kernel<4, 4, DiagGaussianTarget> (d = 1000, a team of four wavefronts per chain)
+        ("e2e_nuts_funnel256", "funnel", 256, "nuts", 2, 60, 20, {"max_treedepth": 12}),
+        ("e2e_nuts_diag1000", "diag_gaussian", 1000, "nuts", 2, 60, 20, {}),
     ]
     for name, fam, d, kind, chains, tune, draws, kw in runs:
         if only and name not in only:

@@ -37,7 +37,8 @@ def test_header_constants_match_binding():
                  "TARGET_AR1", "TARGET_FUNNEL", "TARGET_NORMAL1D", "TARGET_USER", "STAT_STEP_SIZE", "STAT_ACCEPT",
                  "STAT_MODEL_LOGP", "STAT_DEPTH", "STAT_TREE_SIZE", "STAT_DIVERGING", "STAT_TUNE", "STAT_ACCEPTED",
                  "CT_LEAPFROGS", "NUM_COUNTERS", "SDOT_NATIVE", "SDOT_OPENBLAS_SKYLAKEX", "SDOT_OPENBLAS_HASWELL",
-                 "STATUS_BAD_INITIAL_ENERGY"):
+                 "STATUS_BAD_INITIAL_ENERGY", "LDS_PLAN_AUTO", "LDS_PLAN_SHALLOW", "LDS_PLAN_DEEP", "PLANE_F64", "PLANE_I32",
+                 "PLANE_U8", "AS_NATIVE", "AS_F64", "AS_I64", "MAX_PLANES", "MAX_RUN_STREAMS"):
         assert int(consts["LMC_" + name]) == getattr(_abi, name), name
 
 
@@ -52,6 +53,23 @@ def test_config_struct_layout_and_defaults():
     assert cfg.path_length == 2.0 and cfg.start_energy_sdot == _abi.SDOT_OPENBLAS_SKYLAKEX
     fields = re.findall(r"^\s+(?:int32_t|double)\s+(\w+);", HEADER[HEADER.index("typedef struct lmc_config"):], re.M)
     assert [f for f, _ in _abi.Config._fields_] == fields[: len(_abi.Config._fields_)]
+    assert cfg.lds_plan == _abi.LDS_PLAN_AUTO and cfg.reserved0 == 0
+    bad = _abi.Config()
+    lib.lmc_config_defaults(ctypes.byref(bad), 7, 13)
+    bad.lds_plan = 3                       # validated before any HIP call: no GPU needed to see the refusal
+    h = ctypes.c_void_p()
+    assert lib.lmc_engine_create(ctypes.byref(bad), ctypes.byref(h)) == 1 and b"lds_plan" in lib.lmc_last_error(None)
+
+
+def test_window_destination_struct_layout():
+    """struct lmc_window_dst / lmc_window_plane (ABI 8): the ctypes mirror has the header's fields in the header's order and
+    the C compiler's size (8-byte alignment, 16 planes)."""
+    blk = HEADER[HEADER.index("typedef struct lmc_window_plane"):HEADER.index("} lmc_window_dst;")]
+    names = re.findall(r"^\s+(?:int32_t|int64_t|void\*|double\*|lmc_window_plane)\s+(\w+)", blk, re.M)
+    assert names == ["dst", "kind", "idx", "as", "reserved", "n_out", "first", "trace", "n_planes", "reserved", "plane"]
+    assert [f.rstrip("_") for f, _ in _abi.WindowPlane._fields_] == names[:5]
+    assert [f for f, _ in _abi.WindowDst._fields_] == names[5:]
+    assert ctypes.sizeof(_abi.WindowPlane) == 24 and ctypes.sizeof(_abi.WindowDst) == 32 + 16 * 24
 
 
 def test_built_in_targets_and_the_run_time_user_family():

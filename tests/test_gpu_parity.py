@@ -85,7 +85,10 @@ def test_transitions_golden(golden_dir):
 
 
 E2E = ["e2e_hmc_c1", "e2e_nuts_std64", "e2e_nuts_std128", "e2e_nuts_ar1_16", "e2e_nuts_funnel8",
-       "e2e_nuts_diag50", "e2e_nuts_normal1d", "e2e_nuts_ar1_128"]
+       "e2e_nuts_diag50", "e2e_nuts_normal1d", "e2e_nuts_ar1_128",
+       # round 6: reference-held chains at the exact instantiations of BASELINE's C5 and C4 -- run_kernel<4, 1, FunnelTarget>
+       # (d = 256, max_treedepth 12) and run_kernel<4, 4, DiagGaussianTarget> (d = 1000, four wavefronts per chain)
+       "e2e_nuts_funnel256", "e2e_nuts_diag1000"]
 
 
 @pytest.mark.parametrize("name", E2E)
@@ -129,7 +132,8 @@ def test_e2e_golden_through_sample_api(golden_dir, name):
     # Floors = what this build measures on MI355X (round 3: 1637, 71, 39, 149, 159, 105, 400, 32 iterations summed over the
     # captured chains) minus ~20 % for hosts whose float32 BLAS dot rounds differently from the capture host's.
     floors = {"e2e_hmc_c1": 1300, "e2e_nuts_std64": 56, "e2e_nuts_std128": 30, "e2e_nuts_ar1_16": 120,
-              "e2e_nuts_funnel8": 125, "e2e_nuts_diag50": 84, "e2e_nuts_normal1d": 400, "e2e_nuts_ar1_128": 25}
+              "e2e_nuts_funnel8": 125, "e2e_nuts_diag50": 84, "e2e_nuts_normal1d": 400, "e2e_nuts_ar1_128": 25,
+              "e2e_nuts_funnel256": 16, "e2e_nuts_diag1000": 16}
     assert verified >= min(floors[name], chains * (tune + draws)), "%s: only %d iterations verified" % (name, verified)
 
 
@@ -141,38 +145,12 @@ def test_every_iteration_of_the_golden_runs(golden_dir, name):
     adaptation-window switches (101, 202) and of the early-treedepth boundary -- is replayed on the device from
     the oracle's exact pre-iteration state and must reproduce the oracle's iteration: integer stats exactly,
     positions / energies / adaptation state to 1e-10."""
-    from tests._gpu_util import oracle_chain_snapshots, replay_iterations_on_device
+    from tests._gpu_util import replay_golden_run
 
-    g = np.load(os.path.join(golden_dir, name + ".npz"))
-    d, chains, tune, draws = int(g["d"]), int(g["chains"]), int(g["tune"]), int(g["draws"])
-    kw = kwargs_from(g)
-    fam = str(g["family"])
-    f = OT.DiagGaussian(g["params"]) if fam == "diag_gaussian" else OT.make(fam, d)
-    tgt = device_target(fam, d, g["params"])
-    seeds = [int(s) for s in g["seeds"]]
-    start = g["start"]
-    total_checked = total_fragile = 0
-    for c in range(chains):   # every captured chain
-        if str(g["kind"]) == "hmc":
-            ostep = orc.Step(f, d, kind="hmc", **kw)
-            step = lmc.HamiltonianMC(tgt, d, **kw)
-        else:
-            _s, ostep = orc.init_nuts(f, d, seeds=seeds, **kw)
-            _s2, step = lmc.init_nuts(tgt, d, random_seed=seeds, **kw)
-            np.testing.assert_array_equal(_s, _s2)
-            np.testing.assert_array_equal(_s, start)
-        snaps, outs = oracle_chain_snapshots(ostep, start, seeds[c], tune, draws)
-        # the oracle chain IS the golden chain on the capture host; elsewhere (other BLAS) allow drift
-        same = np.allclose(np.array([o["q"] for o in outs]), g["trace"][c], rtol=1e-9, atol=1e-12)
-        checked, fragile = replay_iterations_on_device(step, snaps, outs, label="%s chain %d" % (name, c))
-        total_checked += checked
-        total_fragile += fragile
-        if same:
-            np.testing.assert_array_equal(np.array([o["stats"]["diverging"] for o in outs]),
-                                          g["stat_diverging"][c, :, 0])
-    print("%s: replay checked %d of %d iterations, %d fragile" % (name, total_checked, chains * (tune + draws), total_fragile))
+    total_checked, total_fragile, total = replay_golden_run(golden_dir, name)
+    print("%s: replay checked %d of %d iterations, %d fragile" % (name, total_checked, total, total_fragile))
     # measured on MI355X (round 3): every iteration of every golden checked, none fragile
-    assert total_checked >= chains * (tune + draws) - 2, (total_checked, total_fragile)
+    assert total_checked >= total - 2, (total_checked, total_fragile)
 
 
 @pytest.mark.parametrize("family,d,kw", [("ar1", 200, {}), ("ar1", 300, {}), ("funnel", 600, {"max_treedepth": 9}),

@@ -175,11 +175,9 @@ def test_standalone_integrator_keeps_full_adapt_float64():
 
 # ---- LDS plans of the one-wave sampling kernels (lmc_sampler.hpp: run_kernel<.., PL>; lmc_engine.hip: choose_lds_plan) ------------
 def _plan_job(monkeypatch, plan, tgt, d, chains, n, kw=None):
-    if plan is None:
-        monkeypatch.delenv("LMC_LDS_PLAN", raising=False)
-    else:
-        monkeypatch.setenv("LMC_LDS_PLAN", plan)
-    eng, step = _engine(tgt, d, chains, **(kw or {}))
+    """plan: "0" / "1" pin the LDS plan through lmc_config.lds_plan (ABI 8; an environment variable until round 5), None
+    leaves the choice to the engine."""
+    eng, step = _engine(tgt, d, chains, lds_plan={"0": "shallow", "1": "deep", None: "auto"}[plan], **(kw or {}))
     try:
         eng.reserve(n, keep_trace=True)
         for first in range(0, n, 52):          # launches enqueued one by one, each after the one before has reported tree sizes
@@ -188,6 +186,8 @@ def _plan_job(monkeypatch, plan, tgt, d, chains, n, kw=None):
         assert not eng.status().any()
         out = (eng.trace().copy(), eng.stat_i32(_abi.STAT_TREE_SIZE, 0, n).copy(), eng.stat_f64(_abi.STAT_ENERGY, 0, n).copy(),
                [eng.get_rng_state(c)[2] for c in range(min(chains, 4))])
+        if plan is not None:               # a pinned plan is the plan of every launch
+            assert eng.last_run_plan() == {"0": "shallow", "1": "deep"}[plan]
         return out, eng.run_lds_bytes()
     finally:
         eng.close()
@@ -217,7 +217,6 @@ def test_engine_follows_the_tree_sizes_the_chains_report(monkeypatch):
     """choose_lds_plan: deep trees (AR(1) d = 128 settles at 60-130 leapfrogs per iteration) move the launches that are
     enqueued after the chains have reported to the deep-tree plan -- from iteration 200 on, past the early-treedepth regime
     -- and shallow trees (standard normal, 7 per iteration) stay."""
-    monkeypatch.delenv("LMC_LDS_PLAN", raising=False)
     _out, lds_deep = _plan_job(monkeypatch, None, T.AR1(128, 0.9), 128, 256, 260)
     _out, lds_shallow = _plan_job(monkeypatch, None, T.StdNormal(128), 128, 256, 260)
     _out, lds_plan1 = _plan_job(monkeypatch, "1", T.StdNormal(128), 128, 256, 60)
@@ -232,15 +231,14 @@ def test_sample_is_the_same_job_whatever_plan_the_engine_picks(monkeypatch):
     d, chains, tune, draws = 128, 20000, 350, 250
     tgt = T.AR1(d, 0.9)
     out = []
-    for plan in ("0", None):
-        if plan is None:
-            monkeypatch.delenv("LMC_LDS_PLAN", raising=False)
-        else:
-            monkeypatch.setenv("LMC_LDS_PLAN", plan)
+    for plan in ("shallow", "auto"):
+        # launch_iters explicit: sample()'s own schedule depends on how many chains the device keeps resident, and a job that
+        # fits the slots is ONE launch from iteration 0 -- which takes plan 0 whatever the trees (round 5's advisor)
         trace, stats, eng = lmc.sample(tgt, d, draws=draws, tune=tune, chains=chains, random_seed=99, progressbar=False,
-                                       return_engine=True)
+                                       return_engine=True, launch_iters=100, lds_plan=plan)
         try:
             lds = eng.run_lds_bytes()
+            assert eng.last_run_plan() == ("shallow" if plan == "shallow" else "deep")
         finally:
             eng.close()
         out.append((trace[::97].copy(), stats["tree_size"].copy(), stats["energy"][::97].copy(), lds))

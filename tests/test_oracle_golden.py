@@ -120,7 +120,7 @@ def test_seed_derivation_golden(golden_dir):
 
 
 E2E = ["e2e_hmc_c1", "e2e_nuts_std64", "e2e_nuts_std128", "e2e_nuts_ar1_16", "e2e_nuts_funnel8",
-       "e2e_nuts_diag50", "e2e_nuts_normal1d", "e2e_nuts_ar1_128"]
+       "e2e_nuts_diag50", "e2e_nuts_normal1d", "e2e_nuts_ar1_128", "e2e_nuts_funnel256", "e2e_nuts_diag1000"]
 
 
 @pytest.mark.parametrize("name", E2E)

@@ -3,7 +3,7 @@
 stability limit -- energy drops of hundreds to a thousand (weight-offset moves, rescaled subtree stacks), divergences in
 the first or second leaf of a pair, NaN energies, trees cut by max_treedepth -- fused kernels (one wave and teams)
 against the numpy oracle for the first iterations, every sampler statistic compared.
-Usage: python tools/fuzz_rare.py [n_cases] [seed]"""
+Usage: python tools/fuzz_rare.py [n_cases] [seed] [lds_plan]      (lds_plan: auto | shallow | deep -- lmc_config.lds_plan)"""
 import os
 import sys
 
@@ -16,6 +16,7 @@ from oracle import targets as OT  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+lds_plan = sys.argv[3] if len(sys.argv) > 3 else "auto"
 bad = 0
 seen = {"rescale": 0, "deep_rescale": 0, "diverging": 0, "maxdepth": 0}
 for case in range(n_cases):
@@ -43,7 +44,7 @@ for case in range(n_cases):
     seeds = [int(x) for x in rs.randint(1, 10 ** 6, size=chains)]
     draws = 4
     ostep = orc.Step(f, d, kind="nuts", adapt_step_size=False, step_scale=sc, max_treedepth=md)
-    step = lmc.NUTS(tgt, d, adapt_step_size=False, step_scale=sc, max_treedepth=md)
+    step = lmc.NUTS(tgt, d, adapt_step_size=False, step_scale=sc, max_treedepth=md, lds_plan=lds_plan)
     try:
         ot, ost = orc.sample(f, d, draws=draws, tune=0, step=ostep, chains=chains, start=starts, random_seed=seeds, discard_tuned_samples=False)
         o_err = None
@@ -87,5 +88,5 @@ for case in range(n_cases):
     print("case %3d %-13s d=%3d far=%5.1f frac=%.2f md=%2d  min dE %9.1f  depth<=%d div %d : %s%s" % (
         case, fam, d, far, frac, md, mde.min(), ost["depth"].max(), int(ost["diverging"].sum()), "ok" if ok else "FAIL", msg[:300]))
     bad += 0 if ok else 1
-print("cases that exercised:", seen, " failures:", bad)
+print("lds_plan %s; cases that exercised:" % lds_plan, seen, " failures:", bad)
 sys.exit(1 if bad else 0)
