@@ -272,6 +272,16 @@ int lmc_engine_set_step_sizes(lmc_engine* e, const double* step_sizes);
  * function lmc_engine_run() applies after every tuning iteration. The dense counterpart is lmc_engine_dense_update(). */
 int lmc_engine_diag_update(lmc_engine* e, int32_t tune);
 int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int64_t trace_begin);
+/* Where the draws go, decided after reserve(capacity, trace_begin < 0) and possibly while the job is already running (the
+ * kernel arguments of a launch are fixed when it is enqueued: launches enqueued AFTER this call store the draws of iterations
+ * >= trace_begin, so call it before enqueueing the first launch that reaches trace_begin).
+ *   dst != NULL: the caller's own array [chains][capacity - trace_begin][dim] in device-accessible memory (page-locked host
+ *        memory: lmc_host_alloc / lmc_host_register; or device memory). The sampling kernel stores every draw THERE, one
+ *        coalesced row per chain per iteration, straight over the host link as it is produced -- the array sample() returns
+ *        (sampling.py:207-222) is complete when the last launch is, with no copy and no trace in HBM. The engine never frees
+ *        it; lmc_engine_get_trace() / trace_device_ptr() read through it.
+ *   dst == NULL: the engine allocates the trace in HBM (what reserve(capacity, trace_begin) does). */
+int lmc_engine_attach_trace(lmc_engine* e, double* dst, int64_t trace_begin);
 /* KeyboardInterrupt (sampling.py:324-328, :470-471: the reference keeps what has been drawn so far). stop = 1: every
  * chain leaves the launch it is in at the end of an iteration within ~16 iterations, and a workgroup that STARTS under the
  * request does nothing at all -- launches still queued neither run an iteration nor touch iter_count, and chains of the
@@ -303,14 +313,16 @@ int lmc_engine_get_stat_f64(lmc_engine* e, int32_t stat, double* dst, int64_t it
 int lmc_engine_get_stat_i32(lmc_engine* e, int32_t stat, int32_t* dst, int64_t iter_begin, int64_t n_iters);
 int lmc_engine_get_stat_u8(lmc_engine* e, int32_t stat, uint8_t* dst, int64_t iter_begin, int64_t n_iters);
 /* ---- results, streamed: sampling.py:207-222 hands the caller host arrays; a job's draws are tens of GiB (C3: 64 GiB), so the
- * copy must not wait for the job. copy_window_async() enqueues, on a copy stream of the engine's own, the device->host copy of
- * iterations [iter_begin, iter_begin + n_iters) of EVERY chain into the caller's final arrays, ordered after every
- * lmc_engine_run() enqueued so far and asynchronous to the host and to later launches (the D2H of launch k runs under launch
- * k + 1). Destinations are laid out like the reference's results -- trace [chains][n_out][dim], planes [chains][n_out] --
+ * copy must not wait for the job. copy_window_async() enqueues, on a high-priority copy stream of the engine's own, the device->host
+ * copy of iterations [iter_begin, iter_begin + n_iters) of EVERY chain into the caller's final arrays, ordered after every
+ * lmc_engine_run() enqueued so far and asynchronous to the host and to later launches (the D2H of launch k runs under
+ * launch k + 1). Destinations are laid out like the reference's results -- trace [chains][n_out][dim], planes [chains][n_out] --
  * and iteration `first` lands in row 0; a plane is one statistic out of the per-draw records, converted on the device to the
- * dtype the reference's stats dict carries (nuts.py:87-101, hmc.py:36-50). For the copy to be asynchronous the
- * destinations must be pinned host memory (lmc_host_alloc) or device memory; pageable memory works but blocks.
- * copy_wait() waits for the copies enqueued so far (and nothing else). */
+ * dtype the reference's stats dict carries (nuts.py:87-101, hmc.py:36-50). The copies are kernels that write the
+ * destinations themselves (coalesced stores over the host link, no per-row DMA command), so the destinations must be
+ * DEVICE-ACCESSIBLE: page-locked host memory (lmc_host_alloc, or memory registered with hipHostRegister) or device
+ * memory; pageable memory is refused with LMC_ERR_INVALID. copy_wait() waits for the copies enqueued so far (and
+ * nothing else). */
 #define LMC_PLANE_F64 0      /* idx = LMC_STAT_* f64 slot */
 #define LMC_PLANE_I32 1      /* idx = LMC_STAT_DEPTH / LMC_STAT_TREE_SIZE */
 #define LMC_PLANE_U8 2       /* idx = LMC_STAT_DIVERGING / _TUNE / _ACCEPTED */
@@ -330,7 +342,9 @@ typedef struct lmc_window_dst {
     int64_t first;           /* iteration index that lands in destination row 0 */
     double* trace;           /* [chains][n_out][dim], or NULL */
     int32_t n_planes;
-    int32_t reserved;
+    int32_t copy_workgroups; /* workgroups (of 1024 threads) a window copy may use, all sub-blocks together; 0 = the default (16):
+                              * few and large, so that the copy's stores, which drain at host-link speed, tie up the memory
+                              * path of a handful of compute units only */
     lmc_window_plane plane[LMC_MAX_PLANES];
 } lmc_window_dst;
 int lmc_engine_copy_window_async(lmc_engine* e, const lmc_window_dst* dst, int64_t iter_begin, int64_t n_iters);
@@ -339,6 +353,11 @@ int lmc_engine_copy_wait(lmc_engine* e);
  * in. NULL on failure (lmc_last_error(NULL)); free with lmc_host_free. */
 void* lmc_host_alloc(uint64_t bytes);
 void lmc_host_free(void* p);
+/* Page-lock (and map into every GPU) a range of memory the caller already owns -- e.g. an anonymous mapping it has
+ * pre-faulted from several threads: pinning is dominated by the kernel zeroing fresh pages, which one thread does at
+ * ~12 GiB/s; disjoint ranges may be registered concurrently from several threads. Unregister before unmapping. */
+int lmc_host_register(void* p, uint64_t bytes);
+int lmc_host_unregister(void* p);
 
 /* Device pointers of the engine-owned outputs for zero-copy consumers; valid until the next reserve()/destroy().
  * Trace: [chains][capacity - trace_begin][dim] float64. Statistics: [chains][capacity] records of LMC_STAT_RECORD_BYTES

@@ -60,7 +60,7 @@ class WindowDst(C.Structure):
     """struct lmc_window_dst (include/lmc_hip.h): where lmc_engine_copy_window_async() puts a window of iterations."""
 
     _fields_ = [("n_out", C.c_int64), ("first", C.c_int64), ("trace", C.c_void_p), ("n_planes", C.c_int32),
-                ("reserved", C.c_int32), ("plane", WindowPlane * MAX_PLANES)]
+                ("copy_workgroups", C.c_int32), ("plane", WindowPlane * MAX_PLANES)]
 
 
 _P = C.c_void_p
@@ -122,6 +122,7 @@ _SIGNATURES = {
     "lmc_engine_reset_tuning": (C.c_int, [_P]),
     "lmc_engine_set_dual_average": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_int32]),
     "lmc_engine_reserve": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "lmc_engine_attach_trace": (C.c_int, [_P, _P, C.c_int64]),
     "lmc_engine_run": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32]),
     "lmc_engine_run_streams": (C.c_int, [_P, _P, C.c_int32]),
     "lmc_engine_last_run_plan": (C.c_int32, [_P]),
@@ -129,6 +130,8 @@ _SIGNATURES = {
     "lmc_engine_copy_wait": (C.c_int, [_P]),
     "lmc_host_alloc": (_P, [C.c_uint64]),
     "lmc_host_free": (None, [_P]),
+    "lmc_host_register": (C.c_int, [_P, C.c_uint64]),
+    "lmc_host_unregister": (C.c_int, [_P]),
     "lmc_engine_set_step_jitter": (C.c_int, [_P, C.c_int32, C.c_double, C.c_double]),
     "lmc_engine_set_step_sizes": (C.c_int, [_P, _P]),
     "lmc_engine_diag_update": (C.c_int, [_P, C.c_int32]),

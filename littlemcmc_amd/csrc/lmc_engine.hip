@@ -223,31 +223,57 @@ __global__ void stat_gather_kernel(const StatRecord* rec, long long cap, int cha
     else static_cast<unsigned char*>(out)[k] = static_cast<unsigned char>((r.depth_flags >> (16 + idx)) & 1u);
 }
 
-// All statistics planes of the draws [iter_begin, iter_begin + n) of every chain in ONE pass over the 64-byte records
-// (lmc_engine_copy_window_async): thread k = (chain, draw) reads its record once and writes every plane's element in the
-// dtype the reference's stats dict carries; plane p is a dense [chains][n] array at stage + offset[p].
+// Streamed results (lmc_engine_copy_window_async). Both kernels WRITE THE CALLER'S ARRAYS THEMSELVES -- page-locked host memory
+// mapped into the device, or device memory -- with coalesced stores; there is no staging copy and no copy-engine command per
+// row (hipMemcpy2DAsync into pinned memory measured 2.8 GiB/s for 65 536 rows of 51 KB: one DMA command per row).
+//
+// All statistics planes of the draws [iter_begin, iter_begin + n) of every chain in ONE pass over the 64-byte records: thread
+// k = (chain, draw) reads its record once and writes every plane's element in the dtype the reference's stats dict carries;
+// plane p is the caller's [chains][n_out] array, the window starts at its column row0.
 struct WindowPlanes {
     int n_planes;
     int kind[LMC_MAX_PLANES], idx[LMC_MAX_PLANES], as[LMC_MAX_PLANES];
-    long long offset[LMC_MAX_PLANES];   // bytes from the staging area's base
+    void* dst[LMC_MAX_PLANES];
 };
-__global__ void window_gather_kernel(const StatRecord* rec, long long cap, int chains, long long iter_begin, long long n, int hmc,
-                                     WindowPlanes W, char* stage) {
-    const long long k = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (k >= static_cast<long long>(chains) * n) return;
-    const long long c = k / n, i = k - c * n;
-    const StatRecord r = rec[c * cap + iter_begin + i];
-    for (int p = 0; p < W.n_planes; ++p) {
-        char* out = stage + W.offset[p];
-        if (W.kind[p] == LMC_PLANE_F64) {
-            reinterpret_cast<double*>(out)[k] = r.f64[W.idx[p]];
-        } else if (W.kind[p] == LMC_PLANE_I32) {
-            const int v = (W.idx[p] == kSiTreeSize || hmc) ? r.tree_size : static_cast<int>(r.depth_flags & 0xffffu);
-            if (W.as[p] == LMC_AS_F64) reinterpret_cast<double*>(out)[k] = static_cast<double>(v);
-            else if (W.as[p] == LMC_AS_I64) reinterpret_cast<long long*>(out)[k] = static_cast<long long>(v);
-            else reinterpret_cast<int*>(out)[k] = v;
+__global__ void window_gather_kernel(const StatRecord* rec, long long cap, int chain0, int chains, long long iter_begin, long long n, int hmc,
+                                     WindowPlanes W, long long n_out, long long row0) {
+    const long long total = static_cast<long long>(chains) * n;   // chains [chain0, chain0 + chains) of the engine
+    for (long long k = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; k < total; k += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long c = chain0 + k / n, i = k % n;
+        const StatRecord r = rec[c * cap + iter_begin + i];
+        const long long o = c * n_out + row0 + i;
+        for (int p = 0; p < W.n_planes; ++p) {
+            void* out = W.dst[p];
+            if (W.kind[p] == LMC_PLANE_F64) {
+                static_cast<double*>(out)[o] = r.f64[W.idx[p]];
+            } else if (W.kind[p] == LMC_PLANE_I32) {
+                const int v = (W.idx[p] == kSiTreeSize || hmc) ? r.tree_size : static_cast<int>(r.depth_flags & 0xffffu);
+                if (W.as[p] == LMC_AS_F64) static_cast<double*>(out)[o] = static_cast<double>(v);
+                else if (W.as[p] == LMC_AS_I64) static_cast<long long*>(out)[o] = static_cast<long long>(v);
+                else static_cast<int*>(out)[o] = v;
+            } else {
+                static_cast<unsigned char*>(out)[o] = static_cast<unsigned char>((r.depth_flags >> (16 + W.idx[p])) & 1u);
+            }
+        }
+    }
+}
+
+// The draws of a window: for every chain `row` contiguous doubles from src + c * src_pitch to dst + c * dst_pitch. One
+// workgroup walks chains blockIdx.x, blockIdx.x + gridDim.x, ...; V = 2 moves 16 bytes per lane (row and pitches even). The
+// grid is small on purpose (kWindowCopyBlocks): the kernel shares the GPU with the sampling launches that follow, and a few
+// hundred wavefronts of posted writes saturate the host link.
+template <int V>
+__global__ void window_trace_copy_kernel(const double* __restrict__ src, long long src_pitch, double* __restrict__ dst, long long dst_pitch,
+                                         long long row, int chains) {
+    for (int c = blockIdx.x; c < chains; c += gridDim.x) {
+        const double* s = src + c * src_pitch;
+        double* t = dst + c * dst_pitch;
+        if constexpr (V == 2) {
+            const double2* s2 = reinterpret_cast<const double2*>(s);
+            double2* t2 = reinterpret_cast<double2*>(t);
+            for (long long k = threadIdx.x; k < row / 2; k += blockDim.x) t2[k] = s2[k];
         } else {
-            reinterpret_cast<unsigned char*>(out)[k] = static_cast<unsigned char>((r.depth_flags >> (16 + W.idx[p])) & 1u);
+            for (long long k = threadIdx.x; k < row; k += blockDim.x) t[k] = s[k];
         }
     }
 }
@@ -307,12 +333,11 @@ struct lmc_engine {
     hipStream_t sub_stream[kMaxSub] = {};
     hipEvent_t sub_done[kMaxSub] = {};
     hipEvent_t main_done = nullptr;
-    // streamed results (lmc_engine_copy_window_async): a copy stream of the engine's own, ordered after the launches enqueued so
-    // far by events, and a device staging area the statistics planes of one window are gathered into
+    bool trace_external = false;   // A.trace is the caller's memory (lmc_engine_attach_trace): never freed here
+    // streamed results (lmc_engine_copy_window_async): a high-priority copy stream of the engine's own, ordered after the
+    // launches enqueued so far by events (the copies are kernels that write the caller's device-accessible arrays themselves)
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_dep[kMaxSub + 1] = {};
-    char* copy_stage = nullptr;
-    size_t copy_stage_bytes = 0;
     double* chol64T = nullptr;  // FULL_F64: LT[j][i] = L[i][j] of the covariance's factor (what the state getters hand out; D.fac holds L^-1)
     uint32_t* seeds = nullptr;  // [C] the seeds of lmc_engine_seed (key of LMC_RNG_PHILOX's momentum stream)
     int* stop_host = nullptr;   // pinned, device-mapped host word the sampling kernels poll (lmc_engine_request_stop): the host
@@ -1085,7 +1110,6 @@ void lmc_engine_destroy(lmc_engine* e) {
     if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
     for (hipEvent_t ev : e->copy_dep)
         if (ev) (void)hipEventDestroy(ev);
-    if (e->copy_stage) (void)hipFree(e->copy_stage);
     if (e->stop_host) (void)hipHostFree(e->stop_host);
     for (void* p : e->allocs)
         if (p) (void)hipFree(p);
@@ -1847,7 +1871,9 @@ int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int64_t trace_begin) {
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
     ChainArrays& A = e->A;
-    dev_free(e, A.trace); A.trace = nullptr;
+    if (!e->trace_external) dev_free(e, A.trace);
+    A.trace = nullptr;
+    e->trace_external = false;
     dev_free(e, A.stat_rec); A.stat_rec = nullptr;
     const size_t C = e->cfg.chains, cap = static_cast<size_t>(capacity);
     int rc;
@@ -1856,6 +1882,36 @@ int lmc_engine_reserve(lmc_engine* e, int64_t capacity, int64_t trace_begin) {
     if ((rc = dev_alloc(e, &A.stat_rec, C * cap)) != LMC_OK) return rc;
     A.cap = capacity;
     HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
+    return LMC_OK;
+}
+
+// device_view_of(): below (streamed results)
+static void* device_view_of(void* p);
+
+int lmc_engine_attach_trace(lmc_engine* e, double* dst, int64_t trace_begin) {
+    if (!e) return fail(nullptr, LMC_ERR_INVALID, "null engine");
+    if (e->A.cap <= 0 || !e->A.stat_rec) return fail(e, LMC_ERR_STATE, "lmc_engine_reserve() must be called before attach_trace()");
+    if (trace_begin < 0 || trace_begin >= e->A.cap)
+        return fail(e, LMC_ERR_INVALID, "trace_begin %lld outside [0, %lld)", (long long)trace_begin, (long long)e->A.cap);
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    ChainArrays& A = e->A;
+    if (A.trace && !e->trace_external) {   // an engine-owned trace may still be written by launches in flight
+        HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
+        dev_free(e, A.trace);
+    }
+    A.trace = nullptr;
+    e->trace_external = false;
+    if (dst) {
+        double* view = static_cast<double*>(device_view_of(dst));
+        if (!view) return fail(e, LMC_ERR_INVALID, "trace: the destination is not device-accessible memory (use lmc_host_alloc / lmc_host_register)");
+        A.trace = view;
+        e->trace_external = true;
+    } else {
+        const size_t C = e->cfg.chains;
+        const int rc = dev_alloc(e, &A.trace, C * static_cast<size_t>(A.cap - trace_begin) * e->cfg.dim, false);
+        if (rc != LMC_OK) return rc;
+    }
+    A.trace_begin = trace_begin;
     return LMC_OK;
 }
 
@@ -2139,10 +2195,24 @@ int lmc_engine_get_stat_u8(lmc_engine* e, int32_t stat, uint8_t* dst, int64_t it
 }
 
 // ---- streamed results ------------------------------------------------------------------------------------------------------
-static size_t plane_elem_bytes(const lmc_window_plane& pl) {
-    if (pl.kind == LMC_PLANE_F64) return sizeof(double);
-    if (pl.kind == LMC_PLANE_U8) return 1;
-    return pl.as == LMC_AS_NATIVE ? sizeof(int32_t) : 8;
+#ifndef LMC_WINDOW_COPY_BLOCKS
+#define LMC_WINDOW_COPY_BLOCKS 16
+#endif
+static constexpr int kWindowCopyBlocks = LMC_WINDOW_COPY_BLOCKS;   // workgroups of a window copy, all sub-blocks together (lmc_window_dst.copy_workgroups = 0)
+static constexpr int kWindowCopyThreads = 1024;
+
+// the address a kernel of this engine's device writes `p` through: device memory as it is, page-locked host memory through its
+// device mapping; nullptr for memory the device cannot reach (pageable)
+static void* device_view_of(void* p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) return p;
+    if (attr.type == hipMemoryTypeHost) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return dp;
+    }
+    return nullptr;
 }
 
 int lmc_engine_copy_window_async(lmc_engine* e, const lmc_window_dst* dst, int64_t iter_begin, int64_t n_iters) {
@@ -2155,22 +2225,42 @@ int lmc_engine_copy_window_async(lmc_engine* e, const lmc_window_dst* dst, int64
         return fail(e, LMC_ERR_INVALID, "window [%lld, %lld) outside the destination's iterations [%lld, %lld)", (long long)iter_begin,
                     (long long)(iter_begin + n_iters), (long long)dst->first, (long long)(dst->first + dst->n_out));
     if (dst->n_planes < 0 || dst->n_planes > LMC_MAX_PLANES) return fail(e, LMC_ERR_INVALID, "n_planes %d", dst->n_planes);
+    if (dst->copy_workgroups < 0 || dst->copy_workgroups > 4096) return fail(e, LMC_ERR_INVALID, "copy_workgroups %d", dst->copy_workgroups);
     if (dst->trace && (!e->A.trace || iter_begin < e->A.trace_begin))
         return fail(e, LMC_ERR_INVALID, "draws before iteration %lld were not stored", (long long)e->A.trace_begin);
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    WindowPlanes W;
+    std::memset(&W, 0, sizeof(W));
+    W.n_planes = dst->n_planes;
     for (int p = 0; p < dst->n_planes; ++p) {
         const lmc_window_plane& pl = dst->plane[p];
         const int lim = pl.kind == LMC_PLANE_F64 ? kNumStatF64 : pl.kind == LMC_PLANE_I32 ? kNumStatI32 : pl.kind == LMC_PLANE_U8 ? kNumStatU8 : -1;
         if (!pl.dst || lim < 0 || pl.idx < 0 || pl.idx >= lim || pl.as < LMC_AS_NATIVE || pl.as > LMC_AS_I64 ||
             (pl.kind != LMC_PLANE_I32 && pl.as != LMC_AS_NATIVE))
             return fail(e, LMC_ERR_INVALID, "plane %d: kind %d idx %d as %d", p, pl.kind, pl.idx, pl.as);
+        W.kind[p] = pl.kind; W.idx[p] = pl.idx; W.as[p] = pl.as;
+        W.dst[p] = device_view_of(pl.dst);
+        if (!W.dst[p])
+            return fail(e, LMC_ERR_INVALID, "plane %d: the destination is not device-accessible memory (use lmc_host_alloc)", p);
     }
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    double* trace_dst = nullptr;
+    if (dst->trace) {
+        trace_dst = static_cast<double*>(device_view_of(dst->trace));
+        if (!trace_dst) return fail(e, LMC_ERR_INVALID, "trace: the destination is not device-accessible memory (use lmc_host_alloc)");
+    }
+    // The copies run on a stream of the engine's own, created with HIGH priority: the runtime maps streams of one priority
+    // onto a pool of four hardware queues, which the main stream and the four sub-block streams already share -- a copy that
+    // waits (for ALL sub-blocks of its launch) in a queue it shares with a sub-block stream holds that sub-block's next launch
+    // back, and a copy enqueued on the sub-block streams themselves runs between their launches instead of under them (both
+    // measured: the whole copy time showed up in the job). A high-priority stream gets a hardware queue from another pool.
+    // Ordered after every launch enqueued so far by one event per sub-block stream (and the main stream), waited for on the
+    // device: the host does not block and later launches are not held up.
     if (!e->copy_stream) {
-        HIP_TRY(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        int pr_low = 0, pr_high = 0;
+        HIP_TRY(e, hipDeviceGetStreamPriorityRange(&pr_low, &pr_high));
+        HIP_TRY(e, hipStreamCreateWithPriority(&e->copy_stream, hipStreamNonBlocking, pr_high));
         for (hipEvent_t& ev : e->copy_dep) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
-    // ordered after every launch enqueued so far: one event per sub-block stream (and the main stream), waited for on the
-    // device -- the host does not block, later launches are not held up
     hipStream_t cs = e->copy_stream;
     if (e->n_sub > 1)
         for (int b = 0; b < e->n_sub; ++b) {
@@ -2179,44 +2269,37 @@ int lmc_engine_copy_window_async(lmc_engine* e, const lmc_window_dst* dst, int64
         }
     HIP_TRY(e, hipEventRecord(e->copy_dep[lmc_engine::kMaxSub], e->stream_));
     HIP_TRY(e, hipStreamWaitEvent(cs, e->copy_dep[lmc_engine::kMaxSub], 0));
-
-    const size_t C = e->cfg.chains, d = e->cfg.dim, n = static_cast<size_t>(n_iters), n_out = static_cast<size_t>(dst->n_out);
-    const size_t row0 = static_cast<size_t>(iter_begin - dst->first);
-    if (dst->trace) {
-        const size_t rows = static_cast<size_t>(e->A.cap - e->A.trace_begin);
-        const double* src = e->A.trace + static_cast<size_t>(iter_begin - e->A.trace_begin) * d;
-        HIP_TRY(e, hipMemcpy2DAsync(dst->trace + row0 * d, n_out * d * sizeof(double), src, rows * d * sizeof(double),
-                                    n * d * sizeof(double), C, hipMemcpyDefault, cs));
-    }
-    if (dst->n_planes > 0) {
-        WindowPlanes W;
-        std::memset(&W, 0, sizeof(W));
-        W.n_planes = dst->n_planes;
-        size_t need = 0;
-        for (int p = 0; p < dst->n_planes; ++p) {
-            W.kind[p] = dst->plane[p].kind; W.idx[p] = dst->plane[p].idx; W.as[p] = dst->plane[p].as;
-            W.offset[p] = static_cast<long long>(need);
-            need += (C * n * plane_elem_bytes(dst->plane[p]) + 255) / 256 * 256;
+    const long long C = e->cfg.chains, d = e->cfg.dim, n = n_iters, n_out = dst->n_out;
+    const long long row0 = iter_begin - dst->first;
+    // few, large workgroups: the copy's wavefronts sit on stores that drain at host-link speed, and the vector-memory path of a
+    // compute unit is shared with whatever else runs there -- 256 workgroups of 256 threads (one per CU) slowed every sampling
+    // wavefront of the chip for as long as the copy ran (the whole copy time showed up in the job), a dozen workgroups of 1024
+    // threads saturate the link from a dozen CUs
+    const int want = dst->copy_workgroups > 0 ? dst->copy_workgroups : kWindowCopyBlocks;
+    const long long per_grid = want;
+    const dim3 cblock(kWindowCopyThreads);
+    {
+        const long long lo = 0, hi = C;
+        hipStream_t st = cs;
+        if (trace_dst) {
+            const long long rows = e->A.cap - e->A.trace_begin;
+            const long long row = n * d, sp = rows * d, dp_ = n_out * d;
+            const double* src = e->A.trace + lo * sp + (iter_begin - e->A.trace_begin) * d;
+            double* out = trace_dst + lo * dp_ + row0 * d;
+            const dim3 grid(static_cast<unsigned>(hi - lo < per_grid ? hi - lo : per_grid));
+            const bool v2 = row % 2 == 0 && sp % 2 == 0 && dp_ % 2 == 0 && (reinterpret_cast<uintptr_t>(src) % 16 == 0) &&
+                            (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+            if (v2) { LMC_LAUNCH(window_trace_copy_kernel<2>, grid, cblock, 0, st, src, sp, out, dp_, row, static_cast<int>(hi - lo)); }
+            else { LMC_LAUNCH(window_trace_copy_kernel<1>, grid, cblock, 0, st, src, sp, out, dp_, row, static_cast<int>(hi - lo)); }
+            HIP_TRY(e, hipGetLastError());
         }
-        if (need > e->copy_stage_bytes) {   // (grown between windows only: copies of earlier windows still read the old area)
-            HIP_TRY(e, hipStreamSynchronize(cs));
-            if (e->copy_stage) (void)hipFree(e->copy_stage);
-            e->copy_stage = nullptr; e->copy_stage_bytes = 0;
-            HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->copy_stage), need));
-            e->copy_stage_bytes = need;
-            // (the synchronize above dropped the dependencies of this call: establish them again)
-            if (e->n_sub > 1)
-                for (int b = 0; b < e->n_sub; ++b) HIP_TRY(e, hipStreamWaitEvent(cs, e->copy_dep[b], 0));
-            HIP_TRY(e, hipStreamWaitEvent(cs, e->copy_dep[lmc_engine::kMaxSub], 0));
-        }
-        const size_t total = C * n;
-        LMC_LAUNCH(window_gather_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, cs, e->A.stat_rec, e->A.cap,
-                   e->cfg.chains, iter_begin, n_iters, e->cfg.kind == LMC_KIND_HMC ? 1 : 0, W, e->copy_stage);
-        HIP_TRY(e, hipGetLastError());
-        for (int p = 0; p < dst->n_planes; ++p) {
-            const size_t eb = plane_elem_bytes(dst->plane[p]);
-            HIP_TRY(e, hipMemcpy2DAsync(static_cast<char*>(dst->plane[p].dst) + row0 * eb, n_out * eb, e->copy_stage + W.offset[p], n * eb,
-                                        n * eb, C, hipMemcpyDefault, cs));
+        if (dst->n_planes > 0) {
+            const long long total = (hi - lo) * n;
+            long long blocks = (total + kWindowCopyThreads - 1) / kWindowCopyThreads;
+            if (blocks > per_grid) blocks = per_grid;
+            LMC_LAUNCH(window_gather_kernel, dim3(static_cast<unsigned>(blocks)), cblock, 0, st, e->A.stat_rec, e->A.cap,
+                       static_cast<int>(lo), static_cast<int>(hi - lo), iter_begin, n_iters, e->cfg.kind == LMC_KIND_HMC ? 1 : 0, W, n_out, row0);
+            HIP_TRY(e, hipGetLastError());
         }
     }
     return LMC_OK;
@@ -2243,6 +2326,26 @@ void* lmc_host_alloc(uint64_t bytes) {
 
 void lmc_host_free(void* p) {
     if (p) (void)hipHostFree(p);
+}
+
+int lmc_host_register(void* p, uint64_t bytes) {
+    if (!p || bytes == 0) return fail(nullptr, LMC_ERR_INVALID, "null argument");
+    const hipError_t err = hipHostRegister(p, static_cast<size_t>(bytes), hipHostRegisterPortable | hipHostRegisterMapped);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(nullptr, LMC_ERR_HIP, "hipHostRegister(%llu bytes): %s", (unsigned long long)bytes, hipGetErrorString(err));
+    }
+    return LMC_OK;
+}
+
+int lmc_host_unregister(void* p) {
+    if (!p) return LMC_OK;
+    const hipError_t err = hipHostUnregister(p);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(nullptr, LMC_ERR_HIP, "hipHostUnregister: %s", hipGetErrorString(err));
+    }
+    return LMC_OK;
 }
 
 void* lmc_engine_trace_device_ptr(lmc_engine* e) { return e ? e->A.trace : nullptr; }

@@ -21,35 +21,63 @@ class _TickView:
 
 
 class _PinnedBlock:
-    """Owner of one lmc_host_alloc() block; frees it when the last numpy view is gone."""
+    """Owner of one page-locked block behind a result array: a numpy allocation registered with the HIP runtime
+    (lmc_host_register). Exposes the memory through __array_interface__ (numpy keeps this object alive as the base of every
+    view) and unregisters it when the last view is gone."""
 
-    def __init__(self, lib, ptr):
-        self._lib, self._ptr = lib, ptr
+    def __init__(self, lib, raw, shape, dtype):
+        self._lib, self._raw = lib, raw
+        self.__array_interface__ = {"data": (raw.ctypes.data, False), "shape": tuple(int(x) for x in shape),
+                                    "typestr": np.dtype(dtype).str, "version": 3}
 
     def __del__(self):
         try:
-            if self._ptr:
-                self._lib.lmc_host_free(C.c_void_p(self._ptr))
-                self._ptr = 0
+            if self._raw is not None:
+                self._lib.lmc_host_unregister(C.c_void_p(self._raw.ctypes.data))
+                self._raw = None
         except Exception:
             pass
 
 
-def pinned_empty(shape, dtype, lib=None):
-    """A C-contiguous numpy array in page-locked host memory (lmc_host_alloc: hipHostMalloc, portable across GPUs), freed
-    when the array and every view of it are gone. Device->host copies into it are asynchronous and run at link speed. Raises
-    HipLibraryError if the memory cannot be pinned."""
+def _prefault(address, nbytes, threads):
+    """Touch [address, address + nbytes) from several threads (C memset outside the GIL, 2 MiB-aligned shares): a fresh
+    allocation costs the kernel one zeroed page per fault, which one thread does at ~16 GiB/s and sixteen at ~170 GiB/s."""
+    import threading
+
+    if nbytes <= 0:
+        return
+    threads = max(1, min(int(threads), nbytes >> 24))          # at least 16 MiB per thread
+    share = -(-nbytes // threads // (1 << 21)) * (1 << 21)
+    if threads == 1:
+        C.memset(address, 0, nbytes)
+        return
+    work = [threading.Thread(target=C.memset, args=(address + o, 0, min(share, nbytes - o))) for o in range(0, nbytes, share)]
+    for t in work:
+        t.start()
+    for t in work:
+        t.join()
+
+
+def pinned_empty(shape, dtype, lib=None, threads=None):
+    """A C-contiguous numpy array in page-locked host memory every GPU can write (hipHostRegister, portable + mapped), unpinned
+    and freed when the array and every view of it are gone. The memory is an ordinary numpy allocation (numpy asks for
+    transparent huge pages for large blocks), pre-faulted from ``threads`` threads (default: up to 16 of the usable cores) and
+    then registered: 15.6 GiB take 0.12 s this way against 1.2 s for hipHostMalloc, which faults every page in from one thread
+    (profiles/r06_sample_e2e.txt). Raises HipLibraryError if the memory cannot be pinned."""
     lib = lib or _abi.load()
     dtype = np.dtype(dtype)
     nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
     if nbytes == 0:
         return np.empty(shape, dtype=dtype)
-    p = lib.lmc_host_alloc(nbytes)
-    if not p:
+    if threads is None:
+        import os
+
+        threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    raw = np.empty(nbytes, dtype=np.uint8)
+    _prefault(raw.ctypes.data, nbytes, threads)
+    if lib.lmc_host_register(C.c_void_p(raw.ctypes.data), nbytes) != _abi.OK:
         raise _abi.HipLibraryError("cannot pin %d bytes of host memory: %s" % (nbytes, (lib.lmc_last_error(None) or b"?").decode()))
-    buf = (C.c_char * nbytes).from_address(p)
-    buf._owner = _PinnedBlock(lib, p)          # (numpy keeps `buf` alive as the array's base)
-    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+    return np.asarray(_PinnedBlock(lib, raw, shape, dtype))
 
 
 class StreamedResults:
@@ -60,7 +88,9 @@ class StreamedResults:
 
     ``planes``: (name, kind, idx, as_, numpy dtype) with kind / as_ the LMC_PLANE_* / LMC_AS_* of include/lmc_hip.h."""
 
-    def __init__(self, chains, n_out, first, dim, planes, keep_trace=True, pinned=True, lib=None):
+    def __init__(self, chains, n_out, first, dim, planes, keep_trace=True, pinned=True, lib=None, copy_workgroups=0, direct=False):
+        self.direct = bool(direct)      # the sampling kernel writes ``trace`` itself (Engine.attach_trace): windows carry statistics only
+        self.copy_workgroups = int(copy_workgroups)     # lmc_window_dst.copy_workgroups (0 = the library's default)
         self.chains, self.n_out, self.first, self.dim = int(chains), int(n_out), int(first), int(dim)
         self.planes = list(planes)
         assert len(self.planes) <= _abi.MAX_PLANES
@@ -73,8 +103,9 @@ class StreamedResults:
         """struct lmc_window_dst for the engine that owns chains [chain_lo, chain_lo + eng.chains) of these arrays."""
         w = _abi.WindowDst()
         w.n_out, w.first = self.n_out, self.first
-        w.trace = None if self.trace is None else self.trace[chain_lo:].ctypes.data
+        w.trace = None if (self.trace is None or self.direct) else self.trace[chain_lo:].ctypes.data
         w.n_planes = len(self.planes)
+        w.copy_workgroups = self.copy_workgroups
         for p, (name, kind, idx, as_, _dt) in enumerate(self.planes):
             w.plane[p].dst = self.stats[name][chain_lo:].ctypes.data
             w.plane[p].kind, w.plane[p].idx, w.plane[p].as_ = int(kind), int(idx), int(as_)
@@ -240,6 +271,16 @@ class Engine:
         self.capacity = int(capacity)
         self.keep_trace = bool(keep_trace) and tb < capacity
         self.trace_begin = max(tb, 0)
+
+    def attach_trace(self, out, trace_begin):
+        """Where the draws of iterations >= trace_begin go, after reserve(keep_trace=False): ``out`` = a device-accessible
+        [chains, capacity - trace_begin, dim] float64 array (pinned_empty) the sampling kernel writes directly, or None = a
+        trace in HBM (include/lmc_hip.h: lmc_engine_attach_trace)."""
+        if out is not None:
+            assert out.shape == (self.chains, self.capacity - int(trace_begin), self.dim) and out.dtype == np.float64 and out.flags["C_CONTIGUOUS"]
+        self._check(self._lib.lmc_engine_attach_trace(self._h, None if out is None else C.c_void_p(out.ctypes.data), int(trace_begin)))
+        self._trace_out = out            # (kept alive for as long as the engine may write it)
+        self.keep_trace, self.trace_begin = True, int(trace_begin)
 
     def run(self, n_tune, iter_begin, n_iters):
         if self.target.family == _abi.TARGET_EXTERNAL:
@@ -638,6 +679,10 @@ class EngineGroup:
     def copy_window_async(self, out, iter_begin, n_iters):
         for e, (lo, _hi) in zip(self.engines, self.blocks):
             e.copy_window_async(out, iter_begin, n_iters, chain_lo=lo)
+
+    def attach_trace(self, out, trace_begin):
+        for e, (lo, hi) in zip(self.engines, self.blocks):
+            e.attach_trace(None if out is None else out[lo:hi], trace_begin)
 
     def copy_wait(self):
         self._each("copy_wait")

@@ -87,26 +87,41 @@ class JobProgress:
 
 
 class _ResultStreamer:
-    """Fills the arrays sample() returns while the job runs. The arrays are page-locked host memory, and pinning tens of GiB
-    takes seconds, so they are allocated by a helper thread while the first launches run; the window of every launch is
-    handed to Engine.copy_window_async() as soon as both the launch is enqueued and the arrays exist (windows that come
-    earlier wait in a list -- the draws stay in HBM until the job is over, nothing is lost by copying late)."""
+    """Fills the arrays sample() returns while the job runs (sampling.py:207-222 of the reference returns host arrays; a
+    job's draws are tens of GiB, so nothing may wait for the end of the job). The arrays are page-locked host memory, pinned
+    by a helper thread while the first launches run.
 
-    def __init__(self, eng, chains, n_out, first, dim, planes):
+    * draws: ``direct=True`` -- the sampling kernel stores every draw straight into the returned trace array as it is
+      produced (Engine.attach_trace: coalesced rows over the host link, no trace in HBM, nothing left to copy when the job
+      ends); ``direct=False`` -- the trace stays in HBM and every launch's window is copied under the following launches.
+    * statistics (82 bytes per draw): the window of every launch is gathered out of the per-draw records, converted to the
+      reference's dtypes on the device and written into the returned arrays under the following launches
+      (Engine.copy_window_async). Windows that come before the arrays exist wait in a list."""
+
+    def __init__(self, eng, chains, n_out, first, dim, planes, direct):
         import threading
 
         self.eng, self.first, self.out, self.err, self.waiting = eng, int(first), None, None, []
+        self.direct, self.attached = bool(direct), False
 
         def alloc():
             from .engine import StreamedResults
 
             try:
-                self.out = StreamedResults(chains, n_out, first, dim, planes)
+                self.out = StreamedResults(chains, n_out, first, dim, planes, direct=direct)
             except BaseException as err:     # the host cannot pin that much: the draws are copied after the job instead
                 self.err = err
 
         self._thread = threading.Thread(target=alloc, name="lmc-pin-results", daemon=True)
         self._thread.start()
+
+    def before_launch(self, first, n):
+        """before_enqueue(first, n) of _run_job: the first launch that reaches iteration ``self.first`` needs to know where
+        the draws go (direct mode): wait for the arrays and attach the trace -- or, if they could not be pinned, a trace in HBM."""
+        if self.direct and not self.attached and int(first) + int(n) > self.first:
+            self._thread.join()
+            self.eng.attach_trace(self.out.trace if self.out is not None else None, self.first)
+            self.attached = True
 
     def window(self, first, n):
         """on_enqueued(first, n) of _run_job: iterations [first, first + n) have been launched."""
@@ -133,7 +148,7 @@ class _ResultStreamer:
         return self.out
 
 
-def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None, on_enqueued=None):
+def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None, on_enqueued=None, before_enqueue=None):
     """Enqueue the job's launches, then wait for them in a way Ctrl-C can reach (sampling.py:324-328, :470-471 in the
     reference: a KeyboardInterrupt ends sampling and what has been drawn so far is returned).
 
@@ -145,7 +160,7 @@ def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None, on_enqu
     every launch is enqueued on all devices before anything is waited for, and a launch counts as complete when it is
     complete everywhere. ``on_enqueued(first, n)`` is called right after the launch of iterations [first, first + n) has
     been enqueued (sample() enqueues the copy of that window into the result arrays there, so the copy of launch k runs under
-    launch k + 1). Returns (iterations completed by EVERY chain, interrupted)."""
+    launch k + 1); ``before_enqueue(first, n)`` right before it is. Returns (iterations completed by EVERY chain, interrupted)."""
     import time
 
     engines = getattr(eng, "engines", [eng])
@@ -176,6 +191,8 @@ def _run_job(eng, tune, n_total, per_launch, progressbar, callback=None, on_enqu
 
     def enqueue_next():
         first, n = pending.pop(0)
+        if before_enqueue is not None:
+            before_enqueue(first, n)
         eng.run(tune, first, n)
         if on_enqueued is not None:
             on_enqueued(first, n)
@@ -320,10 +337,12 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
     ``keep_moments`` (the kernel also keeps every chain's running mean / M2 of the post-warm-up draws:
     ``Engine.moments()``). ``callback(trace=None, draw=JobProgress)`` is called from the wait loop as the job advances
     and may raise KeyboardInterrupt to stop it (sampling.py:272-277 of the reference); ``mp_ctx`` and
-    ``pickle_backend`` are accepted and ignored (no worker processes). ``stream_results`` (default True): the returned
-    arrays are allocated up front in page-locked host memory and every launch's draws and statistics are copied into them
-    while the next launch runs (lmc_engine_copy_window_async), instead of in one blocking copy after the job; False keeps
-    the draws on the device until the job is over (the same arrays bit for bit, tests/test_gpu_round6.py).
+    ``pickle_backend`` are accepted and ignored (no worker processes). ``stream_results``: True / "direct" (default) --
+    the returned arrays are page-locked host memory, the sampling kernel writes every draw straight into the returned trace
+    (lmc_engine_attach_trace) and every launch's statistics are copied under the launches that follow
+    (lmc_engine_copy_window_async); "windows" -- the trace stays in HBM and is copied window by window like the statistics;
+    False -- everything stays on the device until the job is over, then one blocking copy. The same arrays bit for bit
+    (tests/test_gpu_round6.py).
     """
     if model_ndim is None:
         model_ndim = size if size is not None else getattr(logp_dlogp_func, "d", None)
@@ -394,7 +413,19 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
             eng.keep_moments(True)
         eng.reset_tuning()                    # step.reset_tuning(); iter_count = 0 (sampling.py:503-509)
         lo = int(tune) if discard_tuned_samples else 0   # sampling.py:473-476
-        eng.reserve(max(n_total, 1), keep_trace=True, trace_begin=min(lo, max(n_total - 1, 0)))
+        host_rand = getattr(step, "_host_step_rand", lambda: None)() is not None
+        # Streamed results (the default): the arrays the caller gets are pinned while the first launches run, the sampling
+        # kernel writes the draws straight into them ("direct") and every launch's statistics are copied under the launches
+        # that follow (_ResultStreamer). Not for jobs that launch per iteration (a host step_rand) or per tick (a torch /
+        # Python callable): their results are copied when the job is over.
+        mode = {True: "direct", False: None, None: None}.get(stream_results, stream_results)
+        if mode not in (None, "direct", "windows"):
+            raise ValueError("stream_results must be True / 'direct', 'windows' or False")
+        if host_rand or target.family == _abi.TARGET_EXTERNAL or n_total - lo <= 0 or not hasattr(step, "_result_planes"):
+            mode = None
+        if return_engine and mode == "direct":
+            mode = "windows"     # whoever keeps the engine reads the draws where diagnostics want them: in HBM
+        eng.reserve(max(n_total, 1), keep_trace=mode != "direct", trace_begin=min(lo, max(n_total - 1, 0)))
         # one launch for the whole job unless asked otherwise: every launch ends with a tail in which the chains with
         # the longest trees run alone (ragged targets: DESIGN.md section 6), so fewer, longer launches are faster
         per_launch = int(launch_iters) if launch_iters else max(1, min(n_total, 4000))
@@ -419,19 +450,16 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
                 per_launch = min(per_launch, 200)   # general kernels (one workgroup per chain, a few hundred resident): same reason
         if target.family == _abi.TARGET_EXTERNAL and not launch_iters:
             per_launch = max(n_total, 1)   # ticks: chains never wait for each other inside one request
-        host_rand = getattr(step, "_host_step_rand", lambda: None)() is not None
-        # Streamed results: the arrays the caller gets are allocated now (pinned), and the window of every launch is copied into
-        # them as soon as the launch is over, under the launches that follow (lmc_engine_copy_window_async). Not for jobs that
-        # launch per iteration (a host step_rand) or per tick (a torch / Python callable): their draws are copied at the end.
         streamer = None
-        if stream_results and not host_rand and target.family != _abi.TARGET_EXTERNAL and n_total - lo > 0 and hasattr(step, "_result_planes"):
-            streamer = _ResultStreamer(eng, chains, n_total - lo, lo, model_ndim, step._result_planes())
+        if mode is not None:
+            streamer = _ResultStreamer(eng, chains, n_total - lo, lo, model_ndim, step._result_planes(), direct=mode == "direct")
         try:
             if host_rand:
                 n_done, interrupted = _run_job_host_step_rand(eng, step, int(tune), n_total, progressbar, callback)
             else:
                 n_done, interrupted = _run_job(eng, int(tune), n_total, per_launch, progressbar, callback,
-                                               on_enqueued=streamer.window if streamer is not None else None)
+                                               on_enqueued=streamer.window if streamer is not None else None,
+                                               before_enqueue=streamer.before_launch if streamer is not None else None)
         finally:
             streamed = streamer.finish() if streamer is not None else None
         raise_for_status(eng.status())

@@ -66,7 +66,7 @@ def test_window_destination_struct_layout():
     the C compiler's size (8-byte alignment, 16 planes)."""
     blk = HEADER[HEADER.index("typedef struct lmc_window_plane"):HEADER.index("} lmc_window_dst;")]
     names = re.findall(r"^\s+(?:int32_t|int64_t|void\*|double\*|lmc_window_plane)\s+(\w+)", blk, re.M)
-    assert names == ["dst", "kind", "idx", "as", "reserved", "n_out", "first", "trace", "n_planes", "reserved", "plane"]
+    assert names == ["dst", "kind", "idx", "as", "reserved", "n_out", "first", "trace", "n_planes", "copy_workgroups", "plane"]
     assert [f.rstrip("_") for f, _ in _abi.WindowPlane._fields_] == names[:5]
     assert [f for f, _ in _abi.WindowDst._fields_] == names[5:]
     assert ctypes.sizeof(_abi.WindowPlane) == 24 and ctypes.sizeof(_abi.WindowDst) == 32 + 16 * 24

@@ -93,9 +93,11 @@ def test_streamed_results_equal_the_copy_after_the_job(kind, discard):
     tgt = T.AR1(d, 0.9)
     kw = dict(draws=130, tune=170, chains=chains, random_seed=31, progressbar=False, discard_tuned_samples=discard, launch_iters=64)
     mk = (lambda: None) if kind == "nuts" else (lambda: lmc.HamiltonianMC(tgt, d, path_length=1.0))
-    a = lmc.sample(tgt, d, step=mk(), stream_results=True, **kw)
+    a = lmc.sample(tgt, d, step=mk(), stream_results=True, **kw)        # "direct": the kernel writes the returned trace itself
     b = lmc.sample(tgt, d, step=mk(), stream_results=False, **kw)
+    w = lmc.sample(tgt, d, step=mk(), stream_results="windows", **kw)   # trace in HBM, copied window by window
     _same(a, b)
+    _same(w, b)
     n_out = 130 if discard else 300
     assert a[0].shape == (chains, n_out, d) and a[0].flags["C_CONTIGUOUS"]
     want = lmc.NUTS.stats_dtypes[0] if kind == "nuts" else lmc.HamiltonianMC.stats_dtypes[0]
@@ -117,11 +119,18 @@ def test_streamed_results_on_two_engines_and_after_an_interrupt():
     one = lmc.sample(tgt, d, devices=[0], stream_results=False, **kw)
     two = lmc.sample(tgt, d, devices=[0, 0], stream_results=True, **kw)
     _same(one, two)
+    _same(one, lmc.sample(tgt, d, devices=[0, 0], stream_results="windows", **kw))
+    # the team kernels (d = 600: two wavefronts per chain) and the general kernels (d = 1100) store their draws the same way
+    for dd in (600, 1100):
+        kk = dict(draws=6, tune=10, chains=5, random_seed=4, progressbar=False, launch_iters=7)
+        _same(lmc.sample(T.StdNormal(dd), dd, stream_results=True, **kk), lmc.sample(T.StdNormal(dd), dd, stream_results=False, **kk))
 
     def stop_at_50(trace, draw):
         if draw.iteration >= 50:
             raise KeyboardInterrupt
 
+    with pytest.raises(ValueError):
+        lmc.sample(tgt, d, stream_results="sideways", **kw)
     got = lmc.sample(tgt, d, stream_results=True, callback=stop_at_50, **kw)
     n = got[0].shape[1]
     assert 25 <= n < 120, n
@@ -166,6 +175,9 @@ def test_copy_window_async_runs_under_the_next_launch():
         # a window outside the destination is refused, not written
         with pytest.raises(_abi.HipLibraryError, match="outside"):
             eng.copy_window_async(StreamedResults(chains, 10, 50, d, [], pinned=False), 40, 20)
+        # pageable memory is refused (the copies are kernels that write the destination themselves), never silently staged
+        with pytest.raises(_abi.HipLibraryError, match="not device-accessible"):
+            eng.copy_window_async(StreamedResults(chains, 10, 50, d, [], pinned=False), 50, 10)
     finally:
         eng.close()
 
