@@ -105,7 +105,7 @@ def compact_line(out, detail_path=None, limit=LINE_LIMIT):
         line["cpu_baseline"] = cb
     line["tail"] = _pick(out.get("tail", {}), TAIL)
     line["per_rank"] = [_pick(r, ("rank", "chains", "leapfrogs", "kernel_s", "wall_s")) for r in out.get("per_rank", [])]
-    line.update(_pick(out, ("rccl_ranks", "backend", "source_hash")))
+    line.update(_pick(out, ("rccl_ranks", "backend", "source_hash", "source_tree_hash")))
     line["rccl_error"] = None if out.get("rccl_error") is None else _short(out["rccl_error"], 160)
     line["launcher"] = _short(str(out.get("launcher", "")).split(":")[0], 16)
     line["launcher_fallback"] = None if out.get("launcher_fallback") is None else _short(out["launcher_fallback"], 160)
@@ -113,7 +113,7 @@ def compact_line(out, detail_path=None, limit=LINE_LIMIT):
     for s_ in out.get("secondary", []):
         r = s_.get("roofline", {})
         t = s_.get("tail", {})
-        sec.append({"workload": _short(s_.get("workload_short") or s_.get("workload"), 80), "value": s_.get("value"),
+        sec.append({"workload": _short(s_.get("workload_short") or s_.get("workload"), 100), "value": s_.get("value"),
                     "ms_per_step": s_.get("ms_per_step"), "steps": s_.get("steps"),
                     "roofline": _pick(r, ("kernel", "frac", "bound")),
                     "tail": _pick(t, ("mean_wave_slot_occupancy", "implied_wall_lower_bound_s", "lone_wave_us_per_leapfrog"))})

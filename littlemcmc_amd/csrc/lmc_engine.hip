@@ -850,7 +850,17 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     };
     hipError_t se = hipSetDevice(cfg->device);
     if (se != hipSuccess) return bail(fail(nullptr, LMC_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(se)));
-    se = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    // The engine's own (main) stream is created with HIGH priority for the hardware queue that comes with it, not for the
+    // priority: the runtime maps the streams of one priority onto a pool of four hardware queues, and with the main stream in
+    // the same pool the fourth sub-block stream (the fifth stream) shared a queue with an earlier one -- in the first job of a
+    // process its dispatch then began hundreds of iterations after the other three (d = 16), and an interrupt in that window
+    // found 33 chains that had not started and returned nothing (tests/test_gpu_round5.py; LMC_SUB_BLOCKS=3 or
+    // GPU_MAX_HW_QUEUES=5 made it go away, stream warm-ups did not). The main stream carries set-up and read-back work only.
+    {
+        int pr_low = 0, pr_high = 0;
+        se = hipDeviceGetStreamPriorityRange(&pr_low, &pr_high);
+        if (se == hipSuccess) se = hipStreamCreateWithPriority(&e->own_stream, hipStreamNonBlocking, pr_high);
+    }
     if (se != hipSuccess) return bail(fail(nullptr, LMC_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)));
     e->stream_ = e->own_stream;
     // sub-blocks: two halves of the chains on two streams (measured on C3's kernel: +2 % at 65 536 chains, +11 % at

@@ -423,8 +423,8 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
             raise ValueError("stream_results must be True / 'direct', 'windows' or False")
         if host_rand or target.family == _abi.TARGET_EXTERNAL or n_total - lo <= 0 or not hasattr(step, "_result_planes"):
             mode = None
-        if return_engine and mode == "direct":
-            mode = "windows"     # whoever keeps the engine reads the draws where diagnostics want them: in HBM
+        if return_engine and stream_results is True:
+            mode = "windows"     # whoever keeps the engine reads the draws where diagnostics want them: in HBM (an explicit "direct" is honoured)
         eng.reserve(max(n_total, 1), keep_trace=mode != "direct", trace_begin=min(lo, max(n_total - 1, 0)))
         # one launch for the whole job unless asked otherwise: every launch ends with a tail in which the chains with
         # the longest trees run alone (ragged targets: DESIGN.md section 6), so fewer, longer launches are faster
