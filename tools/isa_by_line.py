@@ -59,7 +59,7 @@ def main():
             cur = (files.get(int(m.group(1)), "?"), int(m.group(2)))
             continue
         dm = re.search(r"Depth=(\d+)", l)
-        if re.match(r"^\.LBB", l):
+        if re.match(r"^\.LBB", l) or re.match(r"^; %bb\.\d+:", l):   # (fall-through blocks carry their loop in a comment line only)
             depth = int(dm.group(1)) if dm else 0
         t = l.strip()
         if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
