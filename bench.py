@@ -72,7 +72,7 @@ def compact_line(out, detail_path=None, limit=LINE_LIMIT):
             "leapfrogs_per_launch", "dispatches_per_step", "dispatch_ms_avg", "flop_per_leapfrog", "bytes_per_leapfrog",
             "valu_inst_per_leapfrog", "simd_valu_busy")
     TAIL = ("busiest_chain_leapfrogs", "mean_chain_leapfrogs", "launch_max_over_mean", "critical_path_leapfrogs",
-            "lone_wave_us_per_leapfrog", "implied_wall_lower_bound_s", "kernel_s", "resident_chains", "waves_per_chain",
+            "lone_wave_us_per_leapfrog", "implied_wall_lower_bound_s", "tail_bound_frac", "kernel_s", "resident_chains", "waves_per_chain",
             "lds_bytes_per_workgroup", "mean_wave_slot_occupancy")
 
     def roof(r):
@@ -116,7 +116,7 @@ def compact_line(out, detail_path=None, limit=LINE_LIMIT):
         sec.append({"workload": _short(s_.get("workload_short") or s_.get("workload"), 100), "value": s_.get("value"),
                     "ms_per_step": s_.get("ms_per_step"), "steps": s_.get("steps"),
                     "roofline": _pick(r, ("kernel", "frac", "bound")),
-                    "tail": _pick(t, ("mean_wave_slot_occupancy", "implied_wall_lower_bound_s", "lone_wave_us_per_leapfrog"))})
+                    "tail": _pick(t, ("mean_wave_slot_occupancy", "implied_wall_lower_bound_s", "tail_bound_frac", "lone_wave_us_per_leapfrog"))})
     if sec:
         line["secondary"] = sec
     if detail_path:
@@ -583,13 +583,17 @@ def main():
                 "critical_path_leapfrogs": crit,
                 "lone_wave_us_per_leapfrog": lone_us,
                 "implied_wall_lower_bound_s": crit * lone_us * 1e-6,
+                # share of this job's kernel time that is ONE chain's sequential leapfrogs: near 1 (C5: 0.97) the job cannot
+                # get faster with more GPUs -- every chain block still contains a chain like its busiest one, or waits for it
+                "tail_bound_frac": crit * lone_us * 1e-6 / kernel_s if kernel_s > 0 else None,
                 "kernel_s": kernel_s,
                 "resident_chains": resident, "waves_per_chain": wpc, "lds_bytes_per_workgroup": lds_bytes,
                 "mean_wave_slot_occupancy": (float(ct[:, _abi.CT_WAVE_TICKS].sum()) / hz / (slots * kernel_s)) if slots else None,
                 "note": "per launch each sub-block of chains ends with its busiest chain; critical_path_leapfrogs = max over "
                         "sub-blocks of the sum over launches of that chain's leapfrogs; x the leapfrog latency of a lone "
                         "wavefront (measured on a 1-chain engine of the same kernel, %d post-tuning iterations) = a lower "
-                        "bound on the wall time whatever the number of GPUs; occupancy = resident wave time (device "
+                        "bound on the wall time WHATEVER THE NUMBER OF GPUS (tail_bound_frac = that bound / kernel time: near 1 the "
+                        "multi-GPU line of this workload is flat by construction); occupancy = resident wave time (device "
                         "counter) / (wave slots x kernel time); first chain block of the job" % (n_l - n_l // 2),
             }
 

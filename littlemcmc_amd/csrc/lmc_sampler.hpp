@@ -1333,8 +1333,8 @@ constexpr int kPlanUp = 24, kPlanDown = 14;
 // WHICH chains relay rotates with the iteration index (chain + git / 16 = 0 mod the mask), so that no particular chain
 // has to be alive for the word to arrive (a chain that stopped with "Bad initial energy" used to be able to take the
 // relay with it). A team agrees on ONE value (thread 0's) so that no wave leaves a barrier behind.
-// A launch that STARTS under a request does nothing at all (stop_at_entry): sample() enqueues all launches of a job up
-// front, and the ones still queued when Ctrl-C arrives must neither run an iteration nor touch iter_count.
+// A launch that STARTS under a request does nothing at all (stop_at_entry): sample() keeps two launches of a job in flight
+// (bench.py likewise), and the one still queued when Ctrl-C arrives must neither run an iteration nor touch iter_count.
 // The relay also leaves ITS OWN mean tree size of this launch so far (`leaps` leapfrogs in `it` iterations; leaps < 0: nothing to
 // report) in A.tree_hint, a pinned host word: what the engine picks the next launch's LDS plan from, without touching a stream.
 // Computed inside the relay branch only -- no chain pays for it per iteration.

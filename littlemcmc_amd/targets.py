@@ -120,7 +120,9 @@ class UserTarget(DeviceTarget):
 
     ``jit="hiprtc"`` (default): when an engine is created, the three kernels that depend on the functor -- the
     transition kernel of the engine's shape, the trajectory and the log-density unit kernels -- are compiled in
-    process with hiprtc (about 2 s, cached by content under ``_user_targets/``) and handed to the stock library
+    process with hiprtc (2-4 s -- one-wavefront shapes compile the sampling kernel twice, once per LDS plan, so that the
+    engine can choose the plan per launch as for the built-in densities; cached by content under ``_user_targets/``, which
+    is never shipped to another machine) and handed to the stock library
     (``lmc_engine_load_user_kernels``); no compiler is needed on the machine. Diagonal mass matrices.
     ``jit="hipcc"``: a private build of the whole library around the functor (about 10 s, needs hipcc); this is the
     path for dense mass matrices with a user density."""
