@@ -23,6 +23,7 @@
 //    in LDS) launched between iterations while tuning; see dense_adapt_kernel.
 #pragma once
 #include "lmc_dense_types.hpp"
+#include "lmc_tree_leaf.hpp"
 
 namespace lmc {
 
@@ -387,198 +388,68 @@ struct DenseScratch {
     }
 };
 
-// ---- NUTS transition: the tree of lmc_sampler.hpp with stored velocities -------------------------------------------
+// ---- NUTS / HMC transitions: lmc_tree_leaf.hpp's leaf form / lmc_sampler.hpp's hmc_transition_any with this policy --------
+// One wavefront per chain; a state carries v = C p and w = C g (dense_leapfrog); the node under construction, the running
+// momentum sum and the proposal position live in registers, the trajectory's ends and the subtree stack in DenseScratch
+// (leading slots in LDS, the rest in the chain's scratch row); an end that still is the start state answers the U-turn
+// checks with the velocity STORED in the start State (v0s: float32 for the float32 potentials).
 template <int NS, class MatT, class Target>
-__device__ inline void dense_nuts_transition(Team<1>& tm, const Target& tgt, const DenseMat<MatT>& mm,
-                                             lds_double* xop, RngState& rng, const DenseScratch& scr, double (&q)[NS],
-                                             const double (&p0)[NS], const double (&g0)[NS], const double (&v0)[NS],
-                                             const double (&w0)[NS], const double (&v0s)[NS], double e0, double logp0,
-                                             double step_size, double emax, int max_depth, bool momentum_f32,
-                                             TransitionOut& out) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        scr.st<NS>(DenseScratch::end(r, 0), q); scr.st<NS>(DenseScratch::end(r, 1), p0); scr.st<NS>(DenseScratch::end(r, 2), g0);
-        scr.st<NS>(DenseScratch::end(r, 3), v0); scr.st<NS>(DenseScratch::end(r, 4), w0);
-    }
-    double psum[NS], propq[NS];
-    vcopy(psum, p0); vcopy(propq, q);
-    bool l_start = true, r_start = true;   // the end still is the start state: its stored velocity is v0s
-    double prop_e = e0, prop_logp = logp0;
-    double coff = 0.0, w_start = 1.0, wn = 0.0, an = 0.0, max_de = 0.0;   // linear-domain weights, see lmc_sampler.hpp
-    double c_tot = 0.0;   // offset the accepted totals {w_start, wn, an} are expressed in (see nuts_transition2)
-    int depth = 0, n_leap = 0;
-    bool diverging = false, turning = false, exhausted = true;
-    LevelScalars lsc = {0.0, 0.0, 0.0, 0.0};
+struct DenseTreePolicy {
+    static constexpr int kNS = NS;
+    struct End { double q[NS], p[NS], g[NS], v[NS], w[NS]; };
+    Team<1>& tm; const Target& tgt; const DenseMat<MatT>& mm; lds_double* xop; RngState& rng; const DenseScratch& scr;
+    double (&q)[NS];                                       // in: the chain's position; out: the proposal / accepted position
+    const double (&p0)[NS]; const double (&g0)[NS]; const double (&v0)[NS]; const double (&w0)[NS]; const double (&v0s)[NS];
     UniformWindow win;
-    window_reset(win);
+    bool end_is_start[2];
+    double t_lp[NS], t_lv[NS], t_ps[NS], t_q[NS], psum[NS], propq[NS];
 
-    for (int dd = 0; dd < max_depth; ++dd) {
-        const bool right = window_next(rng, win) < 0.5;   // nuts.py:213
-        const double eps = right ? step_size : -step_size;
-        const int side = right ? 1 : 0;
-        double cq[NS], cp[NS], cg[NS], cv[NS], cw[NS];
-        scr.ld<NS>(DenseScratch::end(side, 0), cq); scr.ld<NS>(DenseScratch::end(side, 1), cp); scr.ld<NS>(DenseScratch::end(side, 2), cg);
-        scr.ld<NS>(DenseScratch::end(side, 3), cv); scr.ld<NS>(DenseScratch::end(side, 4), cw);
-
-        double tlp[NS], tlv[NS], trp[NS], trv[NS], tps[NS], tq[NS];   // in-flight node
-        double tw = 0.0, ta = 0.0, tpe = 0.0, tplogp = 0.0;
-        const int n_leaves = 1 << depth;
-        for (int i = 0; i < n_leaves; ++i) {
-            double energy, logp;
-            dense_leapfrog<NS, MatT>(tm, tgt, mm, xop, eps, cq, cp, cg, cv, cw, energy, logp);
-            ++n_leap;
-            double de = first_f64(energy - e0);
-            if (isnan(de)) de = __builtin_inf();
-            if (fabs(de) > fabs(max_de)) max_de = de;
-            if (!(fabs(de) < emax)) { diverging = true; break; }   // nuts.py:358,370-375
-            const double x = -de;
-            if (x - coff > 600.0) {
-                const double f = exp_uniform(coff - x);
-                lsc.w *= f; lsc.a *= f;
-                coff = x;
-            }
-            tw = exp_uniform_fast(x - coff);
-            const double sat = (coff == 0.0) ? fmin(1.0, tw) : ((x >= 0.0) ? 1.0 : exp_uniform(x));
-            ta = tw * sat;
-            vcopy(tlp, cp); vcopy(trp, cp); vcopy(tps, cp); vcopy(tlv, cv); vcopy(trv, cv); vcopy(tq, cq);
-            tpe = energy; tplogp = logp;
-            int j = 0;
-            while ((i >> j) & 1) {   // merge stack[j] (a, earlier) with t (b); nuts.py:377-417
-                double alp[NS], alv[NS], arp[NS], arv[NS], aps[NS], aq[NS];
-                double aw, aa, ape, aplogp;
-                scr.ld<NS>(DenseScratch::level(j, 0), alp); scr.ld<NS>(DenseScratch::level(j, 1), alv);
-                scr.ld<NS>(DenseScratch::level(j, 2), arp); scr.ld<NS>(DenseScratch::level(j, 3), arv);
-                scr.ld<NS>(DenseScratch::level(j, 4), aps); scr.ld<NS>(DenseScratch::level(j, 5), aq);
-                lsc.get(j, aw, aa, ape, aplogp);
-                double ps[NS];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) ps[s] = aps[s] + tps[s];
-                bool turn;
-                if (j > 0) {   // nuts.py:389-396
-                    double p1[NS], p2[NS];
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) { p1[s] = aps[s] + tlp[s]; p2[s] = arp[s] + tps[s]; }
-                    double dots[6] = {pdot<NS>(ps, alv), pdot<NS>(ps, trv), pdot<NS>(p1, alv),
-                                      pdot<NS>(p1, tlv), pdot<NS>(p2, arv), pdot<NS>(p2, trv)};
-                    turn = tm.any_nonpositive6(dots);
-                } else {
-                    turn = tm.any_nonpositive2(pdot<NS>(ps, alv), pdot<NS>(ps, trv));
-                }
-                const double wsum = aw + tw;
-                const double asum = aa + ta;
-                const bool take_b = uniform_true(window_next(rng, win) * wsum < tw);   // nuts.py:404
-                vcopy(tlp, alp); vcopy(tlv, alv); vcopy(tps, ps);
-                if (!take_b) { vcopy(tq, aq); tpe = ape; tplogp = aplogp; }
-                tw = wsum; ta = asum;
-                ++j;
-                if (turn) { turning = true; break; }
-            }
-            if (turning) break;
-            if (i + 1 < n_leaves) {
-                scr.st<NS>(DenseScratch::level(j, 0), tlp); scr.st<NS>(DenseScratch::level(j, 1), tlv);
-                scr.st<NS>(DenseScratch::level(j, 2), trp); scr.st<NS>(DenseScratch::level(j, 3), trv);
-                scr.st<NS>(DenseScratch::level(j, 4), tps); scr.st<NS>(DenseScratch::level(j, 5), tq);
-                lsc.put(j, tw, ta, tpe, tplogp);
-            }
-        }
-        ++depth;   // nuts.py:315
-        if (diverging || turning) { exhausted = false; break; }
-
-        // ---- accepted subtree: merge into the trajectory (nuts.py:321-340)
-        if (c_tot != coff) {   // the offset moved inside this subtree: bring the accepted totals to it (rare)
-            const double f = exp_uniform(c_tot - coff);
-            wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
-            c_tot = coff;
-        }
-        if (uniform_true(window_next(rng, win) * (w_start + wn) < tw)) {
-            vcopy(propq, tq); prop_e = tpe; prop_logp = tplogp;
-        }
-        wn = first_f64(wn + tw);
-        an = first_f64(an + ta);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {   // in place; float32 storage when the start momentum is float32
-            const double t = psum[s] + tps[s];
-            psum[s] = momentum_f32 ? static_cast<double>(static_cast<float>(t)) : t;
-        }
-        double oLv[NS], oRv[NS], oP[NS];
-        if (l_start) vcopy(oLv, v0s); else scr.ld<NS>(DenseScratch::end(0, 3), oLv);
-        if (r_start) vcopy(oRv, v0s); else scr.ld<NS>(DenseScratch::end(1, 3), oRv);
-        scr.ld<NS>(DenseScratch::end(side, 1), oP);   // momentum of the end that is being replaced
-        double dots[6];
-        double p1[NS], p2[NS];
-        if (right) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) { p1[s] = psum[s] + tlp[s]; p2[s] = oP[s] + tps[s]; }
-            dots[0] = pdot<NS>(psum, oLv); dots[1] = pdot<NS>(psum, trv);
-            dots[2] = pdot<NS>(p1, oLv);   dots[3] = pdot<NS>(p1, tlv);
-            dots[4] = pdot<NS>(p2, oRv);   dots[5] = pdot<NS>(p2, trv);
-            r_start = false;
-        } else {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) { p1[s] = tps[s] + oP[s]; p2[s] = tlp[s] + psum[s]; }
-            dots[0] = pdot<NS>(psum, trv); dots[1] = pdot<NS>(psum, oRv);
-            dots[2] = pdot<NS>(p1, trv);   dots[3] = pdot<NS>(p1, oLv);
-            dots[4] = pdot<NS>(p2, tlv);   dots[5] = pdot<NS>(p2, oRv);
-            l_start = false;
-        }
-        scr.st<NS>(DenseScratch::end(side, 0), cq); scr.st<NS>(DenseScratch::end(side, 1), cp); scr.st<NS>(DenseScratch::end(side, 2), cg);
-        scr.st<NS>(DenseScratch::end(side, 3), cv); scr.st<NS>(DenseScratch::end(side, 4), cw);
-        if (tm.any_nonpositive6(dots)) { turning = true; exhausted = false; break; }
+    __device__ __forceinline__ double uniform() { return team_uniform(tm, rng, win); }
+    __device__ __forceinline__ bool any_nonpositive2(double a, double b) { return tm.any_nonpositive2(a, b); }
+    __device__ __forceinline__ bool any_nonpositive6(double (&d)[6]) { return tm.any_nonpositive6(d); }
+    __device__ __forceinline__ void start_state(End& c) const {
+        vcopy(c.q, q); vcopy(c.p, p0); vcopy(c.g, g0); vcopy(c.v, v0); vcopy(c.w, w0);
     }
-
-    const double mean_accept = (wn > 0.0) ? first_f64(an / wn) : 0.0;   // nuts.py:421-425
-    vcopy(q, propq);
-    out.accept = mean_accept;
-    out.energy = prop_e;
-    out.energy_error = first_f64(prop_e - e0);
-    out.max_energy_error = max_de;
-    out.model_logp = prop_logp;
-    out.depth = depth;
-    out.n_leapfrog = n_leap;
-    out.diverging = diverging;
-    out.exhausted = exhausted;
-    out.accepted = 0;
-}
-
-// ---- HMC transition (hmc.py:140-182) ---------------------------------------------------------------------------
-template <int NS, class MatT, class Target>
-__device__ inline void dense_hmc_transition(Team<1>& tm, const Target& tgt, const DenseMat<MatT>& mm,
-                                            lds_double* xop, RngState& rng, double (&q)[NS], const double (&p0)[NS],
-                                            const double (&g0)[NS], const double (&v0)[NS], const double (&w0)[NS],
-                                            double e0, double logp0, double step_size, double emax, double path_length,
-                                            int max_steps, TransitionOut& out) {
-    UniformWindow win;
-    window_reset(win);
-    const double plen = first_f64(window_next(rng, win) * path_length);
-    int n_steps = static_cast<int>(plen / step_size);
-    n_steps = n_steps < 1 ? 1 : n_steps;
-    n_steps = n_steps > max_steps ? max_steps : n_steps;
-    double cq[NS], cp[NS], cg[NS], cv[NS], cw[NS];
-    vcopy(cq, q); vcopy(cp, p0); vcopy(cg, g0); vcopy(cv, v0); vcopy(cw, w0);
-    double energy = e0, logp = logp0;
-    for (int i = 0; i < n_steps; ++i)
-        dense_leapfrog<NS, MatT>(tm, tgt, mm, xop, step_size, cq, cp, cg, cv, cw, energy, logp);
-    bool diverging = !isfinite(energy);
-    double de = first_f64(e0 - energy);
-    if (isnan(de)) de = -__builtin_inf();
-    if (fabs(de) > emax) diverging = true;
-    const double accept = first_f64(fmin(1.0, exp_uniform(de)));
-    bool accepted = false;
-    if (!diverging) {
-        const double u = window_next(rng, win);
-        if (!(u >= accept)) { accepted = true; vcopy(q, cq); }
+    __device__ __forceinline__ void accept_state(const End& c) { vcopy(q, c.q); }
+    // NUTS: both ends hold the start state, psum = p0, proposal = q
+    __device__ __forceinline__ void begin_tree() {
+        End c;
+        start_state(c);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { end_store(r, c); end_is_start[r] = true; }
+        vcopy(psum, p0); vcopy(propq, q);
     }
-    out.accept = accept;
-    out.energy = energy;
-    out.energy_error = de;
-    out.max_energy_error = plen;
-    out.model_logp = logp;
-    out.depth = n_steps;
-    out.n_leapfrog = n_steps;
-    out.diverging = diverging;
-    out.exhausted = 0;
-    out.accepted = accepted;
-}
+    __device__ __forceinline__ void end_tree() { vcopy(q, propq); }
+    __device__ __forceinline__ void end_load(int side, End& c) const {
+        scr.ld<NS>(DenseScratch::end(side, 0), c.q); scr.ld<NS>(DenseScratch::end(side, 1), c.p); scr.ld<NS>(DenseScratch::end(side, 2), c.g);
+        scr.ld<NS>(DenseScratch::end(side, 3), c.v); scr.ld<NS>(DenseScratch::end(side, 4), c.w);
+    }
+    __device__ __forceinline__ void end_store(int side, const End& c) {
+        scr.st<NS>(DenseScratch::end(side, 0), c.q); scr.st<NS>(DenseScratch::end(side, 1), c.p); scr.st<NS>(DenseScratch::end(side, 2), c.g);
+        scr.st<NS>(DenseScratch::end(side, 3), c.v); scr.st<NS>(DenseScratch::end(side, 4), c.w);
+        end_is_start[side] = false;
+    }
+    __device__ __forceinline__ void end_velocity(int side, double (&v)[NS]) const {
+        if (end_is_start[side]) vcopy(v, v0s); else scr.ld<NS>(DenseScratch::end(side, 3), v);
+    }
+    __device__ __forceinline__ void end_momentum(int side, double (&p)[NS]) const { scr.ld<NS>(DenseScratch::end(side, 1), p); }
+    __device__ __forceinline__ void leapfrog(double eps, End& c, double& energy, double& logp) {
+        dense_leapfrog<NS, MatT>(tm, tgt, mm, xop, eps, c.q, c.p, c.g, c.v, c.w, energy, logp);
+    }
+    template <int F> __device__ __forceinline__ void node_ld(double (&x)[NS]) const {
+        if constexpr (F == kNodeLp) vcopy(x, t_lp); else if constexpr (F == kNodeLv) vcopy(x, t_lv);
+        else if constexpr (F == kNodePs) vcopy(x, t_ps); else vcopy(x, t_q);
+    }
+    template <int F> __device__ __forceinline__ void node_st(const double (&x)[NS]) {
+        if constexpr (F == kNodeLp) vcopy(t_lp, x); else if constexpr (F == kNodeLv) vcopy(t_lv, x);
+        else if constexpr (F == kNodePs) vcopy(t_ps, x); else vcopy(t_q, x);
+    }
+    __device__ __forceinline__ void level_ld(int j, int f, double (&x)[NS]) const { scr.ld<NS>(DenseScratch::level(j, f), x); }
+    __device__ __forceinline__ void level_st(int j, int f, const double (&x)[NS]) { scr.st<NS>(DenseScratch::level(j, f), x); }
+    __device__ __forceinline__ void psum_ld(double (&x)[NS]) const { vcopy(x, psum); }
+    __device__ __forceinline__ void psum_st(const double (&x)[NS]) { vcopy(psum, x); }
+    __device__ __forceinline__ void proposal_from_node() { vcopy(propq, t_q); }
+};
 
 // ---- the iteration kernel ----------------------------------------------------------------------------------------
 // LDS: [0, 2*dpad) doubles = sweep operands / normal(size=d) + its staging / float32 sdot staging; then the chain's
@@ -649,14 +520,15 @@ __device__ __forceinline__ void dense_run_chain(const ChainArrays& A, const Dens
         const double step_size = jitter_step_size(tm, rng, A, P, c, adapt_step ? da.step_now : da.step_bar_now);
 
         TransitionOut out;
+        DenseTreePolicy<NS, MatT, TargetT<NS>> pol{tm, tgt, mm, xop, rng, scr, q, p0, g0, v0, w0, v0s, UniformWindow{0.0, 0, 0}, {true, true}};
         if (P.kind == 0) {
             const int md = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
-            dense_nuts_transition<NS, MatT>(tm, tgt, mm, xop, rng, scr, q, p0, g0, v0, w0, v0s, e0, logp0,
-                                            step_size, P.emax, md, momentum_f32, out);
+            pol.begin_tree();
+            leaf_nuts_transition(pol, e0, logp0, step_size, P.emax, md, momentum_f32, out);   // lmc_tree_leaf.hpp
+            pol.end_tree();
             if (out.exhausted && !tune) ++ct_maxdepth;
         } else {
-            dense_hmc_transition<NS, MatT>(tm, tgt, mm, xop, rng, q, p0, g0, v0, w0, e0, logp0, step_size,
-                                           P.emax, P.path_length, P.max_steps, out);
+            hmc_transition_any(pol, e0, logp0, step_size, P.emax, P.path_length, P.max_steps, out);   // lmc_sampler.hpp
         }
         ct_leap += out.n_leapfrog;
         if (adapt_step) dual_average_update(A, P, out.accept, da);

@@ -596,22 +596,25 @@ struct TransitionOut {
     int accepted;          // HMC
 };
 
-// ---- HMC transition (hmc.py:140-182) -------------------------------------------------------------------
-template <int NS, class Target, class TeamT>
-__device__ inline void hmc_transition(TeamT& tm, const Target& tgt, const double (&var)[NS], RngState& rng,
-                                      double (&q)[NS], const double (&p0)[NS], const double (&g0)[NS],
-                                      double e0, double logp0, double step_size, double emax,
-                                      double path_length, int max_steps, TransitionOut& out) {
-    UniformWindow win;
-    window_reset(win);
-    const double plen = first_f64(team_uniform(tm, rng, win) * path_length);
+// ---- HMC transition (hmc.py:140-182): ONE statement for every kernel family -------------------------------------------------
+// What differs between the families -- how a state is integrated and where the accepted position goes -- is a policy:
+//   typename P::End              the state being integrated (members q, p, g, v [NS] + what the integrator carries along)
+//   double uniform()             next uniform of the chain's stream
+//   void start_state(End&)       the start State (integration.py:52-66)
+//   void leapfrog(eps, End&, energy&, logp&)      integration.py:100-121
+//   void accept_state(const End&)                 the chain's position becomes this state's
+// (FusedHmcPolicy below; DenseTreePolicy in lmc_dense.hpp; WideTreePolicy in lmc_wide.hpp.)
+template <class P>
+__device__ inline void hmc_transition_any(P& pol, double e0, double logp0, double step_size, double emax, double path_length,
+                                          int max_steps, TransitionOut& out) {
+    const double plen = first_f64(pol.uniform() * path_length);
     int n_steps = static_cast<int>(plen / step_size);
     n_steps = n_steps < 1 ? 1 : n_steps;
     n_steps = n_steps > max_steps ? max_steps : n_steps;
-    double cq[NS], cp[NS], cg[NS];
-    vcopy(cq, q); vcopy(cp, p0); vcopy(cg, g0);
+    typename P::End c;
+    pol.start_state(c);
     double energy = e0, logp = logp0;
-    for (int i = 0; i < n_steps; ++i) leapfrog<NS>(tm, tgt, var, step_size, cq, cp, cg, energy, logp);
+    for (int i = 0; i < n_steps; ++i) pol.leapfrog(step_size, c, energy, logp);
     bool diverging = !isfinite(energy);
     double de = first_f64(e0 - energy);
     if (isnan(de)) de = -__builtin_inf();
@@ -619,8 +622,8 @@ __device__ inline void hmc_transition(TeamT& tm, const Target& tgt, const double
     const double accept = first_f64(fmin(1.0, exp_uniform(de)));
     bool accepted = false;
     if (!diverging) {
-        const double u = team_uniform(tm, rng, win);
-        if (!(u >= accept)) { accepted = true; vcopy(q, cq); }
+        const double u = pol.uniform();
+        if (!(u >= accept)) { accepted = true; pol.accept_state(c); }
     }
     out.accept = accept;
     out.energy = energy;
@@ -632,6 +635,30 @@ __device__ inline void hmc_transition(TeamT& tm, const Target& tgt, const double
     out.diverging = diverging;
     out.exhausted = 0;
     out.accepted = accepted;
+}
+
+// the fused diagonal-mass kernels: the state lives in registers, the velocity is recomputed inside leapfrog<>
+template <int NS, class Target, class TeamT>
+struct FusedHmcPolicy {
+    static constexpr int kNS = NS;
+    struct End { double q[NS], p[NS], g[NS]; };
+    TeamT& tm; const Target& tgt; const double (&var)[NS]; RngState& rng;
+    double (&q)[NS]; const double (&p0)[NS]; const double (&g0)[NS];
+    UniformWindow win;
+    __device__ __forceinline__ double uniform() { return team_uniform(tm, rng, win); }
+    __device__ __forceinline__ void start_state(End& c) const { vcopy(c.q, q); vcopy(c.p, p0); vcopy(c.g, g0); }
+    __device__ __forceinline__ void leapfrog(double eps, End& c, double& energy, double& logp) {
+        lmc::leapfrog<NS>(tm, tgt, var, eps, c.q, c.p, c.g, energy, logp);
+    }
+    __device__ __forceinline__ void accept_state(const End& c) { vcopy(q, c.q); }
+};
+template <int NS, class Target, class TeamT>
+__device__ inline void hmc_transition(TeamT& tm, const Target& tgt, const double (&var)[NS], RngState& rng,
+                                      double (&q)[NS], const double (&p0)[NS], const double (&g0)[NS],
+                                      double e0, double logp0, double step_size, double emax,
+                                      double path_length, int max_steps, TransitionOut& out) {
+    FusedHmcPolicy<NS, Target, TeamT> pol{tm, tgt, var, rng, q, p0, g0, UniformWindow{0.0, 0, 0}};
+    hmc_transition_any(pol, e0, logp0, step_size, emax, path_length, max_steps, out);
 }
 
 // ---- NUTS transition (nuts.py:204-224, _Tree :251-435; iterative post-order), pair form ----------------

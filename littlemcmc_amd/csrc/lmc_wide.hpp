@@ -18,6 +18,7 @@
 //   adaptation <- step_sizes.py:49-99, quadpotential.py:226-245, :294-340    iteration <- base_hmc.py:140-190
 #pragma once
 #include "lmc_dense_types.hpp"
+#include "lmc_tree_leaf.hpp"
 
 namespace lmc {
 
@@ -303,195 +304,47 @@ struct WideCtx {   // what every stage of an iteration needs
     double* bcast;        // 8 doubles
 };
 
-// ---- NUTS transition, leaf form with the tree in the scratch row (nuts.py:204-224, _Tree :251-435) --------
-// In: kWLq.. / kWRq.. hold the start state at both ends (velocity slots = the stored start velocity), kWPsum = p0,
-// kWProp = q. Out: kWProp = the proposal.
+// ---- NUTS / HMC transitions: lmc_tree_leaf.hpp's leaf form / lmc_sampler.hpp's hmc_transition_any with this policy --------
+// EVERY vector lives in the chain's scratch row (WideSlot): the trajectory's ends (their velocity slots hold the velocity
+// stored with the State -- the start velocity until the end is replaced), the node under construction, the stack, the running
+// momentum sum and the proposal; only the state being integrated and the operands of the statement at hand are in registers.
+// wide_start() has put the start state at both ends, kWPsum = p0 and kWProp = q; the proposal / accepted position lands in kWProp.
 template <int NS, class Target, class TeamT>
-__device__ inline void wide_nuts_transition(TeamT& tm, const Target& tgt, const WideMass& M, const double (&vard)[NS],
-                                            const WideCtx& cx, RngState& rng, const WideVec<NS>& V, double e0, double logp0,
-                                            double step_size, double emax, int max_depth, bool momentum_f32,
-                                            TransitionOut& out) {
-    double prop_e = e0, prop_logp = logp0;
-    double coff = 0.0, w_start = 1.0, wn = 0.0, an = 0.0, max_de = 0.0;   // linear-domain weights (lmc_sampler.hpp)
-    double c_tot = 0.0;
-    int depth = 0, n_leap = 0;
-    bool diverging = false, turning = false, exhausted = true;
-    LevelScalars lsc = {0.0, 0.0, 0.0, 0.0};
+struct WideTreePolicy {
+    static constexpr int kNS = NS;
+    struct End { double q[NS], p[NS], g[NS], v[NS]; };
+    TeamT& tm; const Target& tgt; const WideMass& M; const double (&vard)[NS]; const WideCtx& cx; RngState& rng; const WideVec<NS>& V;
     UniformWindow win;
-    window_reset(win);
 
-    for (int dd = 0; dd < max_depth; ++dd) {
-        const bool right = team_uniform(tm, rng, win) < 0.5;   // nuts.py:213
-        const double eps = right ? step_size : -step_size;
-        const int e_q = right ? kWRq : kWLq;
-        double cq[NS], cp[NS], cg[NS], cv[NS];
-        V.ld(e_q, cq); V.ld(e_q + 1, cp); V.ld(e_q + 2, cg);
-        double tw = 0.0, ta = 0.0, tpe = 0.0, tplogp = 0.0;
-        const int n_leaves = 1 << depth;
-        for (int i = 0; i < n_leaves; ++i) {
-            double energy, logp;
-            wide_leapfrog<NS>(tm, tgt, M, vard, cx.xop, eps, cq, cp, cg, cv, energy, logp);
-            ++n_leap;
-            double de = first_f64(energy - e0);
-            if (isnan(de)) de = __builtin_inf();
-            if (fabs(de) > fabs(max_de)) max_de = de;
-            if (!(fabs(de) < emax)) { diverging = true; break; }   // nuts.py:358,370-375
-            const double x = -de;
-            if (x - coff > 600.0) {
-                const double f = exp_uniform(coff - x);
-                lsc.w *= f; lsc.a *= f;
-                coff = x;
-            }
-            tw = exp_uniform_fast(x - coff);
-            const double sat = (coff == 0.0) ? fmin(1.0, tw) : ((x >= 0.0) ? 1.0 : exp_uniform(x));
-            ta = tw * sat;
-            V.st(kWTlp, cp); V.st(kWTlv, cv); V.st(kWTps, cp); V.st(kWTq, cq);
-            tpe = energy; tplogp = logp;
-            int j = 0;
-            while ((i >> j) & 1) {   // merge stack[j] (a, earlier) with the node under construction (b); nuts.py:377-417
-                double aw, aa, ape, aplogp;
-                lsc.get(j, aw, aa, ape, aplogp);
-                double ps[NS], alv[NS];
-                {
-                    double aps[NS], tps[NS];
-                    V.ld(wide_level(j, 4), aps); V.ld(kWTps, tps);
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) ps[s] = aps[s] + tps[s];
-                }
-                V.ld(wide_level(j, 1), alv);
-                bool turn;
-                if (j > 0) {   // nuts.py:389-396
-                    double dots[6];
-                    dots[0] = pdot<NS>(ps, alv); dots[1] = pdot<NS>(ps, cv);
-                    {
-                        double aps[NS], tlp[NS], p1[NS], tlv[NS];
-                        V.ld(wide_level(j, 4), aps); V.ld(kWTlp, tlp); V.ld(kWTlv, tlv);
-#pragma unroll
-                        for (int s = 0; s < NS; ++s) p1[s] = aps[s] + tlp[s];
-                        dots[2] = pdot<NS>(p1, alv); dots[3] = pdot<NS>(p1, tlv);
-                    }
-                    {
-                        double arp[NS], tps[NS], p2[NS], arv[NS];
-                        V.ld(wide_level(j, 2), arp); V.ld(kWTps, tps); V.ld(wide_level(j, 3), arv);
-#pragma unroll
-                        for (int s = 0; s < NS; ++s) p2[s] = arp[s] + tps[s];
-                        dots[4] = pdot<NS>(p2, arv); dots[5] = pdot<NS>(p2, cv);
-                    }
-                    turn = tm.any_nonpositive6(dots);
-                } else {
-                    turn = tm.any_nonpositive2(pdot<NS>(ps, alv), pdot<NS>(ps, cv));
-                }
-                const double wsum = aw + tw;
-                const double asum = aa + ta;
-                const bool take_b = uniform_true(team_uniform(tm, rng, win) * wsum < tw);   // nuts.py:404 (drawn even if turning)
-                V.cp(kWTlp, wide_level(j, 0)); V.st(kWTlv, alv); V.st(kWTps, ps);
-                if (!take_b) { V.cp(kWTq, wide_level(j, 5)); tpe = ape; tplogp = aplogp; }
-                tw = wsum; ta = asum;
-                ++j;
-                if (turn) { turning = true; break; }
-            }
-            if (turning) break;
-            if (i + 1 < n_leaves) {   // park the node at level j
-                V.cp(wide_level(j, 0), kWTlp); V.cp(wide_level(j, 1), kWTlv);
-                V.st(wide_level(j, 2), cp); V.st(wide_level(j, 3), cv);
-                V.cp(wide_level(j, 4), kWTps); V.cp(wide_level(j, 5), kWTq);
-                lsc.put(j, tw, ta, tpe, tplogp);
-            }
-        }
-        ++depth;   // nuts.py:315
-        if (diverging || turning) { exhausted = false; break; }
-
-        // ---- accepted subtree: merge into the trajectory (nuts.py:321-340)
-        if (c_tot != coff) {
-            const double f = exp_uniform(c_tot - coff);
-            wn = first_f64(wn * f); an = first_f64(an * f); w_start = first_f64(w_start * f);
-            c_tot = coff;
-        }
-        if (uniform_true(team_uniform(tm, rng, win) * (w_start + wn) < tw)) {   // biased progressive
-            V.cp(kWProp, kWTq); prop_e = tpe; prop_logp = tplogp;
-        }
-        wn = first_f64(wn + tw);
-        an = first_f64(an + ta);
-        double psum[NS], tps[NS];
-        V.ld(kWPsum, psum); V.ld(kWTps, tps);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {   // in place; float32 storage when the start momentum is float32 (nuts.py:329)
-            const double t = psum[s] + tps[s];
-            psum[s] = momentum_f32 ? static_cast<double>(static_cast<float>(t)) : t;
-        }
-        V.st(kWPsum, psum);
-        double dots[6];
-        {
-            double oLv[NS], oRv[NS], oP[NS], tlp[NS], tlv[NS], p1[NS], p2[NS];
-            V.ld(kWLv, oLv); V.ld(kWRv, oRv); V.ld(e_q + 1, oP);   // velocities of both old ends, momentum of the end being replaced
-            V.ld(kWTlp, tlp); V.ld(kWTlv, tlv);
-            if (right) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) { p1[s] = psum[s] + tlp[s]; p2[s] = oP[s] + tps[s]; }
-                dots[0] = pdot<NS>(psum, oLv); dots[1] = pdot<NS>(psum, cv);
-                dots[2] = pdot<NS>(p1, oLv);   dots[3] = pdot<NS>(p1, tlv);
-                dots[4] = pdot<NS>(p2, oRv);   dots[5] = pdot<NS>(p2, cv);
-            } else {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) { p1[s] = tps[s] + oP[s]; p2[s] = tlp[s] + psum[s]; }
-                dots[0] = pdot<NS>(psum, cv);  dots[1] = pdot<NS>(psum, oRv);
-                dots[2] = pdot<NS>(p1, cv);    dots[3] = pdot<NS>(p1, oLv);
-                dots[4] = pdot<NS>(p2, tlv);   dots[5] = pdot<NS>(p2, oRv);
-            }
-        }
-        V.st(e_q, cq); V.st(e_q + 1, cp); V.st(e_q + 2, cg); V.st(e_q + 3, cv);
-        if (tm.any_nonpositive6(dots)) { turning = true; exhausted = false; break; }
+    __device__ __forceinline__ double uniform() { return team_uniform(tm, rng, win); }
+    __device__ __forceinline__ bool any_nonpositive2(double a, double b) { return tm.any_nonpositive2(a, b); }
+    __device__ __forceinline__ bool any_nonpositive6(double (&d)[6]) { return tm.any_nonpositive6(d); }
+    __device__ __forceinline__ void start_state(End& c) const { V.ld(kWRq, c.q); V.ld(kWRp, c.p); V.ld(kWRg, c.g); }
+    __device__ __forceinline__ void accept_state(const End& c) { V.st(kWProp, c.q); }
+    __device__ __forceinline__ void end_load(int side, End& c) const {   // (the velocity is leapfrog's output: not loaded)
+        const int e = side ? kWRq : kWLq;
+        V.ld(e, c.q); V.ld(e + 1, c.p); V.ld(e + 2, c.g);
     }
-
-    out.accept = (wn > 0.0) ? first_f64(an / wn) : 0.0;   // nuts.py:421-425
-    out.energy = prop_e;
-    out.energy_error = first_f64(prop_e - e0);
-    out.max_energy_error = max_de;
-    out.model_logp = prop_logp;
-    out.depth = depth;
-    out.n_leapfrog = n_leap;
-    out.diverging = diverging;
-    out.exhausted = exhausted;
-    out.accepted = 0;
-}
-
-// ---- HMC transition (hmc.py:140-182); the accepted position lands in kWProp
-template <int NS, class Target, class TeamT>
-__device__ inline void wide_hmc_transition(TeamT& tm, const Target& tgt, const WideMass& M, const double (&vard)[NS],
-                                           const WideCtx& cx, RngState& rng, const WideVec<NS>& V, double e0, double logp0,
-                                           double step_size, double emax, double path_length, int max_steps,
-                                           TransitionOut& out) {
-    UniformWindow win;
-    window_reset(win);
-    const double plen = first_f64(team_uniform(tm, rng, win) * path_length);
-    int n_steps = static_cast<int>(plen / step_size);
-    n_steps = n_steps < 1 ? 1 : n_steps;
-    n_steps = n_steps > max_steps ? max_steps : n_steps;
-    double cq[NS], cp[NS], cg[NS], cv[NS];
-    V.ld(kWRq, cq); V.ld(kWRp, cp); V.ld(kWRg, cg);
-    double energy = e0, logp = logp0;
-    for (int i = 0; i < n_steps; ++i) wide_leapfrog<NS>(tm, tgt, M, vard, cx.xop, step_size, cq, cp, cg, cv, energy, logp);
-    bool diverging = !isfinite(energy);
-    double de = first_f64(e0 - energy);
-    if (isnan(de)) de = -__builtin_inf();
-    if (fabs(de) > emax) diverging = true;
-    const double accept = first_f64(fmin(1.0, exp_uniform(de)));
-    bool accepted = false;
-    if (!diverging) {
-        const double u = team_uniform(tm, rng, win);
-        if (!(u >= accept)) { accepted = true; V.st(kWProp, cq); }
+    __device__ __forceinline__ void end_store(int side, const End& c) {
+        const int e = side ? kWRq : kWLq;
+        V.st(e, c.q); V.st(e + 1, c.p); V.st(e + 2, c.g); V.st(e + 3, c.v);
     }
-    out.accept = accept;
-    out.energy = energy;
-    out.energy_error = de;
-    out.max_energy_error = plen;
-    out.model_logp = logp;
-    out.depth = n_steps;
-    out.n_leapfrog = n_steps;
-    out.diverging = diverging;
-    out.exhausted = 0;
-    out.accepted = accepted;
-}
+    __device__ __forceinline__ void end_velocity(int side, double (&v)[NS]) const { V.ld(side ? kWRv : kWLv, v); }
+    __device__ __forceinline__ void end_momentum(int side, double (&p)[NS]) const { V.ld(side ? kWRp : kWLp, p); }
+    __device__ __forceinline__ void leapfrog(double eps, End& c, double& energy, double& logp) {
+        wide_leapfrog<NS>(tm, tgt, M, vard, cx.xop, eps, c.q, c.p, c.g, c.v, energy, logp);
+    }
+    template <int F> static __device__ __forceinline__ constexpr int node_slot() {
+        return F == kNodeLp ? kWTlp : F == kNodeLv ? kWTlv : F == kNodePs ? kWTps : kWTq;
+    }
+    template <int F> __device__ __forceinline__ void node_ld(double (&x)[NS]) const { V.ld(node_slot<F>(), x); }
+    template <int F> __device__ __forceinline__ void node_st(const double (&x)[NS]) { V.st(node_slot<F>(), x); }
+    __device__ __forceinline__ void level_ld(int j, int f, double (&x)[NS]) const { V.ld(wide_level(j, f), x); }
+    __device__ __forceinline__ void level_st(int j, int f, const double (&x)[NS]) { V.st(wide_level(j, f), x); }
+    __device__ __forceinline__ void psum_ld(double (&x)[NS]) const { V.ld(kWPsum, x); }
+    __device__ __forceinline__ void psum_st(const double (&x)[NS]) { V.st(kWPsum, x); }
+    __device__ __forceinline__ void proposal_from_node() { V.cp(kWProp, kWTq); }
+};
 
 // the start of an iteration (base_hmc.py:141-148 / integration.py:52-66): momentum draw, start state -> both ends of the
 // trajectory, kWPsum, kWProp. Returns e0 (non-finite: base_hmc.py:145-148).
@@ -605,12 +458,13 @@ __global__ __launch_bounds__(64 * W) void run_wide_kernel(ChainArrays A, DenseAr
         const bool adapt_step = tune && P.adapt_step_size;
         const double step_size = jitter_step_size(tm, rng, A, P, c, adapt_step ? da.step_now : da.step_bar_now);
         TransitionOut out;
+        WideTreePolicy<NS, TargetT<NS>, Team<W>> pol{tm, tgt, M, vard, cx, rng, V, UniformWindow{0.0, 0, 0}};
         if (P.kind == 0) {
             const int md = (tune && iter_count < 200) ? P.early_max_treedepth : P.max_treedepth;
-            wide_nuts_transition<NS>(tm, tgt, M, vard, cx, rng, V, e0, logp0, step_size, P.emax, md, momentum_f32, out);
+            leaf_nuts_transition(pol, e0, logp0, step_size, P.emax, md, momentum_f32, out);   // lmc_tree_leaf.hpp
             if (out.exhausted && !tune) ++ct_maxdepth;
         } else {
-            wide_hmc_transition<NS>(tm, tgt, M, vard, cx, rng, V, e0, logp0, step_size, P.emax, P.path_length, P.max_steps, out);
+            hmc_transition_any(pol, e0, logp0, step_size, P.emax, P.path_length, P.max_steps, out);   // lmc_sampler.hpp
         }
         __threadfence_block();
         tm.sync();
