@@ -30,6 +30,8 @@ secondary        = north_star's named shape (standard normal, d = 128, same chai
 stdout           = ONE compact JSON line (compact_line(): <= 8192 bytes -- headline fields, config, roofline, cpu_baseline, ESS
                    numbers, a short block per secondary workload); the verbose object (every note, full secondary blocks)
                    is written to bench_detail.json (--detail-out), not to stderr.
+sample_e2e       = the literal drop-in call lmc.sample(...) -> numpy arrays on C3's chains (tune 300 + draws 200), wall time next to
+                   the kernel-only time of the same job (N = 1, default command line).
 cpu_baseline     = the numpy oracle (a port of the reference, oracle/lmc_oracle.py) on this box's host cores, one chain
                    per core, same recipe, bounded sample.
 """
@@ -103,6 +105,8 @@ def compact_line(out, detail_path=None, limit=LINE_LIMIT):
         cb["sample"] = _short(cb.get("sample_short") or cb.get("sample"), 160)
         cb.pop("sample_short", None)
         line["cpu_baseline"] = cb
+    if out.get("sample_e2e"):
+        line["sample_e2e"] = {k: v for k, v in out["sample_e2e"].items() if k not in ("note", "call")}
     line["tail"] = _pick(out.get("tail", {}), TAIL)
     line["per_rank"] = [_pick(r, ("rank", "chains", "leapfrogs", "kernel_s", "wall_s")) for r in out.get("per_rank", [])]
     line.update(_pick(out, ("rccl_ranks", "backend", "source_hash", "source_tree_hash")))
@@ -318,6 +322,8 @@ def main():
     ap.add_argument("--no-trace", action="store_true", help="do not store draws (statistics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end line: the literal lmc.sample() call returning numpy "
+                                                          "arrays (sampling.py:207-222), next to the kernel-only time of the same job")
     ap.add_argument("--no-secondary", action="store_true", help="skip every secondary workload")
     ap.add_argument("--no-baseline-configs", action="store_true",
                     help="skip the C2 / C4 / C5 lines the default command line appends to `secondary` (keeps the north_star shape)")
@@ -806,6 +812,45 @@ def main():
             secondaries.append(run_job("funnel", 256, with_ess=False, job_chains=16384, max_treedepth=12, K=1, ips=K * ips,
                                        tag=" (one launch)"))
 
+    # The literal drop-in call, end to end (N = 1, default primary only): lmc.sample() returning the trace and every statistic as
+    # numpy arrays (the reference's sampling.py:207-222) for C3's chains at a shortened recipe (tune 300 + draws 200: 13.5 GiB
+    # returned, a few seconds), against the kernel-only time of the very same job and launch schedule with the draws left in
+    # HBM. The full-length numbers (67.5 GiB: 3.66 s against 3.29 s) are profiles/r06_sample_e2e.txt.
+    e2e = None
+    if (rank == 0 and n_units == 1 and not inproc and default_primary and not args.no_e2e and args.mass == "diag"
+            and args.kind == "nuts" and args.rng == "numpy"):
+        from littlemcmc_amd import sampling as smp
+
+        e_tune, e_draws = 300, 200
+        tgt_, _desc = make_target(lmc, args.target, args.dim)
+        t0 = time.perf_counter()
+        tr_, st_ = lmc.sample(tgt_, args.dim, draws=e_draws, tune=e_tune, chains=args.chains, random_seed=SEED, progressbar=False)
+        t_call = time.perf_counter() - t0
+        e_leaps = float(st_["tree_size"].sum())
+        gib = (tr_.nbytes + sum(v.nbytes for v in st_.values())) / 2.0 ** 30
+        del tr_, st_
+        seeds_ = smp._derive_seeds(SEED, args.chains)
+        start_, step_ = lmc.init_nuts(tgt_, args.dim, random_seed=seeds_)
+        eng_ = step_._make_engine(args.chains)
+        try:
+            eng_.seed(seeds_)
+            eng_.set_position(start_)
+            eng_.reset_tuning()
+            eng_.reserve(e_tune + e_draws, keep_trace=True, trace_begin=e_tune)
+            slots_ = eng_.resident_chains()
+            per_ = [100, 100, 100, 100, 500] if (slots_ and args.chains >= 6 * slots_) else 100
+            eng_.synchronize()
+            t0 = time.perf_counter()
+            smp._run_job(eng_, e_tune, e_tune + e_draws, per_, False)
+            t_kernel = time.perf_counter() - t0
+        finally:
+            eng_.close()
+        e2e = {"call": "lmc.sample(target, %d, draws=%d, tune=%d, chains=%d) -> numpy trace + statistics" % (args.dim, e_draws, e_tune, args.chains),
+               "returned_GiB": gib, "wall_s": t_call, "kernel_only_s": t_kernel, "wall_over_kernel": t_call / t_kernel,
+               "leapfrogs": e_leaps, "leapfrog_steps_per_s_end_to_end": e_leaps / t_call,
+               "note": "wall_s covers engine creation, seeding, pinning the returned arrays (in a helper thread), the job and the "
+                       "last window of statistics; the draws are written into the returned array by the sampling kernel itself"}
+
     if rank == 0:
         value = primary["leap_all"] / primary["wall"]
         ess = primary["ess"]
@@ -846,6 +891,8 @@ def main():
             "launcher_fallback": launcher_fallback,
             "source_hash": src_hash, "source_tree_hash": _build.source_hash(),
         }
+        if e2e is not None:
+            out["sample_e2e"] = e2e
         if secondaries:
             out["secondary"] = []
             for job in secondaries:   # (a counter-based line is separately labelled, never the headline: not the reference's random stream)
