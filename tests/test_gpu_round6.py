@@ -129,6 +129,13 @@ def test_streamed_results_on_two_engines_and_after_an_interrupt():
         if draw.iteration >= 50:
             raise KeyboardInterrupt
 
+    # an engine kept after a "direct" job reads its draws through the caller's array (lmc_engine_get_trace on an attached trace)
+    tr, _st, eng = lmc.sample(tgt, d, devices=[0], stream_results="direct", return_engine=True, **kw)
+    try:
+        np.testing.assert_array_equal(eng.trace(0, 120), tr)
+        np.testing.assert_array_equal(tr, one[0])
+    finally:
+        eng.close()
     with pytest.raises(ValueError):
         lmc.sample(tgt, d, stream_results="sideways", **kw)
     got = lmc.sample(tgt, d, stream_results=True, callback=stop_at_50, **kw)
