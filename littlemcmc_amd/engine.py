@@ -25,15 +25,15 @@ class _PinnedBlock:
     (lmc_host_register). Exposes the memory through __array_interface__ (numpy keeps this object alive as the base of every
     view) and unregisters it when the last view is gone."""
 
-    def __init__(self, lib, raw, shape, dtype):
-        self._lib, self._raw = lib, raw
-        self.__array_interface__ = {"data": (raw.ctypes.data, False), "shape": tuple(int(x) for x in shape),
+    def __init__(self, lib, raw, base, shape, dtype):
+        self._lib, self._raw, self._base = lib, raw, int(base)
+        self.__array_interface__ = {"data": (self._base, False), "shape": tuple(int(x) for x in shape),
                                     "typestr": np.dtype(dtype).str, "version": 3}
 
     def __del__(self):
         try:
             if self._raw is not None:
-                self._lib.lmc_host_unregister(C.c_void_p(self._raw.ctypes.data))
+                self._lib.lmc_host_unregister(C.c_void_p(self._base))
                 self._raw = None
         except Exception:
             pass
@@ -73,11 +73,21 @@ def pinned_empty(shape, dtype, lib=None, threads=None):
         import os
 
         threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    raw = np.empty(nbytes, dtype=np.uint8)
-    _prefault(raw.ctypes.data, nbytes, threads)
-    if lib.lmc_host_register(C.c_void_p(raw.ctypes.data), nbytes) != _abi.OK:
-        raise _abi.HipLibraryError("cannot pin %d bytes of host memory: %s" % (nbytes, (lib.lmc_last_error(None) or b"?").decode()))
-    return np.asarray(_PinnedBlock(lib, raw, shape, dtype))
+    # Whole pages of its own: pinning works on pages, and a small numpy allocation shares its pages with whatever the allocator
+    # put next to it -- registering two neighbours pins a page twice, and unregistering one of them unpins it under the other,
+    # which the device is still writing (a GPU memory fault that killed the test process once in two runs of the suite,
+    # round 6). The block is over-allocated by a page and the page-aligned interior, rounded up to whole pages, is what is
+    # touched, registered and handed out.
+    import mmap
+
+    page = mmap.PAGESIZE
+    span = -(-nbytes // page) * page
+    raw = np.empty(span + page, dtype=np.uint8)
+    base = raw.ctypes.data + (-raw.ctypes.data) % page
+    _prefault(base, span, threads)
+    if lib.lmc_host_register(C.c_void_p(base), span) != _abi.OK:
+        raise _abi.HipLibraryError("cannot pin %d bytes of host memory: %s" % (span, (lib.lmc_last_error(None) or b"?").decode()))
+    return np.asarray(_PinnedBlock(lib, raw, base, shape, dtype))
 
 
 class StreamedResults:

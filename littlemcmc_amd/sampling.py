@@ -21,6 +21,7 @@ from .quadpotential import QuadPotentialDiagAdapt, QuadPotentialFullAdapt
 from .targets import require_device_target
 
 _log = logging.getLogger("littlemcmc_amd")
+_STREAM_MIN_BYTES = 8 << 20   # results smaller than this are copied when the job is over (stream_results=True only: an explicit mode is honoured)
 
 
 def _derive_seeds(random_seed, chains):
@@ -425,6 +426,8 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
             mode = None
         if return_engine and stream_results is True:
             mode = "windows"     # whoever keeps the engine reads the draws where diagnostics want them: in HBM (an explicit "direct" is honoured)
+        if stream_results is True and chains * (n_total - lo) * (model_ndim * 8 + 82) < _STREAM_MIN_BYTES:
+            mode = None          # a result of a few MiB: pinning twelve arrays and a helper thread cost more than one copy
         eng.reserve(max(n_total, 1), keep_trace=mode != "direct", trace_begin=min(lo, max(n_total - 1, 0)))
         # one launch for the whole job unless asked otherwise: every launch ends with a tail in which the chains with
         # the longest trees run alone (ragged targets: DESIGN.md section 6), so fewer, longer launches are faster
