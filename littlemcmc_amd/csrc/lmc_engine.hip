@@ -2281,15 +2281,16 @@ int lmc_engine_copy_window_async(lmc_engine* e, const lmc_window_dst* dst, int64
     HIP_TRY(e, hipStreamWaitEvent(cs, e->copy_dep[lmc_engine::kMaxSub], 0));
     const long long C = e->cfg.chains, d = e->cfg.dim, n = n_iters, n_out = dst->n_out;
     const long long row0 = iter_begin - dst->first;
-    // few, large workgroups: the copy's wavefronts sit on stores that drain at host-link speed, and the vector-memory path of a
-    // compute unit is shared with whatever else runs there -- 256 workgroups of 256 threads (one per CU) slowed every sampling
-    // wavefront of the chip for as long as the copy ran (the whole copy time showed up in the job), a dozen workgroups of 1024
-    // threads saturate the link from a dozen CUs
+    // Few, large workgroups: the copy's wavefronts sit on stores that drain at host-link speed, so a handful saturates the link
+    // (8 workgroups of 1024 threads reach 47 GiB/s, 16 and more 49-51) and every further one only takes wave slots from the
+    // sampling launches the copy runs under. Measured under a running job (tools/stream_probe.py, profiles/r06_sample_e2e.txt):
+    // 8-16 workgroups cost the job +0.24 ... +0.27 s for 0.34 s of copies of which 0.12 s cannot overlap by construction,
+    // 256-1024 workgroups +0.33 s.
     const int want = dst->copy_workgroups > 0 ? dst->copy_workgroups : kWindowCopyBlocks;
     const long long per_grid = want;
     const dim3 cblock(kWindowCopyThreads);
     {
-        const long long lo = 0, hi = C;
+        const long long lo = 0, hi = C;   // (all chains in one dispatch; the kernels take a chain range)
         hipStream_t st = cs;
         if (trace_dst) {
             const long long rows = e->A.cap - e->A.trace_begin;

@@ -302,3 +302,54 @@ def test_bench_line_is_compact_on_a_default_shaped_result():
     assert "roofline" in line8 and "cpu_baseline" in line8
     tiny = bench.compact_line(verbose, "bench_detail.json", limit=3000)
     assert len(json.dumps(tiny)) + 1 <= 3000 and tiny["roofline"]["frac"] == line["roofline"]["frac"] and "cpu_baseline" in tiny
+
+
+class _StreamFakeEngine(FakeEngine):
+    """FakeEngine + the streamed-results calls: records attach_trace / copy_window_async / copy_wait in call order."""
+
+    def attach_trace(self, out, trace_begin):
+        self.calls.append(("attach", None if out is None else "array", trace_begin))
+
+    def copy_window_async(self, out, first, n):
+        self.calls.append(("copy", first, n))
+
+    def copy_wait(self):
+        self.calls.append(("copy_wait",))
+
+
+@pytest.mark.parametrize("pin_fails", [False, True])
+def test_result_streamer_orders_attach_launch_and_window_copies(monkeypatch, pin_fails):
+    """_ResultStreamer (sampling.py): the returned arrays are pinned by a helper thread; the trace is attached BEFORE the first
+    launch that reaches `first` is enqueued (the kernel arguments of a launch are fixed when it is enqueued); every launch's
+    window of statistics is copied right behind its launch, clipped to [first, ...); if the arrays cannot be pinned the trace
+    goes to HBM instead (attach_trace(None)), nothing is copied per window, and finish() says so by returning None."""
+    from littlemcmc_amd import engine as engine_mod
+
+    class FakeResults:
+        def __init__(self, chains, n_out, first, dim, planes, direct=False):
+            if pin_fails:
+                raise _abi.HipLibraryError("cannot pin")
+            self.trace, self.n_out, self.first = object(), n_out, first
+
+    monkeypatch.setattr(engine_mod, "StreamedResults", FakeResults)
+    eng = _StreamFakeEngine()
+    st = sampling._ResultStreamer(eng, chains=4, n_out=130, first=100, dim=3, planes=[], direct=True)
+    n_done, interrupted = sampling._run_job(eng, tune=100, n_total=230, per_launch=60, progressbar=False,
+                                            on_enqueued=st.window, before_enqueue=st.before_launch)
+    out = st.finish()
+    assert (n_done, interrupted) == (230, False)
+    runs = [i for i, c in enumerate(eng.calls) if c[0] == "run"]
+    attach = [i for i, c in enumerate(eng.calls) if c[0] == "attach"]
+    assert [eng.calls[i] for i in runs] == [("run", 100, 0, 60), ("run", 100, 60, 60), ("run", 100, 120, 60), ("run", 100, 180, 50)]
+    # attached exactly once, after the launch [0, 60) (which never reaches iteration 100) and before the launch [60, 120)
+    assert len(attach) == 1 and runs[0] < attach[0] < runs[1]
+    assert eng.calls[attach[0]] == ("attach", None if pin_fails else "array", 100)
+    copies = [c for c in eng.calls if c[0] == "copy"]
+    if pin_fails:
+        assert out is None and copies == [] and ("copy_wait",) not in eng.calls
+    else:
+        assert out is not None and copies == [("copy", 100, 20), ("copy", 120, 60), ("copy", 180, 50)]   # clipped to >= first
+        assert eng.calls[-1] == ("copy_wait",)
+        # every window's copy follows its own launch
+        for c in copies:
+            assert eng.calls.index(c) > eng.calls.index(("run", 100, c[1] if c[1] != 100 else 60, 60 if c[1] != 180 else 50))
