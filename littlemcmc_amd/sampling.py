@@ -463,8 +463,16 @@ def sample(logp_dlogp_func, model_ndim=None, draws=1000, tune=1000, step=None, i
                 n_done, interrupted = _run_job(eng, int(tune), n_total, per_launch, progressbar, callback,
                                                on_enqueued=streamer.window if streamer is not None else None,
                                                before_enqueue=streamer.before_launch if streamer is not None else None)
-        finally:
-            streamed = streamer.finish() if streamer is not None else None
+        except BaseException:
+            # the job failed: wait for the pinning thread and the copies so that nothing writes the arrays after they are
+            # dropped -- without letting a second failure in here mask the error that is on its way up
+            if streamer is not None:
+                try:
+                    streamer.finish()
+                except Exception as cleanup_err:
+                    _log.warning("waiting for the streamed results after a failed job failed too: %s" % cleanup_err)
+            raise
+        streamed = streamer.finish() if streamer is not None else None
         raise_for_status(eng.status())
 
         n_out = max(n_done - lo, 0)
