@@ -89,7 +89,7 @@ def compact_line(out, detail_path=None, limit=LINE_LIMIT):
     line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                        "vs_baseline", "dtype", "data"))
     cfg = dict(out.get("config", {}))
-    cfg["workload"] = _short(cfg.get("workload_short") or cfg.get("workload"), 120)
+    cfg["workload"] = _short(cfg.get("workload_short") or cfg.get("workload"), 140)
     cfg.pop("workload_short", None)
     cfg["rng"] = _short(cfg.get("rng"), 40)
     line["config"] = cfg
@@ -117,7 +117,7 @@ def compact_line(out, detail_path=None, limit=LINE_LIMIT):
     for s_ in out.get("secondary", []):
         r = s_.get("roofline", {})
         t = s_.get("tail", {})
-        sec.append({"workload": _short(s_.get("workload_short") or s_.get("workload"), 100), "value": s_.get("value"),
+        sec.append({"workload": _short(s_.get("workload_short") or s_.get("workload"), 130), "value": s_.get("value"),
                     "ms_per_step": s_.get("ms_per_step"), "steps": s_.get("steps"),
                     "roofline": _pick(r, ("kernel", "frac", "bound")),
                     "tail": _pick(t, ("mean_wave_slot_occupancy", "implied_wall_lower_bound_s", "tail_bound_frac", "lone_wave_us_per_leapfrog"))})
@@ -726,8 +726,10 @@ def main():
             "label": label, "target": target_name, "dim": dim, "start": start, "mass_desc": mass_desc, "rng": RNG_LABEL[rng], "rng_mode": rng,
             "workload": "%s: %d chains x dim %d %s, %s, %s, tune %d + draws %d in %d launches of %d iterations; %s" % (
                 label, chains_total, dim, target_desc, method, mass_desc, n_tune, n_total - n_tune, K, ips, part),
-            "workload_short": "%s: %d x %d %s, %s, %d x %d it" % (label, chains_total, dim, target_name,
-                                                                  ("NUTS td%d" % md) if args.kind == "nuts" else "HMC", K, ips),
+            "workload_short": "%s: %d chains x dim %d %s, %s, tune %d + draws %d (%d x %d it)" % (
+                label, chains_total, dim, {"ar1": "AR(1) rho=0.9", "std_normal": "std normal", "funnel": "Neal's funnel",
+                                           "diag": "diag Gaussian kappa=1e4"}[target_name],
+                ("NUTS td%d" % md) if args.kind == "nuts" else "HMC", n_tune, n_total - n_tune, K, ips),
             "K": K, "ips": ips, "chains_total": chains_total, "chains_this_gpu": chains, "n_tune": n_tune, "n_total": n_total,
             "wall": wall_max, "leap_all": leap_all, "leap_local": leap_local, "kernel_ms": kernel_ms,
             "dispatch_ms_avg": float(np.mean(dispatch_ms)), "dispatches_per_step": nst,
