@@ -131,6 +131,23 @@ extern "C" {
 
 typedef struct lmc_engine lmc_engine;
 
+/* Kernel-selection and layout knobs, every one 0 = the engine decides. They exist for tests (replaying the small goldens
+ * through the general kernels, the large team, the HBM factorisation) and for A/B measurements; a result never depends on
+ * them beyond the tolerance the selected kernel documents. Until ABI 7 these were environment variables read inside the
+ * library -- hidden inputs to an ABI that takes everything else through lmc_config; the Python host still honours the
+ * variables of the same names (littlemcmc_amd/engine.py: tuning_from_env), but it is the host that reads them. */
+typedef struct lmc_tuning {
+    int32_t sub_blocks;           /* sub-block streams lmc_engine_run() deals the chains to: 1 .. 4 (LMC_SUB_BLOCKS) */
+    int32_t force_general;        /* 1: every shape the general kernels support runs in them (LMC_FORCE_WIDE) */
+    int32_t general_team;         /* 16: the general kernels' 16-wavefront team at every shape (LMC_WIDE_TEAM) */
+    int32_t run_ns, run_w;        /* shape of the fused sampling kernel, 64 * run_ns * run_w = padded dim (LMC_RUN_SHAPE="ns,w") */
+    int32_t dense_coop_off;       /* 1: QuadPotentialFull never takes the cooperative shared-matrix kernel (LMC_DENSE_COOP=0) */
+    int32_t dense_cache_rows_p1;  /* rows of the matrix a dense kernel caches in LDS, PLUS ONE (LMC_DENSE_CACHE_ROWS) */
+    int32_t dense_lds_slots_p1;   /* leading tree slots a dense kernel keeps in LDS, PLUS ONE (LMC_DENSE_LDS_SLOTS) */
+    int32_t chol_hbm;             /* 1: FullAdapt's refresh factorises through HBM at every size (LMC_CHOL_HBM) */
+    int32_t reserved[3];          /* must be 0 */
+} lmc_tuning;
+
 /* Constructor arguments of the step method: BaseHMC.__init__ (base_hmc.py:32-126) +
  * NUTS.__init__ (nuts.py:103-202) + HamiltonianMC.__init__ (hmc.py:52-138). */
 typedef struct lmc_config {
@@ -164,6 +181,7 @@ typedef struct lmc_config {
     int32_t lds_plan;             /* LMC_LDS_PLAN_*: which LDS plan the one-wave sampling kernels run under (results do not
                                    * depend on it). 0 = the engine chooses per launch. */
     int32_t reserved0;            /* must be 0 */
+    lmc_tuning tuning;            /* all zero = the engine decides */
 } lmc_config;
 
 /* Which kernels an engine runs. The FUSED kernels (one chain = one wavefront or a team of 2 / 4, the tree in registers and

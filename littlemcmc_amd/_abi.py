@@ -34,6 +34,14 @@ NUM_COUNTERS = 5
 STAT_RECORD_BYTES = 64   # include/lmc_hip.h: one record of sampler statistics per draw
 
 
+class Tuning(C.Structure):
+    """struct lmc_tuning (include/lmc_hip.h): kernel-selection and layout knobs, 0 = the engine decides."""
+
+    _fields_ = [("sub_blocks", C.c_int32), ("force_general", C.c_int32), ("general_team", C.c_int32), ("run_ns", C.c_int32),
+                ("run_w", C.c_int32), ("dense_coop_off", C.c_int32), ("dense_cache_rows_p1", C.c_int32),
+                ("dense_lds_slots_p1", C.c_int32), ("chol_hbm", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
 class Config(C.Structure):
     """struct lmc_config (include/lmc_hip.h)."""
 
@@ -47,6 +55,7 @@ class Config(C.Structure):
         ("path_length", C.c_double), ("max_steps", C.c_int32), ("adaptation_window", C.c_int32),
         ("lds_levels", C.c_int32), ("start_energy_sdot", C.c_int32), ("adaptation_window_multiplier", C.c_double),
         ("rng_mode", C.c_int32), ("mass_f64", C.c_int32), ("lds_plan", C.c_int32), ("reserved0", C.c_int32),
+        ("tuning", Tuning),
     ]
 
 

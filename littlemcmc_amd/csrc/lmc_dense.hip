@@ -111,10 +111,9 @@ int dense_launch_adapt(hipStream_t stream, const ChainArrays& A, const DenseArra
     const int lds = dense_adapt_lds_bytes(A.d, A.dpad);
     const dim3 grid(n_chains > 0 ? n_chains : A.chains);
     (void)hipGetLastError();
-    // LMC_CHOL_HBM=1 (a test knob): the factorisation through HBM at every size an engine allocated the work area for, so that
-    // the FullAdapt goldens of the small shapes check it against the register form (same factor bit for bit)
-    const char* env = std::getenv("LMC_CHOL_HBM");
-    const bool force_hbm = env && std::atoi(env) != 0 && D.chol_work != nullptr;
+    // lmc_config.tuning.chol_hbm (a test knob): the factorisation through HBM at every size an engine allocated the work area for,
+    // so that the FullAdapt goldens of the small shapes check it against the register form (same factor bit for bit)
+    const bool force_hbm = D.force_chol_hbm != 0 && D.chol_work != nullptr;
     if (D.mat_f64)   // QuadPotentialFullAdapt(dtype="float64"): covariance, factor and factorisation in float64 (general kernels)
         hipLaunchKernelGGL((dense_adapt_kernel<0, double>), grid, dim3(kCholHbmThreads), lds, stream, A, D, multiplier, update_window, mask, chain_begin, expect_iter);
     else if (dense_adapt_grid(A.d) == 8 && !force_hbm)

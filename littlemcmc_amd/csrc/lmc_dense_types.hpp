@@ -28,6 +28,7 @@ struct DenseArrays {
     int* window;            // [C]
     int* chol_failed;       // [C]  number of refreshes whose factorisation failed (old factor kept)
     void* chol_work;        // MatT [C][sweep_rows(d)][dpad] scratch of cholesky_hbm (d > 256 or float64, else nullptr): the factor, transposed
+    int force_chol_hbm;     // lmc_config.tuning.chol_hbm: FullAdapt's refresh factorises through HBM whenever chol_work exists
     int mat_f64;            // covT / fac / chol_work hold doubles (FullInv, Full float64, FullAdapt(dtype="float64")), else floats
 };
 

@@ -605,7 +605,7 @@ static int dense_run(lmc_engine* e, SamplerParams P) {
         const long budget = (163840L / blocks_per_cu) / 1280 * 1280 - dense_lds_doubles(e->dpad) * 8L;
         const long row_bytes = static_cast<long>(e->dpad) * (mat_f64 ? 8 : 4);
         long rows = budget > 0 ? budget / row_bytes : 0;
-        if (const char* env = std::getenv("LMC_DENSE_CACHE_ROWS")) rows = std::atol(env);
+        if (e->cfg.tuning.dense_cache_rows_p1 > 0) rows = e->cfg.tuning.dense_cache_rows_p1 - 1;
         rows = rows / (2 * kSweepBatch) * (2 * kSweepBatch);
         if (rows > sweep_rows(e->cfg.dim)) rows = sweep_rows(e->cfg.dim);
         e->D.cache_rows = static_cast<int>(rows < 0 ? 0 : rows);
@@ -618,7 +618,7 @@ static int dense_run(lmc_engine* e, SamplerParams P) {
         if (fit > by_regs) fit = by_regs;
         if (fit < 1) fit = 1;
         long slots = ((163840L / fit) / 1280 * 1280 - used) / (static_cast<long>(e->dpad) * 8);
-        if (const char* env = std::getenv("LMC_DENSE_LDS_SLOTS")) slots = std::atol(env);
+        if (e->cfg.tuning.dense_lds_slots_p1 > 0) slots = e->cfg.tuning.dense_lds_slots_p1 - 1;
         if (slots > dense_scratch_vectors(max_levels)) slots = dense_scratch_vectors(max_levels);
         e->D.lds_slots = static_cast<int>(slots < 0 ? 0 : slots);
     }
@@ -628,11 +628,11 @@ static int dense_run(lmc_engine* e, SamplerParams P) {
     HIP_TRY(e, order_sub_blocks_after_main(e));
     bool coop = e->cfg.potential == LMC_POT_FULL && !kUserCompiledInDense &&
                 dense_coop_supported(e->cfg.target_family, e->ns, e->cfg.dim, e->dpad) != 0;
-    if (const char* env = std::getenv("LMC_DENSE_COOP")) coop = coop && std::atoi(env) != 0;
+    if (e->cfg.tuning.dense_coop_off) coop = false;
     if (coop) {   // the LDS the panels and private regions leave holds the leading tree slots of the eight chains
         const int max_levels = e->cfg.max_treedepth > e->cfg.early_max_treedepth ? e->cfg.max_treedepth : e->cfg.early_max_treedepth;
         int slots = dense_coop_lds_slots(e->cfg.dim, e->dpad, dense_scratch_vectors(max_levels));
-        if (const char* env = std::getenv("LMC_DENSE_LDS_SLOTS")) slots = std::atoi(env) < slots ? std::atoi(env) : slots;
+        if (e->cfg.tuning.dense_lds_slots_p1 > 0 && e->cfg.tuning.dense_lds_slots_p1 - 1 < slots) slots = e->cfg.tuning.dense_lds_slots_p1 - 1;
         e->D.cache_rows = 0;
         e->D.lds_slots = slots < 0 ? 0 : slots;
     }
@@ -759,6 +759,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     if (cfg->chains < 1 || cfg->dim < 1) return fail(nullptr, LMC_ERR_INVALID, "chains and dim must be >= 1");
     if (cfg->lds_plan < LMC_LDS_PLAN_AUTO || cfg->lds_plan > LMC_LDS_PLAN_DEEP)
         return fail(nullptr, LMC_ERR_INVALID, "unknown lds_plan %d", cfg->lds_plan);
+    if (cfg->reserved0 != 0 || cfg->tuning.reserved[0] != 0 || cfg->tuning.reserved[1] != 0 || cfg->tuning.reserved[2] != 0)
+        return fail(nullptr, LMC_ERR_INVALID, "reserved fields of lmc_config must be 0");
     if (cfg->potential < LMC_POT_DIAG_ADAPT || cfg->potential > LMC_POT_FULL_F64)
         return fail(nullptr, LMC_ERR_INVALID, "unknown potential %d", cfg->potential);
     if (cfg->mass_f64 && cfg->potential > LMC_POT_DIAG && cfg->potential != LMC_POT_FULL_ADAPT)
@@ -768,12 +770,10 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     // (... and a density compiled at run time meets a dense mass matrix there: hiprtc instantiates the general kernel for it)
     const bool rtc_dense = cfg->target_family == LMC_TARGET_USER && !kUserCompiledInDense && cfg->potential >= LMC_POT_FULL &&
                            cfg->potential != LMC_POT_FULL_ADAPT;
-    // LMC_FORCE_WIDE=1 (a test knob like LMC_RUN_SHAPE): every shape the general kernels can run takes them, so that the
-    // goldens of the small shapes replay through them too
-    bool forced = false;
-    if (const char* env = std::getenv("LMC_FORCE_WIDE"))
-        forced = std::atoi(env) != 0 && cfg->rng_mode == LMC_RNG_NUMPY &&
-                 (cfg->target_family != LMC_TARGET_EXTERNAL || cfg->potential < LMC_POT_FULL);
+    // cfg.tuning.force_general (a test knob like tuning.run_ns / run_w): every shape the general kernels can run takes them, so
+    // that the goldens of the small shapes replay through them too
+    const bool forced = cfg->tuning.force_general != 0 && cfg->rng_mode == LMC_RNG_NUMPY &&
+                        (cfg->target_family != LMC_TARGET_EXTERNAL || cfg->potential < LMC_POT_FULL);
     const bool wide = cfg->dim > 1024 || (cfg->potential >= LMC_POT_FULL && cfg->dim > 256) || cfg->mass_f64 != 0 || rtc_dense || forced;
     if (wide) {
         if (cfg->dim > kWideMaxDim)
@@ -823,9 +823,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     if (wide) {   // thread t of the chain's team owns elements t*ns .. t*ns+ns-1
         // one wavefront per chain up to 8 elements per lane (dim <= 512: 2-6x the team's rate there, tools/wide_team_ab.py),
         // else 16 wavefronts; an externally evaluated density always takes the large team (tick_wide_kernel, lmc_wide.hip, is instantiated
-        // for it only). LMC_WIDE_TEAM=16 is a test knob: the large team at every shape, so the small goldens replay through it too
-        const char* team_env = std::getenv("LMC_WIDE_TEAM");
-        const bool large_team = cfg->dim > kWideOneWaveMaxDim || cfg->target_family == LMC_TARGET_EXTERNAL || (team_env && std::atoi(team_env) == 16);
+        // for it only). cfg.tuning.general_team = 16 is a test knob: the large team at every shape, so the small goldens replay through it too
+        const bool large_team = cfg->dim > kWideOneWaveMaxDim || cfg->target_family == LMC_TARGET_EXTERNAL || cfg->tuning.general_team == 16;
         const int threads = large_team ? kWideBlock : 64;
         int wns = 1;
         while (threads * wns < cfg->dim) wns *= 2;
@@ -838,9 +837,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     else if (e->ns == 4) { e->run_ns = 4; e->run_w = 1; }
     else if (e->ns == 8) { e->run_ns = 4; e->run_w = 2; }
     else { e->run_ns = 4; e->run_w = 4; }
-    if (const char* shape = wide ? nullptr : std::getenv("LMC_RUN_SHAPE")) {   // tuning knob: "ns,w" with 64*ns*w == dpad
-        int a = 0, b = 0;
-        if (std::sscanf(shape, "%d,%d", &a, &b) == 2 && 64 * a * b == e->dpad) { e->run_ns = a; e->run_w = b; }
+    if (!wide && cfg->tuning.run_ns > 0 && cfg->tuning.run_w > 0) {   // tuning knob: another shape of the fused kernel, 64 * ns * w == dpad
+        if (64 * cfg->tuning.run_ns * cfg->tuning.run_w == e->dpad) { e->run_ns = cfg->tuning.run_ns; e->run_w = cfg->tuning.run_w; }
     }
     e->initial_step = cfg->step_scale / std::pow(static_cast<double>(cfg->dim), 0.25);   // base_hmc.py:102
 
@@ -869,10 +867,8 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
     // (the dense-mass kernels keep two: their workgroups are large -- the shared-matrix kernel holds one per CU -- and a third
     //  and fourth stream's dispatch starts late enough for an interrupt to find chains that have not begun)
     if (e->n_sub > 2 && cfg->potential >= LMC_POT_FULL) e->n_sub = 2;
-    if (const char* env = std::getenv("LMC_SUB_BLOCKS")) {
-        const int v = std::atoi(env);
-        if (v >= 1 && v <= lmc_engine::kMaxSub && v <= cfg->chains) e->n_sub = v;
-    }
+    if (cfg->tuning.sub_blocks >= 1 && cfg->tuning.sub_blocks <= lmc_engine::kMaxSub && cfg->tuning.sub_blocks <= cfg->chains)
+        e->n_sub = cfg->tuning.sub_blocks;
     if (e->n_sub > 1) {
         for (int b = 0; b < e->n_sub; ++b) {
             se = hipStreamCreateWithFlags(&e->sub_stream[b], hipStreamNonBlocking);
@@ -1074,9 +1070,9 @@ int lmc_engine_create(const lmc_config* cfg, lmc_engine** out) {
             if ((rc = dev_alloc(e, &e->raw1T, d * dp)) != LMC_OK) return bail(rc);
             if ((rc = dev_alloc(e, &e->mean1, dp)) != LMC_OK) return bail(rc);
             // beyond 256 dimensions the refresh factorises through HBM (lmc_dense.hpp: cholesky_hbm) and needs a work area per
-            // chain; LMC_CHOL_HBM=1 (a test knob) gives the small shapes one too, and dense_launch_adapt then takes that form
-            const char* hbm_env = std::getenv("LMC_CHOL_HBM");
-            if (!adapt_f64 && (cfg->dim > kDenseAdaptRegisterMaxDim || (hbm_env && std::atoi(hbm_env) != 0))) {
+            // chain; cfg.tuning.chol_hbm (a test knob) gives the small shapes one too, and dense_launch_adapt then takes that form
+            D.force_chol_hbm = cfg->tuning.chol_hbm != 0 ? 1 : 0;
+            if (!adapt_f64 && (cfg->dim > kDenseAdaptRegisterMaxDim || D.force_chol_hbm)) {
                 float* w = nullptr;
                 if ((rc = dev_alloc(e, &w, C * drows * dp)) != LMC_OK) return bail(rc);
                 D.chol_work = w;

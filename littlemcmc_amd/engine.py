@@ -122,12 +122,49 @@ class StreamedResults:
         return w
 
 
+# Test / A-B knobs of struct lmc_tuning and the environment variables the HOST reads them from when the caller does not pass
+# ``tuning=`` (until ABI 7 the library read these variables itself -- hidden inputs to a C ABI; now they are plain fields of
+# lmc_config and this table is the one place that looks at the environment).
+_TUNING_ENV = {
+    "LMC_SUB_BLOCKS": ("sub_blocks", int),
+    "LMC_FORCE_WIDE": ("force_general", lambda v: int(int(v) != 0)),
+    "LMC_WIDE_TEAM": ("general_team", int),
+    "LMC_DENSE_COOP": ("dense_coop_off", lambda v: int(int(v) == 0)),
+    "LMC_DENSE_CACHE_ROWS": ("dense_cache_rows_p1", lambda v: int(v) + 1),
+    "LMC_DENSE_LDS_SLOTS": ("dense_lds_slots_p1", lambda v: int(v) + 1),
+    "LMC_CHOL_HBM": ("chol_hbm", lambda v: int(int(v) != 0)),
+}
+
+
+def tuning_from_env(environ=None):
+    """dict of lmc_tuning fields from the LMC_* environment variables (empty / malformed values are ignored)."""
+    import os
+
+    environ = os.environ if environ is None else environ
+    out = {}
+    for name, (field, conv) in _TUNING_ENV.items():
+        raw = environ.get(name, "")
+        if raw != "":
+            try:
+                out[field] = conv(raw)
+            except ValueError:
+                pass
+    shape = environ.get("LMC_RUN_SHAPE", "")
+    if shape:
+        try:
+            a, b = (int(x) for x in shape.split(","))
+            out["run_ns"], out["run_w"] = a, b
+        except ValueError:
+            pass
+    return out
+
+
 class Engine:
     def __init__(self, target, chains, kind="nuts", potential="diag_adapt", device=0, lib_path=None,
                  target_accept=0.8, Emax=1000.0, adapt_step_size=True, step_scale=0.25, gamma=0.05, k=0.75,
                  t0=10, path_length=2.0, max_treedepth=10, early_max_treedepth=8, max_steps=1024,
                  adaptation_window=101, adaptation_window_multiplier=1.0, lds_levels=0, sdot=None, rng="numpy",
-                 mass_dtype="float32", lds_plan="auto"):
+                 mass_dtype="float32", lds_plan="auto", tuning=None):
         self._lib = _abi.load(lib_path or getattr(target, "lib_path", None))
         self._h = C.c_void_p()
         self.target = target
@@ -159,6 +196,8 @@ class Engine:
         # include/lmc_hip.h: LMC_LDS_PLAN_* (results do not depend on it; pinned values are for A/B runs and parity tests)
         cfg.lds_plan = {"auto": _abi.LDS_PLAN_AUTO, None: _abi.LDS_PLAN_AUTO, 0: _abi.LDS_PLAN_SHALLOW, "shallow": _abi.LDS_PLAN_SHALLOW,
                         1: _abi.LDS_PLAN_DEEP, "deep": _abi.LDS_PLAN_DEEP}[lds_plan]
+        for field, value in (tuning_from_env() if tuning is None else dict(tuning)).items():   # struct lmc_tuning: test / A-B knobs
+            setattr(cfg.tuning, field, int(value))
         cfg.rng_mode = {"numpy": _abi.RNG_NUMPY, "philox": _abi.RNG_PHILOX}[rng]   # include/lmc_hip.h: LMC_RNG_*
         # QuadPotentialDiagAdapt(dtype=...) (quadpotential.py:159,175-184); float64 runs in the general kernels
         # QuadPotentialFullAdapt(dtype=...) (quadpotential.py:484,497-509) likewise: float64 covariance, factor and momentum

@@ -51,14 +51,31 @@ def test_config_struct_layout_and_defaults():
     assert (cfg.target_accept, cfg.emax, cfg.step_scale, cfg.gamma, cfg.k, cfg.t0) == (0.8, 1000.0, 0.25, 0.05, 0.75, 10.0)
     assert (cfg.max_treedepth, cfg.early_max_treedepth, cfg.max_steps, cfg.adaptation_window) == (10, 8, 1024, 101)
     assert cfg.path_length == 2.0 and cfg.start_energy_sdot == _abi.SDOT_OPENBLAS_SKYLAKEX
-    fields = re.findall(r"^\s+(?:int32_t|double)\s+(\w+);", HEADER[HEADER.index("typedef struct lmc_config"):], re.M)
-    assert [f for f, _ in _abi.Config._fields_] == fields[: len(_abi.Config._fields_)]
+    block = HEADER[HEADER.index("typedef struct lmc_config"):HEADER.index("} lmc_config;")]
+    fields = re.findall(r"^\s+(?:int32_t|double|lmc_tuning)\s+(\w+);", block, re.M)
+    assert [f for f, _ in _abi.Config._fields_] == fields and fields[-1] == "tuning"
+    tblock = HEADER[HEADER.index("typedef struct lmc_tuning"):HEADER.index("} lmc_tuning;")]
+    tfields = re.findall(r"^\s+int32_t\s+([\w, ]+?)(?:\[\d+\])?;", tblock, re.M)
+    tfields = [x.strip() for grp in tfields for x in grp.split(",")]
+    assert [f for f, _ in _abi.Tuning._fields_] == tfields and ctypes.sizeof(_abi.Tuning) == 48
+    assert all(getattr(cfg.tuning, f) == 0 for f, _ in _abi.Tuning._fields_[:-1])   # defaults: the engine decides everything
+    # no entry point reads the environment any more: the knobs are fields, the HOST maps the LMC_* variables onto them
+    from littlemcmc_amd.engine import tuning_from_env
+
+    assert tuning_from_env({"LMC_SUB_BLOCKS": "2", "LMC_FORCE_WIDE": "1", "LMC_RUN_SHAPE": "2,2", "LMC_DENSE_COOP": "0",
+                            "LMC_DENSE_LDS_SLOTS": "0", "LMC_WIDE_TEAM": "", "LMC_CHOL_HBM": "x"}) == {
+        "sub_blocks": 2, "force_general": 1, "run_ns": 2, "run_w": 2, "dense_coop_off": 1, "dense_lds_slots_p1": 1}
+    for unit in ("lmc_engine.hip", "lmc_dense.hip", "lmc_wide.hip", "lmc_tick.hip", "lmc_dense_coop.hip", "lmc_diag.hip"):
+        assert "getenv" not in open(os.path.join(ROOT, "littlemcmc_amd", "csrc", unit)).read(), unit
     assert cfg.lds_plan == _abi.LDS_PLAN_AUTO and cfg.reserved0 == 0
     bad = _abi.Config()
     lib.lmc_config_defaults(ctypes.byref(bad), 7, 13)
     bad.lds_plan = 3                       # validated before any HIP call: no GPU needed to see the refusal
     h = ctypes.c_void_p()
     assert lib.lmc_engine_create(ctypes.byref(bad), ctypes.byref(h)) == 1 and b"lds_plan" in lib.lmc_last_error(None)
+    bad.lds_plan = 0
+    bad.tuning.reserved[1] = 7
+    assert lib.lmc_engine_create(ctypes.byref(bad), ctypes.byref(h)) == 1 and b"reserved" in lib.lmc_last_error(None)
 
 
 def test_window_destination_struct_layout():
