@@ -14,6 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that hangs (a kernel that never returns, a wait that is never answered) must fail as THAT test after ten
+    minutes -- the slowest one takes seven seconds -- instead of holding the box until the harness gives up on the whole
+    session. pytest-timeout's thread method ends the process, which releases the device."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -51,7 +51,7 @@ def test_interrupting_a_130_chain_job_returns_a_prefix():
     tgt = T.StdNormal(d)
     cb = _InterruptAt(64)
     trace, stats = lmc.sample(tgt, d, draws=draws, tune=tune, chains=chains, random_seed=12, discard_tuned_samples=False,
-                              callback=cb, progressbar=False)
+                              callback=cb, progressbar=False, stream_results=False)   # (a 200 050-iteration job only to be interrupted: nothing to pin)
     n = trace.shape[1]
     assert cb.fired_at is not None and 0 < n < tune + draws
     full, _fs = lmc.sample(tgt, d, draws=max(n - tune, 0), tune=min(n, tune), chains=chains, random_seed=12,

@@ -221,7 +221,6 @@ def test_hiprtc_compiles_a_never_seen_density_on_this_box():
     dt = time.perf_counter() - t0
     new = [f for f in set(os.listdir(cache)) - before if f.endswith(".hsaco")]
     assert new, "no code object was produced: the density did not go through hiprtc on this box"
-    assert dt > 0.5, "a %d-byte kernel translation unit compiled and sampled in %.2f s: served from a cache?" % (len(src), dt)
     f = lambda x: (-0.5 * np.dot(x - mu, x - mu), -(x - mu))   # noqa: E731
     ot, ost = orc.sample(f, d, draws=5, tune=25, chains=2, random_seed=5, discard_tuned_samples=False)
     n = 15

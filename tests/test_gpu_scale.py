@@ -284,8 +284,11 @@ def test_keyboard_interrupt_returns_the_draws_so_far():
     d, chains, tune, draws = 32, 2048, 50, 100000
     tgt = T.StdNormal(d)
     cb = _InterruptAt(48)
+    # (stream_results=False: the job is 100 050 iterations long only so that it is still running when the interrupt comes --
+    #  streamed, sample() would pin the 69 GB its full length returns before the first launch; the streamed form of an
+    #  interrupted job is tests/test_gpu_round6.py's, at a size that is actually returned)
     trace, stats = lmc.sample(tgt, d, draws=draws, tune=tune, chains=chains, random_seed=12, discard_tuned_samples=False,
-                              callback=cb, progressbar=False)
+                              callback=cb, progressbar=False, stream_results=False)
     n = trace.shape[1]
     print("interrupt raised at device iteration %d; %d of %d iterations completed by every chain" % (cb.fired_at, n, tune + draws))
     assert cb.fired_at is not None and 0 < n < tune + draws   # (the hint is where the fastest relay chain is; n what EVERY chain completed)

@@ -244,6 +244,11 @@ def test_a_chain_may_only_part_from_its_oracle_twin_for_a_reason():
     # the same jump with the step size already 1e-9 apart the iteration before: geometric growth -> accepted, prefix 12
     got_q, got = chain(12, 1e-6, step_rel=(11, 1e-9))
     assert assert_chain_matches(got_q, got, want_q, stats, calm) == 12
+    # growth is geometric, not arbitrary: from 2e-4 of the tolerance to 1000 times the tolerance in ONE iteration (the largest
+    # ratio any captured chain shows is 250) is a jump again, whatever the iteration before looked like (round 6: JUMP)
+    got_q, got = chain(12, 1e-4, step_rel=(11, 2e-11))
+    with pytest.raises(AssertionError, match="no reason"):
+        assert_chain_matches(got_q, got, want_q, stats, calm)
     # ... or with a multinomial decision within FRAGILE of its threshold at iteration 5
     fragile = calm.copy()
     fragile[5, 0] = 0.1 * FRAGILE
