@@ -1901,6 +1901,11 @@ int lmc_engine_attach_trace(lmc_engine* e, double* dst, int64_t trace_begin) {
         return fail(e, LMC_ERR_INVALID, "trace_begin %lld outside [0, %lld)", (long long)trace_begin, (long long)e->A.cap);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     ChainArrays& A = e->A;
+    double* view = nullptr;
+    if (dst) {   // (checked before anything is given up: a refused destination leaves the engine as it was)
+        view = static_cast<double*>(device_view_of(dst));
+        if (!view) return fail(e, LMC_ERR_INVALID, "trace: the destination is not device-accessible memory (use lmc_host_alloc / lmc_host_register)");
+    }
     if (A.trace && !e->trace_external) {   // an engine-owned trace may still be written by launches in flight
         HIP_TRY(e, hipStreamSynchronize(main_stream(e)));
         dev_free(e, A.trace);
@@ -1908,8 +1913,6 @@ int lmc_engine_attach_trace(lmc_engine* e, double* dst, int64_t trace_begin) {
     A.trace = nullptr;
     e->trace_external = false;
     if (dst) {
-        double* view = static_cast<double*>(device_view_of(dst));
-        if (!view) return fail(e, LMC_ERR_INVALID, "trace: the destination is not device-accessible memory (use lmc_host_alloc / lmc_host_register)");
         A.trace = view;
         e->trace_external = true;
     } else {

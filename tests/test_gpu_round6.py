@@ -197,6 +197,10 @@ def test_copy_window_async_runs_under_the_next_launch():
         # a window outside the destination is refused, not written
         with pytest.raises(_abi.HipLibraryError, match="outside"):
             eng.copy_window_async(StreamedResults(chains, 10, 50, d, [], pinned=False), 40, 20)
+        # ... and so is a pageable trace destination, which leaves the engine's own trace in place
+        with pytest.raises(_abi.HipLibraryError, match="not device-accessible"):
+            eng.attach_trace(np.empty((chains, n, d)), 0)
+        np.testing.assert_array_equal(out.trace[::501], eng.trace(0, n)[::501])
         # pageable memory is refused (the copies are kernels that write the destination themselves), never silently staged
         with pytest.raises(_abi.HipLibraryError, match="not device-accessible"):
             eng.copy_window_async(StreamedResults(chains, 10, 50, d, [], pinned=False), 50, 10)
