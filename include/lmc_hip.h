@@ -360,9 +360,8 @@ typedef struct lmc_window_dst {
     int64_t first;           /* iteration index that lands in destination row 0 */
     double* trace;           /* [chains][n_out][dim], or NULL */
     int32_t n_planes;
-    int32_t copy_workgroups; /* workgroups (of 1024 threads) a window copy may use, all sub-blocks together; 0 = the default (16):
-                              * few and large, so that the copy's stores, which drain at host-link speed, tie up the memory
-                              * path of a handful of compute units only */
+    int32_t copy_workgroups; /* single-wavefront workgroups a window copy may use; 0 = the default (64): enough to saturate the
+                              * host link, few enough to leave the wave slots to the sampling launches it runs under */
     lmc_window_plane plane[LMC_MAX_PLANES];
 } lmc_window_dst;
 int lmc_engine_copy_window_async(lmc_engine* e, const lmc_window_dst* dst, int64_t iter_begin, int64_t n_iters);

@@ -2205,10 +2205,13 @@ int lmc_engine_get_stat_u8(lmc_engine* e, int32_t stat, uint8_t* dst, int64_t it
 
 // ---- streamed results ------------------------------------------------------------------------------------------------------
 #ifndef LMC_WINDOW_COPY_BLOCKS
-#define LMC_WINDOW_COPY_BLOCKS 16
+#define LMC_WINDOW_COPY_BLOCKS 64
 #endif
-static constexpr int kWindowCopyBlocks = LMC_WINDOW_COPY_BLOCKS;   // workgroups of a window copy, all sub-blocks together (lmc_window_dst.copy_workgroups = 0)
-static constexpr int kWindowCopyThreads = 1024;
+#ifndef LMC_WINDOW_COPY_THREADS
+#define LMC_WINDOW_COPY_THREADS 64
+#endif
+static constexpr int kWindowCopyBlocks = LMC_WINDOW_COPY_BLOCKS;   // workgroups of a window copy (lmc_window_dst.copy_workgroups = 0)
+static constexpr int kWindowCopyThreads = LMC_WINDOW_COPY_THREADS; // ONE wavefront each: see lmc_engine_copy_window_async
 
 // the address a kernel of this engine's device writes `p` through: device memory as it is, page-locked host memory through its
 // device mapping; nullptr for memory the device cannot reach (pageable)
@@ -2280,11 +2283,13 @@ int lmc_engine_copy_window_async(lmc_engine* e, const lmc_window_dst* dst, int64
     HIP_TRY(e, hipStreamWaitEvent(cs, e->copy_dep[lmc_engine::kMaxSub], 0));
     const long long C = e->cfg.chains, d = e->cfg.dim, n = n_iters, n_out = dst->n_out;
     const long long row0 = iter_begin - dst->first;
-    // Few, large workgroups: the copy's wavefronts sit on stores that drain at host-link speed, so a handful saturates the link
-    // (8 workgroups of 1024 threads reach 47 GiB/s, 16 and more 49-51) and every further one only takes wave slots from the
-    // sampling launches the copy runs under. Measured under a running job (tools/stream_probe.py, profiles/r06_sample_e2e.txt):
-    // 8-16 workgroups cost the job +0.24 ... +0.27 s for 0.34 s of copies of which 0.12 s cannot overlap by construction,
-    // 256-1024 workgroups +0.33 s.
+    // Few workgroups of ONE wavefront each. The copy's wavefronts sit on stores that drain at host-link speed, so a few dozen
+    // saturate the link (32 single-wave workgroups reach 40 GiB/s, 64 reach 50) and every further one only takes wave slots
+    // from the sampling launches the copy runs under; and a single wavefront finds a slot whenever ONE sampling wavefront
+    // retires, where a 1024-thread workgroup needs sixteen free slots on one compute unit -- under a running launch that is
+    // the launch's tail (rocprofv3 showed a 115 ms dispatch for an 11 ms copy). Measured under a running job
+    // (tools/stream_probe.py, profiles/r06_sample_e2e.txt; 0.34 s of copies of which 0.12 s cannot overlap by construction):
+    // 64 x 64 threads +0.18 s, 16 x 1024 threads +0.23 s, 256 or more workgroups of either size +0.24 ... +0.31 s.
     const int want = dst->copy_workgroups > 0 ? dst->copy_workgroups : kWindowCopyBlocks;
     const long long per_grid = want;
     const dim3 cblock(kWindowCopyThreads);
