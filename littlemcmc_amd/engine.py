@@ -25,16 +25,27 @@ class _PinnedBlock:
     (lmc_host_register). Exposes the memory through __array_interface__ (numpy keeps this object alive as the base of every
     view) and unregisters it when the last view is gone."""
 
-    def __init__(self, lib, raw, base, shape, dtype):
-        self._lib, self._raw, self._base = lib, raw, int(base)
+    def __init__(self, lib, raw, base, span, shape, dtype):
+        self._lib, self._raw, self._base, self._span, self._registered = lib, raw, int(base), int(span), False
         self.__array_interface__ = {"data": (self._base, False), "shape": tuple(int(x) for x in shape),
                                     "typestr": np.dtype(dtype).str, "version": 3}
 
+    def register(self):
+        """Page-lock the block and map it into the GPUs (lmc_host_register). Called from the thread that drives the engine:
+        the allocation and the page faults may come from a helper thread, the HIP call does not (the runtime is entered from
+        one thread at a time by this package)."""
+        if not self._registered:
+            if self._lib.lmc_host_register(C.c_void_p(self._base), self._span) != _abi.OK:
+                raise _abi.HipLibraryError("cannot pin %d bytes of host memory: %s" % (
+                    self._span, (self._lib.lmc_last_error(None) or b"?").decode()))
+            self._registered = True
+
     def __del__(self):
         try:
-            if self._raw is not None:
+            if self._registered:
                 self._lib.lmc_host_unregister(C.c_void_p(self._base))
-                self._raw = None
+                self._registered = False
+            self._raw = None
         except Exception:
             pass
 
@@ -58,12 +69,14 @@ def _prefault(address, nbytes, threads):
         t.join()
 
 
-def pinned_empty(shape, dtype, lib=None, threads=None):
+def pinned_empty(shape, dtype, lib=None, threads=None, register=True):
     """A C-contiguous numpy array in page-locked host memory every GPU can write (hipHostRegister, portable + mapped), unpinned
     and freed when the array and every view of it are gone. The memory is an ordinary numpy allocation (numpy asks for
     transparent huge pages for large blocks), pre-faulted from ``threads`` threads (default: up to 16 of the usable cores) and
     then registered: 15.6 GiB take 0.12 s this way against 1.2 s for hipHostMalloc, which faults every page in from one thread
-    (profiles/r06_sample_e2e.txt). Raises HipLibraryError if the memory cannot be pinned."""
+    (profiles/r06_sample_e2e.txt). Raises HipLibraryError if the memory cannot be pinned.
+    ``register=False`` stops before the HIP call (allocate + pre-fault only: safe in a helper thread); the caller registers
+    later with ``pinned_register(array)`` from the thread that drives the engine."""
     lib = lib or _abi.load()
     dtype = np.dtype(dtype)
     nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
@@ -85,9 +98,20 @@ def pinned_empty(shape, dtype, lib=None, threads=None):
     raw = np.empty(span + page, dtype=np.uint8)
     base = raw.ctypes.data + (-raw.ctypes.data) % page
     _prefault(base, span, threads)
-    if lib.lmc_host_register(C.c_void_p(base), span) != _abi.OK:
-        raise _abi.HipLibraryError("cannot pin %d bytes of host memory: %s" % (span, (lib.lmc_last_error(None) or b"?").decode()))
-    return np.asarray(_PinnedBlock(lib, raw, base, shape, dtype))
+    block = _PinnedBlock(lib, raw, base, span, shape, dtype)
+    if register:
+        block.register()
+    return np.asarray(block)
+
+
+def pinned_register(array):
+    """Register (page-lock + map into the GPUs) an array made by pinned_empty(register=False); a no-op for arrays that are
+    registered already or own no pinned block (zero-size results)."""
+    owner = array
+    while owner is not None and not isinstance(owner, _PinnedBlock):
+        owner = getattr(owner, "base", None)
+    if owner is not None:
+        owner.register()
 
 
 class StreamedResults:
@@ -98,16 +122,26 @@ class StreamedResults:
 
     ``planes``: (name, kind, idx, as_, numpy dtype) with kind / as_ the LMC_PLANE_* / LMC_AS_* of include/lmc_hip.h."""
 
-    def __init__(self, chains, n_out, first, dim, planes, keep_trace=True, pinned=True, lib=None, copy_workgroups=0, direct=False):
+    def __init__(self, chains, n_out, first, dim, planes, keep_trace=True, pinned=True, lib=None, copy_workgroups=0, direct=False,
+                 register=True):
         self.direct = bool(direct)      # the sampling kernel writes ``trace`` itself (Engine.attach_trace): windows carry statistics only
         self.copy_workgroups = int(copy_workgroups)     # lmc_window_dst.copy_workgroups (0 = the library's default)
         self.chains, self.n_out, self.first, self.dim = int(chains), int(n_out), int(first), int(dim)
         self.planes = list(planes)
         assert len(self.planes) <= _abi.MAX_PLANES
-        alloc = (lambda sh, dt: pinned_empty(sh, dt, lib)) if pinned else (lambda sh, dt: np.empty(sh, dtype=dt))
+        # register=False: allocate and pre-fault only (what a helper thread may do); register() later, from the driving thread
+        alloc = (lambda sh, dt: pinned_empty(sh, dt, lib, register=register)) if pinned else (lambda sh, dt: np.empty(sh, dtype=dt))
+        self.registered = bool(register) or not pinned
         self.pinned = bool(pinned)
         self.trace = alloc((self.chains, self.n_out, self.dim), np.float64) if keep_trace else None
         self.stats = {name: alloc((self.chains, self.n_out), dt) for name, _k, _i, _a, dt in self.planes}
+
+    def register(self):
+        """Page-lock every array (HIP calls: from the thread that drives the engine). Raises HipLibraryError on failure."""
+        if not self.registered:
+            for a in ([] if self.trace is None else [self.trace]) + list(self.stats.values()):
+                pinned_register(a)
+            self.registered = True
 
     def window_dst(self, eng, chain_lo=0):
         """struct lmc_window_dst for the engine that owns chains [chain_lo, chain_lo + eng.chains) of these arrays."""

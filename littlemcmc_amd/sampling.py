@@ -89,8 +89,10 @@ class JobProgress:
 
 class _ResultStreamer:
     """Fills the arrays sample() returns while the job runs (sampling.py:207-222 of the reference returns host arrays; a
-    job's draws are tens of GiB, so nothing may wait for the end of the job). The arrays are page-locked host memory, pinned
-    by a helper thread while the first launches run.
+    job's draws are tens of GiB, so nothing may wait for the end of the job). The arrays are page-locked host memory:
+    allocated and PRE-FAULTED by a helper thread while the first launches run (the page faults are the expensive part and pure
+    CPU work), then registered with the HIP runtime (hipHostRegister: 0.03 s per 15 GiB of resident memory) on the thread that
+    drives the engine -- this package never enters the HIP runtime from two threads at once.
 
     * draws: ``direct=True`` -- the sampling kernel stores every draw straight into the returned trace array as it is
       produced (Engine.attach_trace: coalesced rows over the host link, no trace in HBM, nothing left to copy when the job
@@ -109,7 +111,7 @@ class _ResultStreamer:
             from .engine import StreamedResults
 
             try:
-                self.out = StreamedResults(chains, n_out, first, dim, planes, direct=direct)
+                self.out = StreamedResults(chains, n_out, first, dim, planes, direct=direct, register=False)   # CPU work only
             except BaseException as err:     # the host cannot pin that much: the draws are copied after the job instead
                 self.err = err
 
@@ -121,6 +123,7 @@ class _ResultStreamer:
         the draws go (direct mode): wait for the arrays and attach the trace -- or, if they could not be pinned, a trace in HBM."""
         if self.direct and not self.attached and int(first) + int(n) > self.first:
             self._thread.join()
+            self._register()
             self.eng.attach_trace(self.out.trace if self.out is not None else None, self.first)
             self.attached = True
 
@@ -131,8 +134,20 @@ class _ResultStreamer:
             self.waiting.append((a, b - a))
         self._flush()
 
+    def _register(self):
+        """Page-lock the arrays the helper thread prepared (a HIP call: made here, on the driving thread). On failure the job
+        goes on without streamed results (trace in HBM, everything copied when it is over)."""
+        if self.out is not None and not self.out.registered:
+            try:
+                self.out.register()
+            except Exception as err:
+                self.err, self.out = err, None
+
     def _flush(self):
-        if self._thread.is_alive() or self.out is None:
+        if self._thread.is_alive():
+            return
+        self._register()
+        if self.out is None:
             return
         for a, n in self.waiting:
             self.eng.copy_window_async(self.out, a, n)
@@ -141,6 +156,7 @@ class _ResultStreamer:
     def finish(self):
         """Wait for the arrays and for every copy; returns the StreamedResults (None if the memory could not be pinned)."""
         self._thread.join()
+        self._register()
         if self.out is None:
             _log.warning("results were not streamed (%s); copying them now that the job is over" % (self.err,))
             return None

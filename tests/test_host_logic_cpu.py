@@ -330,11 +330,22 @@ def test_result_streamer_orders_attach_launch_and_window_copies(monkeypatch, pin
     goes to HBM instead (attach_trace(None)), nothing is copied per window, and finish() says so by returning None."""
     from littlemcmc_amd import engine as engine_mod
 
+    import threading
+
+    main = threading.current_thread()
+    where = {}
+
     class FakeResults:
-        def __init__(self, chains, n_out, first, dim, planes, direct=False):
+        def __init__(self, chains, n_out, first, dim, planes, direct=False, register=True):
+            assert register is False                              # the helper thread allocates and pre-faults only ...
+            where["alloc"] = threading.current_thread()
+            self.trace, self.n_out, self.first, self.registered = object(), n_out, first, False
+
+        def register(self):                                       # ... the HIP call comes from the thread that drives the engine
+            where["register"] = threading.current_thread()
             if pin_fails:
                 raise _abi.HipLibraryError("cannot pin")
-            self.trace, self.n_out, self.first = object(), n_out, first
+            self.registered = True
 
     monkeypatch.setattr(engine_mod, "StreamedResults", FakeResults)
     eng = _StreamFakeEngine()
@@ -343,6 +354,7 @@ def test_result_streamer_orders_attach_launch_and_window_copies(monkeypatch, pin
                                             on_enqueued=st.window, before_enqueue=st.before_launch)
     out = st.finish()
     assert (n_done, interrupted) == (230, False)
+    assert where["alloc"] is not main and where["register"] is main
     runs = [i for i, c in enumerate(eng.calls) if c[0] == "run"]
     attach = [i for i, c in enumerate(eng.calls) if c[0] == "attach"]
     assert [eng.calls[i] for i in runs] == [("run", 100, 0, 60), ("run", 100, 60, 60), ("run", 100, 120, 60), ("run", 100, 180, 50)]

@@ -4,7 +4,7 @@
 set -u
 tag=$1; out=gpurun_out/${tag}_final
 mkdir -p $out
-python -m pytest tests -q -m gpu 2>&1 | tail -6 > $out/gpu_suite.txt
+PYTHONFAULTHANDLER=1 python -m pytest tests -q -m gpu > $out/gpu_suite_full.log 2>&1; grep -v "Extension modules" $out/gpu_suite_full.log | tail -40 > $out/gpu_suite.txt
 python __graft_entry__.py smoke 2>&1 | tail -2 > $out/smoke.txt
 bash tools/reprofile.sh ${tag}prof $tag > $out/reprofile.log 2>&1
 ( echo "== tools/fuzz_rare.py 2000 777"; python tools/fuzz_rare.py 2000 777 | tail -2
