@@ -108,12 +108,21 @@ class _ResultStreamer:
         self.direct, self.attached = bool(direct), False
 
         def alloc():
+            import gc
+
             from .engine import StreamedResults
 
+            # CPU work only -- and no cyclic garbage collection started from this thread: a collection could finalize an
+            # Engine or a pinned block of an earlier job HERE, i.e. enter the HIP runtime beside the driving thread
+            was_enabled = gc.isenabled()
+            gc.disable()
             try:
-                self.out = StreamedResults(chains, n_out, first, dim, planes, direct=direct, register=False)   # CPU work only
-            except BaseException as err:     # the host cannot pin that much: the draws are copied after the job instead
+                self.out = StreamedResults(chains, n_out, first, dim, planes, direct=direct, register=False)
+            except BaseException as err:     # the host cannot allocate that much: the draws are copied after the job instead
                 self.err = err
+            finally:
+                if was_enabled:
+                    gc.enable()
 
         self._thread = threading.Thread(target=alloc, name="lmc-pin-results", daemon=True)
         self._thread.start()
