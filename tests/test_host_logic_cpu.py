@@ -370,3 +370,55 @@ def test_result_streamer_orders_attach_launch_and_window_copies(monkeypatch, pin
         # every window's copy follows its own launch
         for c in copies:
             assert eng.calls.index(c) > eng.calls.index(("run", 100, c[1] if c[1] != 100 else 60, 60 if c[1] != 180 else 50))
+
+
+def test_pinned_arrays_own_whole_pages_and_register_where_they_are_told():
+    """engine.pinned_empty (no GPU: a stand-in for the two library calls): the block handed to lmc_host_register starts on a
+    page boundary, spans whole pages and covers the array -- so no two pinned arrays share a page, whatever their size --;
+    register=False allocates and pre-faults only, pinned_register() makes the call later (sampling._ResultStreamer: on the
+    driving thread), and the block is unregistered exactly once, when the last view of the array is gone."""
+    import gc
+    import mmap
+
+    from littlemcmc_amd import engine
+
+    class Lib:
+        def __init__(self):
+            self.reg, self.unreg = [], []
+
+        def lmc_host_register(self, p, n):
+            self.reg.append((p.value, n))
+            return 0
+
+        def lmc_host_unregister(self, p):
+            self.unreg.append(p.value)
+            return 0
+
+    lib, page = Lib(), mmap.PAGESIZE
+    a = engine.pinned_empty((3, 5, 7), np.float64, lib=lib, threads=4)
+    b = engine.pinned_empty((11,), np.bool_, lib=lib, threads=4)
+    assert len(lib.reg) == 2
+    for arr, (base, span) in zip((a, b), lib.reg):
+        assert base % page == 0 and span % page == 0 and base <= arr.ctypes.data and arr.ctypes.data + arr.nbytes <= base + span
+        assert arr.flags["C_CONTIGUOUS"] and arr.flags["WRITEABLE"]
+    (b0, s0), (b1, s1) = lib.reg
+    assert b0 + s0 <= b1 or b1 + s1 <= b0                      # disjoint page ranges
+    a[:] = 2.0
+    b[:] = True
+    view = a[:, :2, None]
+    del a
+    gc.collect()
+    assert lib.unreg == [] and view.sum() == 2.0 * 3 * 2 * 7   # a view keeps the block pinned
+    del view, b
+    gc.collect()
+    assert sorted(lib.unreg) == sorted(x for x, _ in lib.reg)
+    # deferred registration
+    c = engine.pinned_empty((1000,), np.float64, lib=lib, register=False)
+    assert len(lib.reg) == 2
+    engine.pinned_register(c[10:20])                            # found through any view
+    engine.pinned_register(c)                                   # idempotent
+    assert len(lib.reg) == 3 and lib.reg[2][1] == 2 * page
+    del c
+    gc.collect()
+    assert len(lib.unreg) == 3
+    assert engine.pinned_empty((0, 4), np.float64, lib=lib).shape == (0, 4) and len(lib.reg) == 3   # nothing to pin
