@@ -409,7 +409,7 @@ def test_pinned_arrays_own_whole_pages_and_register_where_they_are_told():
     del a
     gc.collect()
     assert lib.unreg == [] and view.sum() == 2.0 * 3 * 2 * 7   # a view keeps the block pinned
-    del view, b
+    del view, b, arr                                            # (the loop variable above still named the second array)
     gc.collect()
     assert sorted(lib.unreg) == sorted(x for x, _ in lib.reg)
     # deferred registration
