@@ -227,7 +227,13 @@ class Engine:
         cfg.adaptation_window = int(adaptation_window)
         cfg.adaptation_window_multiplier = float(adaptation_window_multiplier)
         cfg.lds_levels = int(lds_levels)
-        # include/lmc_hip.h: LMC_LDS_PLAN_* (results do not depend on it; pinned values are for A/B runs and parity tests)
+        # include/lmc_hip.h: LMC_LDS_PLAN_* (results do not depend on it; pinned values are for A/B runs and parity tests). Like
+        # the lmc_tuning knobs, the variable the LIBRARY used to read (LMC_LDS_PLAN=0 / 1) is still honoured -- by the host, and
+        # only when the caller left the choice open (tools/ab_lds_plan.sh, tools/sample_path_rate.py)
+        if lds_plan in ("auto", None):
+            import os
+
+            lds_plan = {"0": 0, "1": 1}.get(os.environ.get("LMC_LDS_PLAN", ""), "auto")
         cfg.lds_plan = {"auto": _abi.LDS_PLAN_AUTO, None: _abi.LDS_PLAN_AUTO, 0: _abi.LDS_PLAN_SHALLOW, "shallow": _abi.LDS_PLAN_SHALLOW,
                         1: _abi.LDS_PLAN_DEEP, "deep": _abi.LDS_PLAN_DEEP}[lds_plan]
         for field, value in (tuning_from_env() if tuning is None else dict(tuning)).items():   # struct lmc_tuning: test / A-B knobs
